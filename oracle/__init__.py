@@ -1,0 +1,21 @@
+"""CPU oracle for the 4K-NeRF hot path.  TEST INFRASTRUCTURE ONLY.
+
+Nothing in the product package (``4k-nerf_amd/``) may import this package.  Only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+use it, and only as the checker / the reported CPU baseline -- never as the thing
+measured or shipped.
+
+Parity pin status (see DESIGN.md "Oracle"):
+  * SR decoder (``oracle/sr.py``): pinned against the UNMODIFIED reference module
+    ``/root/reference/lib/sr_esrnet.py`` imported in the build container; golden
+    vectors in ``tests/golden/sr_*.npz`` (generator: ``oracle/gen_golden.py``).
+  * Marcher Python control flow (``oracle/marcher.py``): pinned against the
+    reference's own ``DirectMPIGO.forward`` / ``DirectVoxGO.forward`` /
+    ``DenseGrid`` / ``MaskGrid`` / ``get_rays_of_a_view`` executed in the build
+    container with their three un-importable dependencies stubbed
+    (``oracle/ref_import.py``); golden vectors in ``tests/golden/march_*.npz``.
+  * The 13 native CUDA entry points (``oracle/native_cpu.py``): the reference ships
+    no CPU path, no tests and no golden vectors for them and its ``.cu`` sources
+    cannot be compiled without nvcc / source rewriting -- this layer is a
+    restatement and is "parity unpinned" by the reference itself.
+"""

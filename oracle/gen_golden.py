@@ -1,0 +1,174 @@
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE's own Python in the build container.
+TEST INFRASTRUCTURE ONLY.   Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+Needs ``/root/reference`` (absent on the GPU box -- the fixtures travel instead).
+
+  march_*.npz : reference ``DirectMPIGO`` / ``DirectVoxGO`` (lib/dmpigo.py, lib/dvgo.py,
+                lib/grid.py imported unmodified, see oracle/ref_import.py) evaluated on small
+                seeded scenes.  Pins the Python-level control flow of oracle/marcher.py.  The 13
+                native kernels underneath are oracle/native_cpu.py (the .cu files cannot run here).
+  rays_*.npz  : reference ``get_rays_of_a_view`` (lib/dvgo.py:577-582).
+  sr_*.npz    : UNMODIFIED reference ``SFTNet.forward`` / ``tile_process`` (lib/sr_esrnet.py);
+                weights from oracle.sr.make_state_dict(seed) (stored as the seed, not the tensors).
+"""
+import io
+import contextlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import, marcher, sr as osr   # noqa: E402
+import nerf4k_amd                                    # noqa: E402,F401
+from nerf4k_amd import scene                         # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _np(v):
+    if torch.is_tensor(v):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _kwargs_json(kw):
+    out = {}
+    for k, v in kw.items():
+        if isinstance(v, np.ndarray):
+            out[k] = v.tolist()
+        elif torch.is_tensor(v):
+            out[k] = v.tolist()
+        else:
+            out[k] = v
+    return json.dumps(out)
+
+
+def _save_march(name, ck, rays, ref_out):
+    arrs = {'model_class': np.array(ck['model_class']),
+            'model_kwargs_json': np.array(_kwargs_json(ck['model_kwargs'])),
+            'render_kwargs_json': np.array(json.dumps(ck['render_kwargs']))}
+    for k, v in ck['model_state_dict'].items():
+        arrs['sd/' + k] = _np(v)
+    for k, v in zip(('rays_o', 'rays_d', 'viewdirs'), rays):
+        arrs['in/' + k] = _np(v)
+    for k, v in ref_out.items():
+        arrs['out/' + k] = _np(v)
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB,',
+          {k: tuple(_np(v).shape) for k, v in ref_out.items()})
+
+
+def _ref_model(ref, ck):
+    cls = {'DirectMPIGO': ref.dmpigo.DirectMPIGO, 'DirectVoxGO': ref.dvgo.DirectVoxGO}[ck['model_class']]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = cls(**ck['model_kwargs'])
+    model.load_state_dict(ck['model_state_dict'])
+    return model.eval()
+
+
+def _llff_rays(ref, H, W, pose, subsample):
+    K = scene.LLFF_K.copy()
+    K[:2] *= (W / scene.LLFF_HW[1])
+    ro, rd, vd = ref.dvgo.get_rays_of_a_view(H, W, K, torch.Tensor(pose), True,
+                                             inverse_y=False, flip_x=False, flip_y=False)
+    sel = slice(None, None, subsample)
+    return [x.flatten(0, -2)[sel].contiguous() for x in (ro, rd, vd)]
+
+
+def gen_march(ref):
+    poses = scene.llff_spiral_poses()
+    cases = {
+        'march_mpi_base': dict(seed=11, num_voxels=14 * 14 * 12, mpi_depth=12),
+        'march_mpi_pe': dict(seed=12, num_voxels=12 * 12 * 10, mpi_depth=10, viewbase_pe=2, spatial_pe=1,
+                             rgbnet_dim=5, rgbnet_width=32, rgbnet_depth=4),
+        # (rgbnet_dim=0 is unreachable in the reference: DirectMPIGO.forward reads self.dim_rend,
+        #  which __init__ only sets when rgbnet_dim>0 -- lib/dmpigo.py:69-88,385 -> AttributeError)
+        'march_mpi_half': dict(seed=14, num_voxels=14 * 14 * 12, mpi_depth=12, stepsize=0.5),
+    }
+    for name, cfg in cases.items():
+        ck = scene.make_llff_checkpoint(**cfg)
+        rays = _llff_rays(ref, 24, 32, poses[5], subsample=3)
+        with torch.no_grad():
+            out = _ref_model(ref, ck)(*rays, **ck['render_kwargs'])
+        _save_march(name, ck, rays, out)
+
+    cases = {
+        'march_dvgo_base': dict(seed=21, num_voxels=12 ** 3),
+        'march_dvgo_nodirect': dict(seed=22, num_voxels=11 ** 3, rgbnet_direct=False, rgbnet_dim=9,
+                                    rgbnet_width=32, viewbase_pe=2),
+        'march_dvgo_coarse': dict(seed=23, num_voxels=11 ** 3, rgbnet_dim=0, fast_color_thres=1e-7,
+                                  alpha_init=1e-6),
+    }
+    for name, cfg in cases.items():
+        ck = scene.make_lego_checkpoint(**cfg)
+        H = W = 20
+        ro, rd, vd = ref.dvgo.get_rays_of_a_view(H, W, scene.lego_K(H, W), torch.Tensor(scene.lego_pose()),
+                                                 False, inverse_y=False, flip_x=False, flip_y=False)
+        rays = [x.flatten(0, -2)[::2].contiguous() for x in (ro, rd, vd)]
+        # one ray that misses the box and one with a zero direction component (render_utils_kernel.cu:23-25,53)
+        rays[0] = torch.cat([rays[0], torch.tensor([[5., 5., 5.], [0., 0., 4.]])])
+        rays[1] = torch.cat([rays[1], torch.tensor([[1., 0.2, 0.1], [0., 0., -1.]])])
+        rays[2] = torch.cat([rays[2], torch.tensor([[0.97, 0.2, 0.1], [0., 0., -1.]])])
+        with torch.no_grad():
+            out = _ref_model(ref, ck)(*rays, **ck['render_kwargs'])
+        _save_march(name, ck, rays, out)
+
+
+def gen_rays(ref):
+    poses = scene.llff_spiral_poses()
+    arrs = {}
+    H, W = 9, 12
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    for tag, ndc, pose, Kc in (('ndc', True, poses[3], K), ('persp', False, scene.lego_pose()[:3, :4],
+                                                            scene.lego_K(H, W))):
+        ro, rd, vd = ref.dvgo.get_rays_of_a_view(H, W, Kc, torch.Tensor(pose), ndc,
+                                                 inverse_y=False, flip_x=False, flip_y=False)
+        arrs.update({f'{tag}/K': Kc, f'{tag}/c2w': pose, f'{tag}/rays_o': _np(ro),
+                     f'{tag}/rays_d': _np(rd), f'{tag}/viewdirs': _np(vd)})
+    arrs['H'], arrs['W'] = np.array(H), np.array(W)
+    np.savez_compressed(os.path.join(GOLDEN, 'rays_views.npz'), **arrs)
+    print('rays_views: ok')
+
+
+def gen_sr(ref):
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(5)
+    for name, nb, hw, tile in (('sr_full5', 5, (12, 16), None), ('sr_tiles', 2, (23, 30), 12),
+                               ('sr_tiles510geom', 1, (26, 37), 16)):
+        sd = osr.make_state_dict(seed=100 + nb, num_block=nb)
+        net = ref.sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=nb, num_grow_ch=32, num_cond=1)
+        missing = set(net.state_dict().keys()) ^ set(sd.keys())
+        assert not missing, missing
+        assert list(net.state_dict().keys()) == [k for k, _ in osr.state_dict_spec(num_block=nb)]
+        net.load_state_dict(sd)
+        net.eval()
+        x = torch.rand([1, 3, *hw], generator=g)
+        cond = torch.rand([1, *hw], generator=g)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            if tile is None:
+                y = net(x, cond.unsqueeze(0))
+            else:
+                y = net.tile_process(x, cond, tile_size=tile)
+        np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), seed=np.array(100 + nb), num_block=np.array(nb),
+                            tile=np.array(-1 if tile is None else tile), x=_np(x), cond=_np(cond), y=_np(y))
+        print(name, tuple(y.shape), float(y.abs().mean()))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    ref = ref_import.load_reference()
+    gen_rays(ref)
+    gen_march(ref)
+    gen_sr(ref)
+
+
+if __name__ == '__main__':
+    main()

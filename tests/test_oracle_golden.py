@@ -1,0 +1,91 @@
+"""Pins the CPU oracle against vectors produced by the reference's own Python
+(tests/golden/*.npz, generator oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import marcher, sr as osr, ref_import
+from helpers import GOLDEN, load_march_golden
+
+MARCH = ['march_mpi_base', 'march_mpi_pe', 'march_mpi_half',
+         'march_dvgo_base', 'march_dvgo_nodirect', 'march_dvgo_coarse']
+
+
+@pytest.mark.parametrize('name', MARCH)
+def test_marcher_oracle_matches_reference_python(name):
+    g = load_march_golden(name)
+    fn = {'DirectMPIGO': marcher.mpi_forward, 'DirectVoxGO': marcher.dvgo_forward}[g['model_class']]
+    r = g['rays']
+    out = fn(g['model_kwargs'], g['model_state_dict'], r['rays_o'], r['rays_d'], r['viewdirs'],
+             **g['render_kwargs'])
+    ref = g['out']
+    assert set(ref.keys()) == set(out.keys())
+    # index tensors bit-exact: every mask decision of the reference is reproduced
+    assert torch.equal(out['ray_id'], ref['ray_id'])
+    for k, v in ref.items():
+        o = out[k] if torch.is_tensor(out[k]) else torch.tensor(out[k])
+        assert o.shape == v.shape, k
+        assert torch.allclose(o.float(), v.float(), rtol=0, atol=1e-6), (k, float((o.float() - v.float()).abs().max()))
+    # in-place aliasing of the reference (lib/dmpigo.py:392-397, lib/dvgo.py:425-427)
+    assert out['rgb_marched'] is out['rgb_feature']
+    assert len(ref['weights']) > 100
+
+
+def test_rays_match_reference():
+    z = np.load(os.path.join(GOLDEN, 'rays_views.npz'))
+    H, W = int(z['H']), int(z['W'])
+    for tag, ndc in (('ndc', True), ('persp', False)):
+        ro, rd, vd = marcher.get_rays_of_a_view(H, W, z[f'{tag}/K'], z[f'{tag}/c2w'], ndc)
+        for a, k in ((ro, 'rays_o'), (rd, 'rays_d'), (vd, 'viewdirs')):
+            assert torch.allclose(a, torch.from_numpy(z[f'{tag}/{k}']), rtol=0, atol=1e-6), (tag, k)
+
+
+@pytest.mark.parametrize('name', ['sr_full5', 'sr_tiles', 'sr_tiles510geom'])
+def test_sr_oracle_matches_reference_module(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    sd = osr.make_state_dict(seed=int(z['seed']), num_block=int(z['num_block']))
+    x, cond, y = (torch.from_numpy(z[k]) for k in ('x', 'cond', 'y'))
+    if int(z['tile']) < 0:
+        o = osr.sftnet_forward(sd, x, cond.unsqueeze(0))
+    else:
+        o = osr.tile_process(sd, x, cond, int(z['tile']))
+    assert o.shape == y.shape
+    assert float((o - y).abs().max()) < 2e-5, float((o - y).abs().max())
+
+
+def test_sr_spec_counts():
+    """458 state-dict tensors, 3,955,811 parameters at the default configuration."""
+    spec = osr.state_dict_spec()
+    assert len(spec) == 458
+    assert sum(int(np.prod(s)) for _, s in spec) == 3955811
+
+
+def test_tile_geometry_llff_510():
+    """1008x756 @ tile 510 pad 10 -> padded windows 520x520, 508x520, 520x256, 508x256 (w x h)."""
+    t = osr.tile_geometry(756, 1008, 510, 10)
+    wh = [(xp1 - xp0, yp1 - yp0) for (_, _, _, _, yp0, yp1, xp0, xp1) in t]
+    assert wh == [(520, 520), (508, 520), (520, 256), (508, 256)]
+    assert sum(w * h for w, h in wh) == 797728
+
+
+@pytest.mark.skipif(not ref_import.available(), reason='reference tree only exists on the build container')
+def test_reference_still_importable_and_live_equal():
+    """Live re-check (build container only): reference classes vs oracle on a fresh random case."""
+    import contextlib, io
+    import nerf4k_amd  # noqa: F401
+    from nerf4k_amd import scene
+    ref = ref_import.load_reference()
+    ck = scene.make_llff_checkpoint(seed=3, num_voxels=16 * 16 * 14, mpi_depth=14)
+    ro, rd, vd = marcher.get_rays_of_a_view(18, 24, scene.LLFF_K * np.array([[24 / 1008], [24 / 1008], [1]], dtype=np.float32),
+                                            scene.llff_spiral_poses()[2], ndc=True)
+    rays = [x.reshape(-1, 3) for x in (ro, rd, vd)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.dmpigo.DirectMPIGO(**ck['model_kwargs'])
+    m.load_state_dict(ck['model_state_dict'])
+    with torch.no_grad():
+        want = m(*rays, **ck['render_kwargs'])
+    got = marcher.mpi_forward(ck['model_kwargs'], ck['model_state_dict'], *rays, **ck['render_kwargs'])
+    assert torch.equal(got['ray_id'], want['ray_id'])
+    assert torch.allclose(got['rgb_marched'], want['rgb_marched'], atol=1e-6)
