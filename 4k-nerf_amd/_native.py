@@ -1,0 +1,131 @@
+"""ctypes binding of lib4k_hip.so (C ABI: include/k4nerf.h).
+
+The library is the product: there is NO fallback.  ``lib()`` raises if the shared object is missing
+(run ``python -c "import __graft_entry__ as g; g.build()"``) and every wrapper raises on a non-zero
+return code, on CPU tensors and on non-contiguous / wrong-dtype tensors -- the same guards the
+reference's C++ entry points apply with TORCH_CHECK (lib/cuda/render_utils.cpp:46-48).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'lib4k_hip.so')
+K4_ABI_VERSION = 1
+K4_ERR_UNSUPPORTED = 10002
+
+K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
+
+
+class GridDesc(C.Structure):
+    _fields_ = [('density', C.c_void_p), ('k0', C.c_void_p), ('act_shift', C.c_void_p), ('mask', C.c_void_p),
+                ('dims', C.c_int32 * 3), ('k0_ch', C.c_int32), ('k0_cpad', C.c_int32), ('k0_layout', C.c_int32),
+                ('act_depth', C.c_int32), ('mask_dims', C.c_int32 * 3),
+                ('xyz_min', C.c_float * 3), ('xyz_max', C.c_float * 3),
+                ('xyz2ijk_scale', C.c_float * 3), ('xyz2ijk_shift', C.c_float * 3)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [('packed', C.c_void_p), ('dim0', C.c_int32), ('width', C.c_int32), ('n_hidden', C.c_int32),
+                ('viewbase_pe', C.c_int32), ('spatial_pe', C.c_int32), ('k0_skip', C.c_int32)]
+
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_SIGS = {
+    'k4_abi_version': [],
+    'k4_march_mpi_fwd': [_P, _P, _P, _I64, _I32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _I32, _F, _F, _F,
+                         _P, _P, _P, _P, _P],
+    'k4_march_dvgo_fwd': [_P, _P, _P, _I64, _I32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _F, _F, _F, _I32,
+                          _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    'k4_sample_ndc_pts_on_rays': [_P, _P, _P, _P, _I64, _I32, _P, _P, _P],
+    'k4_infer_t_minmax': [_P, _P, _P, _P, _F, _F, _I64, _P, _P, _P],
+    'k4_infer_n_samples': [_P, _P, _P, _F, _I64, _P, _P],
+    'k4_infer_ray_start_dir': [_P, _P, _P, _I64, _P, _P, _P],
+    'k4_sample_pts_on_rays_count': [_P, _P, _P, _P, _F, _F, _F, _I64, _P, _P, _P, _P],
+    'k4_sample_pts_on_rays_fill': [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _P, _P, _P, _P],
+    'k4_maskcache_lookup': [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P],
+    'k4_raw2alpha': [_P, _F, _F, _P, _I64, _P, _P, _P],
+    'k4_raw2alpha_backward': [_P, _P, _F, _P, _I64, _P, _P],
+    'k4_alpha2weight': [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P],
+    'k4_alpha2weight_backward': [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P],
+    'k4_grid_sample_3d': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
+    'k4_segment_sum': [_P, _P, _I64, _I32, _I64, _P, _P],
+    'k4_repack_k0': [_P, _I32, _I32, _I64, _P, _P],
+}
+_lib = None
+
+
+def lib():
+    """Load lib4k_hip.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the HIP extension is not built (python -c "import __graft_entry__ as g; '
+                f'g.build()").  There is no CPU/PyTorch fallback for the 4K-NeRF hot path.')
+        l = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        for name, (args, res) in _EXTRA_SIGS.items():
+            if hasattr(l, name):
+                fn = getattr(l, name)
+                fn.argtypes = args
+                fn.restype = res
+        if l.k4_abi_version() != K4_ABI_VERSION:
+            raise RuntimeError('lib4k_hip.so ABI version mismatch: rebuild')
+        _lib = l
+    return _lib
+
+
+# SR entry points are registered by sr modules (optional symbols are bound when present)
+_EXTRA_SIGS = {
+    'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, C.c_uint32, _F,
+                        _P, _I32, _F, _P, _I32, _P], C.c_int),
+    'k4_pack_conv_weight_size': ([_I32, _I32, _I32], C.c_int64),
+    'k4_pack_conv_weight': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
+}
+
+
+class K4Error(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc == 10001:
+            msg = 'K4_ERR_BAD_ARG'
+        elif rc == K4_ERR_UNSUPPORTED:
+            msg = 'K4_ERR_UNSUPPORTED'
+        else:
+            msg = f'hipError {rc}'
+        raise K4Error(f'{what} failed: {msg}')
+
+
+def ptr(t):
+    """Device pointer of a CUDA(HIP), contiguous tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise K4Error('tensor must be on the GPU (no CPU path exists for this op)')
+    if not t.is_contiguous():
+        raise K4Error('tensor must be contiguous')
+    return C.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise K4Error(f'expected float32, got {t.dtype}')
+    return ptr(t)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def vec3(t):
+    v = [float(x) for x in t.detach().cpu().reshape(-1).tolist()]
+    assert len(v) == 3
+    return (C.c_float * 3)(*v)

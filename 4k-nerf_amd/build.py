@@ -1,0 +1,51 @@
+"""Build lib4k_hip.so (all HIP kernels + the C ABI of include/k4nerf.h) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  Objects are cached by source mtime; the .so sits next to this
+file so it travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+OUT = os.path.join(PKG, 'lib4k_hip.so')
+ARCH = 'gfx950'
+SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip']  # missing files are skipped
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(verbose=False, force=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(PKG, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+           [os.path.join(ROOT, 'include', 'k4nerf.h')]
+    objs, relink = [], force
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(objdir, src + '.o')
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            relink = True
+        objs.append(o)
+    if relink or not os.path.exists(OUT) or any(_newer(o, OUT) for o in objs):
+        cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(verbose=True, force='--force' in sys.argv))

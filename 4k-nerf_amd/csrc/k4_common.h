@@ -1,0 +1,74 @@
+// Shared device helpers for the gfx950 kernels of lib4k_hip.so.  CDNA4 only: wave64, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "k4nerf.h"
+
+#define K4_WAVE 64
+
+// Uniform (wave-invariant) read-only data -- MLP weights, ray tables read with a wave-uniform index --
+// goes through the constant address space so that hipcc emits s_load_* (scalar cache, SGPR operands for
+// v_fmac) instead of 64 identical vector loads.
+typedef const float __attribute__((address_space(4)))* k4_cptr;
+__device__ __forceinline__ k4_cptr k4_const(const float* p) {
+    return (k4_cptr)(uintptr_t)p;
+}
+
+__device__ __forceinline__ int k4_lane() { return (int)(threadIdx.x & 63u); }
+
+// number of set bits of `m` below this lane (wave64 prefix popcount)
+__device__ __forceinline__ int k4_prefix(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ float k4_readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// C round(): halves away from zero (the reference's maskcache_lookup, render_utils_kernel.cu:385-387)
+__device__ __forceinline__ int k4_round_half_away(float x) { return (int)roundf(x); }
+
+// bijective XCD-aware block remap (hardware places block b on XCD b%8; give each XCD a contiguous
+// range of logical workgroups so neighbours share that XCD's L2).  Speed only, never correctness.
+__device__ __forceinline__ int k4_xcd_remap(int b, int nwg) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// F.grid_sample(bilinear, align_corners=True) coordinate, restating the reference's op sequence:
+//   ind_norm = ((p - min) / (max - min)) * 2 - 1          (lib/grid.py:123)
+//   u        = ((ind_norm + 1) / 2) * (size - 1)          (grid_sampler unnormalize, align_corners)
+__device__ __forceinline__ float k4_norm_coord(float p, float lo, float hi) {
+    return ((p - lo) / (hi - lo)) * 2.f - 1.f;
+}
+__device__ __forceinline__ float k4_unnorm(float n, int size) {
+    return ((n + 1.f) / 2.f) * (float)(size - 1);
+}
+
+// The 8 trilinear corner weights in PyTorch's naming/order (tnw,tne,tsw,tse,bnw,bne,bsw,bse) with
+// torch's ix<->our z (W axis), iy<->y (H), iz<->x (D):  t/b = x lo/hi, n/s = y lo/hi, w/e = z lo/hi.
+struct K4Tri {
+    int x0, y0, z0;
+    float w[8];
+};
+__device__ __forceinline__ K4Tri k4_tri_setup(float ux, float uy, float uz) {
+    K4Tri t;
+    const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+    t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
+    const float xl = (fx + 1.f) - ux, xh = ux - fx;
+    const float yl = (fy + 1.f) - uy, yh = uy - fy;
+    const float zl = (fz + 1.f) - uz, zh = uz - fz;
+    t.w[0] = zl * yl * xl; t.w[1] = zh * yl * xl; t.w[2] = zl * yh * xl; t.w[3] = zh * yh * xl;
+    t.w[4] = zl * yl * xh; t.w[5] = zh * yl * xh; t.w[6] = zl * yh * xh; t.w[7] = zh * yh * xh;
+    return t;
+}
+// corner c -> (dx,dy,dz)
+#define K4_CX(c) (((c) >> 2) & 1)
+#define K4_CY(c) (((c) >> 1) & 1)
+#define K4_CZ(c) ((c) & 1)
+
+static inline int k4_check_launch() {
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}

@@ -1,0 +1,382 @@
+// Staged (one op per launch) gfx950 kernels: one per native function of the reference's
+// `render_utils_cuda` (lib/cuda/render_utils.cpp:170-184) plus the two library ops the reference
+// strings between them (F.grid_sample, torch_scatter.segment_coo).  They exist for callers that need
+// per-sample tensors (training-compatible forward, the `render_utils_cuda` shim); the render path uses
+// the fused kernels of k4_march.hip, which share the arithmetic written here op for op.
+// All are HBM-streaming, one thread per element (or one WAVE per ray for the transmittance scan).
+#include "k4_common.h"
+
+#define K4_THREADS 256
+static inline unsigned k4_blocks(int64_t n) { return (unsigned)((n + K4_THREADS - 1) / K4_THREADS); }
+
+// ---------------------------------------------------------------- sample_ndc_pts_on_rays (.cu:245-270)
+__global__ void k_sample_ndc(const float* __restrict__ o, const float* __restrict__ d,
+                             const float* __restrict__ mn, const float* __restrict__ mx,
+                             int64_t n_rays, int n_samples, float* __restrict__ pts, uint8_t* __restrict__ mask) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rays * n_samples) return;
+    const int64_t ray = idx / n_samples;
+    const int step = (int)(idx % n_samples);
+    const float dist = (float)step / (float)(n_samples - 1);
+    const float px = fmaf(d[ray * 3 + 0], dist, o[ray * 3 + 0]);
+    const float py = fmaf(d[ray * 3 + 1], dist, o[ray * 3 + 1]);
+    const float pz = fmaf(d[ray * 3 + 2], dist, o[ray * 3 + 2]);
+    pts[idx * 3 + 0] = px; pts[idx * 3 + 1] = py; pts[idx * 3 + 2] = pz;
+    mask[idx] = (mn[0] > px) | (mn[1] > py) | (mn[2] > pz) | (mx[0] < px) | (mx[1] < py) | (mx[2] < pz);
+}
+
+// ---------------------------------------------------------------- ray-AABB helpers (.cu:12-79)
+__device__ __forceinline__ void aabb_t(const float* o, const float* d, const float* mn, const float* mx,
+                                        float near, float far, int64_t r, float& t_min, float& t_max) {
+    const float vx = d[r * 3 + 0] == 0.f ? 1e-6f : d[r * 3 + 0];
+    const float vy = d[r * 3 + 1] == 0.f ? 1e-6f : d[r * 3 + 1];
+    const float vz = d[r * 3 + 2] == 0.f ? 1e-6f : d[r * 3 + 2];
+    const float ax = (mx[0] - o[r * 3 + 0]) / vx, ay = (mx[1] - o[r * 3 + 1]) / vy, az = (mx[2] - o[r * 3 + 2]) / vz;
+    const float bx = (mn[0] - o[r * 3 + 0]) / vx, by = (mn[1] - o[r * 3 + 1]) / vy, bz = (mn[2] - o[r * 3 + 2]) / vz;
+    t_min = fmaxf(fminf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), far), near);
+    t_max = fmaxf(fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), far), near);
+}
+__device__ __forceinline__ float ray_norm(const float* d, int64_t r) {
+    return sqrtf(fmaf(d[r * 3 + 2], d[r * 3 + 2], fmaf(d[r * 3 + 1], d[r * 3 + 1], d[r * 3 + 0] * d[r * 3 + 0])));
+}
+__device__ __forceinline__ int64_t n_steps_of(float t_min, float t_max, float rnorm, float stepdist) {
+    return (int64_t)fmaxf(ceilf((t_max - t_min) * rnorm / stepdist), 1.f);      // at least 1 point (.cu:53)
+}
+
+__global__ void k_t_minmax(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ mn,
+                           const float* __restrict__ mx, float near, float far, int64_t n,
+                           float* __restrict__ tmin, float* __restrict__ tmax) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float a, b;
+    aabb_t(o, d, mn, mx, near, far, r, a, b);
+    tmin[r] = a; tmax[r] = b;
+}
+__global__ void k_n_samples(const float* __restrict__ d, const float* __restrict__ tmin, const float* __restrict__ tmax,
+                            float stepdist, int64_t n, int64_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    out[r] = n_steps_of(tmin[r], tmax[r], ray_norm(d, r), stepdist);
+}
+__global__ void k_start_dir(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ tmin,
+                            int64_t n, float* __restrict__ start, float* __restrict__ dir) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float rn = ray_norm(d, r);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        start[r * 3 + c] = fmaf(d[r * 3 + c], tmin[r], o[r * 3 + c]);
+        dir[r * 3 + c] = d[r * 3 + c] / rn;
+    }
+}
+__global__ void k_pts_count(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ mn,
+                            const float* __restrict__ mx, float near, float far, float stepdist, int64_t n,
+                            int64_t* __restrict__ nsteps, float* __restrict__ tmin, float* __restrict__ tmax) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float a, b;
+    aabb_t(o, d, mn, mx, near, far, r, a, b);
+    tmin[r] = a; tmax[r] = b;
+    nsteps[r] = n_steps_of(a, b, ray_norm(d, r), stepdist);
+}
+// one thread per output point; its ray is found by binary search in the inclusive cumsum (replaces the
+// reference's scatter-1 + second cumsum, .cu:144-164,213-219)
+__global__ void k_pts_fill(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ mn,
+                           const float* __restrict__ mx, const float* __restrict__ tmin,
+                           const int64_t* __restrict__ cum, float stepdist, int64_t n_rays, int64_t total,
+                           float* __restrict__ pts, uint8_t* __restrict__ mask, int64_t* __restrict__ ray_id,
+                           int64_t* __restrict__ step_id) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int64_t lo = 0, hi = n_rays - 1;                   // first ray with cum[ray] > idx
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cum[mid] > idx) hi = mid; else lo = mid + 1;
+    }
+    const int64_t r = lo;
+    const int64_t step = idx - (r > 0 ? cum[r - 1] : 0);
+    const float rn = ray_norm(d, r);
+    const float dist = stepdist * (float)step;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float start = fmaf(d[r * 3 + c], tmin[r], o[r * 3 + c]);
+        const float dir = d[r * 3 + c] / rn;
+        p[c] = fmaf(dir, dist, start);
+        pts[idx * 3 + c] = p[c];
+    }
+    mask[idx] = (mn[0] > p[0]) | (mn[1] > p[1]) | (mn[2] > p[2]) | (mx[0] < p[0]) | (mx[1] < p[1]) | (mx[2] < p[2]);
+    ray_id[idx] = r; step_id[idx] = step;
+}
+
+// ---------------------------------------------------------------- maskcache_lookup (.cu:374-392)
+__global__ void k_maskcache(const uint8_t* __restrict__ world, const float* __restrict__ xyz,
+                            const float* __restrict__ sc, const float* __restrict__ sh,
+                            int si, int sj, int sk, int64_t n, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = k4_round_half_away(fmaf(xyz[i * 3 + 0], sc[0], sh[0]));
+    const int b = k4_round_half_away(fmaf(xyz[i * 3 + 1], sc[1], sh[1]));
+    const int c = k4_round_half_away(fmaf(xyz[i * 3 + 2], sc[2], sh[2]));
+    uint8_t v = 0;
+    if ((unsigned)a < (unsigned)si && (unsigned)b < (unsigned)sj && (unsigned)c < (unsigned)sk)
+        v = world[((size_t)a * sj + b) * sk + c] != 0;
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------- raw2alpha (+bwd) (.cu:431-458, 507-530)
+__global__ void k_raw2alpha(const float* __restrict__ den, float shift, float interval, const float* __restrict__ ipp,
+                            int64_t n, float* __restrict__ ex, float* __restrict__ al) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = expf(den[i] + shift);
+    const float iv = ipp ? ipp[i] : interval;
+    ex[i] = e;
+    al[i] = (iv == 1.f) ? 1.f - 1.f / (1.f + e) : 1.f - powf(1.f + e, -iv);
+}
+__global__ void k_raw2alpha_bwd(const float* __restrict__ ex, const float* __restrict__ gb, float interval,
+                                const float* __restrict__ ipp, int64_t n, float* __restrict__ g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float iv = ipp ? ipp[i] : interval;
+    g[i] = fminf(ex[i], 1e10f) * powf(1.f + ex[i], -iv - 1.f) * iv * gb[i];
+}
+
+// ---------------------------------------------------------------- alpha2weight (.cu:577-651)
+// segment bounds from change points of the sorted ray_id (incl. the reference's host-side
+// `i_end[ray_id[n-1]] = n`, done on the device here: no sync)
+__global__ void k_seg_bounds(const int64_t* __restrict__ ray_id, int64_t n, int64_t* __restrict__ i_start,
+                             int64_t* __restrict__ i_end) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i > 0 && ray_id[i] != ray_id[i - 1]) { i_start[ray_id[i]] = i; i_end[ray_id[i - 1]] = i; }
+    if (i == n - 1) i_end[ray_id[i]] = n;
+}
+// one WAVE per ray; lanes take 64 consecutive points; the product is the reference's exact sequential
+// one (ballot + readlane), including the sample that crosses T<1e-3 (.cu:597-600)
+__global__ __launch_bounds__(256) void k_alpha2weight(const float* __restrict__ alpha, int64_t n_rays,
+                                                      float* __restrict__ weight, float* __restrict__ Tout,
+                                                      float* __restrict__ ainv, const int64_t* __restrict__ i_start,
+                                                      int64_t* __restrict__ i_end) {
+    const int lane = k4_lane();
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int64_t s = i_start[ray], e = i_end[ray];
+    float T = 1.f;
+    int64_t stop_at = e;
+    bool stopped = false;
+    for (int64_t base = s; base < e && !stopped; base += 64) {
+        const int64_t i = base + lane;
+        const bool v = i < e;
+        const float a = v ? alpha[i] : 0.f;
+        float myT = 1.f, myw = 0.f;
+        uint64_t bm = __ballot(v);
+        while (bm) {
+            const int l = __builtin_ctzll(bm);
+            const float al = k4_readlane(a, l);
+            if (lane == l) { myT = T; myw = T * al; }
+            T = (float)((double)T * (1.0 - (double)al));
+            bm &= bm - 1;
+            if ((double)T < 1e-3) { stopped = true; stop_at = base + l + 1; break; }
+        }
+        if (v && i < stop_at) { Tout[i] = myT; weight[i] = myw; }
+    }
+    if (lane == 0) { i_end[ray] = stop_at; ainv[ray] = T; }
+}
+__global__ void k_fill2(float* __restrict__ a, float va, float* __restrict__ b, float vb, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = va; if (b) b[i] = vb; }
+}
+__global__ void k_fill_i64(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0; b[i] = 0; }
+}
+// alpha2weight_backward (.cu:654-677): reverse sequential scan, one thread per ray (training path, "next")
+__global__ void k_alpha2weight_bwd(const float* __restrict__ alpha, const float* __restrict__ weight,
+                                   const float* __restrict__ T, const float* __restrict__ ainv,
+                                   const int64_t* __restrict__ i_start, const int64_t* __restrict__ i_end,
+                                   int64_t n_rays, const float* __restrict__ gw, const float* __restrict__ gl,
+                                   float* __restrict__ grad) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float back = gl[r] * ainv[r];
+    for (int64_t i = i_end[r] - 1; i >= i_start[r]; --i) {
+        grad[i] = gw[i] * T[i] - back / (1.f - alpha[i] + 1e-10f);
+        back += gw[i] * weight[i];
+    }
+}
+
+// ---------------------------------------------------------------- DenseGrid.forward (lib/grid.py:117-128)
+__global__ void k_grid_sample(const float* __restrict__ grid, int C, int X, int Y, int Z,
+                              const float* __restrict__ xyz, const float* __restrict__ mn, const float* __restrict__ mx,
+                              int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float nx = k4_norm_coord(xyz[i * 3 + 0], mn[0], mx[0]);
+    const float ny = k4_norm_coord(xyz[i * 3 + 1], mn[1], mx[1]);
+    const float nz = k4_norm_coord(xyz[i * 3 + 2], mn[2], mx[2]);
+    const K4Tri t = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
+    size_t idx[8]; float w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
+        const bool ok = (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
+        idx[c] = ok ? ((size_t)x * Y + y) * Z + z : 0;
+        w[c] = ok ? t.w[c] : 0.f;
+    }
+    const size_t plane = (size_t)X * Y * Z;
+    for (int ch = 0; ch < C; ++ch) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v += grid[plane * ch + idx[c]] * w[c];
+        out[i * C + ch] = v;
+    }
+}
+
+// ---------------------------------------------------------------- segment_coo(sum), sorted index
+// one thread per (segment head, channel): walks its run sequentially -> deterministic, same order as index_add_
+__global__ void k_segment_sum(const float* __restrict__ src, const int64_t* __restrict__ index, int64_t n, int C,
+                              float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    const int64_t i = t / C;
+    const int ch = (int)(t % C);
+    if (i > 0 && index[i - 1] == index[i]) return;
+    const int64_t seg = index[i];
+    float acc = 0.f;
+    for (int64_t j = i; j < n && index[j] == seg; ++j) acc += src[j * C + ch];
+    out[seg * C + ch] += acc;
+}
+
+// ---------------------------------------------------------------- k0 repack [C][V] -> [V][CP]
+__global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t nvox, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvox * CP) return;
+    const int64_t v = t / CP;
+    const int ch = (int)(t % CP);
+    out[t] = ch < C ? in[(size_t)ch * nvox + v] : 0.f;
+}
+
+// ================================================================ C ABI
+#define ST ((hipStream_t)stream)
+#define REQ(c) do { if (!(c)) return K4_ERR_BAD_ARG; } while (0)
+
+extern "C" int k4_sample_ndc_pts_on_rays(const float* o, const float* d, const float* mn, const float* mx,
+                                         int64_t n_rays, int32_t n_samples, float* pts, uint8_t* mask, void* stream) {
+    REQ(o && d && mn && mx && pts && mask && n_rays >= 0 && n_samples >= 2);
+    if (n_rays == 0) return K4_OK;
+    hipLaunchKernelGGL(k_sample_ndc, dim3(k4_blocks(n_rays * n_samples)), dim3(K4_THREADS), 0, ST, o, d, mn, mx, n_rays, n_samples, pts, mask);
+    return k4_check_launch();
+}
+extern "C" int k4_infer_t_minmax(const float* o, const float* d, const float* mn, const float* mx, float near, float far,
+                                 int64_t n, float* tmin, float* tmax, void* stream) {
+    REQ(o && d && mn && mx && tmin && tmax && n >= 0);
+    if (n == 0) return K4_OK;
+    hipLaunchKernelGGL(k_t_minmax, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, o, d, mn, mx, near, far, n, tmin, tmax);
+    return k4_check_launch();
+}
+extern "C" int k4_infer_n_samples(const float* d, const float* tmin, const float* tmax, float stepdist, int64_t n,
+                                  int64_t* out, void* stream) {
+    REQ(d && tmin && tmax && out && n >= 0 && stepdist > 0.f);
+    if (n == 0) return K4_OK;
+    hipLaunchKernelGGL(k_n_samples, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, d, tmin, tmax, stepdist, n, out);
+    return k4_check_launch();
+}
+extern "C" int k4_infer_ray_start_dir(const float* o, const float* d, const float* tmin, int64_t n, float* start,
+                                      float* dir, void* stream) {
+    REQ(o && d && tmin && start && dir && n >= 0);
+    if (n == 0) return K4_OK;
+    hipLaunchKernelGGL(k_start_dir, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, o, d, tmin, n, start, dir);
+    return k4_check_launch();
+}
+extern "C" int k4_sample_pts_on_rays_count(const float* o, const float* d, const float* mn, const float* mx,
+                                           float near, float far, float stepdist, int64_t n,
+                                           int64_t* nsteps, float* tmin, float* tmax, void* stream) {
+    REQ(o && d && mn && mx && nsteps && tmin && tmax && n >= 0 && stepdist > 0.f);
+    if (n == 0) return K4_OK;
+    hipLaunchKernelGGL(k_pts_count, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, o, d, mn, mx, near, far, stepdist, n, nsteps, tmin, tmax);
+    return k4_check_launch();
+}
+extern "C" int k4_sample_pts_on_rays_fill(const float* o, const float* d, const float* mn, const float* mx,
+                                          const float* tmin, const int64_t* cum, float stepdist, int64_t n_rays,
+                                          int64_t total, float* pts, uint8_t* mask, int64_t* ray_id, int64_t* step_id,
+                                          void* stream) {
+    REQ(o && d && mn && mx && tmin && cum && n_rays >= 0 && total >= 0 && stepdist > 0.f);
+    if (total == 0) return K4_OK;
+    REQ(pts && mask && ray_id && step_id);
+    hipLaunchKernelGGL(k_pts_fill, dim3(k4_blocks(total)), dim3(K4_THREADS), 0, ST, o, d, mn, mx, tmin, cum, stepdist, n_rays, total, pts, mask, ray_id, step_id);
+    return k4_check_launch();
+}
+extern "C" int k4_maskcache_lookup(const uint8_t* world, const float* xyz, const float* sc, const float* sh,
+                                   int32_t si, int32_t sj, int32_t sk, int64_t n, uint8_t* out, void* stream) {
+    REQ(world && sc && sh && n >= 0 && si > 0 && sj > 0 && sk > 0);
+    if (n == 0) return K4_OK;
+    REQ(xyz && out);
+    hipLaunchKernelGGL(k_maskcache, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, world, xyz, sc, sh, si, sj, sk, n, out);
+    return k4_check_launch();
+}
+extern "C" int k4_raw2alpha(const float* den, float shift, float interval, const float* ipp, int64_t n,
+                            float* ex, float* al, void* stream) {
+    REQ(n >= 0);
+    if (n == 0) return K4_OK;
+    REQ(den && ex && al);
+    hipLaunchKernelGGL(k_raw2alpha, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, den, shift, interval, ipp, n, ex, al);
+    return k4_check_launch();
+}
+extern "C" int k4_raw2alpha_backward(const float* ex, const float* gb, float interval, const float* ipp, int64_t n,
+                                     float* g, void* stream) {
+    REQ(n >= 0);
+    if (n == 0) return K4_OK;
+    REQ(ex && gb && g);
+    hipLaunchKernelGGL(k_raw2alpha_bwd, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, ex, gb, interval, ipp, n, g);
+    return k4_check_launch();
+}
+extern "C" int k4_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int64_t n_rays,
+                               float* weight, float* T, float* ainv, int64_t* i_start, int64_t* i_end, void* stream) {
+    REQ(n_pts >= 0 && n_rays >= 0 && ainv && i_start && i_end);
+    if (n_rays == 0) return K4_OK;
+    // weight = zeros_like, T = ones_like, alphainv_last = ones, i_start/i_end = zeros (.cu:624-628)
+    hipLaunchKernelGGL(k_fill2, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, ainv, 1.f, (float*)nullptr, 0.f, n_rays);
+    hipLaunchKernelGGL(k_fill_i64, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, i_start, i_end, n_rays);
+    if (n_pts == 0) return k4_check_launch();
+    REQ(alpha && ray_id && weight && T);
+    hipLaunchKernelGGL(k_fill2, dim3(k4_blocks(n_pts)), dim3(K4_THREADS), 0, ST, weight, 0.f, T, 1.f, n_pts);
+    hipLaunchKernelGGL(k_seg_bounds, dim3(k4_blocks(n_pts)), dim3(K4_THREADS), 0, ST, ray_id, n_pts, i_start, i_end);
+    hipLaunchKernelGGL(k_alpha2weight, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, ST, alpha, n_rays, weight, T, ainv, i_start, i_end);
+    return k4_check_launch();
+}
+extern "C" int k4_alpha2weight_backward(const float* alpha, const float* weight, const float* T, const float* ainv,
+                                        const int64_t* i_start, const int64_t* i_end, int64_t n_rays, int64_t n_pts,
+                                        const float* gw, const float* gl, float* grad, void* stream) {
+    REQ(n_rays >= 0 && n_pts >= 0);
+    if (n_pts == 0 || n_rays == 0) return K4_OK;
+    REQ(alpha && weight && T && ainv && i_start && i_end && gw && gl && grad);
+    hipLaunchKernelGGL(k_fill2, dim3(k4_blocks(n_pts)), dim3(K4_THREADS), 0, ST, grad, 0.f, (float*)nullptr, 0.f, n_pts);
+    hipLaunchKernelGGL(k_alpha2weight_bwd, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, alpha, weight, T, ainv, i_start, i_end, n_rays, gw, gl, grad);
+    return k4_check_launch();
+}
+extern "C" int k4_grid_sample_3d(const float* grid, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
+                                 const float* mn, const float* mx, int64_t n, float* out, void* stream) {
+    REQ(grid && mn && mx && C > 0 && X > 0 && Y > 0 && Z > 0 && n >= 0);
+    if (n == 0) return K4_OK;
+    REQ(xyz && out);
+    hipLaunchKernelGGL(k_grid_sample, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, grid, C, X, Y, Z, xyz, mn, mx, n, out);
+    return k4_check_launch();
+}
+extern "C" int k4_segment_sum(const float* src, const int64_t* index, int64_t n, int32_t C, int64_t n_seg, float* out,
+                              void* stream) {
+    REQ(out && C > 0 && n >= 0 && n_seg >= 0);
+    if (n_seg > 0) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_seg * C, ST);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (n == 0) return K4_OK;
+    REQ(src && index);
+    hipLaunchKernelGGL(k_segment_sum, dim3(k4_blocks(n * C)), dim3(K4_THREADS), 0, ST, src, index, n, C, out);
+    return k4_check_launch();
+}
+extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {
+    REQ(in && out && C > 0 && CP >= C && CP % 4 == 0 && nvox > 0);
+    hipLaunchKernelGGL(k_repack_k0, dim3(k4_blocks(nvox * CP)), dim3(K4_THREADS), 0, ST, in, C, CP, nvox, out);
+    return k4_check_launch();
+}

@@ -1,0 +1,254 @@
+"""DirectMPIGO (the LLFF / NDC model) with the reference's interface (/root/reference/lib/dmpigo.py).
+
+Constructor kwargs, ``get_kwargs()``, ``state_dict`` key names (``density.grid``, ``k0.grid``,
+``act_shift.grid`` [1,1,1,1,D], ``rgbnet.*``, ``viewfreq``, ``posfreq``, ``mask_cache.*``) and
+``forward(rays_o, rays_d, viewdirs, global_step=None, **render_kwargs) -> dict`` are the reference's
+(lib/dmpigo.py:18-187,292-427).  Inside, inference is ONE fused HIP launch (``k4_march_mpi_fwd``);
+``k4_staged=True`` / autograd / unsupported MLP shapes take the staged gfx950 kernels and return every
+key of the reference dict.  No CPU path.
+
+Reference quirks honoured: ``act_type`` / ``mode_type`` are required kwargs when
+``rgbnet_dim>0`` (lib/dmpigo.py:89,124); ``rgb_feature`` aliases ``rgb_marched`` in eval
+(lib/dmpigo.py:392-397); ``mode_type`` 'TRANS'/'adain' reference undefined modules upstream and are
+rejected here.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from . import grid
+from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid
+
+
+'''Model'''
+class DirectMPIGO(torch.nn.Module, _FusedMarcher):
+    def __init__(self, xyz_min, xyz_max,
+                 num_voxels=0, mpi_depth=0,
+                 mask_cache_path=None, mask_cache_thres=1e-3, mask_cache_world_size=None,
+                 fast_color_thres=0,
+                 density_type='DenseGrid', k0_type='DenseGrid',
+                 density_config={}, k0_config={},
+                 rgbnet_dim=0,
+                 rgbnet_depth=3, rgbnet_width=128,
+                 viewbase_pe=0,
+                 spatial_pe=0,
+                 **kwargs):
+        super(DirectMPIGO, self).__init__()
+        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
+        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        self.fast_color_thres = fast_color_thres
+        self._set_grid_resolution(num_voxels, mpi_depth)
+
+        self.density_type = density_type
+        self.density_config = density_config
+        self.density = grid.create_grid(
+            density_type, channels=1, world_size=self.world_size,
+            xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.density_config)
+
+        # per-plane density bias so that the initial alphas along a ray are equal (lib/dmpigo.py:48-58)
+        self.act_shift = grid.DenseGrid(
+            channels=1, world_size=[1, 1, mpi_depth], xyz_min=xyz_min, xyz_max=xyz_max)
+        self.act_shift.grid.requires_grad = False
+        with torch.no_grad():
+            g = np.full([mpi_depth], 1. / mpi_depth - 1e-6)
+            p = [1 - g[0]]
+            for i in range(1, len(g)):
+                p.append((1 - g[:i + 1].sum()) / (1 - g[:i].sum()))
+            for i in range(len(p)):
+                self.act_shift.grid[..., i].fill_(np.log(p[i] ** (-1 / self.voxel_size_ratio) - 1))
+
+        self.rgbnet_kwargs = {
+            'rgbnet_dim': rgbnet_dim,
+            'rgbnet_depth': rgbnet_depth, 'rgbnet_width': rgbnet_width,
+            'viewbase_pe': viewbase_pe, 'spatial_pe': spatial_pe,
+        }
+        self.k0_type = k0_type
+        self.k0_config = k0_config
+        self.dim_rend = 3
+        self.act_type = kwargs.get('act_type', 'relu')
+        self.mode_type = kwargs.get('mode_type', 'mlp')
+        if rgbnet_dim <= 0:
+            # colour voxel grid (coarse stage).  Upstream this branch cannot run: forward reads
+            # self.dim_rend which is only set when rgbnet_dim>0 (lib/dmpigo.py:69-88,385).
+            self.k0_dim = 3
+            self.k0 = grid.create_grid(
+                k0_type, channels=self.k0_dim, world_size=self.world_size,
+                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
+            self.rgbnet = None
+        else:
+            self.k0_dim = rgbnet_dim
+            self.k0 = grid.create_grid(
+                k0_type, channels=self.k0_dim, world_size=self.world_size,
+                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
+            self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
+            self.register_buffer('posfreq', torch.FloatTensor([(2 ** i) for i in range(spatial_pe)]))
+            self.dim0 = (3 + 3 * viewbase_pe * 2 + 3 + 3 * spatial_pe * 2) + self.k0_dim
+            self.pe_dim = 3 + 3 * viewbase_pe * 2 + 3 + 3 * spatial_pe * 2
+            self.act_type = kwargs['act_type']
+            self.mode_type = kwargs['mode_type']
+            if self.act_type != 'relu':
+                raise NotImplementedError(f"act_type={self.act_type!r}: every BASELINE config uses 'relu' "
+                                          "(configs/llff/fern_lg_joint_l1.py)")
+            if self.mode_type in ('TRANS', 'adain'):
+                raise NotImplementedError(f'mode_type={self.mode_type!r} needs modules the reference never defines '
+                                          '(lib/dmpigo.py:124-130)')
+            act = nn.ReLU(inplace=True)
+            self.rgbnet = nn.Sequential(
+                nn.Linear(self.dim0, rgbnet_width), act,
+                *[
+                    nn.Sequential(nn.Linear(rgbnet_width, rgbnet_width), act)
+                    for _ in range(rgbnet_depth - 2)
+                ],
+                nn.Linear(rgbnet_width, self.dim_rend),
+            )
+            nn.init.constant_(self.rgbnet[-1].bias, 0)
+
+        self.mask_cache_path = mask_cache_path
+        self.mask_cache_thres = mask_cache_thres
+        if mask_cache_world_size is None:
+            mask_cache_world_size = self.world_size
+        if mask_cache_path is not None and mask_cache_path:
+            mask = coarse_mask_on_grid(mask_cache_path, mask_cache_thres, self.xyz_min, self.xyz_max,
+                                       mask_cache_world_size)
+        else:
+            mask = torch.ones(list(mask_cache_world_size), dtype=torch.bool)
+        self.mask_cache = grid.MaskGrid(path=None, mask=mask, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
+
+    def _set_grid_resolution(self, num_voxels, mpi_depth):
+        # lib/dmpigo.py:156-164
+        self.num_voxels = num_voxels
+        self.mpi_depth = mpi_depth
+        r = (num_voxels / self.mpi_depth / (self.xyz_max - self.xyz_min)[:2].prod()).sqrt()
+        self.world_size = torch.zeros(3, dtype=torch.long)
+        self.world_size[:2] = (self.xyz_max - self.xyz_min)[:2] * r
+        self.world_size[2] = self.mpi_depth
+        self.voxel_size_ratio = 256. / mpi_depth
+
+    def get_kwargs(self):
+        return {
+            'xyz_min': self.xyz_min.cpu().numpy(),
+            'xyz_max': self.xyz_max.cpu().numpy(),
+            'num_voxels': self.num_voxels,
+            'mpi_depth': self.mpi_depth,
+            'voxel_size_ratio': self.voxel_size_ratio,
+            'mask_cache_path': self.mask_cache_path,
+            'mask_cache_thres': self.mask_cache_thres,
+            'mask_cache_world_size': list(self.mask_cache.mask.shape),
+            'fast_color_thres': self.fast_color_thres,
+            'density_type': self.density_type,
+            'k0_type': self.k0_type,
+            'density_config': self.density_config,
+            'k0_config': self.k0_config,
+            'mode_type': self.mode_type,
+            'act_type': self.act_type,
+            'dim_rend': self.dim_rend,
+            **self.rgbnet_kwargs,
+        }
+
+    def activate_density(self, density, interval=None):
+        interval = interval if interval is not None else self.voxel_size_ratio
+        shape = density.shape
+        return Raw2Alpha.apply(density.flatten(), 0, interval).reshape(shape)
+
+    def sample_ray(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
+        '''Sample query points on rays (lib/dmpigo.py:263-290).'''
+        assert near == 0 and far == 1
+        rays_o = rays_o.contiguous()
+        rays_d = rays_d.contiguous()
+        N_samples = int((self.mpi_depth - 1) / stepsize) + 1
+        ray_pts, mask_outbbox = render_utils_cuda.sample_ndc_pts_on_rays(
+            rays_o, rays_d, self.xyz_min, self.xyz_max, N_samples)
+        mask_inbbox = ~mask_outbbox
+        ray_pts = ray_pts.view(-1, 3)
+        ray_pts = ray_pts[mask_inbbox.view(-1)]
+        dev = rays_o.device
+        ray_id = torch.arange(mask_inbbox.shape[0], device=dev).view(-1, 1).expand_as(mask_inbbox)[mask_inbbox]
+        step_id = torch.arange(mask_inbbox.shape[1], device=dev).view(1, -1).expand_as(mask_inbbox)[mask_inbbox]
+        return ray_pts, ray_id, step_id, N_samples, mask_inbbox
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        '''Volume rendering
+        @rays_o:   [N, 3] the starting point of the N shooting rays.
+        @rays_d:   [N, 3] the shooting direction of the N rays.
+        @viewdirs: [N, 3] viewing direction to compute positional embedding for MLP.
+        '''
+        rays_o, rays_d, viewdirs = self._k4_check_rays(rays_o, rays_d, viewdirs)
+        staged = render_kwargs.get('k4_staged', False) or torch.is_grad_enabled() or not self._k4_fusable()
+        if staged:
+            return self._forward_staged(rays_o, rays_d, viewdirs, global_step=global_step, **render_kwargs)
+        return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
+
+    def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
+                       k4_img_w=0, k4_counters=None, **_ignored):
+        assert near == 0 and far == 1                                     # lib/dmpigo.py:275
+        Nr = rays_o.shape[0]
+        dev = rays_o.device
+        rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
+        depth = torch.empty([Nr], dtype=torch.float32, device=dev)
+        ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
+        gd = self._k4_grid(act_shift_grid=self.act_shift.grid)
+        md, _keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
+        N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278
+        interval = float(stepsize * self.voxel_size_ratio)                # lib/dmpigo.py:306
+        N.check(N.lib().k4_march_mpi_fwd(
+            N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
+            N_samples, interval, float(self.fast_color_thres), float(bg),
+            N.f32(rgb), N.f32(depth), N.f32(ainv),
+            None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_mpi_fwd')
+        ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb, 'n_max': N_samples}
+        if render_depth:
+            ret['depth'] = depth
+        return ret
+
+    def _forward_staged(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
+                        global_step=None, rand_bkgd=False, **_ignored):
+        """The reference's op sequence (lib/dmpigo.py:300-427) on the staged gfx950 kernels."""
+        ret_dict = {}
+        Nr = len(rays_o)
+        ray_pts, ray_id, step_id, N_samples, mask_inbbox = self.sample_ray(
+            rays_o=rays_o, rays_d=rays_d, near=near, far=far, stepsize=stepsize)
+        interval = stepsize * self.voxel_size_ratio
+        if self.mask_cache is not None:
+            mask1 = self.mask_cache(ray_pts)
+            ray_pts, ray_id, step_id = ray_pts[mask1], ray_id[mask1], step_id[mask1]
+        density = self.density(ray_pts) + self.act_shift(ray_pts)
+        alpha = self.activate_density(density, interval)
+        if self.fast_color_thres > 0:
+            mask2 = (alpha > self.fast_color_thres)
+            ray_pts, ray_id, step_id, alpha = ray_pts[mask2], ray_id[mask2], step_id[mask2], alpha[mask2]
+        weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
+        if self.fast_color_thres > 0:
+            mask3 = (weights > self.fast_color_thres)
+            ray_pts, ray_id, step_id = ray_pts[mask3], ray_id[mask3], step_id[mask3]
+            alpha, weights = alpha[mask3], weights[mask3]
+        vox_emb = self.k0(ray_pts)
+        if vox_emb.dim() == 1:
+            vox_emb = vox_emb.unsqueeze(-1)
+        pe_spa = ((ray_pts - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
+        if self.rgbnet is None:
+            rgb_raw = torch.sigmoid(vox_emb)
+        else:
+            viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+            viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
+            viewdirs_emb = viewdirs_emb[ray_id]
+            pe_emb = (pe_spa.unsqueeze(-1) * self.posfreq).flatten(-2)
+            pe_emb = torch.cat([pe_spa, pe_emb.sin(), pe_emb.cos()], -1)
+            rgb_raw = torch.sigmoid(self.rgbnet(torch.cat([vox_emb, pe_emb, viewdirs_emb], -1)))
+        rgb_feature = segment_sum(weights.unsqueeze(-1) * rgb_raw, ray_id, Nr)
+        rgb_marched = rgb_feature
+        if rand_bkgd and global_step is not None:
+            rgb_marched = rgb_marched + (alphainv_last.unsqueeze(-1) * torch.rand_like(rgb_marched))
+        else:
+            rgb_marched += (alphainv_last.unsqueeze(-1) * bg)             # aliases rgb_feature (lib/dmpigo.py:397)
+        s = (step_id + 0.5) / N_samples
+        ret_dict.update({
+            'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched,
+            'rgb_feature': rgb_feature, 'raw_alpha': alpha, 'raw_rgb': rgb_raw, 'ray_id': ray_id,
+            'n_max': N_samples, 's': s,
+        })
+        if render_depth:
+            with torch.no_grad():
+                ret_dict['depth'] = segment_sum(weights * s, ray_id, Nr)
+        return ret_dict

@@ -1,0 +1,481 @@
+"""DirectVoxGO with the reference's interface (/root/reference/lib/dvgo.py), MI355X-native inside.
+
+Kept verbatim from the reference contract: constructor kwargs, ``get_kwargs()``
+round trip, ``state_dict`` key names (``density.grid``, ``k0.grid``, ``act_shift``, ``rgbnet.*``,
+``mask_cache.*``, ``viewfreq``), ``forward(rays_o, rays_d, viewdirs, global_step=None,
+**render_kwargs) -> dict`` and the module-level names other reference code imports from here
+(``render_utils_cuda``, ``Raw2Alpha``, ``Alphas2Weights``, ``get_rays*``, ``ndc_rays``).
+
+What is new is everything inside ``forward``:
+  * inference (``torch.no_grad``): ONE fused HIP launch (``k4_march_dvgo_fwd``, csrc/k4_march.hip)
+    returning the keys the render loop consumes (run_sr.py:107): ``rgb_marched`` (is ``rgb_feature``,
+    they alias in the reference too, lib/dvgo.py:425-427), ``depth``, ``alphainv_last``;
+  * ``render_kwargs['k4_staged']=True`` or autograd: the staged path = the reference's op sequence
+    on the gfx950 staged kernels, returning every key of the reference dict (``weights``,
+    ``raw_alpha``, ``raw_rgb``, ``ray_id``).
+There is no CPU path: CPU tensors raise.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _native as N
+from . import grid
+from . import render_utils_cuda
+
+_FUSED_WIDTHS = (32, 64, 128)
+
+
+class _FusedMarcher:
+    """Mixin: device-side descriptors for the fused kernels, cached per parameter version."""
+
+    def _k4_cache(self):
+        if not hasattr(self, '_k4c'):
+            object.__setattr__(self, '_k4c', {})
+        return self._k4c
+
+    def _k4_fusable(self):
+        if self.rgbnet is None:
+            return self.k0_dim == 3
+        lins = [m for m in self.rgbnet.modules() if isinstance(m, nn.Linear)]
+        acts_ok = all(isinstance(m, (nn.Linear, nn.ReLU, nn.Sequential)) for m in self.rgbnet.modules())
+        return (acts_ok and len(lins) in (2, 3) and lins[0].out_features in _FUSED_WIDTHS
+                and lins[-1].out_features == 3 and getattr(self, 'mode_type', 'mlp') not in ('TRANS', 'adain')
+                and not getattr(self, 'rgbnet_full_implicit', False))
+
+    def _k4_k0_channel_last(self):
+        """Load-time repack of k0.grid [1,C,X,Y,Z] -> [X,Y,Z,CP] (CP = C rounded up to 4): the 8 corners of a
+        shaded sample become 4 runs of 2*CP contiguous floats instead of 8*C scattered dwords."""
+        g = self.k0.grid
+        key = ('k0', g.data_ptr(), g._version, str(g.device))
+        c = self._k4_cache()
+        if c.get('k0_key') != key:
+            C = g.shape[1]
+            CP = (C + 3) // 4 * 4
+            nvox = g.shape[2] * g.shape[3] * g.shape[4]
+            out = torch.empty([nvox * CP], dtype=torch.float32, device=g.device)
+            src = g.detach().contiguous()
+            N.check(N.lib().k4_repack_k0(N.f32(src), C, CP, nvox, N.f32(out), N.stream()), 'repack_k0')
+            c['k0_key'], c['k0_cl'], c['k0_cpad'] = key, out, CP
+        return c['k0_cl'], c['k0_cpad']
+
+    def _k4_mlp(self, k0_skip, spatial_pe):
+        md = N.MlpDesc()
+        md.viewbase_pe = int(len(self.viewfreq)) if self.rgbnet is not None else 0
+        md.spatial_pe = int(spatial_pe)
+        md.k0_skip = int(k0_skip)
+        if self.rgbnet is None:
+            md.packed, md.dim0, md.width, md.n_hidden = None, 0, 0, 0
+            return md, None
+        lins = [m for m in self.rgbnet.modules() if isinstance(m, nn.Linear)]
+        key = ('mlp',) + tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in lins)
+        c = self._k4_cache()
+        if c.get('mlp_key') != key:
+            W = lins[0].out_features
+            parts = [lins[0].weight.detach().t().contiguous().reshape(-1), lins[0].bias.detach()]
+            for l in lins[1:-1]:
+                parts += [l.weight.detach().contiguous().reshape(-1), l.bias.detach()]
+            wo = torch.zeros([W, 4], dtype=torch.float32, device=lins[-1].weight.device)
+            wo[:, :3] = lins[-1].weight.detach().t()
+            bo = torch.zeros([4], dtype=torch.float32, device=wo.device)
+            bo[:3] = lins[-1].bias.detach()
+            parts += [wo.reshape(-1), bo]
+            c['mlp_key'], c['mlp_packed'] = key, torch.cat([p.float() for p in parts]).contiguous()
+        md.packed = c['mlp_packed'].data_ptr()
+        md.dim0 = lins[0].in_features
+        md.width = lins[0].out_features
+        md.n_hidden = len(lins) - 2
+        return md, c['mlp_packed']
+
+    def _k4_grid(self, act_shift_grid=None):
+        gd = N.GridDesc()
+        dens = self.density.grid
+        k0cl, cpad = self._k4_k0_channel_last()
+        gd.density = dens.data_ptr()
+        gd.k0 = k0cl.data_ptr()
+        gd.k0_layout = N.K0_CHANNEL_LAST
+        gd.k0_cpad = cpad
+        gd.k0_ch = self.k0.grid.shape[1]
+        gd.dims = (N.C.c_int32 * 3)(*[int(v) for v in dens.shape[2:]])
+        if act_shift_grid is not None:
+            gd.act_shift = act_shift_grid.data_ptr()
+            gd.act_depth = int(act_shift_grid.numel())
+        mc = self.mask_cache
+        gd.mask = mc.mask.data_ptr()
+        gd.mask_dims = (N.C.c_int32 * 3)(*[int(v) for v in mc.mask.shape])
+        c = self._k4_cache()
+        hkey = ('host3', self.xyz_min.data_ptr(), mc.xyz2ijk_scale.data_ptr(), str(dens.device))
+        if c.get('host_key') != hkey:      # tiny D2H copies, once
+            c['host_key'] = hkey
+            c['host'] = (N.vec3(self.xyz_min), N.vec3(self.xyz_max), N.vec3(mc.xyz2ijk_scale), N.vec3(mc.xyz2ijk_shift))
+        gd.xyz_min, gd.xyz_max, gd.xyz2ijk_scale, gd.xyz2ijk_shift = c['host']
+        return gd
+
+    def _k4_host_scalar(self, name, t):
+        """float(t) for a 1-element device buffer without a D2H sync per call (cached per version)."""
+        c = self._k4_cache()
+        key = (t.data_ptr(), t._version)
+        if c.get(name + '_key') != key:
+            c[name + '_key'], c[name] = key, float(t)
+        return c[name]
+
+    @staticmethod
+    def _k4_check_rays(rays_o, rays_d, viewdirs):
+        assert len(rays_o.shape) == 2 and rays_o.shape[-1] == 3, 'Only suuport point queries in [N, 3] format'
+        if not rays_o.is_cuda:
+            raise N.K4Error('rays must be on the GPU: the MI355X-native marcher has no CPU path '
+                            '(the CPU oracle lives in oracle/ and is test infrastructure only)')
+        return rays_o.float().contiguous(), rays_d.float().contiguous(), viewdirs.float().contiguous()
+
+
+'''Model'''
+class DirectVoxGO(torch.nn.Module, _FusedMarcher):
+    def __init__(self, xyz_min, xyz_max,
+                 num_voxels=0, num_voxels_base=0,
+                 alpha_init=None,
+                 mask_cache_path=None, mask_cache_thres=1e-3, mask_cache_world_size=None,
+                 fast_color_thres=0,
+                 density_type='DenseGrid', k0_type='DenseGrid',
+                 density_config={}, k0_config={},
+                 rgbnet_dim=0, rgbnet_direct=False, rgbnet_full_implicit=False,
+                 rgbnet_depth=3, rgbnet_width=128,
+                 viewbase_pe=4,
+                 **kwargs):
+        super(DirectVoxGO, self).__init__()
+        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
+        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        self.fast_color_thres = fast_color_thres
+
+        # base grid resolution / density bias (lib/dvgo.py:41-50)
+        self.num_voxels_base = num_voxels_base
+        self.voxel_size_base = ((self.xyz_max - self.xyz_min).prod() / self.num_voxels_base).pow(1 / 3)
+        self.alpha_init = alpha_init
+        self.register_buffer('act_shift', torch.FloatTensor([np.log(1 / (1 - alpha_init) - 1)]))
+        self._set_grid_resolution(num_voxels)
+
+        self.density_type = density_type
+        self.density_config = density_config
+        self.density = grid.create_grid(
+            density_type, channels=1, world_size=self.world_size,
+            xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.density_config)
+
+        self.rgbnet_kwargs = {
+            'rgbnet_dim': rgbnet_dim, 'rgbnet_direct': rgbnet_direct,
+            'rgbnet_full_implicit': rgbnet_full_implicit,
+            'rgbnet_depth': rgbnet_depth, 'rgbnet_width': rgbnet_width,
+            'viewbase_pe': viewbase_pe,
+        }
+        self.k0_type = k0_type
+        self.k0_config = k0_config
+        self.rgbnet_full_implicit = rgbnet_full_implicit
+        self.dim_rend = 3
+        self.act_type = 'mlp'
+        self.mode_type = 'mlp'
+        if rgbnet_full_implicit:
+            raise NotImplementedError('rgbnet_full_implicit is not used by any BASELINE configuration')
+        if rgbnet_dim <= 0:
+            # colour voxel grid (coarse stage, lib/dvgo.py:74-81)
+            self.k0_dim = 3
+            self.k0 = grid.create_grid(
+                k0_type, channels=self.k0_dim, world_size=self.world_size,
+                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
+            self.rgbnet = None
+            self.rgbnet_direct = True
+        else:
+            # feature voxel grid + shallow MLP (fine stage, lib/dvgo.py:82-124)
+            self.k0_dim = rgbnet_dim
+            self.k0 = grid.create_grid(
+                k0_type, channels=self.k0_dim, world_size=self.world_size,
+                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
+            self.rgbnet_direct = rgbnet_direct
+            self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
+            dim0 = (3 + 3 * viewbase_pe * 2)
+            dim0 += self.k0_dim if rgbnet_direct else self.k0_dim - 3
+            self.dim0 = dim0
+            self.rgbnet = nn.Sequential(
+                nn.Linear(dim0, rgbnet_width), nn.ReLU(inplace=True),
+                *[
+                    nn.Sequential(nn.Linear(rgbnet_width, rgbnet_width), nn.ReLU(inplace=True))
+                    for _ in range(rgbnet_depth - 2)
+                ],
+                nn.Linear(rgbnet_width, 3),
+            )
+            nn.init.constant_(self.rgbnet[-1].bias, 0)
+
+        # occupancy grid (lib/dvgo.py:130-150)
+        self.mask_cache_path = mask_cache_path
+        self.mask_cache_thres = mask_cache_thres
+        if mask_cache_world_size is None:
+            mask_cache_world_size = self.world_size
+        if mask_cache_path is not None and mask_cache_path:
+            mask = coarse_mask_on_grid(mask_cache_path, mask_cache_thres, self.xyz_min, self.xyz_max,
+                                       mask_cache_world_size)
+        else:
+            mask = torch.ones(list(mask_cache_world_size), dtype=torch.bool)
+        self.mask_cache = grid.MaskGrid(path=None, mask=mask, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
+
+    def _set_grid_resolution(self, num_voxels):
+        self.num_voxels = num_voxels
+        self.voxel_size = ((self.xyz_max - self.xyz_min).prod() / num_voxels).pow(1 / 3)
+        self.world_size = ((self.xyz_max - self.xyz_min) / self.voxel_size).long()
+        self.max_world_size = self.world_size.max()
+        self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
+
+    def get_kwargs(self):
+        return {
+            'xyz_min': self.xyz_min.cpu().numpy(),
+            'xyz_max': self.xyz_max.cpu().numpy(),
+            'num_voxels': self.num_voxels,
+            'num_voxels_base': self.num_voxels_base,
+            'alpha_init': self.alpha_init,
+            'voxel_size_ratio': self.voxel_size_ratio,
+            'mask_cache_path': self.mask_cache_path,
+            'mask_cache_thres': self.mask_cache_thres,
+            'mask_cache_world_size': list(self.mask_cache.mask.shape),
+            'fast_color_thres': self.fast_color_thres,
+            'density_type': self.density_type,
+            'k0_type': self.k0_type,
+            'density_config': self.density_config,
+            'k0_config': self.k0_config,
+            'mode_type': self.mode_type,
+            'act_type': self.act_type,
+            'dim_rend': self.dim_rend,
+            **self.rgbnet_kwargs,
+        }
+
+    def activate_density(self, density, interval=None):
+        interval = interval if interval is not None else self.voxel_size_ratio
+        shape = density.shape
+        return Raw2Alpha.apply(density.flatten(), self.act_shift, interval).reshape(shape)
+
+    def sample_ray(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
+        '''Sample query points on rays (lib/dvgo.py:295-325): points sorted near to far.'''
+        far = 1e9  # the given far can be too small while rays stop when hitting scene bbox
+        rays_o = rays_o.contiguous()
+        rays_d = rays_d.contiguous()
+        stepdist = stepsize * self.voxel_size
+        N_samples = int((self.max_world_size - 1) / stepsize) + 1
+        ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max = render_utils_cuda.sample_pts_on_rays(
+            rays_o, rays_d, self.xyz_min, self.xyz_max, near, far, stepdist)
+        mask_inbbox = ~mask_outbbox
+        ray_pts = ray_pts[mask_inbbox]
+        ray_id = ray_id[mask_inbbox]
+        step_id = step_id[mask_inbbox]
+        return ray_pts, ray_id, step_id, None, N_samples
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        '''Volume rendering
+        @rays_o:   [N, 3] the starting point of the N shooting rays.
+        @rays_d:   [N, 3] the shooting direction of the N rays.
+        @viewdirs: [N, 3] viewing direction to compute positional embedding for MLP.
+        '''
+        rays_o, rays_d, viewdirs = self._k4_check_rays(rays_o, rays_d, viewdirs)
+        staged = render_kwargs.get('k4_staged', False) or torch.is_grad_enabled() or not self._k4_fusable()
+        if staged:
+            return self._forward_staged(rays_o, rays_d, viewdirs, **render_kwargs)
+        return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
+
+    def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
+                       k4_img_w=0, k4_counters=None, **_ignored):
+        Nr = rays_o.shape[0]
+        dev = rays_o.device
+        rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
+        depth = torch.empty([Nr], dtype=torch.float32, device=dev)
+        ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
+        gd = self._k4_grid()
+        md, _keep = self._k4_mlp(k0_skip=0 if (self.rgbnet is None or self.rgbnet_direct) else 3, spatial_pe=0)
+        stepdist = float(stepsize * self.voxel_size)                       # lib/dvgo.py:310
+        interval = float(stepsize * self.voxel_size_ratio)                # lib/dvgo.py:341
+        depth_n = int((self.max_world_size - 1) / stepsize) + 1           # lib/dvgo.py:311
+        N.check(N.lib().k4_march_dvgo_fwd(
+            N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
+            float(near), 1e9, stepdist, depth_n, self._k4_host_scalar('act_shift', self.act_shift), interval,
+            float(self.fast_color_thres), float(bg), N.f32(rgb), N.f32(depth), N.f32(ainv),
+            None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_dvgo_fwd')
+        ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb}
+        if render_depth:
+            ret['depth'] = depth
+        return ret
+
+    def _forward_staged(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False, **_ignored):
+        """The reference's op sequence (lib/dvgo.py:338-446) on the staged gfx950 kernels."""
+        ret_dict = {}
+        Nr = len(rays_o)
+        ray_pts, ray_id, step_id, _, N_samples = self.sample_ray(
+            rays_o=rays_o, rays_d=rays_d, near=near, far=far, stepsize=stepsize)
+        interval = stepsize * self.voxel_size_ratio
+        if self.mask_cache is not None:
+            mask1 = self.mask_cache(ray_pts)
+            ray_pts, ray_id, step_id = ray_pts[mask1], ray_id[mask1], step_id[mask1]
+        density = self.density(ray_pts)
+        alpha = self.activate_density(density, interval)
+        if self.fast_color_thres > 0:
+            mask2 = (alpha > self.fast_color_thres)
+            ray_pts, ray_id, step_id = ray_pts[mask2], ray_id[mask2], step_id[mask2]
+            alpha = alpha[mask2]
+        weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
+        if self.fast_color_thres > 0:
+            mask3 = (weights > self.fast_color_thres)
+            weights, alpha = weights[mask3], alpha[mask3]
+            ray_pts, ray_id, step_id = ray_pts[mask3], ray_id[mask3], step_id[mask3]
+        k0 = self.k0(ray_pts)
+        if k0.dim() == 1:
+            k0 = k0.unsqueeze(-1)
+        if self.rgbnet is None:
+            rgb_raw = torch.sigmoid(k0)
+        else:
+            if self.rgbnet_direct:
+                k0_view = k0
+            else:
+                k0_view = k0[:, 3:]
+                k0_diffuse = k0[:, :3]
+            viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+            viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
+            viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
+            rgb_logit = self.rgbnet(torch.cat([k0_view, viewdirs_emb], -1))
+            rgb_raw = torch.sigmoid(rgb_logit if self.rgbnet_direct else rgb_logit + k0_diffuse)
+        rgb_feature = segment_sum(weights.unsqueeze(-1) * rgb_raw, ray_id, Nr)
+        rgb_marched = rgb_feature
+        rgb_marched += (alphainv_last.unsqueeze(-1) * bg)                 # aliases rgb_feature (lib/dvgo.py:425-427)
+        s = (step_id + 0.5) / N_samples
+        ret_dict.update({
+            'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched,
+            'rgb_feature': rgb_feature, 'raw_alpha': alpha, 'raw_rgb': rgb_raw, 'ray_id': ray_id,
+        })
+        if render_depth:
+            with torch.no_grad():
+                ret_dict['depth'] = segment_sum(weights * s, ray_id, Nr)
+        return ret_dict
+
+
+def coarse_mask_on_grid(path, thres, xyz_min, xyz_max, world_size):
+    """Evaluate the coarse-stage occupancy (MaskGrid(path=...)) at the nodes of a finer grid
+    (lib/dvgo.py:136-145).  The lookup itself runs on the GPU kernel."""
+    if not torch.cuda.is_available():
+        raise N.K4Error('mask_cache_path needs the GPU maskcache_lookup kernel (no CPU path)')
+    mc = grid.MaskGrid(path=path, mask_cache_thres=thres).cuda()
+    xyz = torch.stack(torch.meshgrid(
+        torch.linspace(float(xyz_min[0]), float(xyz_max[0]), int(world_size[0])),
+        torch.linspace(float(xyz_min[1]), float(xyz_max[1]), int(world_size[1])),
+        torch.linspace(float(xyz_min[2]), float(xyz_max[2]), int(world_size[2])), indexing='ij'), -1)
+    return mc(xyz.cuda()).cpu()
+
+
+def segment_sum(src, index, n):
+    """torch_scatter.segment_coo(src, index, out=zeros([n,...]), reduce='sum') for a sorted index
+    (lib/dvgo.py:415-419).  Inference: k4_segment_sum; under autograd: differentiable index_add."""
+    if torch.is_grad_enabled() and src.requires_grad:
+        return torch.zeros([n] + list(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, src)
+    C_ = 1 if src.dim() == 1 else src.shape[1]
+    out = torch.empty([n] + list(src.shape[1:]), dtype=torch.float32, device=src.device)
+    srcc = src.detach().float().contiguous()
+    N.check(N.lib().k4_segment_sum(N.f32(srcc), N.ptr(index.contiguous()), srcc.shape[0], C_, n, N.f32(out), N.stream()),
+            'segment_sum')
+    return out
+
+
+''' Misc
+'''
+class Raw2Alpha(torch.autograd.Function):
+    """alpha = 1 - (1 + exp(density + shift)) ^ (-interval)   (lib/dvgo.py:453-477)"""
+    @staticmethod
+    def forward(ctx, density, shift, interval):
+        exp, alpha = render_utils_cuda.raw2alpha(density.contiguous(), float(shift), float(interval))
+        if density.requires_grad:
+            ctx.save_for_backward(exp)
+            ctx.interval = float(interval)
+        return alpha
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        exp = ctx.saved_tensors[0]
+        return render_utils_cuda.raw2alpha_backward(exp, grad_back.contiguous(), ctx.interval), None, None
+
+
+class Raw2Alpha_nonuni(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density, shift, interval):
+        exp, alpha = render_utils_cuda.raw2alpha_nonuni(density.contiguous(), float(shift), interval.contiguous())
+        if density.requires_grad:
+            ctx.save_for_backward(exp, interval)
+        return alpha
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        exp, interval = ctx.saved_tensors
+        return render_utils_cuda.raw2alpha_nonuni_backward(exp, grad_back.contiguous(), interval), None, None
+
+
+class Alphas2Weights(torch.autograd.Function):
+    """(lib/dvgo.py:495-511)"""
+    @staticmethod
+    def forward(ctx, alpha, ray_id, N_):
+        weights, T, alphainv_last, i_start, i_end = render_utils_cuda.alpha2weight(alpha.contiguous(), ray_id.contiguous(), N_)
+        if alpha.requires_grad:
+            ctx.save_for_backward(alpha, weights, T, alphainv_last, i_start, i_end)
+            ctx.n_rays = N_
+        return weights, alphainv_last
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_weights, grad_last):
+        alpha, weights, T, alphainv_last, i_start, i_end = ctx.saved_tensors
+        grad = render_utils_cuda.alpha2weight_backward(
+            alpha, weights, T, alphainv_last, i_start, i_end, ctx.n_rays, grad_weights, grad_last)
+        return grad, None, None
+
+
+''' Ray and batch
+'''
+def get_rays(H, W, K, c2w, inverse_y, flip_x, flip_y, mode='center'):
+    """Pixel -> camera ray, pixel centres at +0.5 (lib/dvgo.py:516-544); runs on c2w's device."""
+    dev = c2w.device
+    K = torch.as_tensor(np.asarray(K), dtype=torch.float32, device=dev) if not torch.is_tensor(K) else K.to(dev).float()
+    i = torch.arange(W, dtype=torch.float32, device=dev)[None, :].expand(H, W)
+    j = torch.arange(H, dtype=torch.float32, device=dev)[:, None].expand(H, W)
+    if mode == 'lefttop':
+        pass
+    elif mode == 'center':
+        i, j = i + 0.5, j + 0.5
+    elif mode == 'random':
+        i = i + torch.rand_like(i)
+        j = j + torch.rand_like(j)
+    else:
+        raise NotImplementedError
+    if flip_x:
+        i = i.flip((1,))
+    if flip_y:
+        j = j.flip((0,))
+    if inverse_y:
+        dirs = torch.stack([(i - K[0][2]) / K[0][0], (j - K[1][2]) / K[1][1], torch.ones_like(i)], -1)
+    else:
+        dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """lib/dvgo.py:557-574"""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='center'):
+    """viewdirs normalised BEFORE the NDC warp (lib/dvgo.py:577-582)."""
+    rays_o, rays_d = get_rays(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y, mode=mode)
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, float(K[0][0]), 1., rays_o, rays_d)
+    return rays_o, rays_d, viewdirs

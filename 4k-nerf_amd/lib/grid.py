@@ -1,0 +1,107 @@
+"""Voxel grids with the reference's interface (/root/reference/lib/grid.py).
+
+``DenseGrid`` (lib/grid.py:108-151) and ``MaskGrid`` (lib/grid.py:274-307) keep constructor
+arguments, parameter / buffer names (``grid``, ``xyz_min``, ``xyz_max``, ``mask``, ``xyz2ijk_scale``,
+``xyz2ijk_shift``) and forward semantics; the lookups run on the gfx950 kernels of lib4k_hip.so.
+``TensoRFGrid`` / ``VQGrid`` are not selected by any BASELINE configuration
+(configs/default.py:85-86) and are out of the hot-path scope.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _native as N
+from . import render_utils_cuda
+
+
+def create_grid(type, **kwargs):
+    if type == 'DenseGrid':
+        return DenseGrid(**kwargs)
+    raise NotImplementedError(f'{type}: only DenseGrid is on the 4K-NeRF hot path (SURVEY.md 2.1 #6)')
+
+
+class DenseGrid(nn.Module):
+    def __init__(self, channels, world_size, xyz_min, xyz_max, **kwargs):
+        super(DenseGrid, self).__init__()
+        self.channels = channels
+        self.world_size = world_size
+        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
+        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        self.grid = nn.Parameter(torch.zeros([1, channels, *world_size]))
+
+    def forward(self, xyz):
+        """Trilinear lookup == F.grid_sample(bilinear, align_corners=True, zero pad) of lib/grid.py:117-128.
+        Inference: HIP kernel (k4_grid_sample_3d).  When autograd needs d/dgrid the PyTorch-ROCm op is
+        used (native backward is a 'next' row)."""
+        shape = xyz.shape[:-1]
+        if torch.is_grad_enabled() and self.grid.requires_grad:
+            ind = ((xyz.reshape(1, 1, 1, -1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
+            out = F.grid_sample(self.grid, ind, mode='bilinear', align_corners=True)
+            out = out.reshape(self.channels, -1).T.reshape(*shape, self.channels)
+        else:
+            pts = xyz.reshape(-1, 3).contiguous()
+            out = torch.empty([pts.shape[0], self.channels], dtype=torch.float32, device=pts.device)
+            g = self.grid.detach()
+            N.check(N.lib().k4_grid_sample_3d(N.f32(g), self.channels, g.shape[2], g.shape[3], g.shape[4],
+                                              N.f32(pts), N.f32(self.xyz_min), N.f32(self.xyz_max),
+                                              pts.shape[0], N.f32(out), N.stream()), 'grid_sample_3d')
+            out = out.reshape(*shape, self.channels)
+        if self.channels == 1:
+            out = out.squeeze(-1)
+        return out
+
+    def scale_volume_grid(self, new_world_size):
+        if self.channels == 0:
+            self.grid = nn.Parameter(torch.zeros([1, self.channels, *new_world_size]))
+        else:
+            self.grid = nn.Parameter(
+                F.interpolate(self.grid.data, size=tuple(new_world_size), mode='trilinear', align_corners=True))
+
+    def total_variation_add_grad(self, wx, wy, wz, dense_mode):
+        raise NotImplementedError('total_variation_add_grad: training-only kernel, "next" row of SURVEY.md 8f')
+
+    def get_dense_grid(self):
+        return self.grid
+
+    @torch.no_grad()
+    def __isub__(self, val):
+        self.grid.data -= val
+        return self
+
+    def extra_repr(self):
+        ws = self.world_size.tolist() if torch.is_tensor(self.world_size) else list(self.world_size)
+        return f'channels={self.channels}, world_size={ws}'
+
+
+class MaskGrid(nn.Module):
+    def __init__(self, path=None, mask_cache_thres=None, mask=None, xyz_min=None, xyz_max=None):
+        super(MaskGrid, self).__init__()
+        if path is not None:
+            # occupancy from a coarse-stage checkpoint (lib/grid.py:277-284)
+            st = torch.load(path, map_location='cpu')
+            self.mask_cache_thres = mask_cache_thres
+            density = F.max_pool3d(st['model_state_dict']['density.grid'], kernel_size=3, padding=1, stride=1)
+            alpha = 1 - torch.exp(-F.softplus(density + st['model_state_dict']['act_shift'])
+                                  * st['model_kwargs']['voxel_size_ratio'])
+            mask = (alpha >= self.mask_cache_thres).squeeze(0).squeeze(0)
+            xyz_min = torch.Tensor(st['model_kwargs']['xyz_min'])
+            xyz_max = torch.Tensor(st['model_kwargs']['xyz_max'])
+        else:
+            mask = mask.bool()
+            xyz_min = torch.Tensor(xyz_min)
+            xyz_max = torch.Tensor(xyz_max)
+        self.register_buffer('mask', mask)
+        xyz_len = xyz_max - xyz_min
+        self.register_buffer('xyz2ijk_scale', (torch.Tensor(list(mask.shape)) - 1) / xyz_len)
+        self.register_buffer('xyz2ijk_shift', -xyz_min * self.xyz2ijk_scale)
+
+    @torch.no_grad()
+    def forward(self, xyz):
+        """Skip known free space: nearest-voxel lookup, C round() (lib/grid.py:295-304)."""
+        shape = xyz.shape[:-1]
+        xyz = xyz.reshape(-1, 3).contiguous()
+        mask = render_utils_cuda.maskcache_lookup(self.mask, xyz, self.xyz2ijk_scale, self.xyz2ijk_shift)
+        return mask.reshape(shape)
+
+    def extra_repr(self):
+        return f'mask.shape={list(self.mask.shape)}'

@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Benchmark of the 4K-NeRF rendering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): Mrays/s on LLFF-fern ``render_test``.  A *step* is one full 1008x756 frame
+(762,048 rays x 256 samples) of BASELINE configs[1] -- "LLFF fern_lg_pretrain render_test at 1008x756,
+1xMI355X, HIP ray-marcher only (no SR)" -- marched by the fused HIP kernel on the seeded synthetic
+LLFF scene (no datasets / checkpoints exist offline), camera poses cycling through the 20-pose spiral.
+Rays are resident in HBM before the timed region (the reference's own timer starts after
+``get_rays_of_a_view`` too, run_sr.py:104-111).
+
+N>1 (strong scaling, BASELINE configs[3]): every frame is split into N horizontal bands of pixel rows,
+each rank marches its band (full replicas of the grids), one RCCL ``all_gather_into_tensor`` of the final
+per-pixel values (rgb, depth, alphainv: 5 floats/ray) per frame -- final pixels only.
+
+Extra objects on the JSON line (rank 0):
+  roofline     -- dominant kernel (fused marcher), HBM bound: algorithmic bytes per launch (device
+                  counters, SURVEY.md 8d formula) / mean kernel time from HIP events on the launch stream.
+  cpu_baseline -- the CPU oracle (oracle/marcher.py, kind "port") timed on this host's cores on a bounded
+                  strided subset of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-stride', type=int, default=4, help='CPU baseline marches every k-th row and column')
+    ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import nerf4k_amd  # noqa: F401
+    from nerf4k_amd import scene, _native
+    from nerf4k_amd.lib import utils, dvgo
+
+    _native.lib()
+    t0 = time.time()
+    if args.small:
+        ck = scene.make_llff_checkpoint(num_voxels=96 * 96 * 64, mpi_depth=64)
+    else:
+        ck = scene.make_llff_checkpoint()
+    model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
+    rk = ck['render_kwargs']
+    H, W = scene.LLFF_HW
+    K = scene.LLFF_K
+    poses = scene.llff_spiral_poses()
+    if rank == 0:
+        print(f'[bench] scene ready in {time.time() - t0:.1f}s: world_size={model.world_size.tolist()} '
+              f'k0_ch={model.k0_dim} rays/frame={H * W}', file=sys.stderr)
+
+    # band of pixel rows owned by this rank (all bands are multiples of 8 rows -> whole 8x8 tiles)
+    rows_per = ((H + world - 1) // world + 7) // 8 * 8
+    r0, r1 = min(rank * rows_per, H), min((rank + 1) * rows_per, H)
+    rays = []
+    with torch.no_grad():
+        for p in poses:
+            ro, rd, vd = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False)
+            rays.append(tuple(x[r0:r1].reshape(-1, 3).contiguous() for x in (ro, rd, vd)))
+    n_band = (r1 - r0) * W
+    gather_in = torch.empty([rows_per * W, 5], dtype=torch.float32, device=dev)
+    gather_out = torch.empty([world * rows_per * W, 5], dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i, counters=None):
+        ro, rd, vd = rays[i % len(rays)]
+        out = model(ro, rd, vd, k4_img_w=W, k4_counters=counters, **rk)
+        if world > 1:
+            gather_in[:n_band, 0:3] = out['rgb_marched']
+            gather_in[:n_band, 3] = out['depth']
+            gather_in[:n_band, 4] = out['alphainv_last']
+            dist.all_gather_into_tensor(gather_out, gather_in)
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        sync()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            ev[i][0].record()
+            ro, rd, vd = rays[i % len(rays)]
+            out = model(ro, rd, vd, k4_img_w=W, **rk)
+            ev[i][1].record()
+            if world > 1:
+                gather_in[:n_band, 0:3] = out['rgb_marched']
+                gather_in[:n_band, 3] = out['depth']
+                gather_in[:n_band, 4] = out['alphainv_last']
+                dist.all_gather_into_tensor(gather_out, gather_in)
+        sync()
+        elapsed = time.perf_counter() - t_start
+        kern_ms = [a.elapsed_time(b) for a, b in ev]
+
+        # algorithmic bytes per launch from device counters (untimed pass over the same frames)
+        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+        for i in range(min(args.steps, len(rays))):
+            step(i, counters=cnt)
+        torch.cuda.synchronize()
+        nf = min(args.steps, len(rays))
+        n_inb, n_mask, n_alpha, n_shade = [c / nf for c in cnt.cpu().tolist()]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        rays_per_step = H * W
+        value = rays_per_step * args.steps / elapsed / 1e6
+        k_ms = float(np.mean(kern_ms))
+        b_alg = n_band * 56 + n_inb * 1 + n_mask * 32 + n_shade * 8 * model.k0_dim * 4
+        achieved = b_alg / (k_ms * 1e-3) / 1e9
+        res = {
+            'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
+            'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: LLFF fern_lg_pretrain render_test 1008x756, DirectMPIGO '
+                                   '417x353x256 grid, 256 samples/ray, rgbnet 15->64->64->3, marcher only (no SR)'
+                                   + (' [REDUCED --small scene]' if args.small else ''),
+                       'rays_per_frame': rays_per_step, 'frames': args.steps,
+                       'parallelism': f'row-bands x{world} + all_gather of final pixels' if world > 1 else 'single GPU'},
+            'frames_per_s_lr': round(args.steps / elapsed, 2),
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'kernel': 'k4_march_kernel<MPI,64,1>', 'kernel_ms': round(k_ms, 4),
+                         'algorithmic_bytes_per_launch': int(b_alg),
+                         'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
+                                                'shaded': int(n_shade)}},
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ck, pose, stride):
+    """The CPU oracle ("port": oracle/marcher.py on torch CPU kernels) on a bounded sample of the same frame."""
+    from oracle import marcher
+    from nerf4k_amd import scene
+    H, W = scene.LLFF_HW
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
+    sel = (slice(None, None, stride), slice(None, None, stride))
+    ro, rd, vd = [x[sel].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
+    marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro[:8192], rd[:8192], vd[:8192],
+                    **ck['render_kwargs'])                                  # warm-up
+    t = time.perf_counter()
+    marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
+    dt = time.perf_counter() - t
+    return {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{len(ro)} rays = every {stride}th row and column of one 1008x756 frame, 8192-ray chunks '
+                      f'as run_sr.py:121-124, {dt:.1f}s of CPU work, torch {torch.__version__} CPU kernels'}
+
+
+if __name__ == '__main__':
+    main()

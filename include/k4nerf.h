@@ -1,0 +1,171 @@
+/*
+ * k4nerf.h -- C ABI of lib4k_hip.so: the MI355X (gfx950) replacement for the native layer of
+ * the 4K-NeRF rendering hot path.
+ *
+ * What it replaces (reference, read-only at /root/reference):
+ *   - the pybind11/libtorch extension `render_utils_cuda`, 13 functions taking torch::Tensor
+ *     (lib/cuda/render_utils.cpp:170-184; kernels lib/cuda/render_utils_kernel.cu), JIT-built at
+ *     import by lib/dvgo.py:14-19 and lib/grid.py:12-17;
+ *   - the PyTorch library ops the reference strings between them on the hot path:
+ *     F.grid_sample (lib/grid.py:124), torch_scatter.segment_coo (lib/dmpigo.py:382-386,
+ *     lib/dvgo.py:415-419), the rgbnet nn.Sequential (lib/dmpigo.py:112-120) and the conv2d /
+ *     leaky_relu / interpolate / cat chain of SFTNet (lib/sr_esrnet.py:112-182,446-465).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + explicit sizes, no torch types; the caller allocates every
+ *     output (torch.empty on the host side) and owns all memory; the library keeps no state.
+ *   - every entry point returns an int: 0 = success, otherwise a hipError_t value (launch errors are
+ *     checked with hipGetLastError, which the reference never does -- render_utils_kernel.cu:93 etc.)
+ *     or K4_ERR_* below for argument errors.
+ *   - the last argument is the HIP stream to launch on (`hipStream_t` passed as void*); the
+ *     reference launches on the legacy default stream (render_utils_kernel.cu:93,230,283...).
+ *   - all floating point is fp32; index tensors are int64 as in the reference.
+ *   - thread-safe / re-entrant: no globals.
+ */
+#ifndef K4NERF_H
+#define K4NERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define K4_OK               0
+#define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
+#define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
+
+#define K4_ABI_VERSION      1
+int k4_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene description shared by the fused marchers.
+ * ------------------------------------------------------------------------------------------- */
+#define K4_K0_CHANNEL_MAJOR 0   /* k0 = [C][X][Y][Z]   (checkpoint layout, `k0.grid` [1,C,X,Y,Z]) */
+#define K4_K0_CHANNEL_LAST  1   /* k0 = [X][Y][Z][CP]  (load-time repack, CP = C rounded up to 4)  */
+
+typedef struct k4_grid_desc {
+    const float*   density;          /* [X][Y][Z] fp32, Z fastest (`density.grid` [1,1,X,Y,Z], lib/grid.py:115) */
+    const float*   k0;               /* feature / colour grid, see k0_layout                              */
+    const float*   act_shift;        /* MPI only: [act_depth] per-plane bias (`act_shift.grid`, lib/dmpigo.py:48-58); NULL for DVGO */
+    const uint8_t* mask;             /* [MX][MY][MZ] bool bytes (`mask_cache.mask`, lib/grid.py:290)    */
+    int32_t dims[3];                 /* X, Y, Z of density / k0                                          */
+    int32_t k0_ch;                   /* C                                                                */
+    int32_t k0_cpad;                 /* CP (channel-last only; multiple of 4)                            */
+    int32_t k0_layout;               /* K4_K0_*                                                          */
+    int32_t act_depth;               /* MPI: mpi_depth                                                   */
+    int32_t mask_dims[3];
+    float   xyz_min[3], xyz_max[3];
+    float   xyz2ijk_scale[3], xyz2ijk_shift[3];   /* lib/grid.py:291-293 */
+} k4_grid_desc;
+
+/* Colour MLP `Sequential(Linear, ReLU, [Sequential(Linear, ReLU)] x n_hidden, Linear)`
+ * (lib/dmpigo.py:112-120, lib/dvgo.py:116-124), repacked by k4_pack_mlp_size/the host into ONE
+ * contiguous fp32 buffer:
+ *     W1^T [dim0][width] | b1 [width] | (W2 [width][width] row-major [out][in] | b2 [width]) x n_hidden
+ *     | Wout^T [width][4] (3 outputs + 1 zero pad) | bout [4]
+ * width == 0 means "no rgbnet": rgb = sigmoid(k0) with k0_ch == 3 (lib/dvgo.py:377-379). */
+typedef struct k4_mlp_desc {
+    const float* packed;
+    int32_t dim0;                    /* input width, must equal the feature count implied below          */
+    int32_t width;                   /* 0 | 32 | 64 | 128                                                */
+    int32_t n_hidden;                /* rgbnet_depth - 2: 0 or 1 in the fused kernel                     */
+    int32_t viewbase_pe;             /* #frequencies 2^0..2^(n-1) on viewdirs                            */
+    int32_t spatial_pe;              /* MPI only: #frequencies on the normalised position                */
+    int32_t k0_skip;                 /* DVGO rgbnet_direct=False: 3 (first 3 k0 channels are added to the logits, lib/dvgo.py:385-386,412), else 0 */
+} k4_mlp_desc;
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused marchers: one launch replaces everything inside DirectMPIGO.forward (lib/dmpigo.py:292-427)
+ * / DirectVoxGO.forward (lib/dvgo.py:327-448) for the four keys the render loop consumes
+ * (run_sr.py:107): rgb_marched (== rgb_feature, they alias in eval), depth, alphainv_last.
+ *
+ *   rays_o, rays_d, viewdirs : [n_rays][3]
+ *   img_w   : 0, or the image width when the n_rays rays are ONE full image in row-major pixel
+ *             order (n_rays = H*img_w); only changes the ray->wavefront tiling (8x8 pixel tiles,
+ *             XCD-banded), never the results.
+ *   out_rgb [n_rays][3], out_depth [n_rays], out_alphainv [n_rays]
+ *   out_counters : NULL or uint64[4] = {in-bbox samples, mask-pass samples, alpha-pass samples,
+ *                  shaded samples}, ACCUMULATED (caller zeroes) -- the counts SURVEY 8(d)'s
+ *                  algorithmic-bytes formula needs.
+ * ------------------------------------------------------------------------------------------- */
+int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,
+                     int64_t n_rays, int32_t img_w,
+                     const k4_grid_desc* grid, const k4_mlp_desc* mlp,
+                     int32_t n_samples,      /* int((mpi_depth-1)/stepsize)+1, lib/dmpigo.py:278   */
+                     float interval,         /* stepsize * voxel_size_ratio, lib/dmpigo.py:306     */
+                     float fast_color_thres, float bg,
+                     float* out_rgb, float* out_depth, float* out_alphainv,
+                     uint64_t* out_counters, void* stream);
+
+int k4_march_dvgo_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,
+                      int64_t n_rays, int32_t img_w,
+                      const k4_grid_desc* grid, const k4_mlp_desc* mlp,
+                      float near, float far,   /* the reference overrides far with 1e9, lib/dvgo.py:307: pass what the kernel should use */
+                      float stepdist,          /* stepsize * voxel_size, lib/dvgo.py:310             */
+                      int32_t depth_n_samples, /* int((max_world_size-1)/stepsize)+1, lib/dvgo.py:311 */
+                      float act_shift,         /* scalar buffer, lib/dvgo.py:46                      */
+                      float interval,          /* stepsize * voxel_size_ratio, lib/dvgo.py:341       */
+                      float fast_color_thres, float bg,
+                      float* out_rgb, float* out_depth, float* out_alphainv,
+                      uint64_t* out_counters, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Staged ops: one per reference native function, for callers that need the per-sample tensors
+ * (training-compatible forward, the `render_utils_cuda` shim).  Same math as the fused kernels.
+ * ------------------------------------------------------------------------------------------- */
+/* sample_ndc_pts_on_rays (render_utils.cpp:87-98): pts [n_rays][n_samples][3], mask_outbbox [n_rays][n_samples] */
+int k4_sample_ndc_pts_on_rays(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
+                              int64_t n_rays, int32_t n_samples, float* out_pts, uint8_t* out_mask_outbbox, void* stream);
+/* infer_t_minmax (render_utils.cpp:50-58) */
+int k4_infer_t_minmax(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
+                      float near, float far, int64_t n_rays, float* out_t_min, float* out_t_max, void* stream);
+/* infer_n_samples (render_utils.cpp:60-65) */
+int k4_infer_n_samples(const float* rays_d, const float* t_min, const float* t_max, float stepdist,
+                       int64_t n_rays, int64_t* out_n_samples, void* stream);
+/* infer_ray_start_dir (render_utils.cpp:67-72) */
+int k4_infer_ray_start_dir(const float* rays_o, const float* rays_d, const float* t_min, int64_t n_rays,
+                           float* out_start, float* out_dir, void* stream);
+/* sample_pts_on_rays (render_utils.cpp:74-85) in two phases because M = sum(N_steps) is data dependent
+ * (the reference syncs with .item(), render_utils_kernel.cu:212):
+ *   count: t_min, t_max, N_steps per ray;  the host takes cumsum(N_steps) and M;
+ *   fill : ray_id/step_id/pts/mask for all M points from the inclusive cumsum. */
+int k4_sample_pts_on_rays_count(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
+                                float near, float far, float stepdist, int64_t n_rays,
+                                int64_t* out_n_steps, float* out_t_min, float* out_t_max, void* stream);
+int k4_sample_pts_on_rays_fill(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
+                               const float* t_min, const int64_t* n_steps_cumsum, float stepdist,
+                               int64_t n_rays, int64_t total_len,
+                               float* out_pts, uint8_t* out_mask_outbbox, int64_t* out_ray_id, int64_t* out_step_id,
+                               void* stream);
+/* maskcache_lookup (render_utils.cpp:109-118) */
+int k4_maskcache_lookup(const uint8_t* world, const float* xyz, const float* xyz2ijk_scale, const float* xyz2ijk_shift,
+                        int32_t sz_i, int32_t sz_j, int32_t sz_k, int64_t n_pts, uint8_t* out, void* stream);
+/* raw2alpha / raw2alpha_backward (render_utils.cpp:120-135); interval_pp != NULL -> the _nonuni variants (:125-140) */
+int k4_raw2alpha(const float* density, float shift, float interval, const float* interval_pp, int64_t n_pts,
+                 float* out_exp, float* out_alpha, void* stream);
+int k4_raw2alpha_backward(const float* exp_d, const float* grad_back, float interval, const float* interval_pp,
+                          int64_t n_pts, float* out_grad, void* stream);
+/* alpha2weight (render_utils.cpp:142-149): weight/T are fully written (0 / 1 past the early stop) */
+int k4_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int64_t n_rays,
+                    float* out_weight, float* out_T, float* out_alphainv_last,
+                    int64_t* out_i_start, int64_t* out_i_end, void* stream);
+/* alpha2weight_backward (render_utils.cpp:151-167) */
+int k4_alpha2weight_backward(const float* alpha, const float* weight, const float* T, const float* alphainv_last,
+                             const int64_t* i_start, const int64_t* i_end, int64_t n_rays, int64_t n_pts,
+                             const float* grad_weights, const float* grad_last, float* out_grad, void* stream);
+/* DenseGrid.forward = F.grid_sample(bilinear, align_corners=True, zero padding) on [C][X][Y][Z] (lib/grid.py:117-128):
+ * out [n_pts][C] */
+int k4_grid_sample_3d(const float* grid, int32_t channels, int32_t X, int32_t Y, int32_t Z,
+                      const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
+                      float* out, void* stream);
+/* segment_coo(src, index, out=zeros, reduce='sum') for a SORTED index (lib/dmpigo.py:382-386): out [n_seg][C] */
+int k4_segment_sum(const float* src, const int64_t* index, int64_t n_pts, int32_t channels, int64_t n_seg,
+                   float* out, void* stream);
+/* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
+int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* K4NERF_H */

@@ -1,0 +1,249 @@
+"""GPU parity of the HIP marcher (fused + staged) against the CPU oracle and the reference-made goldens.
+
+Tolerances (fp32; stated here as the contract):
+  * PSNR(ours || oracle) >= 80 dB on rgb, depth and alphainv_last;
+  * >= 99.9 % of rays within 2e-5 abs; every ray within 2e-3 (a sample whose alpha or weight sits within
+    float rounding of fast_color_thres may flip its mask decision: exp/pow/sigmoid differ by an ulp between
+    libm (oracle) and ocml (GPU); one flipped sample moves a ray by <= thres-sized weights);
+  * mask-decision agreement: device counters (in-bbox / mask / alpha / shaded samples) within 1e-4 relative
+    of the oracle's counts.
+"""
+import numpy as np
+import pytest
+import torch
+
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd import scene, render
+from nerf4k_amd.lib import utils, render_utils_cuda as ruc, grid as kgrid
+from oracle import marcher, native_cpu as nat
+from helpers import load_march_golden, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """render_viewpoints runs under torch.no_grad (run_sr.py:74); with grad enabled the modules take the staged path."""
+    with torch.no_grad():
+        yield
+
+GOLD = ['march_mpi_base', 'march_mpi_pe', 'march_mpi_half', 'march_dvgo_base', 'march_dvgo_nodirect',
+        'march_dvgo_coarse']
+
+
+def _cmp(got, want, name, frac_tol=2e-5, max_tol=2e-3, min_psnr=80.0):
+    got, want = got.detach().cpu().float(), want.float()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    d = (got - want).abs()
+    if d.dim() > 1:
+        d = d.amax(-1)
+    frac = float((d <= frac_tol).float().mean())
+    p = psnr(got, want)
+    assert p >= min_psnr, (name, 'psnr', p)
+    assert frac >= 0.999, (name, 'fraction within tol', frac, float(d.max()))
+    assert float(d.max()) <= max_tol, (name, 'max', float(d.max()))
+    return p
+
+
+def _model(ck):
+    return utils.model_from_checkpoint_dict(ck).cuda().eval()
+
+
+@pytest.mark.parametrize('name', GOLD)
+def test_golden_fused_and_staged(name):
+    """Goldens come from the reference's own Python (oracle/gen_golden.py)."""
+    g = load_march_golden(name)
+    model = _model(g)
+    r = {k: v.cuda() for k, v in g['rays'].items()}
+    with torch.no_grad():
+        staged = model(r['rays_o'], r['rays_d'], r['viewdirs'], k4_staged=True, **g['render_kwargs'])
+        out = model(r['rays_o'], r['rays_d'], r['viewdirs'], **g['render_kwargs'])
+    ref = g['out']
+    # staged path: every key of the reference dict, index tensors exact
+    assert set(ref.keys()) == set(staged.keys())
+    assert torch.equal(staged['ray_id'].cpu(), ref['ray_id'])
+    for k in ('weights', 'raw_alpha', 'raw_rgb', 'rgb_marched', 'depth', 'alphainv_last'):
+        assert torch.allclose(staged[k].cpu(), ref[k], rtol=0, atol=3e-6), (k, float((staged[k].cpu() - ref[k]).abs().max()))
+    assert staged['rgb_marched'] is staged['rgb_feature']
+    # fused path (or staged fallback for MLP shapes outside the fused kernel)
+    for k in ('rgb_marched', 'depth', 'alphainv_last'):
+        assert torch.allclose(out[k].cpu(), ref[k], rtol=0, atol=5e-6), (name, k, float((out[k].cpu() - ref[k]).abs().max()))
+    assert out['rgb_marched'] is out['rgb_feature']
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(seed=31, num_voxels=64 * 64 * 48, mpi_depth=48),
+    dict(seed=32, num_voxels=56 * 56 * 40, mpi_depth=40, viewbase_pe=3, spatial_pe=2, rgbnet_dim=6, rgbnet_width=32),
+    dict(seed=33, num_voxels=56 * 56 * 40, mpi_depth=40, rgbnet_depth=2, rgbnet_width=128, rgbnet_dim=12),
+    dict(seed=34, num_voxels=56 * 56 * 64, mpi_depth=64, stepsize=0.5),
+])
+def test_mpi_frame_vs_oracle(cfg):
+    ck = scene.make_llff_checkpoint(**cfg)
+    model = _model(ck)
+    H, W = 90, 120
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    pose = scene.llff_spiral_poses()[7]
+    cnt = torch.zeros(4, dtype=torch.int64, device='cuda')
+    rk = dict(ck['render_kwargs'], k4_counters=cnt)
+    rays = marcher.get_rays_of_a_view(H, W, K, pose, ndc=True)
+    res = render.render_frame(model, H, W, K, pose, True, rk, rays=[x.cuda() for x in rays])
+    ro, rd, vd = [x.reshape(-1, 3) for x in rays]
+    want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
+    _cmp(res['rgb_marched'].reshape(-1, 3), want['rgb_marched'], 'rgb')
+    _cmp(res['depth'].reshape(-1), want['depth'], 'depth')
+    _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
+    c = want['counters']
+    dev = cnt.cpu().tolist()
+    for got, key in zip(dev, ('n_inbbox', 'n_mask', 'n_alpha', 'n_shade')):
+        assert abs(got - c[key]) <= max(2, 1e-4 * c[key]), (key, got, c[key])
+    # linear (non-image) ray order gives identical results: tiling never changes values
+    lin = model(ro.cuda(), rd.cuda(), vd.cuda(), **ck['render_kwargs'])
+    assert torch.equal(lin['rgb_marched'], res['rgb_marched'].reshape(-1, 3))
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(seed=41, num_voxels=48 ** 3),
+    dict(seed=42, num_voxels=40 ** 3, rgbnet_direct=False, rgbnet_dim=9, rgbnet_width=64, viewbase_pe=2),
+    dict(seed=43, num_voxels=40 ** 3, rgbnet_dim=0, fast_color_thres=0, alpha_init=1e-6),
+])
+def test_dvgo_frame_vs_oracle(cfg):
+    ck = scene.make_lego_checkpoint(**cfg)
+    model = _model(ck)
+    H = W = 64
+    K = scene.lego_K(H, W)
+    pose = scene.lego_pose(theta_deg=40.)
+    cnt = torch.zeros(4, dtype=torch.int64, device='cuda')
+    rays = marcher.get_rays_of_a_view(H, W, K, pose, ndc=False)
+    res = render.render_frame(model, H, W, K, pose[:3, :4], False, dict(ck['render_kwargs'], k4_counters=cnt),
+                              rays=[x.cuda() for x in rays])
+    ro, rd, vd = [x.reshape(-1, 3) for x in rays]
+    want = marcher.forward('DirectVoxGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
+    _cmp(res['rgb_marched'].reshape(-1, 3), want['rgb_marched'], 'rgb')
+    _cmp(res['depth'].reshape(-1), want['depth'], 'depth')
+    _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
+    c = want['counters']
+    for got, key in zip(cnt.cpu().tolist(), ('n_inbbox', 'n_mask', 'n_alpha', 'n_shade')):
+        assert abs(got - c[key]) <= max(2, 1e-4 * c[key]), (key, got, c[key])
+
+
+def test_edge_cases():
+    """Empty ray list, a ray that misses the box (still one sample, .cu:53), zero direction component
+    (-> 1e-6, .cu:23-25), ragged ray counts that do not fill a wave / a tile."""
+    ck = scene.make_lego_checkpoint(seed=44, num_voxels=32 ** 3)
+    model = _model(ck)
+    rk = ck['render_kwargs']
+    e = torch.zeros([0, 3], device='cuda')
+    out = model(e, e, e, **rk)
+    assert out['rgb_marched'].shape == (0, 3)
+    ro = torch.tensor([[5., 5., 5.], [0., 0., 4.], [0.3, -4., 0.2]])
+    rd = torch.tensor([[1., 0.2, 0.1], [0., 0., -1.], [0., 1., 0.]])
+    vd = rd / rd.norm(dim=-1, keepdim=True)
+    out = model(ro.cuda(), rd.cuda(), vd.cuda(), **rk)
+    want = marcher.dvgo_forward(ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **rk)
+    assert torch.allclose(out['rgb_marched'].cpu(), want['rgb_marched'], atol=2e-5)
+    assert float(out['alphainv_last'][0]) == 1.0 and torch.allclose(out['rgb_marched'][0].cpu(), torch.ones(3))
+    for n in (1, 63, 65, 257):
+        H, W = 1, n
+        rays = [x.reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, scene.lego_K(8, 8), scene.lego_pose(), ndc=False)]
+        out = model(*[x.cuda() for x in rays], **rk)
+        want = marcher.dvgo_forward(ck['model_kwargs'], ck['model_state_dict'], *rays, **rk)
+        assert torch.allclose(out['rgb_marched'].cpu(), want['rgb_marched'], atol=2e-5), n
+
+
+def test_staged_ops_vs_oracle():
+    """Each staged kernel against its restated reference function (oracle/native_cpu.py)."""
+    g = torch.Generator().manual_seed(3)
+    n = 777
+    o = torch.rand([n, 3], generator=g) * 2 - 1
+    d = torch.randn([n, 3], generator=g)
+    d[5, 1] = 0.
+    mn, mx = torch.tensor([-1.1, -0.9, -1.0]), torch.tensor([1.0, 1.2, 0.8])
+    c = lambda t: t.cuda()
+    # samplers
+    pts, msk = ruc.sample_ndc_pts_on_rays(c(o), c(d * 0.1), c(mn), c(mx), 33)
+    wp, wm = nat.sample_ndc_pts_on_rays(o, d * 0.1, mn, mx, 33)
+    assert torch.equal(pts.cpu(), wp) and torch.equal(msk.cpu(), wm)
+    o2 = o * 3
+    got = ruc.sample_pts_on_rays(c(o2), c(d), c(mn), c(mx), 0.2, 1e9, 0.05)
+    want = nat.sample_pts_on_rays(o2, d, mn, mx, 0.2, 1e9, 0.05)
+    for a, b, nm in zip(got, want, ('pts', 'mask', 'ray_id', 'step_id', 'N_steps', 't_min', 't_max')):
+        assert a.shape == b.shape, nm
+        if a.dtype == torch.float32:
+            assert torch.allclose(a.cpu(), b, rtol=1e-6, atol=1e-6), nm
+        else:
+            assert torch.equal(a.cpu(), b), nm
+    # mask lookup incl. exact .5 ties (half away from zero, not half-to-even)
+    world = torch.rand([9, 7, 11], generator=g) > 0.5
+    xyz = torch.rand([5000, 3], generator=g) * 2.6 - 1.3
+    sc = (torch.tensor(world.shape).float() - 1) / (mx - mn)
+    sh = -mn * sc
+    xyz[:50] = ((torch.arange(50).float()[:, None] % 6 + 0.5) - sh) / sc
+    assert torch.equal(ruc.maskcache_lookup(c(world), c(xyz), c(sc), c(sh)).cpu(), nat.maskcache_lookup(world, xyz, sc, sh))
+    # raw2alpha / alpha2weight
+    den = torch.randn([4096], generator=g) * 4
+    for shift, interval in ((0., 1.0), (-4.6, 0.5)):
+        ge, ga = ruc.raw2alpha(c(den), shift, interval)
+        we, wa = nat.raw2alpha(den, shift, interval)
+        assert torch.allclose(ga.cpu(), wa, rtol=2e-6, atol=2e-7) and torch.allclose(ge.cpu(), we, rtol=2e-6)
+    ray_id = torch.sort(torch.randint(0, 300, [4096], generator=g)).values
+    alpha = torch.rand([4096], generator=g) * 0.6
+    got = ruc.alpha2weight(c(alpha), c(ray_id), 300)
+    want = nat.alpha2weight(alpha, ray_id, 300)
+    for a, b, nm in zip(got, want, ('weight', 'T', 'ainv', 'i_start', 'i_end')):
+        assert torch.allclose(a.cpu().double(), b.double(), rtol=0, atol=1e-7), nm
+    # empty inputs
+    assert ruc.alpha2weight(c(alpha[:0]), c(ray_id[:0]), 4)[2].cpu().tolist() == [1.0] * 4
+    # trilinear lookup == torch grid_sample (incl. points outside the box -> zero padding)
+    grid = torch.randn([1, 5, 6, 7, 8], generator=g)
+    q = torch.rand([3000, 3], generator=g) * 2.8 - 1.4
+    dg = kgrid.DenseGrid(5, [6, 7, 8], mn, mx)
+    dg.grid.data.copy_(grid)
+    dg = dg.cuda()
+    with torch.no_grad():
+        got = dg(c(q)).cpu()
+    want = marcher.dense_grid(grid, q, mn, mx)
+    assert torch.allclose(got, want, atol=2e-6)
+    # backward kernels
+    gw = torch.randn([4096], generator=g)
+    gl = torch.randn([300], generator=g)
+    w_, T_, ai_, is_, ie_ = want = nat.alpha2weight(alpha, ray_id, 300)
+    gb = ruc.alpha2weight_backward(c(alpha), c(w_), c(T_), c(ai_), c(is_), c(ie_), 300, c(gw), c(gl)).cpu()
+    wb = nat.alpha2weight_backward(alpha, w_, T_, ai_, is_, ie_, 300, gw, gl)
+    assert torch.allclose(gb, wb, rtol=1e-4, atol=1e-5)
+    e_, _ = nat.raw2alpha(den, -1.0, 0.5)
+    assert torch.allclose(ruc.raw2alpha_backward(c(e_), c(gw), 0.5).cpu(), nat.raw2alpha_backward(e_, gw, 0.5), rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_llff_properties():
+    """BASELINE config 2 at FULL size (1008x756, world 417x353x256): the oracle on a strided ray subset +
+    size-independent properties on the whole frame."""
+    ck = scene.make_llff_checkpoint()
+    model = _model(ck)
+    H, W = scene.LLFF_HW
+    pose = scene.llff_spiral_poses()[0]
+    ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
+    drays = [x.cuda() for x in (ro, rd, vd)]
+    res = render.render_frame(model, H, W, scene.LLFF_K, pose, True, ck['render_kwargs'], rays=drays)
+    rgb, depth, ainv = res['rgb_marched'], res['depth'], res['alphainv_last']
+    assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+    assert float(ainv.min()) >= 0 and float(ainv.max()) <= 1.0
+    assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1.0 + 1e-5            # bg=0: sum w*sigmoid <= 1
+    assert float(depth.min()) >= 0 and float(depth.max()) <= 1.0 + 1e-5
+    # sum of weights + alphainv_last <= 1 (+ tolerance); white-background linearity: rgb(bg=1) = rgb(bg=0)+ainv
+    res1 = render.render_frame(model, H, W, scene.LLFF_K, pose, True, dict(ck['render_kwargs'], bg=1), rays=drays)
+    assert torch.allclose(res1['rgb_marched'], rgb + ainv.unsqueeze(-1), atol=1e-6)
+    # determinism
+    res2 = render.render_frame(model, H, W, scene.LLFF_K, pose, True, ck['render_kwargs'], rays=drays)
+    assert torch.equal(res2['rgb_marched'], rgb) and torch.equal(res2['depth'], depth)
+    # oracle on every 9th row/col
+    sel = (slice(None, None, 9), slice(None, None, 9))
+    want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'],
+                           ro[sel].reshape(-1, 3), rd[sel].reshape(-1, 3), vd[sel].reshape(-1, 3), **ck['render_kwargs'])
+    _cmp(rgb[sel].reshape(-1, 3), want['rgb_marched'], 'rgb')
+    _cmp(depth[sel].reshape(-1), want['depth'], 'depth')
+    _cmp(ainv[sel].reshape(-1), want['alphainv_last'], 'alphainv')
+    # device-generated rays equal the oracle's
+    import nerf4k_amd.lib.dvgo as kd
+    gro, grd, gvd = kd.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(pose).cuda(), True, False, False, False)
+    assert torch.allclose(gro.cpu(), ro, atol=1e-6) and torch.allclose(grd.cpu(), rd, atol=1e-6)
