@@ -35,9 +35,9 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     'k4_abi_version': [],
     'k4_march_mpi_fwd': [_P, _P, _P, _I64, _I32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _I32, _F, _F, _F,
-                         _P, _P, _P, _P, _P],
-    'k4_march_dvgo_fwd': [_P, _P, _P, _I64, _I32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _F, _F, _F, _I32,
-                          _F, _F, _F, _F, _P, _P, _P, _P, _P],
+                         _P, _I64, _P, _P, _P, _P, _P],
+    'k4_march_dvgo_fwd': [_P, _P, _P, _I64, _I32, C.POINTER(GridDesc), C.POINTER(MlpDesc), _F, _F, _F, _I32, _I32,
+                          _F, _F, _F, _F, _P, _I64, _P, _P, _P, _P, _P],
     'k4_sample_ndc_pts_on_rays': [_P, _P, _P, _P, _I64, _I32, _P, _P, _P],
     'k4_infer_t_minmax': [_P, _P, _P, _P, _F, _F, _I64, _P, _P, _P],
     'k4_infer_n_samples': [_P, _P, _P, _F, _I64, _P, _P],
@@ -85,6 +85,8 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                         _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_pack_conv_weight_size': ([_I32, _I32, _I32], C.c_int64),
+    'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
+    'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_pack_conv_weight': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
 }
 

@@ -192,11 +192,13 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         md, _keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
         N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278
         interval = float(stepsize * self.voxel_size_ratio)                # lib/dmpigo.py:306
-        N.check(N.lib().k4_march_mpi_fwd(
-            N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
-            N_samples, interval, float(self.fast_color_thres), float(bg),
-            N.f32(rgb), N.f32(depth), N.f32(ainv),
-            None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_mpi_fwd')
+        if Nr > 0:
+            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev)
+            N.check(N.lib().k4_march_mpi_fwd(
+                N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
+                N_samples, interval, float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes,
+                N.f32(rgb), N.f32(depth), N.f32(ainv),
+                None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_mpi_fwd')
         ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb, 'n_max': N_samples}
         if render_depth:
             ret['depth'] = depth

@@ -72,21 +72,25 @@ class _FusedMarcher:
         key = ('mlp',) + tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in lins)
         c = self._k4_cache()
         if c.get('mlp_key') != key:
-            W = lins[0].out_features
-            parts = [lins[0].weight.detach().t().contiguous().reshape(-1), lins[0].bias.detach()]
-            for l in lins[1:-1]:
-                parts += [l.weight.detach().contiguous().reshape(-1), l.bias.detach()]
-            wo = torch.zeros([W, 4], dtype=torch.float32, device=lins[-1].weight.device)
-            wo[:, :3] = lins[-1].weight.detach().t()
-            bo = torch.zeros([4], dtype=torch.float32, device=wo.device)
-            bo[:3] = lins[-1].bias.detach()
-            parts += [wo.reshape(-1), bo]
-            c['mlp_key'], c['mlp_packed'] = key, torch.cat([p.float() for p in parts]).contiguous()
+            c['mlp_key'], c['mlp_packed'] = key, pack_mlp_mfma(lins)
         md.packed = c['mlp_packed'].data_ptr()
         md.dim0 = lins[0].in_features
         md.width = lins[0].out_features
         md.n_hidden = len(lins) - 2
         return md, c['mlp_packed']
+
+    def _k4_workspace(self, n_rays, img_w, max_steps, device):
+        """Scratch between the geometry and the shading kernel: worst-case sized (every sample of every ray
+        shaded), sparsely touched, cached and grown on demand; one per module and stream of use."""
+        need = int(N.lib().k4_march_workspace_bytes(int(n_rays), int(img_w), int(max_steps)))
+        if need < 0:
+            raise N.K4Error('k4_march_workspace_bytes: bad arguments')
+        c = self._k4_cache()
+        ws = c.get('workspace')
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty([max(need, 256)], dtype=torch.uint8, device=device)
+            c['workspace'] = ws
+        return ws, need
 
     def _k4_grid(self, act_shift_grid=None):
         gd = N.GridDesc()
@@ -289,10 +293,18 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         stepdist = float(stepsize * self.voxel_size)                       # lib/dvgo.py:310
         interval = float(stepsize * self.voxel_size_ratio)                # lib/dvgo.py:341
         depth_n = int((self.max_world_size - 1) / stepsize) + 1           # lib/dvgo.py:311
+        diag = self._k4_host_scalar('diag', (self.xyz_max - self.xyz_min).norm())
+        max_steps = int(np.ceil(diag / stepdist)) + 2
+        if Nr == 0:
+            ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb}
+            if render_depth:
+                ret['depth'] = depth
+            return ret
+        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev)
         N.check(N.lib().k4_march_dvgo_fwd(
             N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
-            float(near), 1e9, stepdist, depth_n, self._k4_host_scalar('act_shift', self.act_shift), interval,
-            float(self.fast_color_thres), float(bg), N.f32(rgb), N.f32(depth), N.f32(ainv),
+            float(near), 1e9, stepdist, max_steps, depth_n, self._k4_host_scalar('act_shift', self.act_shift), interval,
+            float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes, N.f32(rgb), N.f32(depth), N.f32(ainv),
             None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_dvgo_fwd')
         ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb}
         if render_depth:
@@ -348,6 +360,45 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             with torch.no_grad():
                 ret_dict['depth'] = segment_sum(weights * s, ray_id, Nr)
         return ret_dict
+
+
+def pack_mlp_mfma(lins):
+    """rgbnet weights in v_mfma_f32_32x32x2_f32 operand order (layout: include/k4nerf.h, k4_mlp_desc)."""
+    dev = lins[0].weight.device
+    W, dim0 = lins[0].out_features, lins[0].in_features
+    NB, k1p = W // 32, (dim0 + 2) & ~1
+    lane = torch.arange(64, device=dev)
+    row = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+    w1 = torch.zeros([W, k1p], dtype=torch.float32, device=dev)
+    w1[:, :dim0] = lins[0].weight.detach().float()
+    w1[:, dim0] = lins[0].bias.detach().float()
+    mb = torch.arange(NB, device=dev)
+    kk = torch.arange(k1p // 2, device=dev)
+    r = torch.arange(16, device=dev)
+    parts = [w1[(mb[:, None, None] * 32 + (lane & 31)[None, None, :]),
+                (2 * kk[None, :, None] + (lane >> 5)[None, None, :])].reshape(-1)]
+    if len(lins) == 3:
+        w2 = lins[1].weight.detach().float()
+        j2 = mb[:, None, None, None] * 32 + (lane & 31)[None, None, None, :]
+        k = mb[None, :, None, None] * 32 + row(r[None, None, :, None], (lane >> 5)[None, None, None, :])
+        parts.append(w2[j2.expand(NB, NB, 16, 64), k.expand(NB, NB, 16, 64)].reshape(-1))
+        b2 = lins[1].bias.detach().float()
+        b2a = torch.zeros([NB, 64], dtype=torch.float32, device=dev)
+        b2a[:, :32] = b2.reshape(NB, 32)
+        parts.append(b2a.reshape(-1))
+    wo = lins[-1].weight.detach().float()                               # [3, W]
+    wot = torch.zeros([NB, 16, 2, 4], dtype=torch.float32, device=dev)
+    h = torch.arange(2, device=dev)
+    idx = mb[:, None, None] * 32 + row(r[None, :, None], h[None, None, :])      # [NB,16,2]
+    wot[..., :3] = wo.t()[idx]
+    parts.append(wot.reshape(-1))
+    bo = torch.zeros([4], dtype=torch.float32, device=dev)
+    bo[:3] = lins[-1].bias.detach().float()
+    parts.append(bo)
+    out = torch.cat(parts).contiguous()
+    want = N.lib().k4_mlp_packed_floats(dim0, W, len(lins) - 2)
+    assert out.numel() == want, (out.numel(), want)
+    return out
 
 
 def coarse_mask_on_grid(path, thres, xyz_min, xyz_max, world_size):

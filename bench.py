@@ -181,7 +181,7 @@ def cpu_baseline(ck, pose, stride):
     from oracle import marcher
     from nerf4k_amd import scene
     H, W = scene.LLFF_HW
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)       # torch CPU kernels stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
     sel = (slice(None, None, stride), slice(None, None, stride))

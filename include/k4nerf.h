@@ -60,41 +60,53 @@ typedef struct k4_grid_desc {
 } k4_grid_desc;
 
 /* Colour MLP `Sequential(Linear, ReLU, [Sequential(Linear, ReLU)] x n_hidden, Linear)`
- * (lib/dmpigo.py:112-120, lib/dvgo.py:116-124), repacked by k4_pack_mlp_size/the host into ONE
- * contiguous fp32 buffer:
- *     W1^T [dim0][width] | b1 [width] | (W2 [width][width] row-major [out][in] | b2 [width]) x n_hidden
- *     | Wout^T [width][4] (3 outputs + 1 zero pad) | bout [4]
+ * (lib/dmpigo.py:112-120, lib/dvgo.py:116-124), repacked by the host into ONE contiguous fp32 buffer in
+ * v_mfma_f32_32x32x2_f32 operand order (k4_mlp_packed_floats() floats; NB = width/32, K1P = dim0+1 rounded
+ * up to even -- the extra input is a constant 1 carrying the bias; row(r,h) = (r&3)+8*(r>>2)+4*h is the
+ * C/D register->row map of the instruction; l = lane 0..63):
+ *     W1A [NB][K1P/2][64]        = W1ext[mb*32+(l&31)][2*kk+(l>>5)],   W1ext = [W1 | b1 | 0]
+ *     n_hidden==1:  W2A [NB][NB][16][64] = W2[mb2*32+(l&31)][mb*32+row(r,l>>5)] ;  B2A [NB][64] = l<32 ? b2[mb2*32+l] : 0
+ *     WOT [NB][16][2][4]         = Wout[c][mb*32+row(r,h)]  (c = 0..2, 3rd padded with 0)
+ *     BO  [4]
  * width == 0 means "no rgbnet": rgb = sigmoid(k0) with k0_ch == 3 (lib/dvgo.py:377-379). */
 typedef struct k4_mlp_desc {
     const float* packed;
     int32_t dim0;                    /* input width, must equal the feature count implied below          */
     int32_t width;                   /* 0 | 32 | 64 | 128                                                */
-    int32_t n_hidden;                /* rgbnet_depth - 2: 0 or 1 in the fused kernel                     */
+    int32_t n_hidden;                /* rgbnet_depth - 2: 0 or 1 in the fused path                       */
     int32_t viewbase_pe;             /* #frequencies 2^0..2^(n-1) on viewdirs                            */
     int32_t spatial_pe;              /* MPI only: #frequencies on the normalised position                */
     int32_t k0_skip;                 /* DVGO rgbnet_direct=False: 3 (first 3 k0 channels are added to the logits, lib/dvgo.py:385-386,412), else 0 */
 } k4_mlp_desc;
+int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden);   /* <0: unsupported shape */
 
 /* ---------------------------------------------------------------------------------------------
- * Fused marchers: one launch replaces everything inside DirectMPIGO.forward (lib/dmpigo.py:292-427)
- * / DirectVoxGO.forward (lib/dvgo.py:327-448) for the four keys the render loop consumes
- * (run_sr.py:107): rgb_marched (== rgb_feature, they alias in eval), depth, alphainv_last.
+ * Fused marchers: two launches (geometry + shading, csrc/k4_march.hip) replace everything inside
+ * DirectMPIGO.forward (lib/dmpigo.py:292-427) / DirectVoxGO.forward (lib/dvgo.py:327-448) for the four
+ * keys the render loop consumes (run_sr.py:107): rgb_marched (== rgb_feature, they alias in eval), depth,
+ * alphainv_last.  No host synchronisation, no per-sample tensor.
  *
  *   rays_o, rays_d, viewdirs : [n_rays][3]
  *   img_w   : 0, or the image width when the n_rays rays are ONE full image in row-major pixel
  *             order (n_rays = H*img_w); only changes the ray->wavefront tiling (8x8 pixel tiles,
  *             XCD-banded), never the results.
+ *   workspace : device scratch of >= k4_march_workspace_bytes(n_rays, img_w, max_steps) bytes (the compacted
+ *             {ray,step,weight} records between the two kernels; worst-case sized, sparsely touched);
+ *             max_steps = n_samples for MPI.  Owned by the caller, reusable across calls on one stream.
  *   out_rgb [n_rays][3], out_depth [n_rays], out_alphainv [n_rays]
  *   out_counters : NULL or uint64[4] = {in-bbox samples, mask-pass samples, alpha-pass samples,
- *                  shaded samples}, ACCUMULATED (caller zeroes) -- the counts SURVEY 8(d)'s
- *                  algorithmic-bytes formula needs.
+ *                  shaded samples} the kernels VISITED (they stop at the T<1e-3 early stop), ACCUMULATED
+ *                  (caller zeroes) -- the counts SURVEY 8(d)'s algorithmic-bytes formula needs.
  * ------------------------------------------------------------------------------------------- */
+int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps);
+
 int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,
                      int64_t n_rays, int32_t img_w,
                      const k4_grid_desc* grid, const k4_mlp_desc* mlp,
                      int32_t n_samples,      /* int((mpi_depth-1)/stepsize)+1, lib/dmpigo.py:278   */
                      float interval,         /* stepsize * voxel_size_ratio, lib/dmpigo.py:306     */
                      float fast_color_thres, float bg,
+                     void* workspace, int64_t workspace_bytes,
                      float* out_rgb, float* out_depth, float* out_alphainv,
                      uint64_t* out_counters, void* stream);
 
@@ -103,10 +115,12 @@ int k4_march_dvgo_fwd(const float* rays_o, const float* rays_d, const float* vie
                       const k4_grid_desc* grid, const k4_mlp_desc* mlp,
                       float near, float far,   /* the reference overrides far with 1e9, lib/dvgo.py:307: pass what the kernel should use */
                       float stepdist,          /* stepsize * voxel_size, lib/dvgo.py:310             */
+                      int32_t max_steps,       /* upper bound of samples on one ray: ceil(bbox diagonal / stepdist) + 2 */
                       int32_t depth_n_samples, /* int((max_world_size-1)/stepsize)+1, lib/dvgo.py:311 */
                       float act_shift,         /* scalar buffer, lib/dvgo.py:46                      */
                       float interval,          /* stepsize * voxel_size_ratio, lib/dvgo.py:341       */
                       float fast_color_thres, float bg,
+                      void* workspace, int64_t workspace_bytes,
                       float* out_rgb, float* out_depth, float* out_alphainv,
                       uint64_t* out_counters, void* stream);
 
