@@ -45,13 +45,16 @@ def _cmp(got, want, name, frac_tol=2e-5, max_tol=2e-3, min_psnr=80.0):
     return p
 
 
-def _check_counters(cnt, c):
+def _check_counters(cnt, c, thres):
     """Mask-decision agreement.  Shaded samples must agree with the oracle (every one carries weight).  The
     fused kernel stops marching a ray at the T<1e-3 early stop, so the samples it *visits* (in-bbox, mask,
     alpha) are a subset of the oracle's -- the reference computes them and then throws them away."""
     inb, msk, alp, shd = cnt.cpu().tolist()
-    assert abs(shd - c['n_shade']) <= max(2, 1e-4 * c['n_shade']), ('n_shade', shd, c['n_shade'])
-    assert c['n_shade'] <= alp <= c['n_alpha'] + 2 and alp <= msk <= c['n_mask'] and msk <= inb <= c['n_inbbox']
+    if thres > 0:
+        assert abs(shd - c['n_shade']) <= max(2, 1e-4 * c['n_shade']), ('n_shade', shd, c['n_shade'])
+    else:   # no thresholds: the reference keeps the zero-weight samples behind the early stop, we never emit them
+        assert shd <= c['n_shade']
+    assert shd <= alp <= c['n_alpha'] + 2 and alp <= msk <= c['n_mask'] and msk <= inb <= c['n_inbbox']
 
 
 def _model(ck):
@@ -102,10 +105,15 @@ def test_mpi_frame_vs_oracle(cfg):
     _cmp(res['rgb_marched'].reshape(-1, 3), want['rgb_marched'], 'rgb')
     _cmp(res['depth'].reshape(-1), want['depth'], 'depth')
     _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
-    _check_counters(cnt, want['counters'])
-    # linear (non-image) ray order gives identical results: tiling never changes values
+    _check_counters(cnt, want['counters'], ck['model_kwargs']['fast_color_thres'])
+    # linear (non-image) ray order: a different ray->wavefront tiling only changes where the 64-record shading
+    # batches cut a ray's samples, i.e. the association order of the per-ray sum (last-bit differences)
     lin = model(ro.cuda(), rd.cuda(), vd.cuda(), **ck['render_kwargs'])
-    assert torch.equal(lin['rgb_marched'], res['rgb_marched'].reshape(-1, 3))
+    assert torch.allclose(lin['rgb_marched'], res['rgb_marched'].reshape(-1, 3), rtol=0, atol=1e-6)
+    assert torch.equal(lin['alphainv_last'], res['alphainv_last'].reshape(-1))
+    # bit-reproducible run to run (no atomics on the data path)
+    lin2 = model(ro.cuda(), rd.cuda(), vd.cuda(), **ck['render_kwargs'])
+    assert torch.equal(lin['rgb_marched'], lin2['rgb_marched']) and torch.equal(lin['depth'], lin2['depth'])
 
 
 @pytest.mark.parametrize('cfg', [
@@ -128,7 +136,7 @@ def test_dvgo_frame_vs_oracle(cfg):
     _cmp(res['rgb_marched'].reshape(-1, 3), want['rgb_marched'], 'rgb')
     _cmp(res['depth'].reshape(-1), want['depth'], 'depth')
     _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
-    _check_counters(cnt, want['counters'])
+    _check_counters(cnt, want['counters'], ck['model_kwargs']['fast_color_thres'])
 
 
 def test_edge_cases():
