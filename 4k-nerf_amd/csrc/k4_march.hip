@@ -50,7 +50,8 @@ struct MarchParams {
     int depth_n;            // denominator of s = (k+0.5)/depth_n
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
-    uint2* entries; int* counts;                   // workspace: [n_bundles][64*max_steps], [n_bundles]
+    uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
+    int n_bundles;
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
 
@@ -63,10 +64,10 @@ __device__ __forceinline__ float step_t(const MarchParams& P, int k) {
 
 struct Bundle { int x, y, lin, id; };
 
-__device__ __forceinline__ Bundle bundle_of(const MarchParams& P, int wv) {
+__device__ __forceinline__ Bundle bundle_from_id(const MarchParams& P, int id) {
     Bundle b;
-    const int wg = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    b.id = wg * 4 + wv;
+    const int wg = id >> 2, wv = id & 3;
+    b.id = id;
     b.x = b.y = b.lin = 0;
     if (P.img_w > 0) {
         const int wgx = (P.img_w + 15) >> 4;
@@ -76,6 +77,9 @@ __device__ __forceinline__ Bundle bundle_of(const MarchParams& P, int wv) {
         b.lin = b.id * 64;
     }
     return b;
+}
+__device__ __forceinline__ Bundle bundle_of(const MarchParams& P, int wv) {
+    return bundle_from_id(P, k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wv);
 }
 __device__ __forceinline__ int ray_index(const MarchParams& P, const Bundle& b, int r) {
     if (P.img_w > 0) {
@@ -116,8 +120,10 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
     const int lane = k4_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const Bundle B = bundle_of(P, wv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.qhead = 0;            // work queue of the shading kernel that follows
     uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
     const k4_cptr c_o = k4_const(P.rays_o), c_d = k4_const(P.rays_d);
+    const bool unit_interval = P.interval == 1.f;
     const bool use_thres = P.thres > 0.f;
     unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0;
     int cnt = 0;
@@ -157,26 +163,30 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
                 const float ny = k4_norm_coord(py, P.miny, P.maxy);
                 const float nz = k4_norm_coord(pz, P.minz, P.maxz);
                 const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
+                // The point is inside the closed bbox, so 0 <= u <= dim-1: only the "+1" corner can leave the grid and
+                // then its weight (u - floor u) is exactly 0 -> clamp the index instead of branching (zero padding of
+                // grid_sample contributes the same +0).
                 float sigma = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
-                    const bool ok = (unsigned)x < (unsigned)P.X && (unsigned)y < (unsigned)P.Y && (unsigned)z < (unsigned)P.Z;
-                    const float v = ok ? P.density[((size_t)x * P.Y + y) * P.Z + z] : 0.f;
-                    sigma += v * t.w[c];
-                }
+                const int x1 = min(t.x0 + 1, P.X - 1), y1 = min(t.y0 + 1, P.Y - 1), z1 = min(t.z0 + 1, P.Z - 1);
+                const unsigned r00 = (unsigned)(t.x0 * P.Y + t.y0) * (unsigned)P.Z, r01 = (unsigned)(t.x0 * P.Y + y1) * (unsigned)P.Z;
+                const unsigned r10 = (unsigned)(x1 * P.Y + t.y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
+                const float d0 = P.density[r00 + t.z0], d1 = P.density[r00 + z1], d2 = P.density[r01 + t.z0], d3 = P.density[r01 + z1];
+                const float d4 = P.density[r10 + t.z0], d5 = P.density[r10 + z1], d6 = P.density[r11 + t.z0], d7 = P.density[r11 + z1];
+                sigma += d0 * t.w[0]; sigma += d1 * t.w[1]; sigma += d2 * t.w[2]; sigma += d3 * t.w[3];
+                sigma += d4 * t.w[4]; sigma += d5 * t.w[5]; sigma += d6 * t.w[6]; sigma += d7 * t.w[7];
                 if (MODE == MODE_MPI) {
                     // act_shift grid [1,1,D]: x/y sizes are 1 -> only z interpolates (lib/dmpigo.py:48-58,316)
                     const float ua = k4_unnorm(nz, P.act_d);
                     const float fa = floorf(ua);
                     const int a0 = (int)fa;
-                    const float lo = ((unsigned)a0 < (unsigned)P.act_d) ? P.act_shift[a0] : 0.f;
-                    const float hi = ((unsigned)(a0 + 1) < (unsigned)P.act_d) ? P.act_shift[a0 + 1] : 0.f;
+                    const float lo = P.act_shift[a0];
+                    const float hi = P.act_shift[min(a0 + 1, P.act_d - 1)];
                     sigma += lo * ((fa + 1.f) - ua) + hi * (ua - fa);
                 }
                 // raw2alpha: e = exp(d+shift); alpha = 1 - (1+e)^(-interval)   render_utils_kernel.cu:439-441
                 const float e = expf(sigma + P.shift);
-                alpha = (P.interval == 1.f) ? 1.f - 1.f / (1.f + e) : 1.f - powf(1.f + e, -P.interval);
+                if (unit_interval) alpha = 1.f - 1.f / (1.f + e);         // wave-uniform branch: powf is ~100 VALU
+                else alpha = 1.f - powf(1.f + e, -P.interval);
                 act = use_thres ? (alpha > P.thres) : true;
             }
             // ---- alpha2weight: exact sequential scan over the active lanes (render_utils_kernel.cu:591-603) ----
@@ -232,7 +242,7 @@ struct MlpLayout {
 };
 
 template <int MODE, int WIDTH, int NHID>
-__global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
+__global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int W = WIDTH > 0 ? WIDTH : 32;
     constexpr int NB = W / 32;
@@ -249,13 +259,20 @@ __global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
     if (WIDTH > 0) {
         for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = P.mlp[i];
     }
-    acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
     __syncthreads();
+    const int half = lane >> 5;
 
-    const Bundle B = bundle_of(P, wv);
+    // persistent waves pull bundles from a global queue (bundles carry 0..thousands of records: static
+    // assignment left SIMDs idle behind the slowest tile); a bundle is still shaded by ONE wave, in order.
+    for (;;) {
+    int bid = 0;
+    if (lane == 0) bid = atomicAdd(P.qhead, 1);
+    bid = __builtin_amdgcn_readfirstlane(bid);
+    if (bid >= P.n_bundles) break;
+    const Bundle B = bundle_from_id(P, bid);
+    acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
     const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
-    const int half = lane >> 5;
 
     for (int base = 0; base < total; base += 64) {
         const int nproc = (total - base) < 64 ? (total - base) : 64;
@@ -276,13 +293,13 @@ __global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
         const float ny = k4_norm_coord(py, P.miny, P.maxy);
         const float nz = k4_norm_coord(pz, P.minz, P.maxz);
         const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
-        size_t cidx[8];
+        unsigned cidx[8];                                        // voxel index (< 2^31 voxels)
         float cw[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
             const bool ok = (unsigned)x < (unsigned)P.X && (unsigned)y < (unsigned)P.Y && (unsigned)z < (unsigned)P.Z;
-            cidx[c] = ok ? ((size_t)x * P.Y + y) * P.Z + z : 0;
+            cidx[c] = ok ? (unsigned)(x * P.Y + y) * (unsigned)P.Z + (unsigned)z : 0u;
             cw[c] = ok ? t.w[c] : 0.f;
         }
         float o0, o1, o2;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float q = (P.k0_layout == K4_K0_CHANNEL_LAST)
-                        ? P.k0[cidx[c] * P.CP + ch]
+                        ? P.k0[(size_t)cidx[c] * P.CP + ch]
                         : P.k0[(size_t)ch * P.X * P.Y * P.Z + cidx[c]];
                     v[ch] += q * cw[c];
                 }
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        const float4 q = *reinterpret_cast<const float4*>(P.k0 + cidx[c] * P.CP + g);
+                        const float4 q = *reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * P.CP + g);
                         v.x += q.x * cw[c]; v.y += q.y * cw[c]; v.z += q.z * cw[c]; v.w += q.w * cw[c];
                     }
                     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -468,6 +485,8 @@ __global__ __launch_bounds__(256) void k4_shade_kernel(const MarchParams P) {
         P.out_rgb[(size_t)ray * 3 + 2] = acc[lane * 4 + 2] + ab;
         P.out_depth[ray] = acc[lane * 4 + 3];
     }
+    __builtin_amdgcn_wave_barrier();
+    }   // bundle queue
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,13 +515,20 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     int rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const dim3 sgrid((unsigned)min(nwg, n_cu * 3));
     const size_t lds = sizeof(float) * (((size_t)P.mlp_floats + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH(WD, NH) do { \
         if (lds > 64 * 1024) { \
             hipError_t e_ = hipFuncSetAttribute((const void*)k4_shade_kernel<MODE, WD, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
-        hipLaunchKernelGGL((k4_shade_kernel<MODE, WD, NH>), grid, block, lds, st, P); } while (0)
+        hipLaunchKernelGGL((k4_shade_kernel<MODE, WD, NH>), sgrid, block, lds, st, P); } while (0)
     if (width == 0) K4_LAUNCH(0, 0);
     else if (width == 32 && nh == 0) K4_LAUNCH(32, 0);
     else if (width == 32 && nh == 1) K4_LAUNCH(32, 1);
@@ -518,7 +544,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
     if (n_rays < 0 || img_w < 0 || max_steps <= 0 || (img_w > 0 && n_rays % img_w != 0)) return -1;
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
-    return nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2) + ((nb * (int64_t)sizeof(int) + 255) / 256) * 256;
+    return nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2) + (((nb + 1) * (int64_t)sizeof(int) + 255) / 256) * 256;
 }
 
 static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -552,6 +578,8 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2));
+    P.qhead = P.counts + nb;
+    P.n_bundles = (int)nb;
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
