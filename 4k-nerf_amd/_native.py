@@ -82,12 +82,11 @@ def lib():
 
 # SR entry points are registered by sr modules (optional symbols are bound when present)
 _EXTRA_SIGS = {
-    'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, C.c_uint32, _F,
+    'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                         _P, _I32, _F, _P, _I32, _P], C.c_int),
-    'k4_pack_conv_weight_size': ([_I32, _I32, _I32], C.c_int64),
+    'k4_conv_weight_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
-    'k4_pack_conv_weight': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
 }
 
 

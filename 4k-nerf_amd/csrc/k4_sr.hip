@@ -1,0 +1,195 @@
+// VC-Decoder (SFTNet, lib/sr_esrnet.py) convolutions for gfx950: NHWC fp32 implicit GEMM on the matrix cores.
+//
+// One kernel template covers every layer of SFTNet.forward (lib/sr_esrnet.py:446-465):
+//   3x3 / 1x1, stride 1, zero "same" padding; C_in 1..192 read from a channel slice of an NHWC buffer
+//   (the dense block's torch.cat((x, x1, ..), 1) of lib/sr_esrnet.py:152-156 is a [H][W][192] buffer whose
+//   slices the convs write in place -- no concat copies); fused epilogues: bias, LeakyReLU(0.2), residual
+//   (y*s + res: x5*0.2+x :158, out*0.2+x :182, body_feat += feat :458), SFT modulation
+//   (x*(scale+1)+shift :123) and nearest x2 upsampling folded into the loader (F.interpolate :461-463).
+//
+// GEMM view per workgroup: M = 256 output pixels (8 rows x 32 columns), N = C_out (32*NT), K = taps*C_in,
+// walked in chunks of KC = 8 input channels.  v_mfma_f32_32x32x2_f32 (exact fp32: the result is a k-ordered
+// fmaf chain): A = 32 pixels of one image row x 2 channels, B = 2 channels x 32 output channels.
+//   * the chunk's haloed input tile sits in LDS channel-major [KC][10][36]: the A operand of tap (dy,dx) is
+//     32 consecutive floats of one row -> one conflict-free ds_read_b32, shifted by the tap;
+//   * the chunk's weights sit in LDS as [tap][KC][32*NT]: the B operand is 32 consecutive floats;
+//   * a wave owns 2 rows x NT column blocks: 2*NT accumulators of 16 VGPRs; every operand read feeds 2 MFMAs.
+// fp32 MFMA issues at the fp32 vector rate (157 TFLOP/s peak), so LDS/HBM are far from limiting: the kernel is
+// matrix-pipe bound; bf16 would be 16x faster but breaks the fp32 parity contract.
+#include "k4_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KC 8
+#define TILE_W 32
+#define TILE_H 8
+
+struct ConvParams {
+    const float* x; int cin; int cin_stride;
+    const float* w; const float* bias;
+    float* y; int cout; int cout_stride;
+    int H, W;            // output size
+    int srcH, srcW;      // input size (H/2, W/2 with K4_PRE_UPSAMPLE2X)
+    unsigned flags; float slope;
+    const float* res; int res_stride; float res_scale;
+    const float* modx; int mod_stride;
+    int tiles_x, tiles_y;
+};
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void k4_conv_kernel(const ConvParams P) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PADW = KS / 2;
+    constexpr int ROWS = TILE_H + 2 * PADW;
+    constexpr int COLS_USED = TILE_W + 2 * PADW;
+    constexpr int COLS = KS == 3 ? 36 : 32;
+    constexpr int NOUT = NT * 32;
+    __shared__ float in_s[KC][ROWS][COLS];
+    __shared__ float w_s[TAPS][KC][NOUT];
+
+    const int lane = k4_lane();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x16)(0.f);
+
+    const int nchunks = (P.cin + KC - 1) / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * KC;
+        // ---- stage the haloed input tile: NHWC global -> channel-major LDS ----
+        for (int p = (int)threadIdx.x; p < ROWS * COLS_USED; p += 256) {
+            const int py = p / COLS_USED, px = p - py * COLS_USED;
+            const int gy = y0 - PADW + py, gx = x0 - PADW + px;
+            float v[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) v[c] = 0.f;
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) {
+                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+                const float* src = P.x + ((size_t)sy * P.srcW + sx) * P.cin_stride + c0;
+                if (c0 + KC <= P.cin && ((((size_t)src) & 15) == 0)) {
+                    const float4 a = *reinterpret_cast<const float4*>(src);
+                    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) if (c0 + c < P.cin) v[c] = src[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) in_s[c][py][px] = v[c];
+        }
+        // ---- stage this chunk's weights (already in LDS order: [chunk][tap][KC][NOUT]) ----
+        {
+            const float4* src = reinterpret_cast<const float4*>(P.w + (size_t)ch * TAPS * KC * NOUT);
+            float4* dst = reinterpret_cast<float4*>(&w_s[0][0][0]);
+            for (int i = (int)threadIdx.x; i < TAPS * KC * NOUT / 4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        // ---- 2 rows x NT column blocks per wave ----
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dy = t / KS, dx = t - dy * KS;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float a0 = in_s[2 * kk + half][wv * 2 + 0 + dy][l31 + dx];
+                const float a1 = in_s[2 * kk + half][wv * 2 + 1 + dy][l31 + dx];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float b = w_s[t][2 * kk + half][n * 32 + l31];
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds output channel n*32+l31 of pixels x0 + row(r,half), rows y0 + wv*2 + m ----
+    const bool modulate = (P.flags & K4_EPI_MODULATE) != 0;
+    constexpr int NW = NT;                    // N tiles written (MODULATE: only the first NT/2)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + wv * 2 + m;
+        if (gy >= P.H) continue;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            if (modulate && n >= NT / 2) continue;
+            const int co = n * 32 + l31;
+            if (co >= P.cout) continue;
+            const float bsc = P.bias[co];
+            const float bsh = modulate ? P.bias[co + (NT / 2) * 32] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (gx >= P.W) continue;
+                const size_t pix = (size_t)gy * P.W + gx;
+                float v = acc[m][n][r] + bsc;
+                if (modulate) {
+                    // SFTLayer: x * (scale + 1) + shift      (lib/sr_esrnet.py:123)
+                    const float sh = acc[m][(n + NT / 2) % NT][r] + bsh;
+                    v = P.modx[pix * P.mod_stride + co] * (v + 1.f) + sh;
+                }
+                if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
+                if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
+                P.y[pix * P.cout_stride + co] = v;
+            }
+        }
+    }
+}
+
+template <int KS, int NT>
+static int launch_conv(const ConvParams& P, hipStream_t st) {
+    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(256);
+    hipLaunchKernelGGL((k4_conv_kernel<KS, NT>), grid, block, 0, st, P);
+    return k4_check_launch();
+}
+
+extern "C" int64_t k4_conv_weight_floats(int32_t cout, int32_t cin, int32_t ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
+    const int64_t nt = (cout + 31) / 32;
+    if (nt != 1 && nt != 2 && nt != 4) return -1;
+    return (int64_t)((cin + KC - 1) / KC) * ksize * ksize * KC * nt * 32;
+}
+
+extern "C" int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
+                              const float* w_packed, const float* bias, int32_t ksize,
+                              float* y, int32_t cout, int32_t cout_stride,
+                              int32_t H, int32_t W, uint32_t flags, float slope,
+                              const float* res, int32_t res_stride, float res_scale,
+                              const float* mod_x, int32_t mod_stride, void* stream) {
+    if (!x || !w_packed || !bias || !y || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return K4_ERR_BAD_ARG;
+    if (cin_stride < cin || (ksize != 1 && ksize != 3)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_EPI_RES) && (!res || res_stride <= 0)) return K4_ERR_BAD_ARG;
+    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
+    if (modulate && (!mod_x || mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_PRE_UPSAMPLE2X) && ((H & 1) || (W & 1))) return K4_ERR_BAD_ARG;
+    // MODULATE: the GEMM produces 2*cout channels ([scale | shift]); cout is what gets written
+    const int gemm_n = modulate ? 2 * cout : cout;
+    const int nt = (gemm_n + 31) / 32;
+    if (cout_stride < cout) return K4_ERR_BAD_ARG;
+    ConvParams P{};
+    P.x = x; P.cin = cin; P.cin_stride = cin_stride; P.w = w_packed; P.bias = bias;
+    P.y = y; P.cout = cout; P.cout_stride = cout_stride; P.H = H; P.W = W;
+    P.srcH = (flags & K4_PRE_UPSAMPLE2X) ? H / 2 : H; P.srcW = (flags & K4_PRE_UPSAMPLE2X) ? W / 2 : W;
+    P.flags = flags; P.slope = slope; P.res = res; P.res_stride = res_stride; P.res_scale = res_scale;
+    P.modx = mod_x; P.mod_stride = mod_stride;
+    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3) {
+        if (nt == 1) return launch_conv<3, 1>(P, st);
+        if (nt == 2) return launch_conv<3, 2>(P, st);
+    } else {
+        if (nt == 1) return launch_conv<1, 1>(P, st);
+        if (nt == 2) return launch_conv<1, 2>(P, st);
+        if (nt == 4) return launch_conv<1, 4>(P, st);
+    }
+    return K4_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,371 @@
+"""VC-Decoder ``SFTNet`` with the reference's interface (/root/reference/lib/sr_esrnet.py), MI355X-native inside.
+
+Same constructor (``SFTNet(n_in_colors, scale, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1,
+dswise=False)``, run_sr.py:1353), same module tree and therefore the same 458 ``state_dict`` keys
+(``conv_first``, ``body.N.rdbM.convK``, ``...sftK.SFT_{scale,shift}_conv{0,1}``, ``CondNet.{0,2,4,6}``, ...),
+same ``forward(x, cond, fea=None)``, ``tile_process(img, cond, tile_size, tile_pad=10)`` (returns a CPU
+tensor like the reference, lib/sr_esrnet.py:477,526), ``load_network`` / ``save_network`` semantics
+(lib/sr_esrnet.py:529-621: ``params_ema`` -> ``params`` fallback, ``module.`` stripping, size-mismatch skipping
+with ``strict=False``).
+
+Inference (``torch.no_grad``) runs on the fp32-MFMA implicit-GEMM kernel of ``csrc/k4_sr.hip`` through
+``k4_conv2d_nhwc``: NHWC activations, the dense block's ``torch.cat`` is a [H][W][192] buffer written slice by
+slice, bias / LeakyReLU / residual / SFT modulation / nearest-x2 upsampling are fused into the conv.  With autograd
+enabled (training, a "next" row of SURVEY.md 8f) the module evaluates the same graph with PyTorch-ROCm ops.
+No CPU path.
+"""
+import math
+import os
+import time
+from copy import deepcopy
+
+import torch
+from torch import nn as nn
+from torch.nn import functional as F
+from torch.nn import init as init
+
+from .. import _native as N
+
+EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X = 2, 4, 8, 16
+
+
+@torch.no_grad()
+def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
+    """lib/sr_esrnet.py:12-40"""
+    if not isinstance(module_list, list):
+        module_list = [module_list]
+    for module in module_list:
+        for m in module.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                init.kaiming_normal_(m.weight, **kwargs)
+                m.weight.data *= scale
+                if m.bias is not None:
+                    m.bias.data.fill_(bias_fill)
+
+
+class SFTLayer(nn.Module):
+    def __init__(self, num_feat=64, num_grow_ch=32):
+        super(SFTLayer, self).__init__()
+        self.SFT_scale_conv0 = nn.Conv2d(num_grow_ch, num_grow_ch, 1)
+        self.SFT_scale_conv1 = nn.Conv2d(num_grow_ch, num_feat, 1)
+        self.SFT_shift_conv0 = nn.Conv2d(num_grow_ch, num_grow_ch, 1)
+        self.SFT_shift_conv1 = nn.Conv2d(num_grow_ch, num_feat, 1)
+
+    def forward(self, x, cond):
+        scale = self.SFT_scale_conv1(F.leaky_relu(self.SFT_scale_conv0(cond), 0.2))
+        shift = self.SFT_shift_conv1(F.leaky_relu(self.SFT_shift_conv0(cond), 0.2))
+        return x * (scale + 1) + shift
+
+
+class ResidualDenseBlock_SFT(nn.Module):
+    def __init__(self, num_feat=64, num_grow_ch=32):
+        super(ResidualDenseBlock_SFT, self).__init__()
+        self.conv1 = nn.Conv2d(num_feat, num_grow_ch, 3, 1, 1)
+        self.conv2 = nn.Conv2d(num_feat + num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv3 = nn.Conv2d(num_feat + 2 * num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv4 = nn.Conv2d(num_feat + 3 * num_grow_ch, num_grow_ch, 3, 1, 1)
+        self.conv5 = nn.Conv2d(num_feat + 4 * num_grow_ch, num_feat, 3, 1, 1)
+        self.sft0 = SFTLayer(num_feat, num_grow_ch)
+        self.sft1 = SFTLayer(num_grow_ch, num_grow_ch)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        default_init_weights([self.conv1, self.conv2, self.conv3, self.conv4, self.conv5], 0.1)
+
+    def forward(self, x):
+        xc0 = self.sft0(x[0], x[1])
+        x1 = self.lrelu(self.conv1(xc0))
+        x2 = self.lrelu(self.conv2(torch.cat((xc0, x1), 1)))
+        x3 = self.lrelu(self.conv3(torch.cat((xc0, x1, x2), 1)))
+        x4 = self.lrelu(self.conv4(torch.cat((xc0, x1, x2, x3), 1)))
+        xc1 = self.sft1(x4, x[1])
+        x5 = self.conv5(torch.cat((xc0, x1, x2, x3, xc1), 1))
+        return (x5 * 0.2 + x[0], x[1])
+
+
+class RRDB_SFT(nn.Module):
+    def __init__(self, num_feat, num_grow_ch=32):
+        super(RRDB_SFT, self).__init__()
+        self.rdb1 = ResidualDenseBlock_SFT(num_feat, num_grow_ch)
+        self.rdb2 = ResidualDenseBlock_SFT(num_feat, num_grow_ch)
+        self.rdb3 = ResidualDenseBlock_SFT(num_feat, num_grow_ch)
+        self.sft0 = SFTLayer(num_feat, num_grow_ch)
+
+    def forward(self, x):
+        out = self.rdb1(x)
+        out = self.rdb2(out)
+        out = self.rdb3(out)
+        out = self.sft0(out[0], x[1])
+        return (out * 0.2 + x[0], x[1])
+
+
+class RRDBNet_bps(nn.Module):
+    """Plain RRDB + PixelShuffle variant (lib/sr_esrnet.py:185-397): defined upstream, instantiated nowhere
+     -- kept as a name only."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('RRDBNet_bps is never instantiated by the reference; only SFTNet is on the hot path')
+
+
+class _Packed:
+    """Conv weights in k4_conv2d_nhwc order: [ceil(cin/8)][k*k][8][32*NT] + zero padded bias."""
+
+    def __init__(self, weight, bias, gemm_n=None):
+        cout, cin, k, _ = weight.shape
+        n = cout if gemm_n is None else gemm_n
+        nt = (n + 31) // 32
+        kc = 8
+        nch = (cin + kc - 1) // kc
+        w = torch.zeros([k * k, nch * kc, nt * 32], dtype=torch.float32, device=weight.device)
+        w[:, :cin, :cout] = weight.detach().float().permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+        self.w = w.reshape(k * k, nch, kc, nt * 32).permute(1, 0, 2, 3).contiguous()
+        want = N.lib().k4_conv_weight_floats(n, cin, k)
+        assert self.w.numel() == want, (self.w.numel(), want)
+        self.b = torch.zeros([nt * 32], dtype=torch.float32, device=weight.device)
+        self.b[:cout] = bias.detach().float()
+        self.cin, self.k = cin, k
+
+
+class SFTNet(nn.Module):
+    def __init__(self, n_in_colors, scale, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1, dswise=False):
+        super(SFTNet, self).__init__()
+        self.scale = scale
+        self.dswise = dswise
+        self.num_feat, self.num_grow_ch, self.num_block, self.num_cond = num_feat, num_grow_ch, num_block, num_cond
+        if dswise:
+            self.conv_first = nn.Conv2d(n_in_colors, num_feat, 1)
+        else:
+            self.conv_first = nn.Conv2d(n_in_colors, num_feat, 3, 1, 1)
+        self.body = nn.Sequential(*[RRDB_SFT(num_feat=num_feat, num_grow_ch=num_grow_ch) for _ in range(num_block)])
+        self.conv_body = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        if n_in_colors > 3:
+            self.conv_fea = nn.Conv2d(n_in_colors, num_feat, 3, 1, 1)
+            self.conv_prefea = nn.Conv2d(2 * num_feat, num_feat, 3, 1, 1)
+        if self.scale > 1:
+            self.conv_up1 = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+            if self.scale == 4:
+                self.conv_up2 = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_hr = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_last = nn.Conv2d(num_feat, 3, 3, 1, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        self.sftbody = SFTLayer(num_feat, num_grow_ch)
+        self.CondNet = nn.Sequential(
+            nn.Conv2d(num_cond, 64, 3, 1, 1), nn.LeakyReLU(0.2, True),
+            nn.Conv2d(64, 64, 1), nn.LeakyReLU(0.2, True),
+            nn.Conv2d(64, 64, 1), nn.LeakyReLU(0.2, True),
+            nn.Conv2d(64, 32, 1))
+        object.__setattr__(self, '_k4', {})
+
+    # ------------------------------------------------------------------ reference graph (autograd path)
+    def _forward_torch(self, x, cond, fea=None):
+        if fea is None:
+            feat = self.conv_first(x)
+        else:
+            feat = self.conv_prefea(torch.cat((self.conv_first(x), fea), dim=1))
+        cond = self.CondNet(cond)
+        body_feat = self.body((feat, cond))
+        body_feat = self.sftbody(body_feat[0], body_feat[1])
+        body_feat = self.conv_body(body_feat)
+        body_feat = body_feat + feat
+        if self.scale > 1:
+            body_feat = self.lrelu(self.conv_up1(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
+            if self.scale == 4:
+                body_feat = self.lrelu(self.conv_up2(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
+        return self.conv_last(self.lrelu(self.conv_hr(body_feat)))
+
+    # ------------------------------------------------------------------ HIP path
+    def _packed(self):
+        """Pack every conv once per parameter version (load-time repack; names/values of parameters never change)."""
+        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device),)
+        c = self._k4
+        if c.get('key') == key:
+            return c['packed']
+        pk = {}
+
+        def sft(prefix, layer):
+            w0 = torch.cat([layer.SFT_scale_conv0.weight, layer.SFT_shift_conv0.weight], 0)
+            b0 = torch.cat([layer.SFT_scale_conv0.bias, layer.SFT_shift_conv0.bias], 0)
+            pk[prefix + '.a'] = _Packed(w0, b0)                                   # cond(32) -> [scale_h | shift_h](64)
+            g, cf = self.num_grow_ch, layer.SFT_scale_conv1.weight.shape[0]
+            w1 = torch.zeros([2 * cf, 2 * g, 1, 1], dtype=torch.float32, device=w0.device)
+            w1[:cf, :g] = layer.SFT_scale_conv1.weight
+            w1[cf:, g:] = layer.SFT_shift_conv1.weight
+            b1 = torch.cat([layer.SFT_scale_conv1.bias, layer.SFT_shift_conv1.bias], 0)
+            pk[prefix + '.b'] = _Packed(w1, b1)                                   # block diagonal -> [scale | shift]
+
+        for name in ('conv_first', 'conv_body', 'conv_up1', 'conv_up2', 'conv_hr', 'conv_last'):
+            if hasattr(self, name):
+                m = getattr(self, name)
+                pk[name] = _Packed(m.weight, m.bias)
+        for i in (0, 2, 4, 6):
+            pk[f'CondNet.{i}'] = _Packed(self.CondNet[i].weight, self.CondNet[i].bias)
+        for b, rr in enumerate(self.body):
+            for r in (1, 2, 3):
+                rdb = getattr(rr, f'rdb{r}')
+                for k in range(1, 6):
+                    m = getattr(rdb, f'conv{k}')
+                    pk[f'body.{b}.rdb{r}.conv{k}'] = _Packed(m.weight, m.bias)
+                sft(f'body.{b}.rdb{r}.sft0', rdb.sft0)
+                sft(f'body.{b}.rdb{r}.sft1', rdb.sft1)
+            sft(f'body.{b}.sft0', rr.sft0)
+        sft('sftbody', self.sftbody)
+        c['key'], c['packed'] = key, pk
+        return pk
+
+    def _buffers(self, h, w, dev):
+        key = (h, w, str(dev))
+        c = self._k4
+        if c.get('buf_key') != key:
+            nf, g, s = self.num_feat, self.num_grow_ch, self.scale
+            e = lambda hh, ww, ch: torch.empty([hh, ww, ch], dtype=torch.float32, device=dev)
+            b = {'feat': e(h, w, nf), 'cond': e(h, w, g), 'c64a': e(h, w, 64), 'c64b': e(h, w, 64),
+                 'trunk': e(h, w, nf), 'rrdb_in': e(h, w, nf), 'blk': e(h, w, nf + 4 * g), 't': e(h, w, 2 * g)}
+            hh, ww = h, w
+            if s > 1:
+                b['up1'] = e(2 * h, 2 * w, nf)
+                hh, ww = 2 * h, 2 * w
+                if s == 4:
+                    b['up2'] = e(4 * h, 4 * w, nf)
+                    hh, ww = 4 * h, 4 * w
+            b['hr'] = e(hh, ww, nf)
+            b['out'] = e(hh, ww, 3)
+            c['buf_key'], c['buf'] = key, b
+        return c['buf']
+
+    @staticmethod
+    def _conv(pk, x, x_off, x_stride, y, y_off, y_stride, cout, H, W, flags=0, res=None, mod=None):
+        """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))"""
+        rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
+        mp, ms = (None, 0) if mod is None else (N.C.c_void_p(mod[0].data_ptr() + 4 * mod[1]), mod[2])
+        N.check(N.lib().k4_conv2d_nhwc(
+            N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.f32(pk.w), N.f32(pk.b), pk.k,
+            N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags, 0.2,
+            rp, rs, rscale, mp, ms, N.stream()), 'k4_conv2d_nhwc')
+
+    def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None):
+        """SFTLayer (lib/sr_esrnet.py:120-123) as two launches: hidden = lrelu([scale0|shift0](cond));
+        y = x*(scale1(hidden)+1) + shift1(hidden) [*res_scale + res]."""
+        self._conv(pk[prefix + '.a'], B['cond'], 0, self.num_grow_ch, B['t'], 0, 2 * self.num_grow_ch,
+                   2 * self.num_grow_ch, h, w, EPI_LRELU)
+        flags = EPI_MODULATE | (EPI_RES if res is not None else 0)
+        self._conv(pk[prefix + '.b'], B['t'], 0, 2 * self.num_grow_ch, y, y_off, y_stride, cfeat, h, w, flags,
+                   res=res, mod=(x, x_off, x_stride))
+
+    @torch.no_grad()
+    def _forward_hip(self, x, cond):
+        assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
+        _, cin, h, w = x.shape
+        dev = x.device
+        nf, g, s = self.num_feat, self.num_grow_ch, self.scale
+        pk = self._packed()
+        B = self._buffers(h, w, dev)
+        xin = x[0].permute(1, 2, 0).contiguous().float()                 # NHWC [h][w][cin]
+        cnd = cond[0].permute(1, 2, 0).contiguous().float()
+        cv = self._conv
+        cv(pk['conv_first'], xin, 0, cin, B['feat'], 0, nf, nf, h, w)
+        cv(pk['CondNet.0'], cnd, 0, cnd.shape[2], B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
+        cv(pk['CondNet.2'], B['c64a'], 0, 64, B['c64b'], 0, 64, 64, h, w, EPI_LRELU)
+        cv(pk['CondNet.4'], B['c64b'], 0, 64, B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
+        cv(pk['CondNet.6'], B['c64a'], 0, 64, B['cond'], 0, g, g, h, w)
+        B['trunk'].copy_(B['feat'])
+        bw = nf + 4 * g
+        for b in range(self.num_block):
+            B['rrdb_in'].copy_(B['trunk'])
+            for r in (1, 2, 3):
+                p = f'body.{b}.rdb{r}'
+                self._sft(pk, p + '.sft0', B, h, w, B['trunk'], 0, nf, B['blk'], 0, bw, nf)          # xc0
+                for k in range(1, 5):                                                               # x1..x4
+                    cv(pk[f'{p}.conv{k}'], B['blk'], 0, bw, B['blk'], nf + (k - 1) * g, bw, g, h, w, EPI_LRELU)
+                self._sft(pk, p + '.sft1', B, h, w, B['blk'], nf + 3 * g, bw, B['blk'], nf + 3 * g, bw, g)  # xc1 in place
+                cv(pk[f'{p}.conv5'], B['blk'], 0, bw, B['trunk'], 0, nf, nf, h, w, EPI_RES,
+                   res=(B['trunk'], 0, nf, 0.2))                                                    # x5*0.2 + x
+            self._sft(pk, f'body.{b}.sft0', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf,
+                      res=(B['rrdb_in'], 0, nf, 0.2))                                               # sft(out)*0.2 + x
+        self._sft(pk, 'sftbody', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf)
+        cv(pk['conv_body'], B['trunk'], 0, nf, B['rrdb_in'], 0, nf, nf, h, w, EPI_RES,
+           res=(B['feat'], 0, nf, 1.0))                                                             # body_feat += feat
+        cur, hh, ww = B['rrdb_in'], h, w
+        if s > 1:
+            cv(pk['conv_up1'], cur, 0, nf, B['up1'], 0, nf, nf, 2 * h, 2 * w, EPI_LRELU | PRE_UP2X)
+            cur, hh, ww = B['up1'], 2 * h, 2 * w
+            if s == 4:
+                cv(pk['conv_up2'], cur, 0, nf, B['up2'], 0, nf, nf, 4 * h, 4 * w, EPI_LRELU | PRE_UP2X)
+                cur, hh, ww = B['up2'], 4 * h, 4 * w
+        cv(pk['conv_hr'], cur, 0, nf, B['hr'], 0, nf, nf, hh, ww, EPI_LRELU)
+        cv(pk['conv_last'], B['hr'], 0, nf, B['out'], 0, 3, 3, hh, ww)
+        return B['out'].permute(2, 0, 1).unsqueeze(0)                     # view [1,3,H,W] of the NHWC result
+
+    def forward(self, x, cond, fea=None):
+        if not x.is_cuda:
+            raise N.K4Error('SFTNet input must be on the GPU: the MI355X-native decoder has no CPU path')
+        if torch.is_grad_enabled() or fea is not None or self.dswise:
+            return self._forward_torch(x, cond, fea)
+        return self._forward_hip(x, cond).clone()
+
+    # ------------------------------------------------------------------ tiling (lib/sr_esrnet.py:467-527)
+    @staticmethod
+    def tile_geometry(height, width, tile_size, tile_pad=10):
+        tiles = []
+        for y in range(math.ceil(height / tile_size)):
+            for x in range(math.ceil(width / tile_size)):
+                x0, y0 = x * tile_size, y * tile_size
+                x1, y1 = min(x0 + tile_size, width), min(y0 + tile_size, height)
+                tiles.append((y0, y1, x0, x1, max(y0 - tile_pad, 0), min(y1 + tile_pad, height),
+                              max(x0 - tile_pad, 0), min(x1 + tile_pad, width)))
+        return tiles
+
+    @torch.no_grad()
+    def tile_process_device(self, img, cond, tile_size, tile_pad=10, tiles=None, out=None):
+        """Same tile geometry as the reference, result assembled on the DEVICE.  ``tiles``: optional subset of
+        ``tile_geometry`` (the multi-GPU renderer passes each rank its share)."""
+        _, ch, height, width = img.shape
+        s = self.scale
+        cond = cond.unsqueeze(0)
+        if out is None:
+            out = img.new_zeros((1, ch, height * s, width * s))
+        for (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in (tiles if tiles is not None else
+                                                      self.tile_geometry(height, width, tile_size, tile_pad)):
+            o = self._forward_hip(img[:, :, yp0:yp1, xp0:xp1], cond[:, :, yp0:yp1, xp0:xp1])
+            oy, ox = (y0 - yp0) * s, (x0 - xp0) * s
+            out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+        return out
+
+    def tile_process(self, img, cond, tile_size, tile_pad=10):
+        """Drop-in: returns a CPU tensor [1,3,scale*H,scale*W] like the reference (lib/sr_esrnet.py:477,526)."""
+        return self.tile_process_device(img, cond, tile_size, tile_pad).to('cpu')
+
+    # ------------------------------------------------------------------ checkpoint I/O (lib/sr_esrnet.py:529-621)
+    def load_network(self, load_path, device, strict=True, param_key='params_ema'):
+        load_net = torch.load(load_path, map_location=device, weights_only=False)
+        if param_key is not None:
+            if param_key not in load_net and 'params' in load_net:
+                param_key = 'params'
+            load_net = load_net[param_key]
+        for k, v in deepcopy(load_net).items():
+            if k.startswith('module.'):
+                load_net[k[7:]] = v
+                load_net.pop(k)
+        self._print_different_keys_loading(load_net, strict)
+        self.load_state_dict(load_net, strict=strict)
+
+    def _print_different_keys_loading(self, load_net, strict=True):
+        crt_net = self.state_dict()
+        if not strict:
+            for k in set(crt_net.keys()) & set(load_net.keys()):
+                if crt_net[k].size() != load_net[k].size():
+                    load_net[k + '.ignore'] = load_net.pop(k)              # skip size-mismatched tensors
+
+    def save_network(self, save_root, net_label, current_iter, param_key='params'):
+        if current_iter == -1:
+            current_iter = 'latest'
+        save_path = os.path.join(save_root, f'{net_label}_{current_iter}.pth')
+        state_dict = {(k[7:] if k.startswith('module.') else k): v.cpu() for k, v in self.state_dict().items()}
+        retry = 3
+        while retry > 0:
+            try:
+                torch.save({param_key: state_dict}, save_path)
+            except Exception:
+                time.sleep(1)
+            else:
+                break
+            finally:
+                retry -= 1

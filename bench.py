@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-stride', type=int, default=4, help='CPU baseline marches every k-th row and column')
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
+    ap.add_argument('--sr-frames', type=int, default=3, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
+                    'secondary frames/s figure (N=1 only; 0 disables)')
     return ap.parse_args()
 
 
@@ -168,12 +170,49 @@ def main():
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
                                                 'shaded': int(n_shade)}},
         }
+        if world == 1 and args.sr_frames > 0 and not args.small:
+            res['four_k'] = four_k_frames(model, rays, rk, H, W, dev, args.sr_frames)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def four_k_frames(model, rays, rk, H, W, dev, n_frames):
+    """BASELINE configs[2]: LLFF 4K render_test = march 1008x756 + SFTNet x4 with test_tile=510 (tile_pad=10) to
+    4032x3024, everything device resident (seeded SFTNet weights, oracle/sr recipe is NOT used: plain default init)."""
+    from nerf4k_amd.lib import sr_esrnet
+    torch.manual_seed(777)
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).eval()
+    flop_per_px = 10377728
+    px = sum((t[5] - t[4]) * (t[7] - t[6]) for t in net.tile_geometry(H, W, 510, 10))
+
+    def frame(i):
+        ro, rd, vd = rays[i % len(rays)]
+        out = model(ro, rd, vd, k4_img_w=W, **rk)
+        img = out['rgb_feature'].reshape(H, W, 3).permute(2, 0, 1).unsqueeze(0)      # unclamped, run_sr.py:1362
+        cond = out['depth'].reshape(1, H, W)
+        return net.tile_process_device(img, cond, 510)
+
+    with torch.no_grad():
+        frame(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = time.perf_counter()
+        e0.record()
+        for i in range(n_frames):
+            hr = frame(i)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n_frames
+    tflops = flop_per_px * px / dt / 1e12
+    return {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'output': list(hr.shape),
+            'workload': 'configs[2]: march 1008x756 + SFTNet x4 tile_process(510, pad 10) -> 4032x3024, fp32',
+            'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': 157.3, 'unit': 'TFLOP/s',
+                            'frac': round(tflops / 157.3, 4), 'flop_per_frame': flop_per_px * px,
+                            'note': 'fp32-input MFMA peak (v_mfma_f32_32x32x2_f32); time includes the marcher'}}
 
 
 def cpu_baseline(ck, pose, stride):

@@ -179,6 +179,34 @@ int k4_segment_sum(const float* src, const int64_t* index, int64_t n_pts, int32_
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Super-resolution decoder (SFTNet "VC-Decoder", lib/sr_esrnet.py:400-465): NHWC fp32 activations, fp32 MFMA
+ * implicit GEMM (csrc/k4_sr.hip).  Replaces the conv2d / leaky_relu / torch.cat / F.interpolate chain of
+ * SFTLayer (:112-123), ResidualDenseBlock_SFT (:149-158), RRDB_SFT (:176-182) and SFTNet.forward (:446-465).
+ * ------------------------------------------------------------------------------------------- */
+#define K4_EPI_LRELU       2u    /* y = y > 0 ? y : slope*y                        (after bias / modulation)   */
+#define K4_EPI_RES         4u    /* y = y*res_scale + res[pix][co]                 (after the activation)      */
+#define K4_EPI_MODULATE    8u    /* SFTLayer tail: the GEMM yields 2*cout channels [scale | shift];
+                                    y[co] = mod_x[pix][co]*(scale[co]+1) + shift[co]   (lib/sr_esrnet.py:123)   */
+#define K4_PRE_UPSAMPLE2X 16u    /* the input is read through a nearest x2 upsample (lib/sr_esrnet.py:461-463)  */
+
+/* stride-1 "same" (zero padded) 3x3 or 1x1 convolution, NHWC:
+ *   x        : [H_in][W_in][cin_stride], channels [0,cin) are read (pre-offset the pointer for a slice);
+ *              H_in,W_in = H,W or H/2,W/2 with K4_PRE_UPSAMPLE2X
+ *   w_packed : k4_conv_weight_floats() floats = [ceil(cin/8)][ksize*ksize][8][32*NT] (input-channel chunk, tap,
+ *              channel in chunk, output channel; zero padded), NT = ceil(N/32), N = cout (2*cout with MODULATE)
+ *   bias     : [32*NT] (zero padded)
+ *   y        : [H][W][cout_stride], channels [0,cout) are written (pre-offset the pointer for a slice)
+ *   res      : [H][W][res_stride] or NULL;  mod_x : [H][W][mod_stride] or NULL (may alias y)
+ * Supported N tiles: 3x3: N <= 64;  1x1: N <= 128. */
+int64_t k4_conv_weight_floats(int32_t cout, int32_t cin, int32_t ksize);
+int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
+                   const float* w_packed, const float* bias, int32_t ksize,
+                   float* y, int32_t cout, int32_t cout_stride,
+                   int32_t H, int32_t W, uint32_t flags, float slope,
+                   const float* res, int32_t res_stride, float res_scale,
+                   const float* mod_x, int32_t mod_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""GPU parity of the MFMA SFTNet decoder against the CPU oracle (oracle/sr.py) and the goldens produced by the
+UNMODIFIED reference module (tests/golden/sr_*.npz).
+
+Tolerance (fp32 MFMA = exact fp32 FMA chains, only the summation order differs from torch's CPU conv):
+PSNR(ours || oracle) >= 100 dB and max |err| <= 2e-4 on outputs of magnitude ~0.1-1 after ~80 stacked convs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd.lib import sr_esrnet
+from oracle import sr as osr
+from helpers import GOLDEN, psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(sd, nb):
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=nb, num_grow_ch=32, num_cond=1)
+    net.load_state_dict(sd)
+    return net.cuda().eval()
+
+
+def _check(got, want, min_psnr=100.0, max_abs=2e-4):
+    got = got.detach().cpu().float()
+    assert got.shape == want.shape
+    err = float((got - want).abs().max())
+    p = psnr(got, want)
+    assert p >= min_psnr and err <= max_abs, (p, err)
+
+
+@pytest.mark.parametrize('name', ['sr_full5', 'sr_tiles', 'sr_tiles510geom'])
+def test_sr_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    nb = int(z['num_block'])
+    sd = osr.make_state_dict(seed=int(z['seed']), num_block=nb)
+    net = _net(sd, nb)
+    x, cond, y = (torch.from_numpy(z[k]) for k in ('x', 'cond', 'y'))
+    with torch.no_grad():
+        if int(z['tile']) < 0:
+            o = net(x.cuda(), cond.unsqueeze(0).cuda())
+        else:
+            o = net.tile_process(x.cuda(), cond.cuda(), int(z['tile']))
+            assert o.device.type == 'cpu'                    # drop-in: the reference returns a CPU tensor
+    _check(o, y)
+
+
+def test_state_dict_keys_match_reference():
+    net = sr_esrnet.SFTNet(3, scale=4)
+    assert list(net.state_dict().keys()) == [k for k, _ in osr.state_dict_spec()]
+    assert len(net.state_dict()) == 458
+
+
+@pytest.mark.parametrize('hw', [(40, 72), (33, 65), (8, 32), (1, 1)])
+def test_sr_vs_oracle_ragged_sizes(hw):
+    """Sizes that do not fill the 8x32 pixel tiles / 32-wide MFMA blocks, incl. a 1x1 image."""
+    sd = osr.make_state_dict(seed=7, num_block=2)
+    net = _net(sd, 2)
+    g = torch.Generator().manual_seed(hw[0] * 100 + hw[1])
+    x = torch.rand([1, 3, *hw], generator=g)
+    cond = torch.rand([1, 1, *hw], generator=g)
+    want = osr.sftnet_forward(sd, x, cond)
+    with torch.no_grad():
+        got = net(x.cuda(), cond.cuda())
+    _check(got, want)
+    # the autograd (PyTorch-ROCm) graph computes the same function
+    got_t = net._forward_torch(x.cuda(), cond.cuda())
+    _check(got_t, want, min_psnr=90.0, max_abs=1e-3)
+
+
+def test_conv_kernel_epilogues():
+    """k4_conv2d_nhwc against F.conv2d for every epilogue / layout feature the decoder uses."""
+    import torch.nn.functional as F
+    from nerf4k_amd.lib.sr_esrnet import _Packed, SFTNet, EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X
+    g = torch.Generator().manual_seed(11)
+    H, W = 21, 45
+    for cin, cout, k in ((160, 32, 3), (192, 64, 3), (3, 64, 3), (64, 3, 3), (64, 32, 1), (1, 64, 3)):
+        x = torch.randn([H, W, 200], generator=g).cuda()             # read a channel slice [8 : 8+cin]
+        off = 8
+        w = (torch.randn([cout, cin, k, k], generator=g) / (cin * k * k) ** 0.5).cuda()
+        b = torch.randn([cout], generator=g).cuda()
+        res = torch.randn([H, W, 70], generator=g).cuda()
+        y = torch.zeros([H, W, 96]).cuda()
+        SFTNet._conv(_Packed(w, b), x, off, 200, y, 16, 96, cout, H, W, EPI_LRELU | EPI_RES, res=(res, 2, 70, 0.2))
+        xn = x[:, :, off:off + cin].permute(2, 0, 1).unsqueeze(0)
+        want = F.leaky_relu(F.conv2d(xn, w, b, padding=k // 2), 0.2)[0].permute(1, 2, 0) * 0.2 + res[:, :, 2:2 + cout]
+        assert torch.allclose(y[:, :, 16:16 + cout], want, atol=2e-5, rtol=1e-5), (cin, cout, k)
+        assert float(y[:, :, :16].abs().max()) == 0 and float(y[:, :, 16 + cout:].abs().max()) == 0
+    # nearest x2 upsample folded into the loader
+    x = torch.randn([10, 18, 64], generator=g).cuda()
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).cuda()
+    b = torch.randn([64], generator=g).cuda()
+    y = torch.empty([20, 36, 64]).cuda()
+    SFTNet._conv(_Packed(w, b), x, 0, 64, y, 0, 64, 64, 20, 36, PRE_UP2X)
+    want = F.conv2d(F.interpolate(x.permute(2, 0, 1).unsqueeze(0), scale_factor=2, mode='nearest'), w, b, padding=1)
+    assert torch.allclose(y, want[0].permute(1, 2, 0), atol=2e-5, rtol=1e-5)
+    # SFT modulation: x*(scale+1)+shift from one [2C] GEMM, in place
+    for C in (64, 32):
+        t = torch.randn([H, W, 64], generator=g).cuda()
+        w = (torch.randn([2 * C, 64, 1, 1], generator=g) / 8).cuda()
+        b = torch.randn([2 * C], generator=g).cuda()
+        xm = torch.randn([H, W, C], generator=g).cuda()
+        want = xm * (F.conv2d(t.permute(2, 0, 1).unsqueeze(0), w[:C], b[:C])[0].permute(1, 2, 0) + 1) + \
+            F.conv2d(t.permute(2, 0, 1).unsqueeze(0), w[C:], b[C:])[0].permute(1, 2, 0)
+        SFTNet._conv(_Packed(w, b), t, 0, 64, xm, 0, C, C, H, W, EPI_MODULATE, mod=(xm, 0, C))
+        assert torch.allclose(xm, want, atol=2e-5, rtol=1e-5), C
+
+
+def test_load_network_semantics(tmp_path):
+    sd = osr.make_state_dict(seed=3, num_block=1)
+    net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
+    p = tmp_path / 'a.pth'
+    torch.save({'params': {('module.' + k): v for k, v in sd.items()}}, p)       # params_ema missing, module. prefix
+    net.load_network(str(p), 'cpu')
+    assert torch.equal(net.conv_first.weight, sd['conv_first.weight'])
+    bad = dict(sd)
+    bad['conv_last.weight'] = torch.zeros(3, 8, 3, 3)                            # size mismatch is skipped when strict=False
+    torch.save({'params_ema': bad}, p)
+    net.load_network(str(p), 'cpu', strict=False)
+    net.save_network(str(tmp_path), 'sresrnet', -1)
+    assert 'params' in torch.load(tmp_path / 'sresrnet_latest.pth', weights_only=False)
