@@ -211,7 +211,7 @@ class SFTNet(nn.Module):
         c['key'], c['packed'] = key, pk
         return pk
 
-    def _buffers(self, h, w, dev):
+    def _k4_buffers(self, h, w, dev):
         key = (h, w, str(dev))
         c = self._k4
         if c.get('buf_key') != key:
@@ -257,7 +257,7 @@ class SFTNet(nn.Module):
         dev = x.device
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         pk = self._packed()
-        B = self._buffers(h, w, dev)
+        B = self._k4_buffers(h, w, dev)
         xin = x[0].permute(1, 2, 0).contiguous().float()                 # NHWC [h][w][cin]
         cnd = cond[0].permute(1, 2, 0).contiguous().float()
         cv = self._conv
