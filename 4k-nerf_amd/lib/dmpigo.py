@@ -181,13 +181,17 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                       k4_img_w=0, k4_counters=None, **_ignored):
+                       k4_img_w=0, k4_counters=None, k4_out=None, **_ignored):
         assert near == 0 and far == 1                                     # lib/dmpigo.py:275
         Nr = rays_o.shape[0]
         dev = rays_o.device
-        rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
-        depth = torch.empty([Nr], dtype=torch.float32, device=dev)
-        ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
+        if k4_out is not None:                  # caller-provided outputs (e.g. slices of an all-gather send buffer)
+            rgb, depth, ainv = k4_out
+            assert rgb.shape == (Nr, 3) and depth.shape == (Nr,) and ainv.shape == (Nr,)
+        else:
+            rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
+            depth = torch.empty([Nr], dtype=torch.float32, device=dev)
+            ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
         gd = self._k4_grid(act_shift_grid=self.act_shift.grid)
         md, _keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
         N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278

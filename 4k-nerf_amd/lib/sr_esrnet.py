@@ -212,24 +212,25 @@ class SFTNet(nn.Module):
         return pk
 
     def _k4_buffers(self, h, w, dev):
-        key = (h, w, str(dev))
+        """NHWC activation buffers: flat, capacity-cached (tile_process calls with several window sizes), viewed per call."""
+        nf, g, s = self.num_feat, self.num_grow_ch, self.scale
+        spec = {'feat': (1, nf), 'cond': (1, g), 'c64a': (1, 64), 'c64b': (1, 64), 'trunk': (1, nf), 'rrdb_in': (1, nf),
+                'blk': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3)}
+        if s > 1:
+            spec['up1'] = (2, nf)
+            if s == 4:
+                spec['up2'] = (4, nf)
         c = self._k4
-        if c.get('buf_key') != key:
-            nf, g, s = self.num_feat, self.num_grow_ch, self.scale
-            e = lambda hh, ww, ch: torch.empty([hh, ww, ch], dtype=torch.float32, device=dev)
-            b = {'feat': e(h, w, nf), 'cond': e(h, w, g), 'c64a': e(h, w, 64), 'c64b': e(h, w, 64),
-                 'trunk': e(h, w, nf), 'rrdb_in': e(h, w, nf), 'blk': e(h, w, nf + 4 * g), 't': e(h, w, 2 * g)}
-            hh, ww = h, w
-            if s > 1:
-                b['up1'] = e(2 * h, 2 * w, nf)
-                hh, ww = 2 * h, 2 * w
-                if s == 4:
-                    b['up2'] = e(4 * h, 4 * w, nf)
-                    hh, ww = 4 * h, 4 * w
-            b['hr'] = e(hh, ww, nf)
-            b['out'] = e(hh, ww, 3)
-            c['buf_key'], c['buf'] = key, b
-        return c['buf']
+        flat = c.setdefault('flat', {})
+        B = {}
+        for name, (m, ch) in spec.items():
+            need = h * m * w * m * ch
+            t = flat.get(name)
+            if t is None or t.numel() < need or t.device != dev:
+                t = torch.empty([need], dtype=torch.float32, device=dev)
+                flat[name] = t
+            B[name] = t[:need].view(h * m, w * m, ch)
+        return B
 
     @staticmethod
     def _conv(pk, x, x_off, x_stride, y, y_off, y_stride, cout, H, W, flags=0, res=None, mod=None):

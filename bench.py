@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-stride', type=int, default=4, help='CPU baseline marches every k-th row and column')
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
+    ap.add_argument('--backend', default='nccl', help=argparse.SUPPRESS)          # gloo + --same-device: 1-GPU logic smoke test
+    ap.add_argument('--same-device', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--sr-frames', type=int, default=3, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
                     'secondary frames/s figure (N=1 only; 0 disables)')
     return ap.parse_args()
@@ -56,11 +58,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)         # nccl IS RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -86,29 +93,42 @@ def main():
         print(f'[bench] scene ready in {time.time() - t0:.1f}s: world_size={model.world_size.tolist()} '
               f'k0_ch={model.k0_dim} rays/frame={H * W}', file=sys.stderr)
 
-    # band of pixel rows owned by this rank (all bands are multiples of 8 rows -> whole 8x8 tiles)
-    rows_per = ((H + world - 1) // world + 7) // 8 * 8
-    r0, r1 = min(rank * rows_per, H), min((rank + 1) * rows_per, H)
+    # band of pixel rows owned by this rank (multiples of 8 rows -> whole 8x8 wave tiles)
+    from nerf4k_amd import tile_parallel as tp
+    r0, r1, rows_per = tp.shard_rows(H, world, rank)
     rays = []
     with torch.no_grad():
         for p in poses:
             ro, rd, vd = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False)
             rays.append(tuple(x[r0:r1].reshape(-1, 3).contiguous() for x in (ro, rd, vd)))
     n_band = (r1 - r0) * W
-    gather_in = torch.empty([rows_per * W, 5], dtype=torch.float32, device=dev)
-    gather_out = torch.empty([world * rows_per * W, 5], dtype=torch.float32, device=dev) if world > 1 else None
+    slot = rows_per * W
+    # all-gather buffers (double buffered): [rgb n x 3 | depth n | alphainv n] -- the marcher writes straight into them
+    send = [torch.zeros([5 * slot], dtype=torch.float32, device=dev) for _ in range(2)]
+    recv = [torch.empty([world * 5 * slot], dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    outs = [(b[:3 * n_band].view(n_band, 3), b[3 * slot:3 * slot + n_band], b[4 * slot:4 * slot + n_band]) for b in send]
+    works = [None, None]
 
-    def step(i, counters=None):
+    def step(i, counters=None, timed=None):
+        b = i & 1
+        if works[b] is not None:
+            works[b].wait()                      # the collective that last read send[b] has finished
+            works[b] = None
         ro, rd, vd = rays[i % len(rays)]
-        out = model(ro, rd, vd, k4_img_w=W, k4_counters=counters, **rk)
-        if world > 1:
-            gather_in[:n_band, 0:3] = out['rgb_marched']
-            gather_in[:n_band, 3] = out['depth']
-            gather_in[:n_band, 4] = out['alphainv_last']
-            dist.all_gather_into_tensor(gather_out, gather_in)
+        if timed is not None:
+            timed[0].record()
+        out = model(ro, rd, vd, k4_img_w=W, k4_counters=counters, k4_out=outs[b], **rk)
+        if timed is not None:
+            timed[1].record()
+        if world > 1:                            # final pixels only; asynchronous, overlaps the next frame's march
+            works[b] = dist.all_gather_into_tensor(recv[b], send[b], async_op=True)
         return out
 
     def sync():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -120,15 +140,7 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         t_start = time.perf_counter()
         for i in range(args.steps):
-            ev[i][0].record()
-            ro, rd, vd = rays[i % len(rays)]
-            out = model(ro, rd, vd, k4_img_w=W, **rk)
-            ev[i][1].record()
-            if world > 1:
-                gather_in[:n_band, 0:3] = out['rgb_marched']
-                gather_in[:n_band, 3] = out['depth']
-                gather_in[:n_band, 4] = out['alphainv_last']
-                dist.all_gather_into_tensor(gather_out, gather_in)
+            step(i, timed=ev[i])
         sync()
         elapsed = time.perf_counter() - t_start
         kern_ms = [a.elapsed_time(b) for a, b in ev]
@@ -137,7 +149,7 @@ def main():
         cnt = torch.zeros(4, dtype=torch.int64, device=dev)
         for i in range(min(args.steps, len(rays))):
             step(i, counters=cnt)
-        torch.cuda.synchronize()
+        sync()
         nf = min(args.steps, len(rays))
         n_inb, n_mask, n_alpha, n_shade = [c / nf for c in cnt.cpu().tolist()]
 
@@ -165,13 +177,17 @@ def main():
             'frames_per_s_lr': round(args.steps / elapsed, 2),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'kernel': 'k4_march_kernel<MPI,64,1>', 'kernel_ms': round(k_ms, 4),
+                         'kernel': 'k4_geom_kernel<MPI> + k4_shade_kernel<MPI,64,1> (one marcher call)', 'kernel_ms': round(k_ms, 4),
                          'algorithmic_bytes_per_launch': int(b_alg),
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
                                                 'shaded': int(n_shade)}},
         }
-        if world == 1 and args.sr_frames > 0 and not args.small:
-            res['four_k'] = four_k_frames(model, rays, rk, H, W, dev, args.sr_frames)
+    four_k = None
+    if args.sr_frames > 0 and not args.small:
+        four_k = four_k_frames(model, poses, rk, H, W, K, dev, args.sr_frames, world)
+    if rank == 0:
+        if four_k is not None:
+            res['four_k'] = four_k
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
         print(json.dumps(res), flush=True)
@@ -180,39 +196,45 @@ def main():
         dist.destroy_process_group()
 
 
-def four_k_frames(model, rays, rk, H, W, dev, n_frames):
-    """BASELINE configs[2]: LLFF 4K render_test = march 1008x756 + SFTNet x4 with test_tile=510 (tile_pad=10) to
-    4032x3024, everything device resident (seeded SFTNet weights, oracle/sr recipe is NOT used: plain default init)."""
-    from nerf4k_amd.lib import sr_esrnet
+def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world):
+    """BASELINE configs[2] (N=1) / configs[3] (N>1): LLFF 4K render_test = march 1008x756 + SFTNet x4 to 4032x3024,
+    reference tile geometry (test_tile=510, tile_pad=10; 189 when more than 4 ranks need tiles), tiles sharded over
+    the ranks, ONE all-gather of the final HR pixels per frame.  SFTNet weights: seeded default init."""
+    from nerf4k_amd.lib import sr_esrnet, dvgo
+    from nerf4k_amd import tile_parallel as tp
     torch.manual_seed(777)
     net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).eval()
+    tile = {1: 510, 2: 510, 4: 252}.get(world, 189)       # balanced tile counts: 4 / 4 / 12 / 24 tiles
     flop_per_px = 10377728
-    px = sum((t[5] - t[4]) * (t[7] - t[6]) for t in net.tile_geometry(H, W, 510, 10))
-
-    def frame(i):
-        ro, rd, vd = rays[i % len(rays)]
-        out = model(ro, rd, vd, k4_img_w=W, **rk)
-        img = out['rgb_feature'].reshape(H, W, 3).permute(2, 0, 1).unsqueeze(0)      # unclamped, run_sr.py:1362
-        cond = out['depth'].reshape(1, H, W)
-        return net.tile_process_device(img, cond, 510)
-
+    px = sum((t[5] - t[4]) * (t[7] - t[6]) for t in tp.tile_geometry(H, W, tile, 10))
+    march_fn, sr_fn = tp.hip_march_fn(model, rk), tp.hip_sr_fn(net)
+    frames = []
     with torch.no_grad():
-        frame(0)
+        for p in poses[:max(2, min(n_frames, len(poses)))]:
+            frames.append(dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False))
+        hr = tp.render_frame_tiles(frames[0], H, W, march_fn, sr_fn, tile)           # warm-up (buffers, packing)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t = time.perf_counter()
-        e0.record()
         for i in range(n_frames):
-            hr = frame(i)
-        e1.record()
+            hr = tp.render_frame_tiles(frames[i % len(frames)], H, W, march_fn, sr_fn, tile, out=hr)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / n_frames
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
     tflops = flop_per_px * px / dt / 1e12
     return {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'output': list(hr.shape),
-            'workload': 'configs[2]: march 1008x756 + SFTNet x4 tile_process(510, pad 10) -> 4032x3024, fp32',
-            'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': 157.3, 'unit': 'TFLOP/s',
-                            'frac': round(tflops / 157.3, 4), 'flop_per_frame': flop_per_px * px,
-                            'note': 'fp32-input MFMA peak (v_mfma_f32_32x32x2_f32); time includes the marcher'}}
+            'n_gpus': world, 'test_tile': tile,
+            'workload': ('configs[2]' if world == 1 else 'configs[3]') + ': march 1008x756 + SFTNet x4 tile_process('
+                        f'{tile}, pad 10) -> 4032x3024, fp32' + (f', tiles sharded over {world} GPUs + all-gather of HR pixels' if world > 1 else ''),
+            'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': 157.3 * world, 'unit': 'TFLOP/s',
+                            'frac': round(tflops / (157.3 * world), 4), 'flop_per_frame': flop_per_px * px,
+                            'note': 'fp32-input MFMA peak (v_mfma_f32_32x32x2_f32) x n_gpus; time includes marcher + all-gather'}}
 
 
 def cpu_baseline(ck, pose, stride):
