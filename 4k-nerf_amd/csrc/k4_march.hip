@@ -30,6 +30,7 @@
 //     5 floats per ray are the only other global writes.
 // Deterministic: no atomics on the data path, fixed summation order.
 #include "k4_common.h"
+#include <stdlib.h>
 
 #define MODE_MPI  0
 #define MODE_DVGO 1
@@ -52,6 +53,7 @@ struct MarchParams {
     float stepdist, near_, far_, shift, interval, thres, bg;
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
     int n_bundles;
+    int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
 
@@ -128,6 +130,8 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
     unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0;
     int cnt = 0;
     float my_ainv = 1.f;
+    const float tk0 = step_t<MODE>(P, lane), tk1 = step_t<MODE>(P, 64 + lane), tk2 = step_t<MODE>(P, 128 + lane),
+                tk3 = step_t<MODE>(P, 192 + lane);
 
     for (int r = 0; r < 64; ++r) {
         const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, r));
@@ -141,7 +145,10 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
         for (int base = 0; base < nsteps; base += 64) {
             // ------------------ 64 consecutive samples of ray r ------------------
             const int k = base + lane;
-            const float tk = step_t<MODE>(P, k);
+            float tk;
+            if (MODE == MODE_MPI && base < 256) {       // t_k = k/(Ns-1) does not depend on the ray: the division is hoisted
+                tk = base == 0 ? tk0 : (base == 64 ? tk1 : (base == 128 ? tk2 : tk3));
+            } else tk = step_t<MODE>(P, k);
             const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
             const bool inb = (k < nsteps) &&
                 !((P.minx > px) | (P.miny > py) | (P.minz > pz) | (P.maxx < px) | (P.maxy < py) | (P.maxz < pz));
@@ -170,8 +177,12 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
                 const int x1 = min(t.x0 + 1, P.X - 1), y1 = min(t.y0 + 1, P.Y - 1), z1 = min(t.z0 + 1, P.Z - 1);
                 const unsigned r00 = (unsigned)(t.x0 * P.Y + t.y0) * (unsigned)P.Z, r01 = (unsigned)(t.x0 * P.Y + y1) * (unsigned)P.Z;
                 const unsigned r10 = (unsigned)(x1 * P.Y + t.y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
-                const float d0 = P.density[r00 + t.z0], d1 = P.density[r00 + z1], d2 = P.density[r01 + t.z0], d3 = P.density[r01 + z1];
-                const float d4 = P.density[r10 + t.z0], d5 = P.density[r10 + z1], d6 = P.density[r11 + t.z0], d7 = P.density[r11 + z1];
+                float d0, d1, d2, d3, d4, d5, d6, d7;
+                if (P.debug & 16) { d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = -3.f + t.w[0]; }
+                else {
+                d0 = P.density[r00 + t.z0]; d1 = P.density[r00 + z1]; d2 = P.density[r01 + t.z0]; d3 = P.density[r01 + z1];
+                d4 = P.density[r10 + t.z0]; d5 = P.density[r10 + z1]; d6 = P.density[r11 + t.z0]; d7 = P.density[r11 + z1];
+                }
                 sigma += d0 * t.w[0]; sigma += d1 * t.w[1]; sigma += d2 * t.w[2]; sigma += d3 * t.w[3];
                 sigma += d4 * t.w[4]; sigma += d5 * t.w[5]; sigma += d6 * t.w[6]; sigma += d7 * t.w[7];
                 if (MODE == MODE_MPI) {
@@ -194,13 +205,17 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
             if (P.counters) n_alpha += __popcll(bm);
             float w = 0.f;
             bool proc = false, stop = false;
+            if (P.debug & 32) { w = alpha * 0.01f; proc = act; bm = 0; }
             while (bm) {
                 const int l = __builtin_ctzll(bm);
                 const float a = k4_readlane(alpha, l);
                 if (lane == l) { w = T * a; proc = true; }
-                T = (float)((double)T * (1.0 - (double)a));               // `T_cum *= (1. - alpha[i])`
+                // `T_cum *= (1. - alpha[i])` is evaluated in double by the CUDA source and rounded to float:
+                // round(T*(1-a)) with an exact (1-a).  fmaf(-T,a,T) = round(T - T*a) is the same single rounding of the
+                // same real number (the double route differs only by double rounding, p ~ 2^-29 per step), at a third of the cost.
+                T = fmaf(-T, a, T);
                 bm &= bm - 1;
-                if ((double)T < 1e-3) { stop = true; break; }             // sample l itself is still counted (:597-600)
+                if (T < 1e-3f) { stop = true; break; }                    // == (double)T < 1e-3 for every float T; sample l is still counted (:597-600)
             }
             const bool shade = proc && (use_thres ? (w > P.thres) : true);
             const uint64_t sm = __ballot(shade);
@@ -240,6 +255,87 @@ struct MlpLayout {
     __device__ static int bo(int k1p) { return wot(k1p) + NB * 16 * 2 * 4; }
     __device__ static int total(int k1p) { return bo(k1p) + 4; }
 };
+
+// rgbnet on the matrix cores: logits[3] of the sample owned by this lane, features read from LDS feat[K1P][64].
+template <int W, int NHID>
+__device__ __forceinline__ void mlp_mfma(const float* wl, const float* feat, int k1p_, int lane, int half, int debug_,
+                                         float& out0, float& out1, float& out2) {
+    constexpr int NB = W / 32;
+    typedef MlpLayout<W, NHID> ML;
+    const struct { int k1p; int debug; } P = {k1p_, debug_};
+    // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s]  ----------------
+    f32x16 h1[NB][2];
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) { h1[mb][0] = (f32x16)(0.f); h1[mb][1] = (f32x16)(0.f); }
+    const float* const w1a = wl + ML::w1a(P.k1p);
+    const int ksteps = (P.debug & 2) ? 0 : (P.k1p >> 1);
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const float b0 = feat[(2 * kk + half) * 64 + (lane & 31)];
+        const float b1 = feat[(2 * kk + half) * 64 + 32 + (lane & 31)];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+            const float a = w1a[(mb * ksteps + kk) * 64 + lane];
+            h1[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, h1[mb][0], 0, 0, 0);
+            h1[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, h1[mb][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { h1[mb][0][r] = fmaxf(h1[mb][0][r], 0.f); h1[mb][1][r] = fmaxf(h1[mb][1][r], 0.f); }
+
+    // partial output sums of the two 32-sample tiles (this lane: neurons row(r,half) of each block)
+    float pt[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const float* const wot = wl + ML::wot(P.k1p);
+    if (NHID == 1 && !(P.debug & 2)) {
+        const float* const w2a = wl + ML::w2a(P.k1p);
+        const float* const b2a = wl + ML::b2a(P.k1p);
+#pragma unroll 1
+        for (int mb2 = 0; mb2 < NB; ++mb2) {
+            f32x16 c0 = (f32x16)(0.f), c1 = (f32x16)(0.f);
+            {   // bias: k-step with A = [b2 | 0], B = 1
+                const float a = b2a[mb2 * 64 + lane];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.f, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.f, c1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = w2a[((mb2 * NB + mb) * 16 + r) * 64 + lane];
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[mb][0][r], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[mb][1][r], c1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
+                const float a0 = fmaxf(c0[r], 0.f), a1 = fmaxf(c1[r], 0.f);
+                pt[0][0] = fmaf(wo.x, a0, pt[0][0]); pt[0][1] = fmaf(wo.y, a0, pt[0][1]); pt[0][2] = fmaf(wo.z, a0, pt[0][2]);
+                pt[1][0] = fmaf(wo.x, a1, pt[1][0]); pt[1][1] = fmaf(wo.y, a1, pt[1][1]); pt[1][2] = fmaf(wo.z, a1, pt[1][2]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
+                const float a0 = h1[mb][0][r], a1 = h1[mb][1][r];
+                pt[0][0] = fmaf(wo.x, a0, pt[0][0]); pt[0][1] = fmaf(wo.y, a0, pt[0][1]); pt[0][2] = fmaf(wo.z, a0, pt[0][2]);
+                pt[1][0] = fmaf(wo.x, a1, pt[1][0]); pt[1][1] = fmaf(wo.y, a1, pt[1][1]); pt[1][2] = fmaf(wo.z, a1, pt[1][2]);
+            }
+    }
+    // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of each tile
+    const float* const bo = wl + ML::bo(P.k1p);
+    float q[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[tt][c] = pt[tt][c] + __shfl_xor(pt[tt][c], 32) + bo[c];
+    out0 = half ? q[1][0] : q[0][0];
+    out1 = half ? q[1][1] : q[0][1];
+    out2 = half ? q[1][2] : q[0][2];
+}
 
 template <int MODE, int WIDTH, int NHID>
 __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
@@ -324,7 +420,7 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        const float4 q = *reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * P.CP + g);
+                        const float4 q = (P.debug & 1) ? make_float4(cw[c], 0.5f, 0.25f, 1.f) : *reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * P.CP + g);
                         v.x += q.x * cw[c]; v.y += q.y * cw[c]; v.z += q.z * cw[c]; v.w += q.w * cw[c];
                     }
                     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -382,78 +478,9 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
             for (int kx = fi + 1; kx < P.k1p; ++kx) feat[kx * 64 + lane] = 0.f;
             __builtin_amdgcn_wave_barrier();
 
-            // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s]  ----------------
-            f32x16 h1[NB][2];
-#pragma unroll
-            for (int mb = 0; mb < NB; ++mb) { h1[mb][0] = (f32x16)(0.f); h1[mb][1] = (f32x16)(0.f); }
-            const float* const w1a = wl + ML::w1a(P.k1p);
-            const int ksteps = P.k1p >> 1;
-            for (int kk = 0; kk < ksteps; ++kk) {
-                const float b0 = feat[(2 * kk + half) * 64 + (lane & 31)];
-                const float b1 = feat[(2 * kk + half) * 64 + 32 + (lane & 31)];
-#pragma unroll
-                for (int mb = 0; mb < NB; ++mb) {
-                    const float a = w1a[(mb * ksteps + kk) * 64 + lane];
-                    h1[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, h1[mb][0], 0, 0, 0);
-                    h1[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, h1[mb][1], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { h1[mb][0][r] = fmaxf(h1[mb][0][r], 0.f); h1[mb][1][r] = fmaxf(h1[mb][1][r], 0.f); }
-
-            // partial output sums of the two 32-sample tiles (this lane: neurons row(r,half) of each block)
-            float pt[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            const float* const wot = wl + ML::wot(P.k1p);
-            if (NHID == 1) {
-                const float* const w2a = wl + ML::w2a(P.k1p);
-                const float* const b2a = wl + ML::b2a(P.k1p);
-#pragma unroll 1
-                for (int mb2 = 0; mb2 < NB; ++mb2) {
-                    f32x16 c0 = (f32x16)(0.f), c1 = (f32x16)(0.f);
-                    {   // bias: k-step with A = [b2 | 0], B = 1
-                        const float a = b2a[mb2 * 64 + lane];
-                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.f, c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.f, c1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float a = w2a[((mb2 * NB + mb) * 16 + r) * 64 + lane];
-                            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[mb][0][r], c0, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[mb][1][r], c1, 0, 0, 0);
-                        }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
-                        const float a0 = fmaxf(c0[r], 0.f), a1 = fmaxf(c1[r], 0.f);
-                        pt[0][0] = fmaf(wo.x, a0, pt[0][0]); pt[0][1] = fmaf(wo.y, a0, pt[0][1]); pt[0][2] = fmaf(wo.z, a0, pt[0][2]);
-                        pt[1][0] = fmaf(wo.x, a1, pt[1][0]); pt[1][1] = fmaf(wo.y, a1, pt[1][1]); pt[1][2] = fmaf(wo.z, a1, pt[1][2]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
-                        const float a0 = h1[mb][0][r], a1 = h1[mb][1][r];
-                        pt[0][0] = fmaf(wo.x, a0, pt[0][0]); pt[0][1] = fmaf(wo.y, a0, pt[0][1]); pt[0][2] = fmaf(wo.z, a0, pt[0][2]);
-                        pt[1][0] = fmaf(wo.x, a1, pt[1][0]); pt[1][1] = fmaf(wo.y, a1, pt[1][1]); pt[1][2] = fmaf(wo.z, a1, pt[1][2]);
-                    }
-            }
-            // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of each tile
-            const float* const bo = wl + ML::bo(P.k1p);
-            float q[2][3];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) q[tt][c] = pt[tt][c] + __shfl_xor(pt[tt][c], 32) + bo[c];
-            o0 = (half ? q[1][0] : q[0][0]) + dif0;                      // rgb_logit + k0_diffuse (lib/dvgo.py:412)
-            o1 = (half ? q[1][1] : q[0][1]) + dif1;
-            o2 = (half ? q[1][2] : q[0][2]) + dif2;
+            float l0, l1, l2;
+            mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
+            o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
         }
         // sigmoid, blend
@@ -489,6 +516,212 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
     }   // bundle queue
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// K2, software-pipelined form (k0 channel-last with CP == 12, i.e. 9..12 feature channels -- both BASELINE models).
+// Measured on the plain form: gather phase (dependent loads, ~14 us per 64-sample batch per wave) and MFMA phase
+// (164 x 64 cycles) simply ADD, the waves of a SIMD do not hide each other.  Here each wave hides its own latency:
+// the 24 x 16-B corner gathers of batch i+1 are issued BEFORE the MFMAs of batch i and consumed after them, the
+// 8-byte records are fetched two batches ahead, and the per-ray setup (start, dir, viewdir) of the bundle's 64 rays
+// sits in LDS so the only global dependency chain left is record -> gather.
+// -----------------------------------------------------------------------------------------------------
+struct ShadePrep {
+    float w; int rl; int k; bool lact;
+    float nx, ny, nz;
+    float cw[8];
+};
+
+__device__ __forceinline__ unsigned k4_lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// async global -> LDS copy of 16 B per lane (LDS-DMA, no VGPR round trip): lands at lds_dst + lane*16.  hipcc does not
+// count it in its vmcnt bookkeeping: the consumer waits explicitly (shade_wait_stage).
+__device__ __forceinline__ void k4_glds16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void shade_wait_stage() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Decode one record, look the ray up in the bundle table, and put the 8 x 48-B corner reads of the sample in flight
+// towards the wave's LDS staging area stage[c*3+q][lane] (float4).
+template <int MODE>
+__device__ __forceinline__ void shade_issue(const MarchParams& P, const float* raytab, uint2 en, bool lact,
+                                            ShadePrep& S, unsigned stage_lds) {
+    S.lact = lact;
+    S.w = lact ? __uint_as_float(en.y) : 0.f;
+    S.rl = (int)(en.x >> 24);
+    S.k = (int)(en.x & 0xffffffu);
+    const float* rt = raytab + S.rl * 12;
+    const float tk = step_t<MODE>(P, S.k);
+    const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
+    S.nx = k4_norm_coord(px, P.minx, P.maxx);
+    S.ny = k4_norm_coord(py, P.miny, P.maxy);
+    S.nz = k4_norm_coord(pz, P.minz, P.maxz);
+    const K4Tri t = k4_tri_setup(k4_unnorm(S.nx, P.X), k4_unnorm(S.ny, P.Y), k4_unnorm(S.nz, P.Z));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous batch's reads of the staging area are done
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
+        const bool ok = (unsigned)x < (unsigned)P.X && (unsigned)y < (unsigned)P.Y && (unsigned)z < (unsigned)P.Z;
+        const unsigned idx = ok ? (unsigned)(x * P.Y + y) * (unsigned)P.Z + (unsigned)z : 0u;
+        S.cw[c] = ok ? t.w[c] : 0.f;
+        const float* src = P.k0 + (size_t)idx * 12;
+        k4_glds16(src, stage_lds + (unsigned)((c * 3 + 0) * 1024));
+        k4_glds16(src + 4, stage_lds + (unsigned)((c * 3 + 1) * 1024));
+        k4_glds16(src + 8, stage_lds + (unsigned)((c * 3 + 2) * 1024));
+    }
+}
+
+template <int MODE, int WIDTH, int NHID>
+__global__ __launch_bounds__(256, 2) void k4_shade_pipe_kernel(const MarchParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int W = WIDTH;
+    const int lane = k4_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int mlp_pad = (P.mlp_floats + 3) & ~3;
+    float* const wl = smem;
+    const int per_wave = 64 * 4 + P.k1p * 64 + 64 * 12 + 24 * 64 * 4;
+    float* const acc = smem + mlp_pad + wv * per_wave;        // [64][4]  r,g,b,depth
+    float* const feat = acc + 64 * 4;                          // [K1P][64]
+    float* const raytab = feat + P.k1p * 64;                   // [64][12] start xyz, dir xyz, viewdir xyz
+    const float4* const stage = reinterpret_cast<const float4*>(raytab + 64 * 12);   // [24][64] float4: gathered corners
+    const unsigned stage_lds = __builtin_amdgcn_readfirstlane(k4_lds_addr(stage));
+    for (int i = threadIdx.x; i < P.mlp_floats; i += 256) wl[i] = P.mlp[i];
+    __syncthreads();
+    const int half = lane >> 5;
+
+    for (;;) {
+        int bid = 0;
+        if (lane == 0) bid = atomicAdd(P.qhead, 1);
+        bid = __builtin_amdgcn_readfirstlane(bid);
+        if (bid >= P.n_bundles) break;
+        const Bundle B = bundle_from_id(P, bid);
+        const uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+        const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
+        const int myray = ray_index(P, B, lane);
+        acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
+        if (total > 0) {
+            // per-ray table of the bundle (lane = ray)
+            const int rs = myray < 0 ? 0 : myray;
+            float sx, sy, sz, dx, dy, dz;
+            int nsteps_unused;
+            ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
+                            P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps_unused);
+            float* rt = raytab + lane * 12;
+            rt[0] = sx; rt[1] = sy; rt[2] = sz; rt[3] = dx; rt[4] = dy; rt[5] = dz;
+            rt[6] = P.viewdirs[rs * 3 + 0]; rt[7] = P.viewdirs[rs * 3 + 1]; rt[8] = P.viewdirs[rs * 3 + 2];
+            __builtin_amdgcn_wave_barrier();
+
+            const int nb = (total + 63) >> 6;
+            ShadePrep cur;
+            uint2 e_next = ent[lane < total ? lane : 0];
+            shade_issue<MODE>(P, raytab, e_next, lane < total, cur, stage_lds);
+            e_next = ent[(64 + lane) < total ? (64 + lane) : 0];
+
+            for (int i = 0; i < nb; ++i) {
+                // ---- 1. features of batch i from the corners staged in LDS (the only wait on the gathers) ----
+                shade_wait_stage();
+                float v[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) v[q] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float wc = cur.cw[c];
+                    const float4 g0 = stage[(c * 3 + 0) * 64 + lane], g1 = stage[(c * 3 + 1) * 64 + lane], g2 = stage[(c * 3 + 2) * 64 + lane];
+                    v[0] += g0.x * wc; v[1] += g0.y * wc; v[2] += g0.z * wc; v[3] += g0.w * wc;
+                    v[4] += g1.x * wc; v[5] += g1.y * wc; v[6] += g1.z * wc; v[7] += g1.w * wc;
+                    v[8] += g2.x * wc; v[9] += g2.y * wc; v[10] += g2.z * wc; v[11] += g2.w * wc;
+                }
+                float dif0 = 0.f, dif1 = 0.f, dif2 = 0.f;
+                if (P.k0_skip) { dif0 = v[0]; dif1 = v[1]; dif2 = v[2]; }
+#pragma unroll
+                for (int q = 0; q < 12; ++q)
+                    if (q >= P.k0_skip && q < P.C) feat[(q - P.k0_skip) * 64 + lane] = v[q];
+                int fi = P.C - P.k0_skip;
+                if (MODE == MODE_MPI) {
+                    const float pe[3] = {cur.nz, cur.ny, cur.nx};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) feat[(fi + c) * 64 + lane] = pe[c];
+                    fi += 3;
+                    for (int f = 0; f < P.spe; ++f) {
+                        const float fr = (float)(1 << f);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            feat[(fi + c * P.spe + f) * 64 + lane] = sinf(pe[c] * fr);
+                            feat[(fi + 3 * P.spe + c * P.spe + f) * 64 + lane] = cosf(pe[c] * fr);
+                        }
+                    }
+                    fi += 6 * P.spe;
+                }
+                {
+                    const float* rt2 = raytab + cur.rl * 12;
+                    const float vd[3] = {rt2[6], rt2[7], rt2[8]};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) feat[(fi + c) * 64 + lane] = vd[c];
+                    fi += 3;
+                    for (int f = 0; f < P.vpe; ++f) {
+                        const float fr = (float)(1 << f);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            feat[(fi + c * P.vpe + f) * 64 + lane] = sinf(vd[c] * fr);
+                            feat[(fi + 3 * P.vpe + c * P.vpe + f) * 64 + lane] = cosf(vd[c] * fr);
+                        }
+                    }
+                    fi += 6 * P.vpe;
+                }
+                feat[fi * 64 + lane] = 1.f;
+                for (int kx = fi + 1; kx < P.k1p; ++kx) feat[kx * 64 + lane] = 0.f;
+                const float w_i = cur.w;
+                const int k_i = cur.k, rl_i = cur.rl;
+                const bool lact_i = cur.lact;
+                __builtin_amdgcn_wave_barrier();
+
+                // ---- 2. put batch i+1 in flight: gathers now, its record was fetched one iteration ago ----
+                // (unconditional: a branch here makes hipcc drain vmcnt at the join, i.e. before the MFMAs; past the last
+                //  batch the lanes are inactive and re-read record 0 of the bundle -- harmless, cache resident)
+                {
+                    const int b1 = (i + 1) * 64;
+                    shade_issue<MODE>(P, raytab, e_next, (b1 + lane) < total, cur, stage_lds);
+                    const int b2 = b1 + 64 + lane;
+                    e_next = ent[b2 < total ? b2 : 0];
+                }
+
+                // ---- 3. MLP of batch i on the matrix cores (the gathers of batch i+1 fly meanwhile) ----
+                float l0, l1, l2;
+                mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
+                const float o0 = l0 + dif0, o1 = l1 + dif1, o2 = l2 + dif2;
+
+                // ---- 4. sigmoid, blend, segmented scan per ray ----
+                float v0 = w_i * (1.f / (1.f + expf(-o0)));
+                float v1 = w_i * (1.f / (1.f + expf(-o1)));
+                float v2 = w_i * (1.f / (1.f + expf(-o2)));
+                float v3 = w_i * (((float)k_i + 0.5f) / (float)P.depth_n);
+                const int keyr = lact_i ? rl_i : (256 + lane);
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int ok_ = __shfl_up(keyr, off);
+                    const float u0 = __shfl_up(v0, off), u1 = __shfl_up(v1, off), u2 = __shfl_up(v2, off), u3 = __shfl_up(v3, off);
+                    if (lane >= off && ok_ == keyr) { v0 += u0; v1 += u1; v2 += u2; v3 += u3; }
+                }
+                const int nextk = __shfl_down(keyr, 1);
+                if (lact_i && (lane == 63 || nextk != keyr)) {
+                    acc[rl_i * 4 + 0] += v0; acc[rl_i * 4 + 1] += v1; acc[rl_i * 4 + 2] += v2; acc[rl_i * 4 + 3] += v3;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (myray >= 0) {
+            const float ab = P.out_ainv[myray] * P.bg;
+            P.out_rgb[(size_t)myray * 3 + 0] = acc[lane * 4 + 0] + ab;
+            P.out_rgb[(size_t)myray * 3 + 1] = acc[lane * 4 + 1] + ab;
+            P.out_rgb[(size_t)myray * 3 + 2] = acc[lane * 4 + 2] + ab;
+            P.out_depth[myray] = acc[lane * 4 + 3];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -521,14 +754,22 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    const dim3 sgrid((unsigned)min(nwg, n_cu * 3));
-    const size_t lds = sizeof(float) * (((size_t)P.mlp_floats + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    const size_t lds_base = sizeof(float) * (((size_t)P.mlp_floats + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    const size_t lds_pipe = lds_base + sizeof(float) * 4 * (64 * 12 + 24 * 64 * 4);       // + ray table + 24 KB staging per wave
+    // pipelined kernel: k0 channel-last with 12 channels and room for the staging area beside the weights (W<=64)
+    const bool pipe = width != 0 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && lds_pipe <= 160 * 1024 &&
+                      !getenv("K4_NO_PIPE");
+    const int wg_per_cu = pipe ? 1 : 3;             // the pipelined kernel runs ONE self-overlapping wave per SIMD
+    const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
+    const size_t lds = pipe ? lds_pipe : lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
-#define K4_LAUNCH(WD, NH) do { \
+#define K4_LAUNCH_K(KERN) do { \
         if (lds > 64 * 1024) { \
-            hipError_t e_ = hipFuncSetAttribute((const void*)k4_shade_kernel<MODE, WD, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
-        hipLaunchKernelGGL((k4_shade_kernel<MODE, WD, NH>), sgrid, block, lds, st, P); } while (0)
+        hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)
+#define K4_LAUNCH(WD, NH) do { if (pipe && WD > 0) K4_LAUNCH_K((k4_shade_pipe_kernel<MODE, (WD > 0 ? WD : 32), NH>)); \
+                               else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH>)); } while (0)
     if (width == 0) K4_LAUNCH(0, 0);
     else if (width == 32 && nh == 0) K4_LAUNCH(32, 0);
     else if (width == 32 && nh == 1) K4_LAUNCH(32, 1);
@@ -537,6 +778,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     else if (width == 128 && nh == 0) K4_LAUNCH(128, 0);
     else if (width == 128 && nh == 1) K4_LAUNCH(128, 1);
     else return K4_ERR_UNSUPPORTED;
+#undef K4_LAUNCH_K
 #undef K4_LAUNCH
     return k4_check_launch();
 }
@@ -580,6 +822,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.counts = (int*)((char*)workspace + nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
     P.n_bundles = (int)nb;
+    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;

@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void k_alpha2weight(const float* __restrict__ 
             const int l = __builtin_ctzll(bm);
             const float al = k4_readlane(a, l);
             if (lane == l) { myT = T; myw = T * al; }
-            T = (float)((double)T * (1.0 - (double)al));
+            T = fmaf(-T, al, T);                      // == round(T*(1-al)), see k4_march.hip
             bm &= bm - 1;
-            if ((double)T < 1e-3) { stopped = true; stop_at = base + l + 1; break; }
+            if (T < 1e-3f) { stopped = true; stop_at = base + l + 1; break; }
         }
         if (v && i < stop_at) { Tout[i] = myT; weight[i] = myw; }
     }

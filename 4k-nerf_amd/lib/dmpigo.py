@@ -181,7 +181,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                       k4_img_w=0, k4_counters=None, k4_out=None, **_ignored):
+                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, **_ignored):
         assert near == 0 and far == 1                                     # lib/dmpigo.py:275
         Nr = rays_o.shape[0]
         dev = rays_o.device
@@ -197,7 +197,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278
         interval = float(stepsize * self.voxel_size_ratio)                # lib/dmpigo.py:306
         if Nr > 0:
-            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev)
+            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot)
             N.check(N.lib().k4_march_mpi_fwd(
                 N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
                 N_samples, interval, float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes,

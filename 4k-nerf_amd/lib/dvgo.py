@@ -79,17 +79,18 @@ class _FusedMarcher:
         md.n_hidden = len(lins) - 2
         return md, c['mlp_packed']
 
-    def _k4_workspace(self, n_rays, img_w, max_steps, device):
+    def _k4_workspace(self, n_rays, img_w, max_steps, device, slot=0):
         """Scratch between the geometry and the shading kernel: worst-case sized (every sample of every ray
-        shaded), sparsely touched, cached and grown on demand; one per module and stream of use."""
+        shaded), sparsely touched, cached and grown on demand.  One per ``slot``: calls that may be in flight
+        concurrently (different HIP streams) must use different slots (render_kwargs['k4_ws_slot'])."""
         need = int(N.lib().k4_march_workspace_bytes(int(n_rays), int(img_w), int(max_steps)))
         if need < 0:
             raise N.K4Error('k4_march_workspace_bytes: bad arguments')
         c = self._k4_cache()
-        ws = c.get('workspace')
+        ws = c.get(('workspace', slot))
         if ws is None or ws.numel() < need or ws.device != device:
             ws = torch.empty([max(need, 256)], dtype=torch.uint8, device=device)
-            c['workspace'] = ws
+            c[('workspace', slot)] = ws
         return ws, need
 
     def _k4_grid(self, act_shift_grid=None):
@@ -282,7 +283,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                       k4_img_w=0, k4_counters=None, k4_out=None, **_ignored):
+                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, **_ignored):
         Nr = rays_o.shape[0]
         dev = rays_o.device
         if k4_out is not None:                  # caller-provided outputs (e.g. slices of an all-gather send buffer)
@@ -304,7 +305,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             if render_depth:
                 ret['depth'] = depth
             return ret
-        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev)
+        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot)
         N.check(N.lib().k4_march_dvgo_fwd(
             N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
             float(near), 1e9, stepdist, max_steps, depth_n, self._k4_host_scalar('act_shift', self.act_shift), interval,
