@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-stride', type=int, default=4, help='CPU baseline marches every k-th row and column')
+    ap.add_argument('--cpu-stride', type=int, default=1, help='CPU baseline marches every k-th row and column')
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams frames alternate on (2: the geometry kernel of frame '
                     'i+1 overlaps the matrix-core shading kernel of frame i)')
