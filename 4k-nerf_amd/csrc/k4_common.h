@@ -42,6 +42,16 @@ __device__ __forceinline__ int k4_xcd_remap(int b, int nwg) {
 __device__ __forceinline__ float k4_norm_coord(float p, float lo, float hi) {
     return ((p - lo) / (hi - lo)) * 2.f - 1.f;
 }
+// Same value, 3 VALU instead of ~10: correctly rounded a/b from the correctly rounded reciprocal y = RN(1/b) of a
+// wave-uniform divisor (Markstein: q0 = RN(a*y); r = a - b*q0 exactly (FMA); q = RN(q0 + r*y) is RN(a/b)).
+__device__ __forceinline__ float k4_div_by(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = fmaf(-b, q0, a);
+    return fmaf(r, y, q0);
+}
+__device__ __forceinline__ float k4_norm_coord_r(float p, float lo, float len, float rlen) {
+    return k4_div_by(p - lo, len, rlen) * 2.f - 1.f;
+}
 __device__ __forceinline__ float k4_unnorm(float n, int size) {
     return ((n + 1.f) / 2.f) * (float)(size - 1);
 }

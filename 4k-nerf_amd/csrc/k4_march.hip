@@ -45,6 +45,7 @@ struct MarchParams {
     int MX, MY, MZ;
     float minx, miny, minz, maxx, maxy, maxz;
     float msx, msy, msz, mtx, mty, mtz;
+    float lenx, leny, lenz, rlenx, rleny, rlenz;     // xyz_max - xyz_min and its correctly rounded reciprocal
     const float* mlp; int mlp_floats; int dim0; int k1p; int vpe; int spe; int k0_skip;
     int n_samples;          // MPI: samples per ray
     int max_steps;          // capacity per ray in the workspace
@@ -52,8 +53,10 @@ struct MarchParams {
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
+    int* ghead;                                    // geometry work-queue head (zeroed by the launcher)
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
+    int geom_persist;       // 0: one bundle per wave, static XCD-banded map (default, fastest measured); 1: per-XCD work queues
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
 
@@ -166,9 +169,9 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
             float alpha = 0.f;
             bool act = false;
             if (m) {
-                const float nx = k4_norm_coord(px, P.minx, P.maxx);
-                const float ny = k4_norm_coord(py, P.miny, P.maxy);
-                const float nz = k4_norm_coord(pz, P.minz, P.maxz);
+                const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
+                const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
+                const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
                 const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
                 // The point is inside the closed bbox, so 0 <= u <= dim-1: only the "+1" corner can leave the grid and
                 // then its weight (u - floor u) is exactly 0 -> clamp the index instead of branching (zero padding of
@@ -231,6 +234,227 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
     if (P.counters && lane == 0) {
         atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
         atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], (unsigned long long)cnt);
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------------------
+// K1, compacting form (default).  Profiling of the per-ray form above (profiles/r01_marcher_split_v1_pmc.md):
+// VALU-issue bound, and two thirds of the issue slots were spent with most lanes idle -- the density stage ran on
+// the ~35 % of lanes that pass the occupancy mask, the transmittance scan on one lane at a time.  Here
+//   A. the occupancy stage still walks a ray with lanes = 64 consecutive samples, but mask-passing samples are
+//      compacted (ballot/mbcnt) ACROSS blocks and rays into a 128-entry LDS ring;
+//   B. the density / act_shift / raw2alpha stage runs on 64 ring entries at a time: all lanes busy;
+//      alpha-passing samples are appended to the bundle's workspace slice as {ray,step | alpha};
+//   C. the transmittance scan is transposed: lane = RAY, all 64 rays of the bundle advance their exact
+//      sequential products in parallel (fmaf chain, identical rounding to the reference's loop), writing w over alpha;
+//   D. a last pass compacts the w > thres survivors in place -> the records the shading kernel consumes.
+// The early stop therefore no longer saves density fetches behind it (they were ~13 % of the mask-passing samples);
+// results are unchanged: a sample behind the stop never gets a weight.
+// -----------------------------------------------------------------------------------------------------
+struct Geom2Lds {
+    float raytab[64][6];     // start xyz, dir xyz of the bundle's rays
+    unsigned qk[128];        // ring of mask-passing samples: ray_local<<24 | step
+    int acnt[64];            // alpha-passing samples per ray
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k4_geom2_kernel(const MarchParams P) {
+    __shared__ Geom2Lds lds_all[4];
+    const int lane = k4_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Geom2Lds& L = lds_all[wv];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.qhead = 0;            // work queue of the shading kernel that follows
+    const k4_cptr c_o = k4_const(P.rays_o), c_d = k4_const(P.rays_d);
+    const bool unit_interval = P.interval == 1.f;
+    const bool use_thres = P.thres > 0.f;
+    unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0, n_shade = 0;
+    float tk0 = step_t<MODE>(P, lane), tk1 = step_t<MODE>(P, 64 + lane), tk2 = step_t<MODE>(P, 128 + lane),
+          tk3 = step_t<MODE>(P, 192 + lane);
+    asm volatile("" : "+v"(tk0), "+v"(tk1), "+v"(tk2), "+v"(tk3));   // keep the hoisted divisions in registers (no rematerialisation)
+
+    // persistent waves pull bundles from a global queue: tiles differ ~10x in occupied samples and a static
+    // wave->tile map left 40 % of the wave slots empty behind the slow ones (SQ_WAVE_CYCLES, profiles/)
+    // (one queue per XCD over a contiguous band of tiles keeps the band's grid columns in that XCD's L2 -- a single
+    //  global queue cost +25 % kernel time; a drained XCD steals from the others)
+    const int my_xcd = (int)(blockIdx.x & 7);
+    int steal = 0;
+    bool first = true;
+    for (;;) {
+    int bid = -1;
+    if (!P.geom_persist) {                       // static map: measured 6-15 % faster than either queue form
+        if (first) bid = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wv;
+        first = false;
+    } else
+    while (steal < 8) {
+        const int q = (my_xcd + steal) & 7;
+        const int lo = (int)(((long long)P.n_bundles * q) >> 3), hi = (int)(((long long)P.n_bundles * (q + 1)) >> 3);
+        int got = 0;
+        if (lane == 0) got = atomicAdd(&P.ghead[q], 1);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (lo + got < hi) { bid = lo + got; break; }
+        steal += 1;
+    }
+    if (bid < 0) break;
+    const Bundle B = bundle_from_id(P, bid);
+    uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+    L.acnt[lane] = 0;
+    int qn = 0, qh = 0;          // ring fill / head (wave-uniform)
+    int na = 0;                  // alpha-passing records written so far (wave-uniform)
+
+    // ---- stage B: density + activation on `nproc` ring entries, lane = sample ----
+    auto stage_b = [&](int nproc) {
+        const bool lact = lane < nproc;
+        const unsigned key = L.qk[(qh + (lact ? lane : 0)) & 127];
+        const int rl = (int)(key >> 24);
+        const int k = (int)(key & 0xffffffu);
+        const float* rt = L.raytab[rl];
+        const float tk = step_t<MODE>(P, k);
+        const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
+        const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
+        const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
+        const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
+        const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
+        // inside the closed bbox 0 <= u <= dim-1: only the "+1" corner can leave the grid and then its weight is exactly 0
+        const int x1 = min(t.x0 + 1, P.X - 1), y1 = min(t.y0 + 1, P.Y - 1), z1 = min(t.z0 + 1, P.Z - 1);
+        const unsigned r00 = (unsigned)(t.x0 * P.Y + t.y0) * (unsigned)P.Z, r01 = (unsigned)(t.x0 * P.Y + y1) * (unsigned)P.Z;
+        const unsigned r10 = (unsigned)(x1 * P.Y + t.y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
+        const float d0 = P.density[r00 + t.z0], d1 = P.density[r00 + z1], d2 = P.density[r01 + t.z0], d3 = P.density[r01 + z1];
+        const float d4 = P.density[r10 + t.z0], d5 = P.density[r10 + z1], d6 = P.density[r11 + t.z0], d7 = P.density[r11 + z1];
+        float sigma = 0.f;
+        sigma += d0 * t.w[0]; sigma += d1 * t.w[1]; sigma += d2 * t.w[2]; sigma += d3 * t.w[3];
+        sigma += d4 * t.w[4]; sigma += d5 * t.w[5]; sigma += d6 * t.w[6]; sigma += d7 * t.w[7];
+        if (MODE == MODE_MPI) {
+            // act_shift grid [1,1,D]: x/y sizes are 1 -> only z interpolates (lib/dmpigo.py:48-58,316)
+            const float ua = k4_unnorm(nz, P.act_d);
+            const float fa = floorf(ua);
+            const int a0 = (int)fa;
+            sigma += P.act_shift[a0] * ((fa + 1.f) - ua) + P.act_shift[min(a0 + 1, P.act_d - 1)] * (ua - fa);
+        }
+        // raw2alpha: e = exp(d+shift); alpha = 1 - (1+e)^(-interval)   render_utils_kernel.cu:439-441
+        const float e = expf(sigma + P.shift);
+        float alpha;
+        if (unit_interval) alpha = 1.f - 1.f / (1.f + e);
+        else alpha = 1.f - powf(1.f + e, -P.interval);
+        const bool act = lact && (use_thres ? (alpha > P.thres) : true);
+        const uint64_t bm = __ballot(act);
+        if (act) {
+            ent[na + k4_prefix(bm)] = make_uint2(key, __float_as_uint(alpha));
+            atomicAdd(&L.acnt[rl], 1);
+        }
+        na += __popcll(bm);
+        qh = (qh + nproc) & 127;
+        qn -= nproc;
+    };
+
+    // ---- stage A: occupancy, one ray at a time, lanes = 64 consecutive samples ----
+    for (int r = 0; r < 64; ++r) {
+        const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, r));
+        if (ray < 0) continue;
+        float sx, sy, sz, dx, dy, dz;
+        int nsteps;
+        ray_setup<MODE>(P, c_o[ray * 3 + 0], c_o[ray * 3 + 1], c_o[ray * 3 + 2],
+                        c_d[ray * 3 + 0], c_d[ray * 3 + 1], c_d[ray * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
+        nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+        if (lane == 0) {
+            L.raytab[r][0] = sx; L.raytab[r][1] = sy; L.raytab[r][2] = sz;
+            L.raytab[r][3] = dx; L.raytab[r][4] = dy; L.raytab[r][5] = dz;
+        }
+        // 4 blocks of 64 samples at a time: the 4 occupancy bytes are fetched together (one memory round trip per 256
+        // samples instead of four dependent ones), branch-free (clamped index, validity folded into the predicate)
+        for (int base0 = 0; base0 < nsteps; base0 += 256) {
+            unsigned mbyte[4];
+            bool inbv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = base0 + j * 64 + lane;
+                float tk;
+                if (MODE == MODE_MPI && base0 == 0) tk = j == 0 ? tk0 : (j == 1 ? tk1 : (j == 2 ? tk2 : tk3));   // hoisted k/(Ns-1)
+                else tk = step_t<MODE>(P, k);
+                const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
+                const bool inb = (k < nsteps) &&
+                    !((P.minx > px) | (P.miny > py) | (P.minz > pz) | (P.maxx < px) | (P.maxy < py) | (P.maxz < pz));
+                const int mi = k4_round_half_away(fmaf(px, P.msx, P.mtx));
+                const int mj = k4_round_half_away(fmaf(py, P.msy, P.mty));
+                const int mk = k4_round_half_away(fmaf(pz, P.msz, P.mtz));
+                const bool ok = inb && (unsigned)mi < (unsigned)P.MX && (unsigned)mj < (unsigned)P.MY && (unsigned)mk < (unsigned)P.MZ;
+                const unsigned midx = ok ? (unsigned)(mi * P.MY + mj) * (unsigned)P.MZ + (unsigned)mk : 0u;    // < 2^32 mask voxels
+                mbyte[j] = ok ? (unsigned)P.mask[midx] : 0u;
+                inbv[j] = inb;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (base0 + j * 64 >= nsteps) break;
+                const bool m = mbyte[j] != 0;
+                const uint64_t mball = __ballot(m);
+                if (P.counters) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball); }
+                if (!mball) continue;
+                if (m) L.qk[(qh + qn + k4_prefix(mball)) & 127] = ((unsigned)r << 24) | (unsigned)(base0 + j * 64 + lane);
+                qn += __popcll(mball);
+                if (qn >= 64) stage_b(64);
+            }
+        }
+    }
+    if (qn > 0) stage_b(qn);
+
+    // the wave now re-reads records other lanes stored: drain its stores first (same wave, same L1: in-order afterwards)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- stage C: transposed transmittance scan, lane = ray (render_utils_kernel.cu:591-603) ----
+    const int c = L.acnt[lane];
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const int seg = incl - c;
+    int maxc = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+    maxc = __builtin_amdgcn_readfirstlane(maxc);
+    float T = 1.f;
+    bool stopped = false;
+    for (int j0 = 0; j0 < maxc; j0 += 4) {
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (j0 + u < c) ? __uint_as_float(ent[seg + j0 + u].y) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u < c) {
+                float w = -1.f;                                        // behind the early stop: never shaded
+                if (!stopped) {
+                    w = T * a[u];
+                    T = fmaf(-T, a[u], T);                             // == (float)((double)T*(1.-a)), see k4_geom_kernel
+                    if (T < 1e-3f) stopped = true;                     // the crossing sample is still counted (:597-600)
+                }
+                ent[seg + j0 + u].y = __float_as_uint(w);
+            }
+        }
+    }
+    const float my_ainv = T;                                           // alphainv_last of ray `lane` (1 if it has no samples)
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- stage D: keep w > thres, in place, order preserved ----
+    int cnt = 0;
+    for (int base = 0; base < na; base += 64) {
+        const int i = base + lane;
+        const bool v = i < na;
+        const uint2 e = ent[v ? i : 0];
+        const float w = __uint_as_float(e.y);
+        const bool shade = v && (use_thres ? (w > P.thres) : (w >= 0.f));
+        const uint64_t sm = __ballot(shade);
+        if (shade) ent[cnt + k4_prefix(sm)] = e;
+        cnt += __popcll(sm);
+    }
+    if (lane == 0) P.counts[B.id] = cnt;
+    const int myray = ray_index(P, B, lane);
+    if (myray >= 0) P.out_ainv[myray] = my_ainv;
+    n_alpha += (unsigned long long)na; n_shade += (unsigned long long)cnt;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }   // bundle queue
+    if (P.counters && lane == 0) {
+        atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
+        atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade);
     }
 }
 
@@ -385,9 +609,9 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
                         P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps_unused);
         const float tk = step_t<MODE>(P, k);
         const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
-        const float nx = k4_norm_coord(px, P.minx, P.maxx);
-        const float ny = k4_norm_coord(py, P.miny, P.maxy);
-        const float nz = k4_norm_coord(pz, P.minz, P.maxz);
+        const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
+        const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
+        const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
         const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
         unsigned cidx[8];                                        // voxel index (< 2^31 voxels)
         float cw[8];
@@ -555,9 +779,9 @@ __device__ __forceinline__ void shade_issue(const MarchParams& P, const float* r
     const float* rt = raytab + S.rl * 12;
     const float tk = step_t<MODE>(P, S.k);
     const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
-    S.nx = k4_norm_coord(px, P.minx, P.maxx);
-    S.ny = k4_norm_coord(py, P.miny, P.maxy);
-    S.nz = k4_norm_coord(pz, P.minz, P.maxz);
+    S.nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
+    S.ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
+    S.nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
     const K4Tri t = k4_tri_setup(k4_unnorm(S.nx, P.X), k4_unnorm(S.ny, P.Y), k4_unnorm(S.nz, P.Z));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous batch's reads of the staging area are done
 #pragma unroll
@@ -744,21 +968,28 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const int nwg = n_workgroups(P.n_rays, P.img_w);
     if (nwg <= 0) return K4_OK;
     const dim3 grid(nwg), block(256);
-    hipLaunchKernelGGL((k4_geom_kernel<MODE>), grid, block, 0, st, P);
-    int rc = k4_check_launch();
-    if (rc) return rc;
-    const int width = mlp->width, nh = mlp->n_hidden;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
+    if (getenv("K4_GEOM_V1")) hipLaunchKernelGGL((k4_geom_kernel<MODE>), grid, block, 0, st, P);
+    else {
+        hipError_t e0 = hipMemsetAsync(P.ghead, 0, 8 * sizeof(int), st);
+        if (e0 != hipSuccess) return (int)e0;
+        const int per_cu = 7;                                      // 7 waves/SIMD (SGPR bound)
+        hipLaunchKernelGGL((k4_geom2_kernel<MODE>), P.geom_persist ? dim3((unsigned)min(nwg, n_cu * per_cu)) : grid, block, 0, st, P);
+    }
+    int rc = k4_check_launch();
+    if (rc) return rc;
+    const int width = mlp->width, nh = mlp->n_hidden;
     const size_t lds_base = sizeof(float) * (((size_t)P.mlp_floats + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
     const size_t lds_pipe = lds_base + sizeof(float) * 4 * (64 * 12 + 24 * 64 * 4);       // + ray table + 24 KB staging per wave
-    // pipelined kernel: k0 channel-last with 12 channels and room for the staging area beside the weights (W<=64)
+    // pipelined kernel (opt-in, K4_PIPE=1): 10 % faster in isolation, but its 150 KB of LDS per workgroup keeps the geometry
+    // kernel of the next frame off the CU, and overlapped frames are what the render loop runs (bench.py --streams)
     const bool pipe = width != 0 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && lds_pipe <= 160 * 1024 &&
-                      !getenv("K4_NO_PIPE");
+                      getenv("K4_PIPE");
     const int wg_per_cu = pipe ? 1 : 3;             // the pipelined kernel runs ONE self-overlapping wave per SIMD
     const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
     const size_t lds = pipe ? lds_pipe : lds_base;
@@ -786,7 +1017,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
     if (n_rays < 0 || img_w < 0 || max_steps <= 0 || (img_w > 0 && n_rays % img_w != 0)) return -1;
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
-    return nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2) + (((nb + 1) * (int64_t)sizeof(int) + 255) / 256) * 256;
+    return nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2) + (((nb + 9) * (int64_t)sizeof(int) + 255) / 256) * 256;
 }
 
 static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -813,6 +1044,8 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.maxx = g->xyz_max[0]; P.maxy = g->xyz_max[1]; P.maxz = g->xyz_max[2];
     P.msx = g->xyz2ijk_scale[0]; P.msy = g->xyz2ijk_scale[1]; P.msz = g->xyz2ijk_scale[2];
     P.mtx = g->xyz2ijk_shift[0]; P.mty = g->xyz2ijk_shift[1]; P.mtz = g->xyz2ijk_shift[2];
+    P.lenx = P.maxx - P.minx; P.leny = P.maxy - P.miny; P.lenz = P.maxz - P.minz;       // fp32 subtraction, as lib/grid.py:123
+    P.rlenx = 1.0f / P.lenx; P.rleny = 1.0f / P.leny; P.rlenz = 1.0f / P.lenz;           // IEEE division: correctly rounded
     P.mlp = m->packed; P.dim0 = m->dim0; P.k1p = (m->dim0 + 2) & ~1;
     P.mlp_floats = (int)mlp_floats_of(m, P.k1p);
     P.vpe = m->viewbase_pe; P.spe = m->spatial_pe; P.k0_skip = m->k0_skip;
@@ -821,8 +1054,9 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
+    P.ghead = P.qhead + 1;
     P.n_bundles = (int)nb;
-    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; }
+    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; P.geom_persist = getenv("K4_GEOM_PERSIST") ? 1 : 0; }
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
