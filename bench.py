@@ -213,6 +213,10 @@ def main():
     if rank == 0:
         if four_k is not None:
             res['four_k'] = four_k
+        if world == 1 and not args.small:
+            res['reference_pipeline_baseline'] = reference_pipeline_baseline(model, rays[0], rk)
+            res['reference_pipeline_baseline']['speedup_of_value'] = round(
+                value / res['reference_pipeline_baseline']['value'], 1)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
         print(json.dumps(res), flush=True)
@@ -260,6 +264,27 @@ def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world):
             'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': 157.3 * world, 'unit': 'TFLOP/s',
                             'frac': round(tflops / (157.3 * world), 4), 'flop_per_frame': flop_per_px * px,
                             'note': 'fp32-input MFMA peak (v_mfma_f32_32x32x2_f32) x n_gpus; time includes marcher + all-gather'}}
+
+
+def reference_pipeline_baseline(model, rays, rk, chunk=8192, frames=2):
+    """the REFERENCE's pipeline structure on this MI355X -- 8192-ray chunks (run_sr.py:121-124), one
+    launch per op (sampler, maskcache_lookup, grid_sample, raw2alpha, alpha2weight, segment sum: the staged gfx950
+    kernels of this package; rgbnet on rocBLAS), boolean-mask compactions with their host syncs, exactly the op
+    sequence of lib/dmpigo.py:300-427.  It is what `k4_staged=True` runs; same outputs as the fused path."""
+    ro, rd, vd = rays
+    def frame():
+        outs = [model(a, b, c, k4_staged=True, **rk) for a, b, c in zip(ro.split(chunk, 0), rd.split(chunk, 0), vd.split(chunk, 0))]
+        return torch.cat([o['rgb_marched'] for o in outs])
+    with torch.no_grad():
+        frame()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(frames):
+            frame()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / frames
+    return {'value': round(ro.shape[0] / dt / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(dt * 1e3, 2),
+            'what': 'reference op sequence, per-op launches, 8192-ray chunks, on the same GPU (k4_staged=True)'}
 
 
 def cpu_baseline(ck, pose, stride):
