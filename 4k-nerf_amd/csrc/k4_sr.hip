@@ -36,6 +36,41 @@ struct ConvParams {
     int tiles_x, tiles_y;
 };
 
+// shared epilogue: lane holds output channel n*32+l31 of pixels x0 + row(r,half), rows y0 + wv*2 + m
+template <int NT>
+__device__ __forceinline__ void k4_conv_epilogue(const ConvParams& P, f32x16 (&acc)[2][NT], int x0, int y0, int wv, int half, int l31) {
+    const bool modulate = (P.flags & K4_EPI_MODULATE) != 0;
+    constexpr int NW = NT;                    // N tiles written (MODULATE: only the first NT/2)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + wv * 2 + m;
+        if (gy >= P.H) continue;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            if (modulate && n >= NT / 2) continue;
+            const int co = n * 32 + l31;
+            if (co >= P.cout) continue;
+            const float bsc = P.bias[co];
+            const float bsh = modulate ? P.bias[co + (NT / 2) * 32] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (gx >= P.W) continue;
+                const size_t pix = (size_t)gy * P.W + gx;
+                float v = acc[m][n][r] + bsc;
+                if (modulate) {
+                    // SFTLayer: x * (scale + 1) + shift      (lib/sr_esrnet.py:123)
+                    const float sh = acc[m][(n + NT / 2) % NT][r] + bsh;
+                    v = P.modx[pix * P.mod_stride + co] * (v + 1.f) + sh;
+                }
+                if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
+                if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
+                P.y[pix * P.cout_stride + co] = v;
+            }
+        }
+    }
+}
+
 template <int KS, int NT>
 __global__ __launch_bounds__(256) void k4_conv_kernel(const ConvParams P) {
     constexpr int TAPS = KS * KS;
@@ -112,37 +147,127 @@ __global__ __launch_bounds__(256) void k4_conv_kernel(const ConvParams P) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds output channel n*32+l31 of pixels x0 + row(r,half), rows y0 + wv*2 + m ----
-    const bool modulate = (P.flags & K4_EPI_MODULATE) != 0;
-    constexpr int NW = NT;                    // N tiles written (MODULATE: only the first NT/2)
+    k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant (opt-in, "bf16x3"): every fp32 operand is split into two bf16 numbers x = x_hi + x_lo
+// (x_hi = RNE_bf16(x), x_lo = RNE_bf16(x - x_hi): 16 significant bits) and a product is evaluated as
+// x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error ~2^-16 per
+// product instead of bf16's 2^-8, at 3 matrix instructions of 32 cycles per 32x32x16 block = 5.3x the rate of the
+// fp32-input MFMA.  Activations stay fp32 in HBM; the split happens while the input chunk is staged into LDS.
+// Same tiling as k4_conv_kernel; K is walked in chunks of 16 input channels (one MFMA K-step per tap).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define KC2 16
+
+__device__ __forceinline__ unsigned k4_bf16_rne_bits(float x) {          // fp32 -> bf16 (round to nearest even), in the top 16 bits
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+__device__ __forceinline__ void k4_split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    unsigned h[8], l[8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int gy = y0 + wv * 2 + m;
-        if (gy >= P.H) continue;
+    for (int i = 0; i < 8; ++i) {
+        h[i] = k4_bf16_rne_bits(v[i]);
+        l[i] = k4_bf16_rne_bits(v[i] - __uint_as_float(h[i]));
+    }
+    hi = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+    lo = make_uint4((l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]);
+}
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void k4_conv_bf16x3_kernel(const ConvParams P) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PADW = KS / 2;
+    constexpr int ROWS = TILE_H + 2 * PADW;
+    constexpr int COLS = TILE_W + 2 * PADW;
+    constexpr int NOUT = NT * 32;
+    __shared__ uint4 in_s[2][2][ROWS][COLS];          // [hi|lo][channel group of 8][row][col] x 8 bf16
+    __shared__ uint4 w_s[2][TAPS][2][NOUT];            // [hi|lo][tap][channel group][cout] x 8 bf16
+
+    const int lane = k4_lane();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
+
+    f32x16 acc[2][NT];
 #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            if (modulate && n >= NT / 2) continue;
-            const int co = n * 32 + l31;
-            if (co >= P.cout) continue;
-            const float bsc = P.bias[co];
-            const float bsh = modulate ? P.bias[co + (NT / 2) * 32] : 0.f;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (gx >= P.W) continue;
-                const size_t pix = (size_t)gy * P.W + gx;
-                float v = acc[m][n][r] + bsc;
-                if (modulate) {
-                    // SFTLayer: x * (scale + 1) + shift      (lib/sr_esrnet.py:123)
-                    const float sh = acc[m][(n + NT / 2) % NT][r] + bsh;
-                    v = P.modx[pix * P.mod_stride + co] * (v + 1.f) + sh;
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x16)(0.f);
+
+    const int nchunks = (P.cin + KC2 - 1) / KC2;
+    const uint4* wsrc_all = reinterpret_cast<const uint4*>(P.w);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * KC2;
+        // ---- stage + split the haloed input tile: items = (pixel, channel group of 8) ----
+        for (int it = (int)threadIdx.x; it < ROWS * COLS * 2; it += 256) {
+            const int kg = it & 1, p = it >> 1;
+            const int py = p / COLS, px = p - py * COLS;
+            const int gy = y0 - PADW + py, gx = x0 - PADW + px;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = 0.f;
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) {
+                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+                const int cb = c0 + kg * 8;
+                const float* src = P.x + ((size_t)sy * P.srcW + sx) * P.cin_stride + cb;
+                if (cb + 8 <= P.cin && ((((size_t)src) & 15) == 0)) {
+                    const float4 a = *reinterpret_cast<const float4*>(src);
+                    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (cb + c < P.cin) v[c] = src[c];
                 }
-                if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-                if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
-                P.y[pix * P.cout_stride + co] = v;
+            }
+            uint4 hi, lo;
+            k4_split8(v, hi, lo);
+            in_s[0][kg][py][px] = hi;
+            in_s[1][kg][py][px] = lo;
+        }
+        // ---- stage this chunk's pre-split weights ([chunk][hi|lo][tap][group][cout] x 16 B, LDS order) ----
+        {
+            const uint4* src = wsrc_all + (size_t)ch * 2 * TAPS * 2 * NOUT;
+            uint4* dst = &w_s[0][0][0][0];
+            for (int i = (int)threadIdx.x; i < 2 * TAPS * 2 * NOUT; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dy = t / KS, dx = t - dy * KS;
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = __builtin_bit_cast(bf16x8, in_s[0][half][wv * 2 + m + dy][l31 + dx]);
+                al[m] = __builtin_bit_cast(bf16x8, in_s[1][half][wv * 2 + m + dy][l31 + dx]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, w_s[0][t][half][n * 32 + l31]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, w_s[1][t][half][n * 32 + l31]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+                }
             }
         }
+        __syncthreads();
     }
+    k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
+}
+
+template <int KS, int NT>
+static int launch_conv_bf16x3(const ConvParams& P, hipStream_t st) {
+    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(256);
+    hipLaunchKernelGGL((k4_conv_bf16x3_kernel<KS, NT>), grid, block, 0, st, P);
+    return k4_check_launch();
 }
 
 template <int KS, int NT>
@@ -190,6 +315,47 @@ extern "C" int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
         if (nt == 1) return launch_conv<1, 1>(P, st);
         if (nt == 2) return launch_conv<1, 2>(P, st);
         if (nt == 4) return launch_conv<1, 4>(P, st);
+    }
+    return K4_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t k4_conv_weight_bf16x3_bytes(int32_t cout, int32_t cin, int32_t ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
+    const int64_t nt = (cout + 31) / 32;
+    if (nt != 1 && nt != 2 && nt != 4) return -1;
+    return (int64_t)((cin + KC2 - 1) / KC2) * 2 * ksize * ksize * 2 * nt * 32 * 16;
+}
+
+extern "C" int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
+                                     const void* w_split, const float* bias, int32_t ksize,
+                                     float* y, int32_t cout, int32_t cout_stride,
+                                     int32_t H, int32_t W, uint32_t flags, float slope,
+                                     const float* res, int32_t res_stride, float res_scale,
+                                     const float* mod_x, int32_t mod_stride, void* stream) {
+    if (!x || !w_split || !bias || !y || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return K4_ERR_BAD_ARG;
+    if (cin_stride < cin || (ksize != 1 && ksize != 3)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_EPI_RES) && (!res || res_stride <= 0)) return K4_ERR_BAD_ARG;
+    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
+    if (modulate && (!mod_x || mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_PRE_UPSAMPLE2X) && ((H & 1) || (W & 1))) return K4_ERR_BAD_ARG;
+    const int gemm_n = modulate ? 2 * cout : cout;
+    const int nt = (gemm_n + 31) / 32;
+    if (cout_stride < cout) return K4_ERR_BAD_ARG;
+    ConvParams P{};
+    P.x = x; P.cin = cin; P.cin_stride = cin_stride; P.w = (const float*)w_split; P.bias = bias;
+    P.y = y; P.cout = cout; P.cout_stride = cout_stride; P.H = H; P.W = W;
+    P.srcH = (flags & K4_PRE_UPSAMPLE2X) ? H / 2 : H; P.srcW = (flags & K4_PRE_UPSAMPLE2X) ? W / 2 : W;
+    P.flags = flags; P.slope = slope; P.res = res; P.res_stride = res_stride; P.res_scale = res_scale;
+    P.modx = mod_x; P.mod_stride = mod_stride;
+    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3) {
+        if (nt == 1) return launch_conv_bf16x3<3, 1>(P, st);
+        if (nt == 2) return launch_conv_bf16x3<3, 2>(P, st);
+    } else {
+        if (nt == 1) return launch_conv_bf16x3<1, 1>(P, st);
+        if (nt == 2) return launch_conv_bf16x3<1, 2>(P, st);
+        if (nt == 4) return launch_conv_bf16x3<1, 4>(P, st);
     }
     return K4_ERR_UNSUPPORTED;
 }

@@ -107,20 +107,33 @@ class RRDBNet_bps(nn.Module):
 
 
 class _Packed:
-    """Conv weights in k4_conv2d_nhwc order: [ceil(cin/8)][k*k][8][32*NT] + zero padded bias."""
+    """Conv weights in k4_conv2d_nhwc order: fp32 [ceil(cin/8)][k*k][8][32*NT], or the split-bf16 order
+    [ceil(cin/16)][hi|lo][k*k][2][32*NT][8] (include/k4nerf.h); zero padded bias."""
 
-    def __init__(self, weight, bias, gemm_n=None):
+    def __init__(self, weight, bias, mode='fp32'):
         cout, cin, k, _ = weight.shape
-        n = cout if gemm_n is None else gemm_n
-        nt = (n + 31) // 32
-        kc = 8
-        nch = (cin + kc - 1) // kc
-        w = torch.zeros([k * k, nch * kc, nt * 32], dtype=torch.float32, device=weight.device)
-        w[:, :cin, :cout] = weight.detach().float().permute(2, 3, 1, 0).reshape(k * k, cin, cout)
-        self.w = w.reshape(k * k, nch, kc, nt * 32).permute(1, 0, 2, 3).contiguous()
-        want = N.lib().k4_conv_weight_floats(n, cin, k)
-        assert self.w.numel() == want, (self.w.numel(), want)
-        self.b = torch.zeros([nt * 32], dtype=torch.float32, device=weight.device)
+        nt = (cout + 31) // 32
+        dev = weight.device
+        wf = weight.detach().float()
+        self.mode = mode
+        if mode == 'fp32':
+            kc = 8
+            nch = (cin + kc - 1) // kc
+            w = torch.zeros([k * k, nch * kc, nt * 32], dtype=torch.float32, device=dev)
+            w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+            self.w = w.reshape(k * k, nch, kc, nt * 32).permute(1, 0, 2, 3).contiguous()
+            assert self.w.numel() == N.lib().k4_conv_weight_floats(cout, cin, k)
+        else:
+            nch = (cin + 15) // 16
+            w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)
+            w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+            hi = w.to(torch.bfloat16)                                  # round to nearest even, as the kernel splits activations
+            lo = (w - hi.float()).to(torch.bfloat16)
+            both = torch.stack([hi, lo], 0)                            # [2][taps][nch*16][NOUT]
+            both = both.reshape(2, k * k, nch, 2, 8, nt * 32).permute(2, 0, 1, 3, 5, 4).contiguous()   # [nch][2][taps][2][NOUT][8]
+            self.w = both.view(torch.int16)
+            assert self.w.numel() * 2 == N.lib().k4_conv_weight_bf16x3_bytes(cout, cin, k)
+        self.b = torch.zeros([nt * 32], dtype=torch.float32, device=dev)
         self.b[:cout] = bias.detach().float()
         self.cin, self.k = cin, k
 
@@ -154,6 +167,9 @@ class SFTNet(nn.Module):
             nn.Conv2d(64, 64, 1), nn.LeakyReLU(0.2, True),
             nn.Conv2d(64, 32, 1))
         object.__setattr__(self, '_k4', {})
+        # 'fp32': v_mfma_f32_32x32x2_f32, exact fp32 (default, the parity-grade path);
+        # 'bf16x3': split-bf16 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation (opt-in fast path)
+        self.k4_mode = os.environ.get('K4_SR_MODE', 'fp32')
 
     # ------------------------------------------------------------------ reference graph (autograd path)
     def _forward_torch(self, x, cond, fea=None):
@@ -175,7 +191,8 @@ class SFTNet(nn.Module):
     # ------------------------------------------------------------------ HIP path
     def _packed(self):
         """Pack every conv once per parameter version (load-time repack; names/values of parameters never change)."""
-        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device),)
+        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device), self.k4_mode)
+        mode = self.k4_mode
         c = self._k4
         if c.get('key') == key:
             return c['packed']
@@ -184,26 +201,26 @@ class SFTNet(nn.Module):
         def sft(prefix, layer):
             w0 = torch.cat([layer.SFT_scale_conv0.weight, layer.SFT_shift_conv0.weight], 0)
             b0 = torch.cat([layer.SFT_scale_conv0.bias, layer.SFT_shift_conv0.bias], 0)
-            pk[prefix + '.a'] = _Packed(w0, b0)                                   # cond(32) -> [scale_h | shift_h](64)
+            pk[prefix + '.a'] = _Packed(w0, b0, mode)                                   # cond(32) -> [scale_h | shift_h](64)
             g, cf = self.num_grow_ch, layer.SFT_scale_conv1.weight.shape[0]
             w1 = torch.zeros([2 * cf, 2 * g, 1, 1], dtype=torch.float32, device=w0.device)
             w1[:cf, :g] = layer.SFT_scale_conv1.weight
             w1[cf:, g:] = layer.SFT_shift_conv1.weight
             b1 = torch.cat([layer.SFT_scale_conv1.bias, layer.SFT_shift_conv1.bias], 0)
-            pk[prefix + '.b'] = _Packed(w1, b1)                                   # block diagonal -> [scale | shift]
+            pk[prefix + '.b'] = _Packed(w1, b1, mode)                                   # block diagonal -> [scale | shift]
 
         for name in ('conv_first', 'conv_body', 'conv_up1', 'conv_up2', 'conv_hr', 'conv_last'):
             if hasattr(self, name):
                 m = getattr(self, name)
-                pk[name] = _Packed(m.weight, m.bias)
+                pk[name] = _Packed(m.weight, m.bias, mode)
         for i in (0, 2, 4, 6):
-            pk[f'CondNet.{i}'] = _Packed(self.CondNet[i].weight, self.CondNet[i].bias)
+            pk[f'CondNet.{i}'] = _Packed(self.CondNet[i].weight, self.CondNet[i].bias, mode)
         for b, rr in enumerate(self.body):
             for r in (1, 2, 3):
                 rdb = getattr(rr, f'rdb{r}')
                 for k in range(1, 6):
                     m = getattr(rdb, f'conv{k}')
-                    pk[f'body.{b}.rdb{r}.conv{k}'] = _Packed(m.weight, m.bias)
+                    pk[f'body.{b}.rdb{r}.conv{k}'] = _Packed(m.weight, m.bias, mode)
                 sft(f'body.{b}.rdb{r}.sft0', rdb.sft0)
                 sft(f'body.{b}.rdb{r}.sft1', rdb.sft1)
             sft(f'body.{b}.sft0', rr.sft0)
@@ -237,8 +254,9 @@ class SFTNet(nn.Module):
         """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))"""
         rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
         mp, ms = (None, 0) if mod is None else (N.C.c_void_p(mod[0].data_ptr() + 4 * mod[1]), mod[2])
-        N.check(N.lib().k4_conv2d_nhwc(
-            N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.f32(pk.w), N.f32(pk.b), pk.k,
+        fn = N.lib().k4_conv2d_nhwc if pk.mode == 'fp32' else N.lib().k4_conv2d_nhwc_bf16x3
+        N.check(fn(
+            N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.k,
             N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags, 0.2,
             rp, rs, rscale, mp, ms, N.stream()), 'k4_conv2d_nhwc')
 

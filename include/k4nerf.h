@@ -207,6 +207,19 @@ int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
                    const float* res, int32_t res_stride, float res_scale,
                    const float* mod_x, int32_t mod_stride, void* stream);
 
+/* Split-bf16 ("bf16x3") variant of the same convolution (opt-in): x = x_hi + x_lo with x_hi = RNE_bf16(x),
+ * x_lo = RNE_bf16(x - x_hi); products as x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation -- ~2^-16 relative error per product, 5.3x the matrix rate of the fp32-input MFMA.  Activations stay
+ * fp32 in memory.  w_split : k4_conv_weight_bf16x3_bytes() bytes =
+ * [ceil(cin/16)][hi|lo][ksize*ksize][2 channel groups][32*NT][8] bf16 (zero padded).  Other arguments as above. */
+int64_t k4_conv_weight_bf16x3_bytes(int32_t cout, int32_t cin, int32_t ksize);
+int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
+                          const void* w_split, const float* bias, int32_t ksize,
+                          float* y, int32_t cout, int32_t cout_stride,
+                          int32_t H, int32_t W, uint32_t flags, float slope,
+                          const float* res, int32_t res_stride, float res_scale,
+                          const float* mod_x, int32_t mod_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,3 +121,46 @@ def test_load_network_semantics(tmp_path):
     net.load_network(str(p), 'cpu', strict=False)
     net.save_network(str(tmp_path), 'sresrnet', -1)
     assert 'params' in torch.load(tmp_path / 'sresrnet_latest.pth', weights_only=False)
+
+
+def test_split_bf16_conv_and_network():
+    """Opt-in 'bf16x3' mode: fp32 operands split into bf16 hi+lo, 3 MFMA products, fp32 accumulation.
+    Tolerance: ~2^-16 relative per product -> conv outputs within 2e-4 of fp32; whole network PSNR >= 75 dB
+    against the fp32 oracle (SURVEY 8c asked >= 60 dB for an fp32-MFMA path, >= 50 dB for plain bf16)."""
+    import torch.nn.functional as F
+    from nerf4k_amd.lib.sr_esrnet import _Packed, SFTNet, EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X
+    g = torch.Generator().manual_seed(5)
+    H, W = 19, 41
+    for cin, cout, k in ((160, 32, 3), (192, 64, 3), (3, 64, 3), (64, 3, 3), (32, 64, 1), (1, 64, 3)):
+        x = torch.randn([H, W, 200], generator=g).cuda()
+        w = (torch.randn([cout, cin, k, k], generator=g) / (cin * k * k) ** 0.5).cuda()
+        b = torch.randn([cout], generator=g).cuda()
+        res = torch.randn([H, W, 70], generator=g).cuda()
+        y = torch.zeros([H, W, 96]).cuda()
+        SFTNet._conv(_Packed(w, b, 'bf16x3'), x, 8, 200, y, 16, 96, cout, H, W, EPI_LRELU | EPI_RES, res=(res, 2, 70, 0.2))
+        xn = x[:, :, 8:8 + cin].permute(2, 0, 1).unsqueeze(0)
+        want = F.leaky_relu(F.conv2d(xn, w, b, padding=k // 2), 0.2)[0].permute(1, 2, 0) * 0.2 + res[:, :, 2:2 + cout]
+        err = float((y[:, :, 16:16 + cout] - want).abs().max())
+        assert err < 3e-4, (cin, cout, k, err)
+    # SFT modulation + upsample paths share the epilogue/loader with the fp32 kernel: one spot check each
+    t = torch.randn([H, W, 64], generator=g).cuda()
+    w = (torch.randn([128, 64, 1, 1], generator=g) / 8).cuda()
+    b = torch.randn([128], generator=g).cuda()
+    xm = torch.randn([H, W, 64], generator=g).cuda()
+    tn = t.permute(2, 0, 1).unsqueeze(0)
+    want = xm * (F.conv2d(tn, w[:64], b[:64])[0].permute(1, 2, 0) + 1) + F.conv2d(tn, w[64:], b[64:])[0].permute(1, 2, 0)
+    SFTNet._conv(_Packed(w, b, 'bf16x3'), t, 0, 64, xm, 0, 64, 64, H, W, EPI_MODULATE, mod=(xm, 0, 64))
+    assert float((xm - want).abs().max()) < 1e-3
+    # whole network
+    sd = osr.make_state_dict(seed=7, num_block=5)
+    net = _net(sd, 5)
+    x = torch.rand([1, 3, 40, 56], generator=g)
+    cond = torch.rand([1, 1, 40, 56], generator=g)
+    want = osr.sftnet_forward(sd, x, cond)
+    with torch.no_grad():
+        fp32 = net(x.cuda(), cond.cuda()).cpu()
+        net.k4_mode = 'bf16x3'
+        got = net(x.cuda(), cond.cuda()).cpu()
+    p32, p16 = psnr(fp32, want), psnr(got, want)
+    print(f'SFTNet PSNR vs oracle: fp32-MFMA {p32:.1f} dB, split-bf16 {p16:.1f} dB, max|err| {float((got - want).abs().max()):.2e}')
+    assert p32 >= 100.0 and p16 >= 75.0, (p32, p16)
