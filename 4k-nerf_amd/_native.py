@@ -85,6 +85,8 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                         _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_conv_weight_floats': ([_I32, _I32, _I32], C.c_int64),
+    'k4_sft_weight_floats': ([_I32], C.c_int64),
+    'k4_sft_nhwc': ([_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I64, _F, _P, _I32, _F, _P], C.c_int),
     'k4_conv_weight_bf16x3_bytes': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_nhwc_bf16x3': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                                _P, _I32, _F, _P, _I32, _P], C.c_int),

@@ -138,6 +138,38 @@ class _Packed:
         self.cin, self.k = cin, k
 
 
+def pack_sft(layer):
+    """SFTLayer weights in the operand order of the fused kernel (include/k4nerf.h, k4_sft_nhwc)."""
+    dev = layer.SFT_scale_conv0.weight.device
+    g = layer.SFT_scale_conv0.weight.shape[1]
+    assert g == 32 and layer.SFT_scale_conv0.weight.shape[0] == 32
+    C = layer.SFT_scale_conv1.weight.shape[0]
+    lane = torch.arange(64, device=dev)
+    l31, half = lane & 31, lane >> 5
+    row = lambda r: (r & 3) + 8 * (r >> 2)
+
+    def block(w2d, bias, nblk, k_of):
+        """[nblk][17][64]: steps 0..15 = w2d[blk*32 + l31][k_of(step, half)], step 16 = bias on the lower half-wave"""
+        out = torch.zeros([nblk, 17, 64], dtype=torch.float32, device=dev)
+        for blk in range(nblk):
+            for st in range(16):
+                out[blk, st] = w2d[blk * 32 + l31, k_of(st, half)]
+            out[blk, 16, :32] = bias[blk * 32:(blk + 1) * 32]
+        return out.reshape(-1)
+
+    wa = torch.cat([layer.SFT_scale_conv0.weight, layer.SFT_shift_conv0.weight], 0).detach().float().reshape(64, 32)
+    ba = torch.cat([layer.SFT_scale_conv0.bias, layer.SFT_shift_conv0.bias], 0).detach().float()
+    ws = layer.SFT_scale_conv1.weight.detach().float().reshape(C, 32)
+    wh = layer.SFT_shift_conv1.weight.detach().float().reshape(C, 32)
+    parts = [block(wa, ba, 2, lambda st, h: 2 * st + h),
+             block(ws, layer.SFT_scale_conv1.bias.detach().float(), C // 32, lambda st, h: row(st) + 4 * h),
+             block(wh, layer.SFT_shift_conv1.bias.detach().float(), C // 32, lambda st, h: row(st) + 4 * h)]
+    out = torch.cat(parts).contiguous()
+    assert out.numel() == N.lib().k4_sft_weight_floats(C)
+    out.channels = C
+    return out
+
+
 class SFTNet(nn.Module):
     def __init__(self, n_in_colors, scale, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1, dswise=False):
         super(SFTNet, self).__init__()
@@ -199,15 +231,7 @@ class SFTNet(nn.Module):
         pk = {}
 
         def sft(prefix, layer):
-            w0 = torch.cat([layer.SFT_scale_conv0.weight, layer.SFT_shift_conv0.weight], 0)
-            b0 = torch.cat([layer.SFT_scale_conv0.bias, layer.SFT_shift_conv0.bias], 0)
-            pk[prefix + '.a'] = _Packed(w0, b0, mode)                                   # cond(32) -> [scale_h | shift_h](64)
-            g, cf = self.num_grow_ch, layer.SFT_scale_conv1.weight.shape[0]
-            w1 = torch.zeros([2 * cf, 2 * g, 1, 1], dtype=torch.float32, device=w0.device)
-            w1[:cf, :g] = layer.SFT_scale_conv1.weight
-            w1[cf:, g:] = layer.SFT_shift_conv1.weight
-            b1 = torch.cat([layer.SFT_scale_conv1.bias, layer.SFT_shift_conv1.bias], 0)
-            pk[prefix + '.b'] = _Packed(w1, b1, mode)                                   # block diagonal -> [scale | shift]
+            pk[prefix] = pack_sft(layer)
 
         for name in ('conv_first', 'conv_body', 'conv_up1', 'conv_up2', 'conv_hr', 'conv_last'):
             if hasattr(self, name):
@@ -261,13 +285,13 @@ class SFTNet(nn.Module):
             rp, rs, rscale, mp, ms, N.stream()), 'k4_conv2d_nhwc')
 
     def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None):
-        """SFTLayer (lib/sr_esrnet.py:120-123) as two launches: hidden = lrelu([scale0|shift0](cond));
-        y = x*(scale1(hidden)+1) + shift1(hidden) [*res_scale + res]."""
-        self._conv(pk[prefix + '.a'], B['cond'], 0, self.num_grow_ch, B['t'], 0, 2 * self.num_grow_ch,
-                   2 * self.num_grow_ch, h, w, EPI_LRELU)
-        flags = EPI_MODULATE | (EPI_RES if res is not None else 0)
-        self._conv(pk[prefix + '.b'], B['t'], 0, 2 * self.num_grow_ch, y, y_off, y_stride, cfeat, h, w, flags,
-                   res=res, mod=(x, x_off, x_stride))
+        """SFTLayer (lib/sr_esrnet.py:120-123) in one launch: y = x*(scale(cond)+1) + shift(cond) [*res_scale + res]."""
+        wp = pk[prefix]
+        rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
+        N.check(N.lib().k4_sft_nhwc(
+            N.f32(B['cond']), self.num_grow_ch, N.f32(wp),
+            N.C.c_void_p(x.data_ptr() + 4 * x_off), x_stride, N.C.c_void_p(y.data_ptr() + 4 * y_off), y_stride,
+            cfeat, h * w, 0.2, rp, rs, rscale, N.stream()), 'k4_sft_nhwc')
 
     @torch.no_grad()
     def _forward_hip(self, x, cond):

@@ -220,6 +220,16 @@ int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
                           const float* res, int32_t res_stride, float res_scale,
                           const float* mod_x, int32_t mod_stride, void* stream);
 
+/* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then
+ * *res_scale + res if res != NULL), scale/shift = conv1x1(lrelu(conv1x1(cond))) evaluated in one launch, the hidden
+ * activations stay in registers.  cond: [n_pix][cond_stride] (32 channels, 16-B aligned rows); channels = 32 or 64;
+ * w_packed: k4_sft_weight_floats(channels) floats = WA [2][17][64] | WS [C/32][17][64] | WH [C/32][17][64] in
+ * v_mfma_f32_32x32x2_f32 operand order (k-step 16 carries the bias); y may alias x. */
+int64_t k4_sft_weight_floats(int32_t channels);
+int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
+                const float* x, int32_t x_stride, float* y, int32_t y_stride, int32_t channels,
+                int64_t n_pix, float slope, const float* res, int32_t res_stride, float res_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,27 @@ def test_split_bf16_conv_and_network():
     p32, p16 = psnr(fp32, want), psnr(got, want)
     print(f'SFTNet PSNR vs oracle: fp32-MFMA {p32:.1f} dB, split-bf16 {p16:.1f} dB, max|err| {float((got - want).abs().max()):.2e}')
     assert p32 >= 100.0 and p16 >= 75.0, (p32, p16)
+
+
+@pytest.mark.parametrize('C', [64, 32])
+def test_fused_sft_layer(C):
+    """k4_sft_nhwc (both 1x1 convs + LeakyReLU + modulation [+ residual] in one launch) against the module graph,
+    on a pixel count that is not a multiple of the 64-pixel wave tile, with channel-sliced in-place x/y."""
+    from nerf4k_amd import _native as N
+    torch.manual_seed(C)
+    layer = sr_esrnet.SFTLayer(C, 32).cuda()
+    for p in layer.parameters():
+        p.data.normal_(0, 0.3)
+    H, W = 13, 37
+    cond = torch.randn([H, W, 32]).cuda()
+    buf = torch.randn([H, W, 96]).cuda()                 # x lives in channels [16, 16+C) of a wider buffer
+    res = torch.randn([H, W, C]).cuda()
+    x = buf[:, :, 16:16 + C].clone()
+    with torch.no_grad():
+        want = layer(x.permute(2, 0, 1).unsqueeze(0), cond.permute(2, 0, 1).unsqueeze(0))[0].permute(1, 2, 0) * 0.2 + res
+    wp = sr_esrnet.pack_sft(layer)
+    keep = buf.clone()
+    N.check(N.lib().k4_sft_nhwc(N.f32(cond), 32, N.f32(wp), N.C.c_void_p(buf.data_ptr() + 64), 96,
+                                N.C.c_void_p(buf.data_ptr() + 64), 96, C, H * W, 0.2, N.f32(res), C, 0.2, N.stream()), 'sft')
+    assert torch.allclose(buf[:, :, 16:16 + C], want, atol=3e-5, rtol=1e-5), float((buf[:, :, 16:16 + C] - want).abs().max())
+    assert torch.equal(buf[:, :, :16], keep[:, :, :16]) and torch.equal(buf[:, :, 16 + C:], keep[:, :, 16 + C:])
