@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'lib4k_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip']  # missing files are skipped
+SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip', 'k4_opt.hip']  # missing files are skipped
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 

@@ -1,0 +1,212 @@
+// Training-step streaming kernels for the voxel grids: the three Adam variants of the
+// reference's `adam_upd_cuda` (lib/cuda/adam_upd_kernel.cu:8-58, host wrappers :60-133) and
+// `total_variation_add_grad` (lib/cuda/total_variation_kernel.cu:13-66).  All are HBM-bound element-wise passes
+// over grids of up to 4.5e8 floats (k0 at 417x353x256x12), so the design is about bytes, not flops:
+//   * 128-bit accesses (one thread = 4 consecutive floats), scalar tail / scalar kernel for unaligned sizes;
+//   * the masked variants test the gradient FIRST and touch param / moments only where some lane has grad != 0:
+//     sparse-touched grids (a training batch of 8192 rays touches <1 % of k0) then cost 4 B/voxel instead of 28;
+//   * the TV stencil is launched with the XCD-aware block map so that the i-1 / i / i+1 planes a workgroup reads
+//     live in one XCD's L2 (a plane of the LLFF grid is 361 KB; the stencil re-reads come from L2, not HBM).
+// Arithmetic follows the reference op for op (same association; a*b+c written as fmaf where nvcc contracts it).
+#include "k4_common.h"
+#include <math.h>
+
+#define K4_OPT_THREADS 256
+
+enum { K4_ADAM_PLAIN = 0, K4_ADAM_MASKED = 1, K4_ADAM_PERLR = 2 };
+
+__device__ __forceinline__ void k4_adam_one(float& p, float g, float& m, float& v, float lrs, float step_size,
+                                            float beta1, float beta2, float omb1, float omb2, float eps) {
+    m = fmaf(beta1, m, omb1 * g);                          // .cu:19 / :37 / :54
+    v = fmaf(beta2, v, (omb2 * g) * g);                    // .cu:20 / :38 / :55
+    p -= (step_size * lrs * m) / (sqrtf(v) + eps);         // .cu:21 / :39 / :56 (lrs = perlr or exactly 1)
+}
+
+template <int MODE>
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_vec_kernel(
+    float4* __restrict__ param, const float4* __restrict__ grad, float4* __restrict__ exp_avg,
+    float4* __restrict__ exp_avg_sq, const float4* __restrict__ perlr, int64_t n4, float step_size, float beta1,
+    float beta2, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * K4_OPT_THREADS + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = grad[i];
+    if (MODE == K4_ADAM_MASKED && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
+    float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+    float4 l = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (MODE == K4_ADAM_PERLR) l = perlr[i];
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    if (MODE != K4_ADAM_MASKED || g.x != 0.f) k4_adam_one(p.x, g.x, m.x, v.x, l.x, step_size, beta1, beta2, omb1, omb2, eps);
+    if (MODE != K4_ADAM_MASKED || g.y != 0.f) k4_adam_one(p.y, g.y, m.y, v.y, l.y, step_size, beta1, beta2, omb1, omb2, eps);
+    if (MODE != K4_ADAM_MASKED || g.z != 0.f) k4_adam_one(p.z, g.z, m.z, v.z, l.z, step_size, beta1, beta2, omb1, omb2, eps);
+    if (MODE != K4_ADAM_MASKED || g.w != 0.f) k4_adam_one(p.w, g.w, m.w, v.w, l.w, step_size, beta1, beta2, omb1, omb2, eps);
+    param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_scalar_kernel(
+    float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
+    float* __restrict__ exp_avg_sq, const float* __restrict__ perlr, int64_t first, int64_t n, float step_size,
+    float beta1, float beta2, float eps) {
+    const int64_t i = first + (int64_t)blockIdx.x * K4_OPT_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float g = grad[i];
+    if (MODE == K4_ADAM_MASKED && g == 0.f) return;
+    float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+    const float l = MODE == K4_ADAM_PERLR ? perlr[i] : 1.f;
+    k4_adam_one(p, g, m, v, l, step_size, beta1, beta2, 1.f - beta1, 1.f - beta2, eps);
+    param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+}
+
+static inline bool k4_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int MODE>
+static int k4_adam_launch(float* param, const float* grad, float* m, float* v, const float* perlr, int64_t n, int step,
+                          float beta1, float beta2, float lr, float eps, hipStream_t st) {
+    if (n < 0 || step < 1 || !param || !grad || !m || !v || (MODE == K4_ADAM_PERLR && !perlr)) return K4_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    // host scalar exactly as adam_upd_kernel.cu:71 (all float arithmetic)
+    const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
+    const bool vec = k4_aligned16(param) && k4_aligned16(grad) && k4_aligned16(m) && k4_aligned16(v) &&
+                     (MODE != K4_ADAM_PERLR || k4_aligned16(perlr));
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        const int64_t blocks = (n4 + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+        if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+        hipLaunchKernelGGL(k4_adam_vec_kernel<MODE>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, (float4*)param,
+                           (const float4*)grad, (float4*)m, (float4*)v, (const float4*)perlr, n4, step_size, beta1, beta2, eps);
+    }
+    const int64_t first = n4 * 4;
+    if (first < n) {
+        const int64_t blocks = (n - first + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+        if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+        hipLaunchKernelGGL(k4_adam_scalar_kernel<MODE>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, m, v,
+                           perlr, first, n, step_size, beta1, beta2, eps);
+    }
+    return k4_check_launch();
+}
+
+extern "C" int k4_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                           float beta1, float beta2, float lr, float eps, void* stream) {
+    return k4_adam_launch<K4_ADAM_PLAIN>(param, grad, exp_avg, exp_avg_sq, nullptr, n, step, beta1, beta2, lr, eps,
+                                         (hipStream_t)stream);
+}
+extern "C" int k4_masked_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  int32_t step, float beta1, float beta2, float lr, float eps, void* stream) {
+    return k4_adam_launch<K4_ADAM_MASKED>(param, grad, exp_avg, exp_avg_sq, nullptr, n, step, beta1, beta2, lr, eps,
+                                          (hipStream_t)stream);
+}
+extern "C" int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                      const float* perlr, int64_t n, int32_t step, float beta1, float beta2, float lr,
+                                      float eps, void* stream) {
+    return k4_adam_launch<K4_ADAM_PERLR>(param, grad, exp_avg, exp_avg_sq, perlr, n, step, beta1, beta2, lr, eps,
+                                         (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ total variation
+__device__ __forceinline__ float k4_clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
+
+// One thread = 4 consecutive k (needs sz_k % 4 == 0 and 16-byte aligned bases).  The +-1 neighbours along k are the
+// adjacent lanes' values except at the two ends of the 4-group, fetched as scalars (same cache lines).
+template <bool DENSE>
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* __restrict__ param, float* __restrict__ grad,
+                                                                   float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
+                                                                   int64_t sz_k, int64_t n4) {
+    const int b = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int64_t t = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
+    if (t >= n4) return;
+    const int64_t index = t * 4;
+    float4 g = *(const float4*)(grad + index);
+    if (!DENSE && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
+    const int64_t k = index % sz_k;
+    const int64_t j = index / sz_k % sz_j;
+    const int64_t i = index / sz_k / sz_j % sz_i;
+    const int64_t sj = sz_k, si = sz_k * sz_j;
+    const float4 c = *(const float4*)(param + index);
+    const float cv[4] = {c.x, c.y, c.z, c.w};
+    float add[4] = {0.f, 0.f, 0.f, 0.f};
+    // k axis (.cu:28-29): term order of the reference: k-1, k+1, j-1, j+1, i-1, i+1
+    const float km = k == 0 ? 0.f : param[index - 1];
+    const float kp = k + 4 >= sz_k ? 0.f : param[index + 4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool has_m = (k + e) != 0, has_p = (k + e) != sz_k - 1;
+        const float vm = e == 0 ? km : cv[e - 1];
+        const float vp = e == 3 ? kp : cv[e + 1];
+        if (has_m) add[e] = fmaf(wx, k4_clamp1(cv[e] - vm), add[e]);
+        if (has_p) add[e] = fmaf(wx, k4_clamp1(cv[e] - vp), add[e]);
+    }
+    if (j != 0) {
+        const float4 q = *(const float4*)(param + index - sj);
+        add[0] = fmaf(wy, k4_clamp1(cv[0] - q.x), add[0]); add[1] = fmaf(wy, k4_clamp1(cv[1] - q.y), add[1]);
+        add[2] = fmaf(wy, k4_clamp1(cv[2] - q.z), add[2]); add[3] = fmaf(wy, k4_clamp1(cv[3] - q.w), add[3]);
+    }
+    if (j != sz_j - 1) {
+        const float4 q = *(const float4*)(param + index + sj);
+        add[0] = fmaf(wy, k4_clamp1(cv[0] - q.x), add[0]); add[1] = fmaf(wy, k4_clamp1(cv[1] - q.y), add[1]);
+        add[2] = fmaf(wy, k4_clamp1(cv[2] - q.z), add[2]); add[3] = fmaf(wy, k4_clamp1(cv[3] - q.w), add[3]);
+    }
+    if (i != 0) {
+        const float4 q = *(const float4*)(param + index - si);
+        add[0] = fmaf(wz, k4_clamp1(cv[0] - q.x), add[0]); add[1] = fmaf(wz, k4_clamp1(cv[1] - q.y), add[1]);
+        add[2] = fmaf(wz, k4_clamp1(cv[2] - q.z), add[2]); add[3] = fmaf(wz, k4_clamp1(cv[3] - q.w), add[3]);
+    }
+    if (i != sz_i - 1) {
+        const float4 q = *(const float4*)(param + index + si);
+        add[0] = fmaf(wz, k4_clamp1(cv[0] - q.x), add[0]); add[1] = fmaf(wz, k4_clamp1(cv[1] - q.y), add[1]);
+        add[2] = fmaf(wz, k4_clamp1(cv[2] - q.z), add[2]); add[3] = fmaf(wz, k4_clamp1(cv[3] - q.w), add[3]);
+    }
+    if (DENSE || g.x != 0.f) g.x += add[0];
+    if (DENSE || g.y != 0.f) g.y += add[1];
+    if (DENSE || g.z != 0.f) g.z += add[2];
+    if (DENSE || g.w != 0.f) g.w += add[3];
+    *(float4*)(grad + index) = g;
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_scalar_kernel(const float* __restrict__ param, float* __restrict__ grad,
+                                                                      float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
+                                                                      int64_t sz_k, int64_t n) {
+    const int b = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int64_t index = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
+    if (index >= n) return;
+    const float g = grad[index];
+    if (!DENSE && g == 0.f) return;
+    const int64_t k = index % sz_k;
+    const int64_t j = index / sz_k % sz_j;
+    const int64_t i = index / sz_k / sz_j % sz_i;
+    const int64_t sj = sz_k, si = sz_k * sz_j;
+    const float c = param[index];
+    float add = 0.f;
+    if (k != 0) add = fmaf(wx, k4_clamp1(c - param[index - 1]), add);
+    if (k != sz_k - 1) add = fmaf(wx, k4_clamp1(c - param[index + 1]), add);
+    if (j != 0) add = fmaf(wy, k4_clamp1(c - param[index - sj]), add);
+    if (j != sz_j - 1) add = fmaf(wy, k4_clamp1(c - param[index + sj]), add);
+    if (i != 0) add = fmaf(wz, k4_clamp1(c - param[index - si]), add);
+    if (i != sz_i - 1) add = fmaf(wz, k4_clamp1(c - param[index + si]), add);
+    grad[index] = g + add;
+}
+
+extern "C" int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
+                                           int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream) {
+    if (!param || !grad || n < 0 || sz_i <= 0 || sz_j <= 0 || sz_k <= 0 || n % (sz_i * sz_j * sz_k) != 0)
+        return K4_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    wx /= 6.f; wy /= 6.f; wz /= 6.f;                       // total_variation_kernel.cu:46-48
+    const bool vec = (sz_k % 4 == 0) && k4_aligned16(param) && k4_aligned16(grad);
+    const int64_t units = vec ? n / 4 : n;
+    const int64_t blocks = (units + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+    if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+    if (vec) {
+        if (dense_mode)
+            hipLaunchKernelGGL(k4_tv_vec_kernel<true>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
+        else
+            hipLaunchKernelGGL(k4_tv_vec_kernel<false>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
+    } else {
+        if (dense_mode)
+            hipLaunchKernelGGL(k4_tv_scalar_kernel<true>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
+        else
+            hipLaunchKernelGGL(k4_tv_scalar_kernel<false>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
+    }
+    return k4_check_launch();
+}

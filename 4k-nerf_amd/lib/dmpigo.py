@@ -146,6 +146,18 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             **self.rgbnet_kwargs,
         }
 
+    def density_total_variation_add_grad(self, weight, dense_mode):
+        '''lib/dmpigo.py:248-251: separate in-plane / depth weights (the reference passes them as wx=wy=wxy, wz).'''
+        wxy = weight * self.world_size[:2].max() / 128
+        wz = weight * self.mpi_depth / 128
+        self.density.total_variation_add_grad(wxy, wxy, wz, dense_mode)
+
+    def k0_total_variation_add_grad(self, weight, dense_mode):
+        '''lib/dmpigo.py:253-256.'''
+        wxy = weight * self.world_size[:2].max() / 128
+        wz = weight * self.mpi_depth / 128
+        self.k0.total_variation_add_grad(wxy, wxy, wz, dense_mode)
+
     def activate_density(self, density, interval=None):
         interval = interval if interval is not None else self.voxel_size_ratio
         shape = density.shape

@@ -249,6 +249,16 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             **self.rgbnet_kwargs,
         }
 
+    def density_total_variation_add_grad(self, weight, dense_mode):
+        '''lib/dvgo.py:268-270: isotropic TV weight scaled by max(world_size)/128.'''
+        w = weight * self.world_size.max() / 128
+        self.density.total_variation_add_grad(w, w, w, dense_mode)
+
+    def k0_total_variation_add_grad(self, weight, dense_mode):
+        '''lib/dvgo.py:272-274.'''
+        w = weight * self.world_size.max() / 128
+        self.k0.total_variation_add_grad(w, w, w, dense_mode)
+
     def activate_density(self, density, interval=None):
         interval = interval if interval is not None else self.voxel_size_ratio
         shape = density.shape

@@ -14,6 +14,20 @@ from .. import _native as N
 from . import render_utils_cuda
 
 
+def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+    """total_variation_cuda.total_variation_add_grad (lib/cuda/total_variation.cpp:16-20): grad += TV gradient of param,
+    in place.  param, grad: [1, C, X, Y, Z] contiguous fp32 device tensors (CHECK_INPUT upstream)."""
+    if param.dim() != 5 or grad.shape != param.shape:
+        raise ValueError('total_variation_add_grad: param/grad must be [1,C,X,Y,Z] of equal shape')
+    for t in (param, grad):
+        if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError('total_variation_add_grad: tensors must be contiguous fp32 device tensors')
+    N.check(N.lib().k4_total_variation_add_grad(N.ptr(param), N.ptr(grad), float(wx), float(wy), float(wz),
+                                                param.size(2), param.size(3), param.size(4), param.numel(),
+                                                1 if dense_mode else 0, N.stream()),
+            'k4_total_variation_add_grad')
+
+
 def create_grid(type, **kwargs):
     if type == 'DenseGrid':
         return DenseGrid(**kwargs)
@@ -58,7 +72,8 @@ class DenseGrid(nn.Module):
                 F.interpolate(self.grid.data, size=tuple(new_world_size), mode='trilinear', align_corners=True))
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
-        raise NotImplementedError('total_variation_add_grad: training-only kernel, "next" row of SURVEY.md 8f')
+        '''Add gradients by total variation loss in-place (lib/grid.py:137-140).'''
+        total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
 
     def get_dense_grid(self):
         return self.grid

@@ -1,14 +1,42 @@
 """Checkpoint helpers with the reference's formats (/root/reference/lib/utils.py:50-66).
 
 DVGO/MPI checkpoints: ``{'global_step', 'model_kwargs', 'model_state_dict', 'optimizer_state_dict'}``
-(run_sr.py:1173-1178).  Only what the render path needs is restated; metrics (SSIM/LPIPS) and the
-optimiser factory are out of scope.
+(run_sr.py:1173-1178).  Only what the render / training-step path needs is restated; metrics (SSIM/LPIPS) are out
+of scope.
 """
 import numpy as np
 import torch
+import torch.nn as nn
+
+from .masked_adam import MaskedAdam
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)     # lib/utils.py:19
 mse2psnr = lambda x: -10. * torch.log10(x)
+
+
+def create_optimizer_or_freeze_model(model, cfg_train, global_step):
+    """lib/utils.py:21-48: one param group per `lrate_<name>` entry of cfg_train whose attribute exists on the model;
+    lr decays by 0.1 every `lrate_decay` k-steps; lr == 0 freezes the parameter.  cfg_train: attribute-style mapping
+    (mmcv ConfigDict upstream; anything with .keys() and getattr works)."""
+    decay = 0.1 ** (global_step / (cfg_train.lrate_decay * 1000))
+    names = [key[len('lrate_'):] for key in cfg_train.keys() if key.startswith('lrate_')]
+    param_group = []
+    for name in names:
+        target = getattr(model, name, None)
+        if target is None:
+            if hasattr(model, name):
+                print(f'create_optimizer_or_freeze_model: param {name} not exist')
+            continue
+        lr = getattr(cfg_train, 'lrate_' + name) * decay
+        if lr <= 0:
+            print(f'create_optimizer_or_freeze_model: param {name} freeze')
+            target.requires_grad = False        # (a plain attribute on an nn.Module, exactly as upstream)
+            continue
+        print(f'create_optimizer_or_freeze_model: param {name} lr {lr}')
+        param_group.append({'params': target.parameters() if isinstance(target, nn.Module) else target,
+                            'lr': lr, 'kname': name,
+                            'skip_zero_grad': name in cfg_train.skip_zero_grad_fields})
+    return MaskedAdam(param_group)
 
 
 def load_checkpoint(model, optimizer, ckpt_path, no_reload_optimizer):

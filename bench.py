@@ -197,7 +197,7 @@ def main():
             'frames_per_s_lr': round(args.steps / elapsed, 2),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'kernel': 'marcher call = k4_geom_kernel<MPI> + k4_shade_pipe_kernel<MPI,64,1>',
+                         'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>',
                          'kernel_ms': round(iso_ms, 4),
                          'kernel_ms_note': 'isolated launch duration (1 stream, HIP events on the launch stream); in the '
                                            'timed region frames overlap on %d streams: %.4f ms/frame effective = %.1f GB/s '
@@ -221,6 +221,8 @@ def main():
             res['reference_pipeline_baseline'] = reference_pipeline_baseline(model, rays[0], rk)
             res['reference_pipeline_baseline']['speedup_of_value'] = round(
                 value / res['reference_pipeline_baseline']['value'], 1)
+        if world == 1 and not args.small:
+            res['training_step_kernels'] = training_step_kernels(dev)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
         print(json.dumps(res), flush=True)
@@ -274,6 +276,48 @@ def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world, mode='fp32'):
             'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': 157.3 * world, 'unit': 'TFLOP/s',
                             'frac': round(tflops / (157.3 * world), 4), 'flop_per_frame': flop_per_px * px,
                             'note': 'fp32-input MFMA peak (v_mfma_f32_32x32x2_f32) x n_gpus; time includes marcher + all-gather'}}
+
+
+def training_step_kernels(dev, reps=5):
+    """MaskedAdam + total_variation_add_grad on the LLFF k0 grid (12 x 417 x 353 x 256 fp32 =
+    1.81 GB per tensor, far beyond the 256 MB infinity cache), HIP-event timed.  Algorithmic bytes per voxel:
+    dense Adam 28 (param/exp_avg/exp_avg_sq read+write, grad read), TV 12 (param read once, grad read+write),
+    masked Adam 4 + 24 x touched fraction (here 1 % of the voxels, in 64-voxel runs as a ray batch leaves them)."""
+    from nerf4k_amd.lib import masked_adam as MA, grid as G
+    shape = (1, 12, 417, 353, 256)
+    n = int(np.prod(shape))
+    gen = torch.Generator(device=dev).manual_seed(0)
+    p = torch.randn(shape, device=dev, generator=gen)
+    g = torch.randn(shape, device=dev, generator=gen)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    gs = torch.zeros(n // 64, 64, device=dev)
+    touched = torch.rand(n // 64, device=dev, generator=gen) < 0.01
+    gs[touched] = 1.0
+    frac_touched = float(touched.float().mean())
+    gs = gs.reshape(shape)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+    out = {'grid': list(shape), 'voxels': n}
+    for name, fn, bpe in (
+            ('adam_upd', lambda: MA.adam_upd(p, g, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 28.0),
+            ('masked_adam_upd_1pct', lambda: MA.masked_adam_upd(p, gs, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 4.0 + 24.0 * frac_touched),
+            ('total_variation_add_grad_dense', lambda: G.total_variation_add_grad(p, g, 1e-3, 1e-3, 1e-3, True), 12.0),
+            ('total_variation_add_grad_sparse_1pct', lambda: G.total_variation_add_grad(p, gs, 1e-3, 1e-3, 1e-3, False), 4.0 + 8.0 * frac_touched)):
+        ms = timed(fn)
+        gbs = n * bpe / (ms * 1e-3) / 1e9
+        out[name] = {'ms': round(ms, 3), 'algorithmic_bytes_per_voxel': round(bpe, 2), 'achieved_GBs': round(gbs, 1),
+                     'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def reference_pipeline_baseline(model, rays, rk, chunk=8192, frames=2):

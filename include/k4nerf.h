@@ -230,6 +230,28 @@ int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
                 const float* x, int32_t x_stride, float* y, int32_t y_stride, int32_t channels,
                 int64_t n_pix, float slope, const float* res, int32_t res_stride, float res_scale, void* stream);
 
+/* ---- training-step streaming kernels --------------------------------------------------------
+ * Replace the reference extension `adam_upd_cuda` (lib/cuda/adam_upd.cpp:10-67 -> adam_upd_kernel.cu:60-133) that
+ * MaskedAdam.step calls (lib/masked_adam.py:39-71).  fp32, n contiguous elements, updated in place; `step` >= 1 is
+ * the 1-based step count the bias correction uses (step_size = lr*sqrt(1-beta2^step)/(1-beta1^step), .cu:71).
+ *   k4_adam_upd            : every element                                      (adam_upd_kernel.cu:8-23)
+ *   k4_masked_adam_upd     : only elements with grad != 0 (moments untouched)   (adam_upd_kernel.cu:25-41)
+ *   k4_adam_upd_with_perlr : every element, step scaled by perlr[i]             (adam_upd_kernel.cu:43-58)      */
+int k4_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                float beta1, float beta2, float lr, float eps, void* stream);
+int k4_masked_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                       float beta1, float beta2, float lr, float eps, void* stream);
+int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* perlr,
+                           int64_t n, int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
+
+/* total_variation_cuda.total_variation_add_grad (lib/cuda/total_variation.cpp:16-20 ->
+ * total_variation_kernel.cu:13-66), called by DenseGrid.total_variation_add_grad (lib/grid.py:137-140).
+ * param/grad: [1, C, sz_i, sz_j, sz_k] contiguous fp32, n = C*sz_i*sz_j*sz_k; grad += sum over the 6 neighbours of
+ * (w_axis/6)*clamp(param - param_nb, -1, 1) with wx on the k (fastest) axis, wy on j, wz on i -- the reference's
+ * naming; dense_mode == 0 restricts the update to elements whose grad is non-zero. */
+int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
+                                int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
