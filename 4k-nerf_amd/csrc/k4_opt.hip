@@ -62,8 +62,9 @@ static inline bool k4_aligned16(const void* p) { return ((uintptr_t)p & 15u) == 
 template <int MODE>
 static int k4_adam_launch(float* param, const float* grad, float* m, float* v, const float* perlr, int64_t n, int step,
                           float beta1, float beta2, float lr, float eps, hipStream_t st) {
-    if (n < 0 || step < 1 || !param || !grad || !m || !v || (MODE == K4_ADAM_PERLR && !perlr)) return K4_ERR_BAD_ARG;
-    if (n == 0) return 0;
+    if (n < 0 || step < 1) return K4_ERR_BAD_ARG;
+    if (n == 0) return 0;                                  // empty tensors carry NULL data pointers
+    if (!param || !grad || !m || !v || (MODE == K4_ADAM_PERLR && !perlr)) return K4_ERR_BAD_ARG;
     // host scalar exactly as adam_upd_kernel.cu:71 (all float arithmetic)
     const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
     const bool vec = k4_aligned16(param) && k4_aligned16(grad) && k4_aligned16(m) && k4_aligned16(v) &&
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_scalar_kernel(const floa
 
 extern "C" int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
                                            int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream) {
-    if (!param || !grad || n < 0 || sz_i <= 0 || sz_j <= 0 || sz_k <= 0 || n % (sz_i * sz_j * sz_k) != 0)
-        return K4_ERR_BAD_ARG;
+    if (n < 0 || sz_i <= 0 || sz_j <= 0 || sz_k <= 0 || n % (sz_i * sz_j * sz_k) != 0) return K4_ERR_BAD_ARG;
     if (n == 0) return 0;
+    if (!param || !grad) return K4_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     wx /= 6.f; wy /= 6.f; wz /= 6.f;                       // total_variation_kernel.cu:46-48
     const bool vec = (sz_k % 4 == 0) && k4_aligned16(param) && k4_aligned16(grad);
