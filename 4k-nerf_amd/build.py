@@ -13,7 +13,10 @@ CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'lib4k_hip.so')
 ARCH = 'gfx950'
 SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip', 'k4_opt.hip']  # missing files are skipped
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+# -ffp-contract=on: a*b+c fuses only where the SOURCE expression says so (and in explicit fmaf).  hipcc's default
+# (fast-honor-pragmas) lets the backend fuse any fmul/fadd pair it finds after inlining, so two inlined copies of one
+# routine (expf/powf included) could round differently -- a ray's result then depended on which copy served its sample.
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 
 def _newer(a, b):

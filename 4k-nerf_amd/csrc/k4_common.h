@@ -21,8 +21,27 @@ __device__ __forceinline__ int k4_prefix(uint64_t m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// index of the run of equal `key` values this lane belongs to (runs = maximal groups of consecutive lanes)
+__device__ __forceinline__ int k4_run_id(int key, int lane) {
+    const int prev = __shfl_up(key, 1);
+    const uint64_t heads = __ballot(lane == 0 || prev != key);
+    return __popcll(heads & (~0ull >> (63 - lane)));
+}
+
+// LDS float accumulate (ds_add_f32, no return value)
+__device__ __forceinline__ void k4_lds_add(float* p, float v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ float k4_readlane(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// 64-bit fetch of two adjacent floats that are only 4-byte aligned (global_load_dwordx2 needs dword alignment only)
+struct __attribute__((packed, aligned(4))) k4_f2u { float x, y; };
+__device__ __forceinline__ float2 k4_ld2(const float* p) {
+    const k4_f2u v = *reinterpret_cast<const k4_f2u*>(p);
+    return make_float2(v.x, v.y);
 }
 
 // C round(): halves away from zero (the reference's maskcache_lookup, render_utils_kernel.cu:385-387)

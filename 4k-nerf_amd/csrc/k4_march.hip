@@ -49,6 +49,7 @@ struct MarchParams {
     const float* mlp; int mlp_floats; int dim0; int k1p; int vpe; int spe; int k0_skip;
     int n_samples;          // MPI: samples per ray
     int max_steps;          // capacity per ray in the workspace
+    int ent_stride;         // records per bundle in the workspace: 64 * max_steps rounded up to 256 (4 depth quarters)
     int depth_n;            // denominator of s = (k+0.5)/depth_n
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const Bundle B = bundle_of(P, wv);
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.qhead = 0;            // work queue of the shading kernel that follows
-    uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+    uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const k4_cptr c_o = k4_const(P.rays_o), c_d = k4_const(P.rays_d);
     const bool unit_interval = P.interval == 1.f;
     const bool use_thres = P.thres > 0.f;
@@ -252,15 +253,24 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
 // The early stop therefore no longer saves density fetches behind it (they were ~13 % of the mask-passing samples);
 // results are unchanged: a sample behind the stop never gets a weight.
 // -----------------------------------------------------------------------------------------------------
+#define K4_RING 512
 struct Geom2Lds {
     float raytab[64][6];     // start xyz, dir xyz of the bundle's rays
-    unsigned qk[128];        // ring of mask-passing samples: ray_local<<24 | step
+    unsigned qk[K4_RING];    // ring of mask-passing samples: ray_local<<24 | step (residual < 64 + one group of 256)
     int acnt[64];            // alpha-passing samples per ray
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k4_geom2_kernel(const MarchParams P) {
-    __shared__ Geom2Lds lds_all[4];
+// SPLIT (default): the 4 waves of a workgroup share ONE bundle, wave w taking depth quarter w of every ray.  A wave's
+// footprint between two neighbouring rays drops from 4 rows x 1 KB to 4 rows x 256 B, which turns the row reuse of
+// adjacent rays into L1/L2 hits (rocprofv3 PMC on the unsplit form: 116 M L1-miss requests and 2 GB of fabric reads per
+// frame for 190 MB of unique grid data; the kernel ran as fast at 3 waves/SIMD as at 6 -- cache-throughput bound).
+// Records of quarter w go to quarter w of the bundle's workspace slice; after a workgroup barrier wave 0 runs the
+// transmittance scan over the four runs of each ray in depth order and compacts the survivors.
+template <int MODE, int WPB, bool SPLIT>
+__global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P) {
+    static_assert(!SPLIT || WPB == 4, "depth split uses 4 waves per bundle");
+    __shared__ Geom2Lds lds_all[WPB];
+    __shared__ int na_sh[WPB];
     const int lane = k4_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     Geom2Lds& L = lds_all[wv];
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256) void k4_geom2_kernel(const MarchParams P) {
     for (;;) {
     int bid = -1;
     if (!P.geom_persist) {                       // static map: measured 6-15 % faster than either queue form
-        if (first) bid = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wv;
+        if (first) bid = SPLIT ? k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) : k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * WPB + wv;
         first = false;
     } else
     while (steal < 8) {
@@ -297,82 +307,165 @@ __global__ __launch_bounds__(256) void k4_geom2_kernel(const MarchParams P) {
     }
     if (bid < 0) break;
     const Bundle B = bundle_from_id(P, bid);
-    uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+    uint2* const ent_base = P.entries + (size_t)B.id * (size_t)P.ent_stride;
+    const int quarter = P.ent_stride >> 2;
+    uint2* const ent = SPLIT ? ent_base + (size_t)wv * quarter : ent_base;       // this wave's run of records
     L.acnt[lane] = 0;
     int qn = 0, qh = 0;          // ring fill / head (wave-uniform)
     int na = 0;                  // alpha-passing records written so far (wave-uniform)
 
-    // ---- stage B: density + activation on `nproc` ring entries, lane = sample ----
-    auto stage_b = [&](int nproc) {
-        const bool lact = lane < nproc;
-        const unsigned key = L.qk[(qh + (lact ? lane : 0)) & 127];
-        const int rl = (int)(key >> 24);
-        const int k = (int)(key & 0xffffffu);
-        const float* rt = L.raytab[rl];
-        const float tk = step_t<MODE>(P, k);
-        const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
-        const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
-        const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
-        const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
-        const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
-        // inside the closed bbox 0 <= u <= dim-1: only the "+1" corner can leave the grid and then its weight is exactly 0
-        const int x1 = min(t.x0 + 1, P.X - 1), y1 = min(t.y0 + 1, P.Y - 1), z1 = min(t.z0 + 1, P.Z - 1);
-        const unsigned r00 = (unsigned)(t.x0 * P.Y + t.y0) * (unsigned)P.Z, r01 = (unsigned)(t.x0 * P.Y + y1) * (unsigned)P.Z;
-        const unsigned r10 = (unsigned)(x1 * P.Y + t.y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
-        const float d0 = P.density[r00 + t.z0], d1 = P.density[r00 + z1], d2 = P.density[r01 + t.z0], d3 = P.density[r01 + z1];
-        const float d4 = P.density[r10 + t.z0], d5 = P.density[r10 + z1], d6 = P.density[r11 + t.z0], d7 = P.density[r11 + z1];
-        float sigma = 0.f;
-        sigma += d0 * t.w[0]; sigma += d1 * t.w[1]; sigma += d2 * t.w[2]; sigma += d3 * t.w[3];
-        sigma += d4 * t.w[4]; sigma += d5 * t.w[5]; sigma += d6 * t.w[6]; sigma += d7 * t.w[7];
-        if (MODE == MODE_MPI) {
-            // act_shift grid [1,1,D]: x/y sizes are 1 -> only z interpolates (lib/dmpigo.py:48-58,316)
-            const float ua = k4_unnorm(nz, P.act_d);
-            const float fa = floorf(ua);
-            const int a0 = (int)fa;
-            sigma += P.act_shift[a0] * ((fa + 1.f) - ua) + P.act_shift[min(a0 + 1, P.act_d - 1)] * (ua - fa);
+    // ---- stage B: density + activation, lane = sample, up to 2 ring entries per lane.  Split in two halves so that the
+    // 8 corner fetches of a batch are in flight while the wave does the occupancy stage of the NEXT 256 samples: the
+    // batch is issued at the end of one group and finished at the end of the following one, so one memory round trip
+    // (the occupancy bytes') covers both.  Per-stage ablation: the fetch wait was 0.52 ms of the kernel's 1.47 ms.
+    int pend_n = 0;              // entries of the batch in flight (wave-uniform), 0 = none
+    unsigned pkey[2];
+    float pfx[2], pfy[2], pfz[2], pfa[2];
+    float pdl[2][4], pdh[2][4];       // the 4 (x,y) rows' (zb, zb+1) density pairs
+    float pa0[2], pa1[2];
+    auto issue_b = [&](int nproc) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) if (s2 * 64 < nproc) {
+            const bool lact = s2 * 64 + lane < nproc;
+            const unsigned key = L.qk[(qh + s2 * 64 + (lact ? lane : 0)) & (K4_RING - 1)];
+            const int rl = (int)(key >> 24);
+            const int k = (int)(key & 0xffffffu);
+            const float* rt = L.raytab[rl];
+            const float tk = step_t<MODE>(P, k);
+            const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
+            const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
+            const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
+            const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
+            const float ux = k4_unnorm(nx, P.X), uy = k4_unnorm(ny, P.Y), uz = k4_unnorm(nz, P.Z);
+            const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+            const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+            // inside the closed bbox 0 <= u <= dim-1: only the "+1" corner can leave the grid and then its weight is exactly 0.
+            // The two z neighbours are adjacent dwords: one 64-bit fetch at zb = min(z0, Z-2) (for z0 == Z-1 the pair is
+            // shifted down by one and its upper element is the z0 corner; the z0+1 corner then has weight exactly 0)
+            const int x1 = min(x0 + 1, P.X - 1), y1 = min(y0 + 1, P.Y - 1);
+            const int zb = min(z0, max(P.Z - 2, 0));
+            const unsigned r00 = (unsigned)(x0 * P.Y + y0) * (unsigned)P.Z, r01 = (unsigned)(x0 * P.Y + y1) * (unsigned)P.Z;
+            const unsigned r10 = (unsigned)(x1 * P.Y + y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
+            pkey[s2] = key; pfx[s2] = ux; pfy[s2] = uy; pfz[s2] = uz;
+            if (P.debug & 16) {                                           // ablation: no density fetch
+                const float c = __uint_as_float(0x3f000000u + (r00 & 0xffffu));
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) pdl[s2][c4] = pdh[s2][c4] = c;
+            } else if (P.Z >= 2) {
+                const float2 v0 = k4_ld2(P.density + r00 + zb), v1 = k4_ld2(P.density + r01 + zb);
+                const float2 v2 = k4_ld2(P.density + r10 + zb), v3 = k4_ld2(P.density + r11 + zb);
+                pdl[s2][0] = v0.x; pdh[s2][0] = v0.y; pdl[s2][1] = v1.x; pdh[s2][1] = v1.y;
+                pdl[s2][2] = v2.x; pdh[s2][2] = v2.y; pdl[s2][3] = v3.x; pdh[s2][3] = v3.y;
+            } else {                                                      // single-plane grid: both z corners are plane 0
+                pdl[s2][0] = pdh[s2][0] = P.density[r00]; pdl[s2][1] = pdh[s2][1] = P.density[r01];
+                pdl[s2][2] = pdh[s2][2] = P.density[r10]; pdl[s2][3] = pdh[s2][3] = P.density[r11];
+            }
+            if (MODE == MODE_MPI) {
+                // act_shift grid [1,1,D]: x/y sizes are 1 -> only z interpolates (lib/dmpigo.py:48-58,316)
+                const float ua = k4_unnorm(nz, P.act_d);
+                const int a0 = (int)floorf(ua);
+                pfa[s2] = ua;
+                pa0[s2] = P.act_shift[a0]; pa1[s2] = P.act_shift[min(a0 + 1, P.act_d - 1)];
+            }
         }
-        // raw2alpha: e = exp(d+shift); alpha = 1 - (1+e)^(-interval)   render_utils_kernel.cu:439-441
-        const float e = expf(sigma + P.shift);
-        float alpha;
-        if (unit_interval) alpha = 1.f - 1.f / (1.f + e);
-        else alpha = 1.f - powf(1.f + e, -P.interval);
-        const bool act = lact && (use_thres ? (alpha > P.thres) : true);
-        const uint64_t bm = __ballot(act);
-        if (act) {
-            ent[na + k4_prefix(bm)] = make_uint2(key, __float_as_uint(alpha));
-            atomicAdd(&L.acnt[rl], 1);
-        }
-        na += __popcll(bm);
-        qh = (qh + nproc) & 127;
+        pend_n = nproc;
+        qh = (qh + nproc) & (K4_RING - 1);
         qn -= nproc;
     };
-
-    // ---- stage A: occupancy, one ray at a time, lanes = 64 consecutive samples ----
-    for (int r = 0; r < 64; ++r) {
-        const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, r));
-        if (ray < 0) continue;
-        float sx, sy, sz, dx, dy, dz;
-        int nsteps;
-        ray_setup<MODE>(P, c_o[ray * 3 + 0], c_o[ray * 3 + 1], c_o[ray * 3 + 2],
-                        c_d[ray * 3 + 0], c_d[ray * 3 + 1], c_d[ray * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
-        nsteps = __builtin_amdgcn_readfirstlane(nsteps);
-        if (lane == 0) {
-            L.raytab[r][0] = sx; L.raytab[r][1] = sy; L.raytab[r][2] = sz;
-            L.raytab[r][3] = dx; L.raytab[r][4] = dy; L.raytab[r][5] = dz;
-        }
-        // 4 blocks of 64 samples at a time: the 4 occupancy bytes are fetched together (one memory round trip per 256
-        // samples instead of four dependent ones), branch-free (clamped index, validity folded into the predicate)
-        for (int base0 = 0; base0 < nsteps; base0 += 256) {
-            unsigned mbyte[4];
-            bool inbv[4];
+    auto finish_b = [&]() {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = base0 + j * 64 + lane;
+        for (int s2 = 0; s2 < 2; ++s2) if (s2 * 64 < pend_n) {
+            const bool lact = s2 * 64 + lane < pend_n;
+            const unsigned key = pkey[s2];
+            const float ux = pfx[s2], uy = pfy[s2], uz = pfz[s2];
+            const K4Tri t = k4_tri_setup(ux, uy, uz);
+            const bool top = t.z0 > max(P.Z - 2, 0);                      // pair shifted down: z0 corner = upper element
+            // explicit FMA chain (grid_sampler accumulates corner by corner, contracted by nvcc): written out so that every
+            // inlined copy of this stage rounds identically -- a ray must not depend on which slot its sample landed in
+            float sigma = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float lo = pdl[s2][c], hi = pdh[s2][c];
+                const float dlo = top ? hi : lo;
+                sigma = fmaf(dlo, t.w[2 * c], sigma); sigma = fmaf(hi, t.w[2 * c + 1], sigma);
+            }
+            if (MODE == MODE_MPI) {
+                const float ua = pfa[s2];
+                const float fa = floorf(ua);
+                sigma += fmaf(pa1[s2], ua - fa, pa0[s2] * ((fa + 1.f) - ua));
+            }
+            // raw2alpha: e = exp(d+shift); alpha = 1 - (1+e)^(-interval)   render_utils_kernel.cu:439-441
+            const float e = expf(sigma + P.shift);
+            float alpha;
+            if (unit_interval) alpha = 1.f - 1.f / (1.f + e);
+            else alpha = 1.f - powf(1.f + e, -P.interval);
+            const bool act = lact && (use_thres ? (alpha > P.thres) : true);
+            const uint64_t bm = __ballot(act);
+            if (act) {
+                ent[na + k4_prefix(bm)] = make_uint2(key, __float_as_uint(alpha));
+                atomicAdd(&L.acnt[(int)(key >> 24)], 1);
+            }
+            na += __popcll(bm);
+        }
+        pend_n = 0;
+    };
+    auto pump_b = [&]() {        // end of a group: retire the batch in flight, start the next one
+        if (pend_n) finish_b();
+        while (qn >= 64) {
+            issue_b(qn >= 128 ? 128 : 64);
+            if (qn >= 64) finish_b(); else break;
+        }
+    };
+
+    // ---- stage A: occupancy, lanes = 64 consecutive samples of one ray.  Work items = (ray, block of 64 samples) in
+    // ray-major order over this wave's depth range of each ray (SPLIT: quarter wv of the ray's blocks; else all of them).
+    int it_r = -1, it_k = 0, it_kend = 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;      // the current ray (wave-uniform values)
+    auto next_item = [&](int& r_out, int& base_out, int& kend_out) -> bool {
+        while (it_k >= it_kend) {
+            ++it_r;
+            if (it_r >= 64) return false;
+            const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, it_r));
+            if (ray < 0) continue;
+            int nsteps;
+            ray_setup<MODE>(P, c_o[ray * 3 + 0], c_o[ray * 3 + 1], c_o[ray * 3 + 2],
+                            c_d[ray * 3 + 0], c_d[ray * 3 + 1], c_d[ray * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
+            nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+            if (lane == 0) {
+                L.raytab[it_r][0] = sx; L.raytab[it_r][1] = sy; L.raytab[it_r][2] = sz;
+                L.raytab[it_r][3] = dx; L.raytab[it_r][4] = dy; L.raytab[it_r][5] = dz;
+            }
+            if (SPLIT) {
+                const int nb4 = (((nsteps + 63) >> 6) + 3) >> 2;               // blocks per depth quarter of this ray
+                it_k = wv * nb4 * 64;
+                it_kend = min((wv + 1) * nb4 * 64, nsteps);
+            } else { it_k = 0; it_kend = nsteps; }
+        }
+        r_out = it_r; base_out = it_k; kend_out = it_kend;
+        it_k += 64;
+        return true;
+    };
+    // groups of 4 items: the 4 occupancy bytes are fetched together (one memory round trip per 256 samples), branch-free
+    // (clamped index, validity folded into the predicate); all 4 are consumed (ballots) before any density batch is
+    // issued, so the only fetches in flight across the next group's wait are that batch's
+    for (bool more = true; more;) {
+        unsigned mbyte[4];
+        bool inbv[4];
+        unsigned ikey[4];
+        int nitems = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r_ = 0, base_ = 0, kend_ = 0;
+            mbyte[j] = 0u; inbv[j] = false; ikey[j] = 0u;
+            if (more) more = next_item(r_, base_, kend_);
+            if (more) {
+                nitems = j + 1;
+                const int k = base_ + lane;
                 float tk;
-                if (MODE == MODE_MPI && base0 == 0) tk = j == 0 ? tk0 : (j == 1 ? tk1 : (j == 2 ? tk2 : tk3));   // hoisted k/(Ns-1)
+                if (MODE == MODE_MPI && base_ < 256) tk = base_ == 0 ? tk0 : (base_ == 64 ? tk1 : (base_ == 128 ? tk2 : tk3));   // hoisted k/(Ns-1)
                 else tk = step_t<MODE>(P, k);
                 const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
-                const bool inb = (k < nsteps) &&
+                const bool inb = (k < kend_) &&
                     !((P.minx > px) | (P.miny > py) | (P.minz > pz) | (P.maxx < px) | (P.maxy < py) | (P.maxz < pz));
                 const int mi = k4_round_half_away(fmaf(px, P.msx, P.mtx));
                 const int mj = k4_round_half_away(fmaf(py, P.msy, P.mty));
@@ -381,75 +474,99 @@ __global__ __launch_bounds__(256) void k4_geom2_kernel(const MarchParams P) {
                 const unsigned midx = ok ? (unsigned)(mi * P.MY + mj) * (unsigned)P.MZ + (unsigned)mk : 0u;    // < 2^32 mask voxels
                 mbyte[j] = ok ? (unsigned)P.mask[midx] : 0u;
                 inbv[j] = inb;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (base0 + j * 64 >= nsteps) break;
-                const bool m = mbyte[j] != 0;
-                const uint64_t mball = __ballot(m);
-                if (P.counters) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball); }
-                if (!mball) continue;
-                if (m) L.qk[(qh + qn + k4_prefix(mball)) & 127] = ((unsigned)r << 24) | (unsigned)(base0 + j * 64 + lane);
-                qn += __popcll(mball);
-                if (qn >= 64) stage_b(64);
+                ikey[j] = ((unsigned)r_ << 24) | (unsigned)k;
             }
         }
+        if (nitems == 0) break;
+        uint64_t mball[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mball[j] = __ballot(mbyte[j] != 0);
+            if (P.counters) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!mball[j]) continue;
+            if (mbyte[j] != 0) L.qk[(qh + qn + k4_prefix(mball[j])) & (K4_RING - 1)] = ikey[j];
+            qn += __popcll(mball[j]);
+        }
+        pump_b();
     }
-    if (qn > 0) stage_b(qn);
+    if (pend_n) finish_b();
+    while (qn > 0) { issue_b(min(qn, 128)); finish_b(); }
 
-    // the wave now re-reads records other lanes stored: drain its stores first (same wave, same L1: in-order afterwards)
+    // the scan re-reads records other lanes (SPLIT: other waves) stored: drain the stores first
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    // ---- stage C: transposed transmittance scan, lane = ray (render_utils_kernel.cu:591-603) ----
-    const int c = L.acnt[lane];
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
+    constexpr int NRUN = SPLIT ? 4 : 1;
+    if (SPLIT) {
+        if (lane == 0) na_sh[wv] = na;
+        __syncthreads();
+        if (wv != 0) break;                                            // quarters 1..3 are done; wave 0 finishes the bundle
     }
-    const int seg = incl - c;
-    int maxc = c;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
-    maxc = __builtin_amdgcn_readfirstlane(maxc);
+    // ---- stage C: transposed transmittance scan, lane = ray (render_utils_kernel.cu:591-603); a ray's records are
+    // NRUN runs (one per depth quarter), visited in depth order ----
     float T = 1.f;
     bool stopped = false;
-    for (int j0 = 0; j0 < maxc; j0 += 4) {
-        float a[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = (j0 + u < c) ? __uint_as_float(ent[seg + j0 + u].y) : 0.f;
+    for (int w = 0; w < NRUN; ++w) {
+        uint2* const run = ent_base + (size_t)w * quarter;
+        const int c = lds_all[SPLIT ? w : wv].acnt[lane];
+        int incl = c;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j0 + u < c) {
-                float w = -1.f;                                        // behind the early stop: never shaded
-                if (!stopped) {
-                    w = T * a[u];
-                    T = fmaf(-T, a[u], T);                             // == (float)((double)T*(1.-a)), see k4_geom_kernel
-                    if (T < 1e-3f) stopped = true;                     // the crossing sample is still counted (:597-600)
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const int seg = incl - c;
+        int maxc = c;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+        maxc = __builtin_amdgcn_readfirstlane(maxc);
+        if (P.debug & 32) maxc = 0;                                    // ablation: no transmittance scan
+        for (int j0 = 0; j0 < maxc; j0 += 4) {
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = (j0 + u < c) ? __uint_as_float(run[seg + j0 + u].y) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < c) {
+                    float wgt = -1.f;                                  // behind the early stop: never shaded
+                    if (!stopped) {
+                        wgt = T * a[u];
+                        T = fmaf(-T, a[u], T);                         // == (float)((double)T*(1.-a)), see k4_geom_kernel
+                        if (T < 1e-3f) stopped = true;                 // the crossing sample is still counted (:597-600)
+                    }
+                    run[seg + j0 + u].y = __float_as_uint(wgt);
                 }
-                ent[seg + j0 + u].y = __float_as_uint(w);
             }
         }
     }
     const float my_ainv = T;                                           // alphainv_last of ray `lane` (1 if it has no samples)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- stage D: keep w > thres, in place, order preserved ----
-    int cnt = 0;
-    for (int base = 0; base < na; base += 64) {
-        const int i = base + lane;
-        const bool v = i < na;
-        const uint2 e = ent[v ? i : 0];
-        const float w = __uint_as_float(e.y);
-        const bool shade = v && (use_thres ? (w > P.thres) : (w >= 0.f));
-        const uint64_t sm = __ballot(shade);
-        if (shade) ent[cnt + k4_prefix(sm)] = e;
-        cnt += __popcll(sm);
+    // ---- stage D: keep w > thres, compacted to the front of the bundle's slice, run order preserved ----
+    int cnt = 0, na_all = 0;
+#pragma unroll
+    for (int w = 0; w < NRUN; ++w) {
+        const uint2* const run = ent_base + (size_t)w * quarter;
+        int naw = SPLIT ? na_sh[w] : na;
+        na_all += naw;
+        if (P.debug & 128) naw = 0;                                    // ablation: no survivor compaction (nothing shaded)
+        for (int base = 0; base < naw; base += 64) {
+            const int i = base + lane;
+            const bool v = i < naw;
+            const uint2 e = run[v ? i : 0];
+            const float wgt = __uint_as_float(e.y);
+            const bool shade = v && (use_thres ? (wgt > P.thres) : (wgt >= 0.f));
+            const uint64_t sm = __ballot(shade);
+            if (shade) ent_base[cnt + k4_prefix(sm)] = e;               // cnt + prefix <= position of e: never overtakes the reads
+            cnt += __popcll(sm);
+        }
     }
     if (lane == 0) P.counts[B.id] = cnt;
     const int myray = ray_index(P, B, lane);
     if (myray >= 0) P.out_ainv[myray] = my_ainv;
-    n_alpha += (unsigned long long)na; n_shade += (unsigned long long)cnt;
+    n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }   // bundle queue
     if (P.counters && lane == 0) {
@@ -591,7 +708,7 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
     if (bid >= P.n_bundles) break;
     const Bundle B = bundle_from_id(P, bid);
     acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
-    const uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+    const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
 
     for (int base = 0; base < total; base += 64) {
@@ -712,8 +829,9 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
         float v1 = w * (1.f / (1.f + expf(-o1)));
         float v2 = w * (1.f / (1.f + expf(-o2)));
         float v3 = w * (((float)k + 0.5f) / (float)P.depth_n);       // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
-        // segmented inclusive scan keyed by ray (records are sorted by ray)
-        const int keyr = lact ? rl : (256 + lane);
+        // segmented inclusive scan over RUNS of equal ray (a ray's records are contiguous within a depth quarter, so
+        // one batch can hold two runs of the same ray: key = index of the run, not the ray)
+        const int keyr = k4_run_id(lact ? rl : (256 + lane), lane);
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int ok_ = __shfl_up(keyr, off);
@@ -722,7 +840,8 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
         }
         const int nextk = __shfl_down(keyr, 1);
         if (lact && (lane == 63 || nextk != keyr)) {
-            acc[rl * 4 + 0] += v0; acc[rl * 4 + 1] += v1; acc[rl * 4 + 2] += v2; acc[rl * 4 + 3] += v3;
+            // ds_add_f32: two runs of one ray can end in the same batch (sparse bundles), a plain read-modify-write would lose one
+            k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -821,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void k4_shade_pipe_kernel(const MarchParams
         bid = __builtin_amdgcn_readfirstlane(bid);
         if (bid >= P.n_bundles) break;
         const Bundle B = bundle_from_id(P, bid);
-        const uint2* __restrict__ ent = P.entries + (size_t)B.id * 64 * (size_t)P.max_steps;
+        const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
         const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
         const int myray = ray_index(P, B, lane);
         acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
@@ -921,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void k4_shade_pipe_kernel(const MarchParams
                 float v1 = w_i * (1.f / (1.f + expf(-o1)));
                 float v2 = w_i * (1.f / (1.f + expf(-o2)));
                 float v3 = w_i * (((float)k_i + 0.5f) / (float)P.depth_n);
-                const int keyr = lact_i ? rl_i : (256 + lane);
+                const int keyr = k4_run_id(lact_i ? rl_i : (256 + lane), lane);
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const int ok_ = __shfl_up(keyr, off);
@@ -930,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void k4_shade_pipe_kernel(const MarchParams
                 }
                 const int nextk = __shfl_down(keyr, 1);
                 if (lact_i && (lane == 63 || nextk != keyr)) {
-                    acc[rl_i * 4 + 0] += v0; acc[rl_i * 4 + 1] += v1; acc[rl_i * 4 + 2] += v2; acc[rl_i * 4 + 3] += v3;
+                    k4_lds_add(&acc[rl_i * 4 + 0], v0); k4_lds_add(&acc[rl_i * 4 + 1], v1); k4_lds_add(&acc[rl_i * 4 + 2], v2); k4_lds_add(&acc[rl_i * 4 + 3], v3);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -979,7 +1098,14 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         hipError_t e0 = hipMemsetAsync(P.ghead, 0, 8 * sizeof(int), st);
         if (e0 != hipSuccess) return (int)e0;
         const int per_cu = 7;                                      // 7 waves/SIMD (SGPR bound)
-        hipLaunchKernelGGL((k4_geom2_kernel<MODE>), P.geom_persist ? dim3((unsigned)min(nwg, n_cu * per_cu)) : grid, block, 0, st, P);
+        static const int wpb = getenv("K4_GEOM_WPB") ? atoi(getenv("K4_GEOM_WPB")) : 4;
+        static const int split = getenv("K4_GEOM_SPLIT") ? atoi(getenv("K4_GEOM_SPLIT")) : 1;
+        static const int ldspad = getenv("K4_GEOM_LDSPAD") ? atoi(getenv("K4_GEOM_LDSPAD")) : 0;      // occupancy experiments
+        if (P.geom_persist) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false>), dim3((unsigned)min(nwg, n_cu * per_cu)), block, 0, st, P);
+        else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        else if (wpb == 1) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
+        else if (wpb == 2) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 2, false>), dim3((unsigned)nwg * 2), dim3(128), 0, st, P);
+        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false>), grid, block, 0, st, P);
     }
     int rc = k4_check_launch();
     if (rc) return rc;
@@ -1014,10 +1140,13 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     return k4_check_launch();
 }
 
+// records per bundle: 64 rays x max_steps rounded up to a whole number of 64-sample blocks per depth quarter
+static inline int64_t ent_stride_of(int32_t max_steps) { return 64 * (((int64_t)max_steps + 255) / 256 * 256); }
+
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
     if (n_rays < 0 || img_w < 0 || max_steps <= 0 || (img_w > 0 && n_rays % img_w != 0)) return -1;
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
-    return nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2) + (((nb + 9) * (int64_t)sizeof(int) + 255) / 256) * 256;
+    return nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2) + (((nb + 9) * (int64_t)sizeof(int) + 255) / 256) * 256;
 }
 
 static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -1050,9 +1179,11 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.mlp_floats = (int)mlp_floats_of(m, P.k1p);
     P.vpe = m->viewbase_pe; P.spe = m->spatial_pe; P.k0_skip = m->k0_skip;
     P.max_steps = max_steps;
+    if (ent_stride_of(max_steps) > 0x7fffffff) return K4_ERR_BAD_ARG;
+    P.ent_stride = (int)ent_stride_of(max_steps);
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
     P.entries = (uint2*)workspace;
-    P.counts = (int*)((char*)workspace + nb * 64 * (int64_t)max_steps * (int64_t)sizeof(uint2));
+    P.counts = (int*)((char*)workspace + nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
     P.ghead = P.qhead + 1;
     P.n_bundles = (int)nb;

@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams frames alternate on (2: the geometry kernel of frame '
                     'i+1 overlaps the matrix-core shading kernel of frame i)')
+    ap.add_argument('--no-extras', action='store_true', help='marcher line only: skip the reference-pipeline and training-step '
+                    'side measurements (profiling runs)')
     ap.add_argument('--backend', default='nccl', help=argparse.SUPPRESS)          # gloo + --same-device: 1-GPU logic smoke test
     ap.add_argument('--same-device', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--sr-frames', type=int, default=3, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
@@ -217,11 +219,11 @@ def main():
         if four_k is not None:
             res['four_k'] = four_k
             res['four_k_bf16x3'] = four_k_fast
-        if world == 1 and not args.small:
+        if world == 1 and not args.small and not args.no_extras:
             res['reference_pipeline_baseline'] = reference_pipeline_baseline(model, rays[0], rk)
             res['reference_pipeline_baseline']['speedup_of_value'] = round(
                 value / res['reference_pipeline_baseline']['value'], 1)
-        if world == 1 and not args.small:
+        if world == 1 and not args.small and not args.no_extras:
             res['training_step_kernels'] = training_step_kernels(dev)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)

@@ -107,11 +107,13 @@ def test_mpi_frame_vs_oracle(cfg):
     _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
     _check_counters(cnt, want['counters'], ck['model_kwargs']['fast_color_thres'])
     # linear (non-image) ray order: a different ray->wavefront tiling only changes where the 64-record shading
-    # batches cut a ray's samples, i.e. the association order of the per-ray sum (last-bit differences)
+    # batches and the depth quarters cut a ray's samples, i.e. the association order of the per-ray sum (last-bit
+    # differences: a few fp32 ulps of values <= 1)
     lin = model(ro.cuda(), rd.cuda(), vd.cuda(), **ck['render_kwargs'])
-    assert torch.allclose(lin['rgb_marched'], res['rgb_marched'].reshape(-1, 3), rtol=0, atol=1e-6)
+    dmax = float((lin['rgb_marched'] - res['rgb_marched'].reshape(-1, 3)).abs().max())
+    assert dmax <= 2e-6, dmax
     assert torch.equal(lin['alphainv_last'], res['alphainv_last'].reshape(-1))
-    # bit-reproducible run to run (no atomics on the data path)
+    # bit-reproducible run to run (no global atomics on the data path; LDS adds of one wave retire in lane order)
     lin2 = model(ro.cuda(), rd.cuda(), vd.cuda(), **ck['render_kwargs'])
     assert torch.equal(lin['rgb_marched'], lin2['rgb_marched']) and torch.equal(lin['depth'], lin2['depth'])
 
