@@ -19,6 +19,9 @@ SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip', 'k4_opt.hip']  # missin
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 
+FLAGS += os.environ.get('K4_EXTRA_HIPCC_FLAGS', '').split()      # experiments only (e.g. -DK4_SHADE_WG_PER_CU=2)
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 

@@ -30,6 +30,8 @@
 //     5 floats per ray are the only other global writes.
 // Deterministic: no atomics on the data path, fixed summation order.
 #include "k4_common.h"
+#include <string.h>
+#include <stdlib.h>
 #include <stdlib.h>
 
 #define MODE_MPI  0
@@ -46,7 +48,7 @@ struct MarchParams {
     float minx, miny, minz, maxx, maxy, maxz;
     float msx, msy, msz, mtx, mty, mtz;
     float lenx, leny, lenz, rlenx, rleny, rlenz;     // xyz_max - xyz_min and its correctly rounded reciprocal
-    const float* mlp; int mlp_floats; int dim0; int k1p; int vpe; int spe; int k0_skip;
+    const float* mlp; int mlp_floats; int mlp_floats_b3; int dim0; int k1p; int vpe; int spe; int k0_skip;
     int n_samples;          // MPI: samples per ray
     int max_steps;          // capacity per ray in the workspace
     int ent_stride;         // records per bundle in the workspace: 64 * max_steps rounded up to 256 (4 depth quarters)
@@ -57,6 +59,7 @@ struct MarchParams {
     int* ghead;                                    // geometry work-queue head (zeroed by the launcher)
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
+    int serp;               // 1: serpentine ray order inside a tile (default)
     int geom_persist;       // 0: one bundle per wave, static XCD-banded map (default, fastest measured); 1: per-XCD work queues
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
@@ -89,7 +92,10 @@ __device__ __forceinline__ Bundle bundle_of(const MarchParams& P, int wv) {
 }
 __device__ __forceinline__ int ray_index(const MarchParams& P, const Bundle& b, int r) {
     if (P.img_w > 0) {
-        const int px = b.x + (r & 7), py = b.y + (r >> 3);
+        // boustrophedon order inside the 8x8 tile: consecutive ray slots are always neighbouring pixels, so the grid rows
+        // a ray touches were touched by the previous slot too (row reuse distance = one ray)
+        const int py = b.y + (r >> 3);
+        const int px = b.x + ((P.serp && ((r >> 3) & 1)) ? 7 - (r & 7) : (r & 7));
         return (px < P.img_w && py < P.img_h) ? py * P.img_w + px : -1;
     }
     const int ray = b.lin + r;
@@ -253,6 +259,9 @@ __global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
 // The early stop therefore no longer saves density fetches behind it (they were ~13 % of the mask-passing samples);
 // results are unchanged: a sample behind the stop never gets a weight.
 // -----------------------------------------------------------------------------------------------------
+#ifndef K4_SHADE_WG_PER_CU
+#define K4_SHADE_WG_PER_CU 2      // 256 VGPRs per wave: at 3 (168 VGPRs) the batch loop spilled ~90 dwords and its scratch reloads cost 0.4 ms/frame
+#endif
 #define K4_RING 512
 struct Geom2Lds {
     float raytab[64][6];     // start xyz, dir xyz of the bundle's rays
@@ -678,8 +687,157 @@ __device__ __forceinline__ void mlp_mfma(const float* wl, const float* feat, int
     out2 = half ? q[1][2] : q[0][2];
 }
 
-template <int MODE, int WIDTH, int NHID>
-__global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Same MLP on the bf16 matrix pipe with fp32-equivalent accuracy (default for width <= 64).  gfx950 has no fast fp32
+// MFMA (v_mfma_f32_32x32x2_f32: 256 flop/clk/CU-SIMD; v_mfma_f32_32x32x16_bf16: 1024), and the fp32 form made this kernel
+// matrix-pipe bound.  Every fp32 value v is split EXACTLY into three bf16 terms v = v0 + v1 + v2 (v0 = RNE_bf16(v),
+// v1 = RNE_bf16(v - v0), v2 = v - v0 - v1: 8+8+8 significant bits); a product x*w is accumulated as the 6 partial
+// products x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 (smallest first) in the fp32 accumulator.  The 3 dropped terms are
+// <= 2^-23 |x w|, i.e. the size of one fp32 rounding of the product: the result differs from the fp32-MFMA path like
+// one summation order differs from another (tests/test_march_gpu.py holds both to the same oracle tolerance).
+// Split-weight section of the packed buffer (after the fp32 section; host: dvgo.py::pack_mlp_mfma), units of 16 B:
+//   W1S [NB][KB1][3][64]   lane l, 8 bf16: W1ext[j = mb*32+(l&31)][k = kb*16 + 8*(l>>5) + e]     KB1 = ceil(K1P/16)
+//   W2S [NB][W/16][3][64]  lane l, 8 bf16: W2[j2 = mb2*32+(l&31)][n(kb,l>>5,e)],  n = (kb>>1)*32 + (e&3) + 8*(2*(kb&1)+(e>>2)) + 4*(l>>5)
+//   B2S [NB][2][16] fp32   b2[mb2*32 + row(r,half)]    (accumulator initial value)
+//   WOT [NB][16][2][4] fp32, BO [4] fp32 as in the fp32 section
+// n(kb,h,e) is the neuron whose layer-1 accumulator lane-half h holds in register 8*(kb&1)+e of block kb>>1: the C layout of
+// one layer is already the B-operand layout of the next, no data moves between lanes.
+typedef __bf16 k4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 k4_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float k4_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned k4_pk_bf16(float lo, float hi) {               // v_cvt_pk_bf16_f32 (RNE)
+    const k4_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, k4_bf16x2));
+}
+// 8 floats -> three 8 x bf16 operands (exact 3-term split)
+__device__ __forceinline__ void k4_split3(const float (&v)[8], uint4& t0, uint4& t1, uint4& t2) {
+    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        p0[i] = k4_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(p0[i] << 16), rb = b - __uint_as_float(p0[i] & 0xffff0000u);
+        p1[i] = k4_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(p1[i] << 16), sb = rb - __uint_as_float(p1[i] & 0xffff0000u);
+        p2[i] = k4_pk_bf16(sa, sb);
+    }
+    t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+}
+#define K4_MFMA_B3(ACC, A0, A1, A2, B0, B1, B2) do { \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A2), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B2), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B1), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B1), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); } while (0)
+
+template <int W, int NHID>
+struct MlpLayoutB3 {                      // offsets in floats from the start of the split section
+    static constexpr int NB = W / 32;
+    __host__ __device__ static int kb1(int k1p) { return (k1p + 15) >> 4; }
+    __host__ __device__ static int w1s(int k1p) { (void)k1p; return 0; }
+    __host__ __device__ static int w2s(int k1p) { return NB * kb1(k1p) * 3 * 64 * 4; }
+    __host__ __device__ static int b2s(int k1p) { return w2s(k1p) + (NHID ? NB * (W / 16) * 3 * 64 * 4 : 0); }
+    __host__ __device__ static int wot(int k1p) { return b2s(k1p) + (NHID ? NB * 2 * 16 : 0); }
+    __host__ __device__ static int bo(int k1p) { return wot(k1p) + NB * 16 * 2 * 4; }
+    __host__ __device__ static int total(int k1p) { return bo(k1p) + 4; }
+};
+
+template <int W, int NHID>
+__device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, int k1p, int lane, int half, int debug,
+                                            float& out0, float& out1, float& out2) {
+    constexpr int NB = W / 32;
+    constexpr int KB2 = W / 16;
+    typedef MlpLayoutB3<W, NHID> ML;
+    const int l31 = lane & 31;
+    const int kb1 = (debug & 2) ? 0 : ML::kb1(k1p);
+    const uint4* const w1s = reinterpret_cast<const uint4*>(ws + ML::w1s(k1p));
+    const uint4* const w2s = reinterpret_cast<const uint4*>(ws + ML::w2s(k1p));
+    const float* const b2s = ws + ML::b2s(k1p);
+    const float* const wot = ws + ML::wot(k1p);
+    const float* const bo = ws + ML::bo(k1p);
+    out0 = out1 = out2 = 0.f;
+    // one 32-sample tile at a time, NOT unrolled: the live set is one tile's accumulators + split operands (~110 VGPRs),
+    // the second tile reuses the code and the registers
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s] ----------------
+        f32x16 h1[NB];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) h1[mb] = (f32x16)(0.f);
+        for (int kb = 0; kb < kb1; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * 16 + 8 * half + e;
+                v[e] = k < k1p ? feat[k * 64 + t * 32 + l31] : 0.f;
+            }
+            uint4 x0, x1, x2;
+            k4_split3(v, x0, x1, x2);
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb) {
+                const uint4* const wp = w1s + ((mb * ML::kb1(k1p) + kb) * 3) * 64 + lane;
+                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                K4_MFMA_B3(h1[mb], a0, a1, a2, x0, x1, x2);
+            }
+        }
+        float pt[3] = {0.f, 0.f, 0.f};
+        if (NHID == 1 && !(debug & 2)) {
+            // relu + split of this tile's hidden activations once; the NB output blocks accumulate side by side
+            uint4 hs[KB2][3];
+#pragma unroll
+            for (int kb = 0; kb < KB2; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(h1[kb >> 1][8 * (kb & 1) + e], 0.f);
+                k4_split3(v, hs[kb][0], hs[kb][1], hs[kb][2]);
+            }
+            f32x16 c[NB];
+#pragma unroll
+            for (int mb2 = 0; mb2 < NB; ++mb2)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 bv = *reinterpret_cast<const float4*>(b2s + (mb2 * 2 + half) * 16 + r4 * 4);
+                    c[mb2][r4 * 4 + 0] = bv.x; c[mb2][r4 * 4 + 1] = bv.y; c[mb2][r4 * 4 + 2] = bv.z; c[mb2][r4 * 4 + 3] = bv.w;
+                }
+#pragma unroll
+            for (int kb = 0; kb < KB2; ++kb)
+#pragma unroll
+                for (int mb2 = 0; mb2 < NB; ++mb2) {
+                    const uint4* const wp = w2s + ((mb2 * KB2 + kb) * 3) * 64 + lane;
+                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                    K4_MFMA_B3(c[mb2], a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][2]);
+                }
+#pragma unroll
+            for (int mb2 = 0; mb2 < NB; ++mb2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
+                    const float a0 = fmaxf(c[mb2][r], 0.f);
+                    pt[0] = fmaf(wo.x, a0, pt[0]); pt[1] = fmaf(wo.y, a0, pt[1]); pt[2] = fmaf(wo.z, a0, pt[2]);
+                }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
+                    const float a0 = fmaxf(h1[mb][r], 0.f);
+                    pt[0] = fmaf(wo.x, a0, pt[0]); pt[1] = fmaf(wo.y, a0, pt[1]); pt[2] = fmaf(wo.z, a0, pt[2]);
+                }
+        }
+        // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of this tile; sample 32*t + (l&31) belongs to
+        // lane 32*t + (l&31)
+        const float q0 = pt[0] + __shfl_xor(pt[0], 32) + bo[0];
+        const float q1 = pt[1] + __shfl_xor(pt[1], 32) + bo[1];
+        const float q2 = pt[2] + __shfl_xor(pt[2], 32) + bo[2];
+        if (half == t) { out0 = q0; out1 = q1; out2 = q2; }
+    }
+}
+
+template <int MODE, int WIDTH, int NHID, bool B3>
+__global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const MarchParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int W = WIDTH > 0 ? WIDTH : 32;
     constexpr int NB = W / 32;
@@ -687,14 +845,16 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
     const int lane = k4_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // LDS carve: [mlp weights][per wave: acc 64x4 | feat K1P x 64]
-    const int mlp_floats = WIDTH > 0 ? P.mlp_floats : 0;
+    // B3: only the split-bf16 section of the packed buffer is staged (it carries its own copy of the fp32 tail)
+    const int mlp_floats = WIDTH > 0 ? (B3 ? P.mlp_floats_b3 : P.mlp_floats) : 0;
     const int mlp_pad = (mlp_floats + 3) & ~3;
     float* const wl = smem;
     const int per_wave = 64 * 4 + (WIDTH > 0 ? P.k1p * 64 : 0);
     float* const acc = smem + mlp_pad + wv * per_wave;        // [64][4]  r,g,b,depth
     float* const feat = acc + 64 * 4;                          // [K1P][64]
     if (WIDTH > 0) {
-        for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = P.mlp[i];
+        const float* const src = P.mlp + (B3 ? P.mlp_floats : 0);
+        for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = src[i];
     }
     __syncthreads();
     const int half = lane >> 5;
@@ -710,20 +870,30 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
     acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
+    // the bundle's 64 rays live in registers, lane = ray slot; a record reads its ray's with ds_bpermute (__shfl).
+    // One fetch round per bundle instead of a dependent one per 64-record batch (the batch loop was 59 % s_waitcnt:
+    // record -> ray -> 3 rounds of corner fetches were five serial round trips; now the corner fetches are the only one)
+    float my_sx, my_sy, my_sz, my_dx, my_dy, my_dz, my_vx, my_vy, my_vz;
+    {
+        const int mray = ray_index(P, B, lane);
+        const int ms = mray < 0 ? 0 : mray;
+        int nsteps_unused;
+        ray_setup<MODE>(P, P.rays_o[ms * 3 + 0], P.rays_o[ms * 3 + 1], P.rays_o[ms * 3 + 2],
+                        P.rays_d[ms * 3 + 0], P.rays_d[ms * 3 + 1], P.rays_d[ms * 3 + 2], my_sx, my_sy, my_sz, my_dx, my_dy, my_dz, nsteps_unused);
+        my_vx = P.viewdirs[ms * 3 + 0]; my_vy = P.viewdirs[ms * 3 + 1]; my_vz = P.viewdirs[ms * 3 + 2];
+    }
+    uint2 en_next = ent[lane < total ? lane : 0];
 
     for (int base = 0; base < total; base += 64) {
         const int nproc = (total - base) < 64 ? (total - base) : 64;
         const bool lact = lane < nproc;
-        const uint2 en = ent[base + (lact ? lane : 0)];
+        const uint2 en = en_next;
+        en_next = ent[(base + 64 + lane < total) ? base + 64 + lane : 0];       // next batch's records fly during this batch
         const float w = lact ? __uint_as_float(en.y) : 0.f;
-        const int rl = (int)(en.x >> 24);
+        const int rl = lact ? (int)(en.x >> 24) : 0;
         const int k = (int)(en.x & 0xffffffu);
-        const int ray = ray_index(P, B, rl);
-        const int rs = ray < 0 ? 0 : ray;
-        float sx, sy, sz, dx, dy, dz;
-        int nsteps_unused;
-        ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
-                        P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps_unused);
+        const float sx = __shfl(my_sx, rl), sy = __shfl(my_sy, rl), sz = __shfl(my_sz, rl);
+        const float dx = __shfl(my_dx, rl), dy = __shfl(my_dy, rl), dz = __shfl(my_dz, rl);
         const float tk = step_t<MODE>(P, k);
         const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
         const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
@@ -756,7 +926,31 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
         } else {
             // ---------------- features -> LDS feat[k][sample] ----------------
             float dif0 = 0.f, dif1 = 0.f, dif2 = 0.f;                // k0[:, :3] when rgbnet_direct=False
-            if (P.k0_layout == K4_K0_CHANNEL_LAST) {
+            if (P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && !(P.debug & 1)) {
+                // 12 padded channels (rgbnet_dim 9..12): the 8 corners x 48 B are 24 independent 16-byte fetches, issued
+                // together (one memory round trip); accumulation order per channel = corner order, as below
+                float4 q[3][8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4* const src = reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * 12);
+                    q[0][c] = src[0]; q[1][c] = src[1]; q[2][c] = src[2];
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 3; ++g4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        v.x += q[g4][c].x * cw[c]; v.y += q[g4][c].y * cw[c]; v.z += q[g4][c].z * cw[c]; v.w += q[g4][c].w * cw[c];
+                    }
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int ch = g4 * 4 + cc;
+                        if (ch < P.k0_skip) { if (ch == 0) dif0 = vv[cc]; else if (ch == 1) dif1 = vv[cc]; else dif2 = vv[cc]; }
+                        else if (ch < P.C) feat[(ch - P.k0_skip) * 64 + lane] = vv[cc];
+                    }
+                }
+            } else if (P.k0_layout == K4_K0_CHANNEL_LAST) {
                 for (int g = 0; g < P.CP; g += 4) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -801,7 +995,7 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
             }
             {
                 // viewdirs_emb[ray_id]   lib/dmpigo.py:347-349, lib/dvgo.py:387-389
-                const float vd[3] = {P.viewdirs[rs * 3 + 0], P.viewdirs[rs * 3 + 1], P.viewdirs[rs * 3 + 2]};
+                const float vd[3] = {__shfl(my_vx, rl), __shfl(my_vy, rl), __shfl(my_vz, rl)};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) feat[(fi + c) * 64 + lane] = vd[c];
                 fi += 3;
@@ -820,7 +1014,8 @@ __global__ __launch_bounds__(256, 3) void k4_shade_kernel(const MarchParams P) {
             __builtin_amdgcn_wave_barrier();
 
             float l0, l1, l2;
-            mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
+            if (B3) mlp_mfma_b3<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
+            else mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
         }
@@ -1073,6 +1268,15 @@ static int n_workgroups(int64_t n_rays, int img_w) {
     return (int)((n_rays + 255) / 256);
 }
 
+static size_t mlp_floats_b3_of(const k4_mlp_desc* m, int k1p) {       // split-bf16 section (MlpLayoutB3)
+    if (m->width == 0) return 0;
+    const size_t nb = m->width / 32, kb1 = (size_t)(k1p + 15) / 16;
+    size_t n = nb * kb1 * 3 * 64 * 4;
+    if (m->n_hidden) n += nb * (m->width / 16) * 3 * 64 * 4 + nb * 2 * 16;
+    n += nb * 16 * 2 * 4 + 4;
+    return n;
+}
+
 static size_t mlp_floats_of(const k4_mlp_desc* m, int k1p) {
     if (m->width == 0) return 0;
     const size_t nb = m->width / 32;
@@ -1110,13 +1314,17 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     int rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
-    const size_t lds_base = sizeof(float) * (((size_t)P.mlp_floats + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; K4_MLP=fp32 selects the
+    // fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
+    static const bool mlp_fp32 = getenv("K4_MLP") && !strcmp(getenv("K4_MLP"), "fp32");
+    const bool b3 = width != 0 && width <= 64 && !mlp_fp32;
+    const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
     const size_t lds_pipe = lds_base + sizeof(float) * 4 * (64 * 12 + 24 * 64 * 4);       // + ray table + 24 KB staging per wave
     // pipelined kernel (opt-in, K4_PIPE=1): 10 % faster in isolation, but its 150 KB of LDS per workgroup keeps the geometry
     // kernel of the next frame off the CU, and overlapped frames are what the render loop runs (bench.py --streams)
-    const bool pipe = width != 0 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && lds_pipe <= 160 * 1024 &&
+    const bool pipe = !b3 && width != 0 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && lds_pipe <= 160 * 1024 &&
                       getenv("K4_PIPE");
-    const int wg_per_cu = pipe ? 1 : 3;             // the pipelined kernel runs ONE self-overlapping wave per SIMD
+    const int wg_per_cu = pipe ? 1 : K4_SHADE_WG_PER_CU;             // the pipelined kernel runs ONE self-overlapping wave per SIMD
     const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
     const size_t lds = pipe ? lds_pipe : lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
@@ -1126,7 +1334,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
             if (e_ != hipSuccess) return (int)e_; } \
         hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)
 #define K4_LAUNCH(WD, NH) do { if (pipe && WD > 0) K4_LAUNCH_K((k4_shade_pipe_kernel<MODE, (WD > 0 ? WD : 32), NH>)); \
-                               else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH>)); } while (0)
+                               else if (b3 && WD > 0 && WD <= 64) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD > 0 && WD <= 64 ? WD : 32), NH, true>)); \
+                               else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, false>)); } while (0)
     if (width == 0) K4_LAUNCH(0, 0);
     else if (width == 32 && nh == 0) K4_LAUNCH(32, 0);
     else if (width == 32 && nh == 1) K4_LAUNCH(32, 1);
@@ -1177,6 +1386,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.rlenx = 1.0f / P.lenx; P.rleny = 1.0f / P.leny; P.rlenz = 1.0f / P.lenz;           // IEEE division: correctly rounded
     P.mlp = m->packed; P.dim0 = m->dim0; P.k1p = (m->dim0 + 2) & ~1;
     P.mlp_floats = (int)mlp_floats_of(m, P.k1p);
+    P.mlp_floats_b3 = (int)mlp_floats_b3_of(m, P.k1p);
     P.vpe = m->viewbase_pe; P.spe = m->spatial_pe; P.k0_skip = m->k0_skip;
     P.max_steps = max_steps;
     if (ent_stride_of(max_steps) > 0x7fffffff) return K4_ERR_BAD_ARG;
@@ -1187,7 +1397,8 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.qhead = P.counts + nb;
     P.ghead = P.qhead + 1;
     P.n_bundles = (int)nb;
-    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; P.geom_persist = getenv("K4_GEOM_PERSIST") ? 1 : 0; }
+    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; P.geom_persist = getenv("K4_GEOM_PERSIST") ? 1 : 0;
+      P.serp = getenv("K4_SERP") ? atoi(getenv("K4_SERP")) : 1; }
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
@@ -1200,7 +1411,7 @@ extern "C" int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_h
     if ((width != 32 && width != 64 && width != 128) || n_hidden < 0 || n_hidden > 1 || dim0 <= 0) return -1;
     k4_mlp_desc m{};
     m.width = width; m.n_hidden = n_hidden; m.dim0 = dim0;
-    return (int64_t)mlp_floats_of(&m, (dim0 + 2) & ~1);
+    return (int64_t)(mlp_floats_of(&m, (dim0 + 2) & ~1) + mlp_floats_b3_of(&m, (dim0 + 2) & ~1));
 }
 
 extern "C" int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,

@@ -410,10 +410,58 @@ def pack_mlp_mfma(lins):
     bo = torch.zeros([4], dtype=torch.float32, device=dev)
     bo[:3] = lins[-1].bias.detach().float()
     parts.append(bo)
+    parts += _pack_mlp_split_bf16(w1, lins, wot, bo)
     out = torch.cat(parts).contiguous()
     want = N.lib().k4_mlp_packed_floats(dim0, W, len(lins) - 2)
     assert out.numel() == want, (out.numel(), want)
     return out
+
+
+def _split3_bf16(x):
+    """Exact 3-term bf16 split of an fp32 tensor: x == t0 + t1 + t2 (each RNE to bf16 of the running remainder)."""
+    t0 = x.to(torch.bfloat16)
+    r1 = x - t0.float()
+    t1 = r1.to(torch.bfloat16)
+    t2 = (r1 - t1.float()).to(torch.bfloat16)
+    return t0, t1, t2
+
+
+def _pack_mlp_split_bf16(w1ext, lins, wot, bo):
+    """Split-bf16 section of the packed rgbnet buffer (layout: csrc/k4_march.hip, MlpLayoutB3), returned as fp32-typed
+    views of the raw bytes.  v_mfma_f32_32x32x16_bf16 operand order: lane l holds 8 bf16 = row (l&31), k = 8*(l>>5)+e."""
+    dev = w1ext.device
+    W, k1p = w1ext.shape
+    NB, KB1, KB2 = W // 32, (k1p + 15) // 16, W // 16
+    lane = torch.arange(64, device=dev)
+    e = torch.arange(8, device=dev)
+    mb = torch.arange(NB, device=dev)
+
+    def as_f32(terms, index_fn):
+        # [..., 3 terms, 64 lanes, 8] bf16 -> flat fp32 view
+        g = torch.stack([index_fn(t) for t in terms], dim=-3)
+        return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+    w1p = torch.zeros([W, KB1 * 16], dtype=torch.float32, device=dev)
+    w1p[:, :k1p] = w1ext
+    kb = torch.arange(KB1, device=dev)
+    j = (mb[:, None, None, None] * 32 + (lane & 31)[None, None, :, None]).expand(NB, KB1, 64, 8)
+    k = (kb[None, :, None, None] * 16 + 8 * (lane >> 5)[None, None, :, None] + e[None, None, None, :]).expand(NB, KB1, 64, 8)
+    parts = [as_f32(_split3_bf16(w1p), lambda t: t[j, k])]
+    if len(lins) == 3:
+        w2 = lins[1].weight.detach().float()
+        kb = torch.arange(KB2, device=dev)
+        h = (lane >> 5)[None, None, :, None]
+        n = ((kb >> 1)[None, :, None, None] * 32 + (e & 3)[None, None, None, :]
+             + 8 * (2 * (kb & 1)[None, :, None, None] + (e >> 2)[None, None, None, :]) + 4 * h).expand(NB, KB2, 64, 8)
+        j2 = (mb[:, None, None, None] * 32 + (lane & 31)[None, None, :, None]).expand(NB, KB2, 64, 8)
+        parts.append(as_f32(_split3_bf16(w2), lambda t: t[j2, n]))
+        b2 = lins[1].bias.detach().float()
+        r = torch.arange(16, device=dev)
+        hh = torch.arange(2, device=dev)
+        row = (r & 3)[None, None, :] + 8 * (r >> 2)[None, None, :] + 4 * hh[None, :, None]
+        parts.append(b2[mb[:, None, None] * 32 + row].reshape(-1))
+    parts += [wot.reshape(-1), bo]
+    return parts
 
 
 def coarse_mask_on_grid(path, thres, xyz_min, xyz_max, world_size):
