@@ -94,6 +94,9 @@ _EXTRA_SIGS = {
     'k4_masked_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_adam_upd_with_perlr': ([_P, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_total_variation_add_grad': ([_P, _P, _F, _F, _F, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
+    'k4_conv_weight_bf16x6_bytes': ([_I32, _I32, _I32], C.c_int64),
+    'k4_conv2d_nhwc_bf16x6': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
+                               _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
 }

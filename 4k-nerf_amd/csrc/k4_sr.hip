@@ -361,6 +361,232 @@ extern "C" int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_st
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 3-term split ("bf16x6", the default decoder arithmetic): fp32-EQUIVALENT convolutions on the bf16 matrix pipe.
+// Every fp32 operand is split exactly into three bf16 terms v = v0 + v1 + v2 (8+8+8 significant bits, RNE of the running
+// remainder, v_cvt_pk_bf16_f32); a product is accumulated as x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 (smallest first) in
+// the fp32 accumulator.  The three dropped partial products are <= 2^-23 |x w| -- one fp32 rounding of the product -- so
+// the result differs from the fp32-input MFMA kernel above the way one fp32 summation order differs from another, while
+// 6 x v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace 8 x v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 2.67x less
+// matrix-pipe time.  Workgroup = 8 waves, tile 16 rows x 32 columns (one workgroup per CU: 114 KB of LDS for the split
+// 3x3 chunk); a wave owns 2 rows x NT column blocks.  The NEXT chunk's activations and pre-split weights are fetched into
+// registers before the current chunk's MFMAs and split/stored after them, so HBM/L2 latency hides behind the matrix pipe.
+// ------------------------------------------------------------------------------------------------------------------
+#define TILE_HB 16
+typedef __bf16 k4s_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float k4s_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned k4s_pk_bf16(float lo, float hi) {              // v_cvt_pk_bf16_f32 (RNE)
+    const k4s_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, k4s_bf16x2));
+}
+__device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4& t1, uint4& t2) {
+    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        p0[i] = k4s_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(p0[i] << 16), rb = b - __uint_as_float(p0[i] & 0xffff0000u);
+        p1[i] = k4s_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(p1[i] << 16), sb = rb - __uint_as_float(p1[i] & 0xffff0000u);
+        p2[i] = k4s_pk_bf16(sa, sb);
+    }
+    t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+}
+
+template <int KS, int NT>
+__global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
+    constexpr int TAPS = KS * KS;
+    constexpr int PADW = KS / 2;
+    constexpr int ROWS = TILE_HB + 2 * PADW;
+    constexpr int COLS = TILE_W + 2 * PADW;
+    constexpr int NOUT = NT * 32;
+    constexpr int IN_ITEMS = ROWS * COLS * 2;                 // (pixel, channel group of 8)
+    constexpr int IN_PER = (IN_ITEMS + 511) / 512;
+    constexpr int W_ITEMS = 3 * TAPS * 2 * NOUT;              // 16-byte units of one chunk's split weights
+    constexpr int W_PER = (W_ITEMS + 511) / 512;
+    constexpr int IN_PLANE = 2 * ROWS * COLS;                 // uint4 per term
+    extern __shared__ uint4 k4_b6_smem[];
+    uint4* const in_s = k4_b6_smem;                           // [term][channel group][row][col] x 8 bf16
+    uint4* const w_s = k4_b6_smem + 3 * IN_PLANE;             // [term][tap][channel group][cout] x 8 bf16
+
+    const int tid = (int)threadIdx.x;
+    const int lane = k4_lane();
+    const int wv = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_HB;
+    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x16)(0.f);
+
+    // per-thread source of each staged item (chunk independent part)
+    const float* isrc[IN_PER];
+    bool iin[IN_PER];
+    int ikg[IN_PER], idst[IN_PER];
+#pragma unroll
+    for (int i = 0; i < IN_PER; ++i) {
+        const int it = tid + i * 512;
+        const int itc = it < IN_ITEMS ? it : 0;
+        const int kg = itc & 1, pp = itc >> 1;
+        const int py = pp / COLS, px = pp - py * COLS;
+        const int gy = y0 - PADW + py, gx = x0 - PADW + px;
+        const bool inside = it < IN_ITEMS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        const int sy = inside ? (ups ? (gy >> 1) : gy) : 0, sx = inside ? (ups ? (gx >> 1) : gx) : 0;
+        isrc[i] = P.x + ((size_t)sy * P.srcW + sx) * P.cin_stride + kg * 8;
+        iin[i] = inside; ikg[i] = kg;
+        idst[i] = it < IN_ITEMS ? (kg * ROWS + py) * COLS + px : -1;
+    }
+    const int nchunks = (P.cin + KC2 - 1) / KC2;
+    const uint4* const wsrc_all = reinterpret_cast<const uint4*>(P.w);
+
+    // staged items live in registers between the fetch (before the MFMAs) and the split/store (after them); written
+    // as macros, not lambdas, so that the arrays are promoted to registers (captured arrays ended up in scratch)
+    float4 rva[IN_PER], rvb[IN_PER];
+    uint4 wr[W_PER];
+    // all pixels of the tensor share their alignment when the channel stride is a multiple of 4 floats: the vector path
+    // is then a WORKGROUP-uniform decision per chunk (no divergent branches; out-of-image items fetch a valid dummy
+    // address and are zeroed by a select)
+    const bool vec_ok = (P.cin_stride & 3) == 0 && (((size_t)P.x) & 15) == 0;
+#define K4_B6_LOAD(CH) do { \
+        const int c0_ = (CH) * KC2; \
+        if (vec_ok && c0_ + KC2 <= P.cin) { \
+            _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+                const float* src = iin[i] ? isrc[i] + c0_ : P.x; \
+                const float4 va = *reinterpret_cast<const float4*>(src); \
+                const float4 vb = *reinterpret_cast<const float4*>(src + 4); \
+                rva[i] = iin[i] ? va : make_float4(0.f, 0.f, 0.f, 0.f); \
+                rvb[i] = iin[i] ? vb : make_float4(0.f, 0.f, 0.f, 0.f); \
+            } \
+        } else { \
+            _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+                const int cb = c0_ + ikg[i] * 8; \
+                const float* src = isrc[i] + c0_; \
+                float e8[8]; \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c) { \
+                    const bool ok_ = iin[i] && cb + c < P.cin; \
+                    const float q_ = *(ok_ ? src + c : P.x); \
+                    e8[c] = ok_ ? q_ : 0.f; \
+                } \
+                rva[i] = make_float4(e8[0], e8[1], e8[2], e8[3]); rvb[i] = make_float4(e8[4], e8[5], e8[6], e8[7]); \
+            } \
+        } \
+        const uint4* wsrc_ = wsrc_all + (size_t)(CH) * W_ITEMS; \
+        _Pragma("unroll") for (int j = 0; j < W_PER; ++j) { \
+            const int it = tid + j * 512; \
+            wr[j] = wsrc_[it < W_ITEMS ? it : 0]; \
+        } } while (0)
+#define K4_B6_STORE() do { \
+        _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+            const float v8[8] = {rva[i].x, rva[i].y, rva[i].z, rva[i].w, rvb[i].x, rvb[i].y, rvb[i].z, rvb[i].w}; \
+            uint4 t0, t1, t2; \
+            k4s_split3(v8, t0, t1, t2); \
+            if (idst[i] >= 0) { in_s[idst[i]] = t0; in_s[IN_PLANE + idst[i]] = t1; in_s[2 * IN_PLANE + idst[i]] = t2; } \
+        } \
+        _Pragma("unroll") for (int j = 0; j < W_PER; ++j) { \
+            const int it = tid + j * 512; \
+            if (it < W_ITEMS) w_s[it] = wr[j]; \
+        } } while (0)
+
+    K4_B6_LOAD(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        K4_B6_STORE();
+        __syncthreads();
+        { const int chn = ch + 1 < nchunks ? ch + 1 : ch; K4_B6_LOAD(chn); }     // unconditional: flies during the MFMAs below
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dy = t / KS, dx = t - dy * KS;
+            bf16x8 a[3][2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    a[q][m] = __builtin_bit_cast(bf16x8, in_s[q * IN_PLANE + (half * ROWS + wv * 2 + m + dy) * COLS + l31 + dx]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, w_s[((q * TAPS + t) * 2 + half) * NOUT + n * 32 + l31]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][m], b[0], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[2], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef K4_B6_LOAD
+#undef K4_B6_STORE
+    k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
+}
+
+template <int KS, int NT>
+static int launch_conv_b6(const ConvParams& P, hipStream_t st) {
+    constexpr int TAPS = KS * KS, PADW = KS / 2;
+    constexpr size_t lds = ((size_t)3 * 2 * (TILE_HB + 2 * PADW) * (TILE_W + 2 * PADW) + (size_t)3 * TAPS * 2 * NT * 32) * sizeof(uint4);
+    static_assert(lds <= 160 * 1024, "split chunk must fit the CU's LDS");
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_b6_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(512);
+    hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT>), grid, block, lds, st, P);
+    return k4_check_launch();
+}
+
+extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_t ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
+    const int64_t nt = (cout + 31) / 32;
+    if (nt != 1 && nt != 2 && nt != 4) return -1;
+    return (int64_t)((cin + KC2 - 1) / KC2) * 3 * ksize * ksize * 2 * nt * 32 * 16;
+}
+
+extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
+                                     const void* w_split, const float* bias, int32_t ksize,
+                                     float* y, int32_t cout, int32_t cout_stride,
+                                     int32_t H, int32_t W, uint32_t flags, float slope,
+                                     const float* res, int32_t res_stride, float res_scale,
+                                     const float* mod_x, int32_t mod_stride, void* stream) {
+    if (!x || !w_split || !bias || !y || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return K4_ERR_BAD_ARG;
+    if (cin_stride < cin || (ksize != 1 && ksize != 3)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_EPI_RES) && (!res || res_stride <= 0)) return K4_ERR_BAD_ARG;
+    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
+    if (modulate && (!mod_x || mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_PRE_UPSAMPLE2X) && ((H & 1) || (W & 1))) return K4_ERR_BAD_ARG;
+    const int gemm_n = modulate ? 2 * cout : cout;
+    const int nt = (gemm_n + 31) / 32;
+    if (cout_stride < cout) return K4_ERR_BAD_ARG;
+    ConvParams P{};
+    P.x = x; P.cin = cin; P.cin_stride = cin_stride; P.w = (const float*)w_split; P.bias = bias;
+    P.y = y; P.cout = cout; P.cout_stride = cout_stride; P.H = H; P.W = W;
+    P.srcH = (flags & K4_PRE_UPSAMPLE2X) ? H / 2 : H; P.srcW = (flags & K4_PRE_UPSAMPLE2X) ? W / 2 : W;
+    P.flags = flags; P.slope = slope; P.res = res; P.res_stride = res_stride; P.res_scale = res_scale;
+    P.modx = mod_x; P.mod_stride = mod_stride;
+    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_HB - 1) / TILE_HB;
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3) {
+        if (nt == 1) return launch_conv_b6<3, 1>(P, st);
+        if (nt == 2) return launch_conv_b6<3, 2>(P, st);
+    } else {
+        if (nt == 1) return launch_conv_b6<1, 1>(P, st);
+        if (nt == 2) return launch_conv_b6<1, 2>(P, st);
+        if (nt == 4) return launch_conv_b6<1, 4>(P, st);
+    }
+    return K4_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fused SFTLayer (lib/sr_esrnet.py:112-123): y = x * (scale(cond) + 1) + shift(cond) [* res_scale + res] in ONE launch,
 // scale/shift = 1x1 conv -> LeakyReLU(0.2) -> 1x1 conv of the 32-channel condition map.  As two separate convolutions
 // the pair was bound by launch/sync overhead and by the round trip of the 64-channel hidden map through HBM (it took

@@ -14,7 +14,9 @@ One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL on ROCm); the 
 ``march_fn`` / ``sr_fn`` are injectable so that the sharding / gather / assembly logic is exercised by world_size-2
 ``gloo`` tests on CPU (tests/test_tile_parallel.py) with the CPU oracle standing in for the HIP kernels.
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -69,18 +71,31 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
     dev = rays[0].device
     send = torch.zeros([3, slot], dtype=torch.float32, device=dev)
     off = 0
-    for i in owned[rk]:
+    # this rank's tiles are independent until the gather: on a GPU each runs on its own HIP stream (own marcher workspace
+    # and decoder buffers, `slot`), so that the short last round of one tile's kernels is filled by another tile's
+    n_str = _n_streams(dev, len(owned[rk]), march_fn, sr_fn)
+    pool = _stream_pool(dev, n_str) if n_str > 1 else None
+    cur = torch.cuda.current_stream(dev) if n_str > 1 else None
+    if pool:
+        for st in pool:
+            st.wait_stream(cur)
+    for j, i in enumerate(owned[rk]):
         y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
-        ro, rd, vd = [r[yp0:yp1, xp0:xp1].reshape(-1, 3).contiguous() for r in rays]
-        rgb, depth = march_fn(ro, rd, vd, xp1 - xp0)
-        hh, ww = yp1 - yp0, xp1 - xp0
-        img = rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0)
-        cond = depth.reshape(1, 1, hh, ww)
-        hr = sr_fn(img, cond)
-        oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
         th, tw = (y1 - y0) * scale, (x1 - x0) * scale
-        send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
+        with (torch.cuda.stream(pool[j % n_str]) if pool else contextlib.nullcontext()):
+            kw = {'slot': j % n_str} if pool else {}
+            ro, rd, vd = [r[yp0:yp1, xp0:xp1].reshape(-1, 3).contiguous() for r in rays]
+            rgb, depth = march_fn(ro, rd, vd, xp1 - xp0, **kw)
+            hh, ww = yp1 - yp0, xp1 - xp0
+            img = rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0)
+            cond = depth.reshape(1, 1, hh, ww)
+            hr = sr_fn(img, cond, **kw)
+            oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
+            send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
         off += th * tw
+    if pool:
+        for st in pool:
+            cur.wait_stream(st)
     if ws > 1:
         recv = torch.empty([ws, 3, slot], dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(recv.view(ws * 3, slot), send, group=group)      # final pixels only
@@ -98,19 +113,40 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
     return out
 
 
+_POOLS = {}
+
+
+def _stream_pool(dev, n):
+    pool = _POOLS.setdefault(str(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
+def _n_streams(dev, n_tiles, march_fn, sr_fn):
+    """Streams for this rank's tiles: only for the HIP-backed functions (they take a `slot`), K4_TILE_STREAMS (default 4)."""
+    if dev.type != 'cuda' or not (getattr(march_fn, 'k4_slots', False) and getattr(sr_fn, 'k4_slots', False)):
+        return 1
+    return max(1, min(n_tiles, int(os.environ.get('K4_TILE_STREAMS', '4'))))
+
+
 def hip_march_fn(model, render_kwargs):
     """march_fn backed by the fused HIP marcher (DirectMPIGO / DirectVoxGO modules of this package)."""
     kw = dict(render_kwargs)
     kw['render_depth'] = True
 
-    def fn(ro, rd, vd, window_w):
-        o = model(ro, rd, vd, k4_img_w=window_w, **kw)
+    def fn(ro, rd, vd, window_w, slot=0):
+        o = model(ro, rd, vd, k4_img_w=window_w, k4_ws_slot=8 + slot, **kw)
         return o['rgb_feature'], o['depth']
+    fn.k4_slots = True
     return fn
 
 
 def hip_sr_fn(net_sr):
-    return lambda img, cond: net_sr._forward_hip(img, cond)
+    def fn(img, cond, slot=0):
+        return net_sr._forward_hip(img, cond, slot=slot)
+    fn.k4_slots = True
+    return fn
 
 
 def shard_rows(H, world_size, rank, align=8):

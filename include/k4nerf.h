@@ -220,6 +220,19 @@ int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
                           const float* res, int32_t res_stride, float res_scale,
                           const float* mod_x, int32_t mod_stride, void* stream);
 
+/* 3-term split ("bf16x6", default decoder arithmetic): same contract as k4_conv2d_nhwc, fp32-equivalent results.
+ * x = x0 + x1 + x2 exactly (bf16 terms), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
+ * the dropped terms are <= 2^-23 |x w| per product.  w_split : k4_conv_weight_bf16x6_bytes() bytes =
+ * [ceil(cin/16)][3 terms][ksize*ksize][2 channel groups][32*NT][8] bf16 (zero padded, term t = RNE_bf16 of the remainder
+ * after terms < t).  Replaces the same nn.Conv2d calls of lib/sr_esrnet.py:446-465. */
+int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_t ksize);
+int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
+                          const void* w_split, const float* bias, int32_t ksize,
+                          float* y, int32_t cout, int32_t cout_stride,
+                          int32_t H, int32_t W, uint32_t flags, float slope,
+                          const float* res, int32_t res_stride, float res_scale,
+                          const float* mod_x, int32_t mod_stride, void* stream);
+
 /* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then
  * *res_scale + res if res != NULL), scale/shift = conv1x1(lrelu(conv1x1(cond))) evaluated in one launch, the hidden
  * activations stay in registers.  cond: [n_pix][cond_stride] (32 channels, 16-B aligned rows); channels = 32 or 64;

@@ -1,0 +1,16 @@
+import sys, time, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nerf4k_amd
+from nerf4k_amd.lib import sr_esrnet
+torch.manual_seed(777)
+net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).cuda().eval()
+x = torch.rand([1, 3, 756, 1008]).cuda(); c = torch.rand([1, 756, 1008]).cuda()
+for mode in sys.argv[1:]:
+    net.k4_mode = mode
+    with torch.no_grad():
+        out = net.tile_process_device(x, c, 510, 10) if hasattr(net, 'tile_process_device') else None
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(2):
+            out = net.tile_process_device(x, c, 510, 10)
+        torch.cuda.synchronize()
+    print(mode, 'ms/frame', round((time.perf_counter() - t) / 2 * 1e3, 2), tuple(out.shape))
