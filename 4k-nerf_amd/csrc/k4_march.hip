@@ -275,7 +275,9 @@ struct Geom2Lds {
 // frame for 190 MB of unique grid data; the kernel ran as fast at 3 waves/SIMD as at 6 -- cache-throughput bound).
 // Records of quarter w go to quarter w of the bundle's workspace slice; after a workgroup barrier wave 0 runs the
 // transmittance scan over the four runs of each ray in depth order and compacts the survivors.
-template <int MODE, int WPB, bool SPLIT>
+// COUNT: the sample counters of bench.py / the tests (k4_march_*_fwd `counters`) are a separate instantiation, so that
+// the render path carries no counting code and a profile lists the two under different names.
+template <int MODE, int WPB, bool SPLIT, bool COUNT>
 __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P) {
     static_assert(!SPLIT || WPB == 4, "depth split uses 4 waves per bundle");
     __shared__ Geom2Lds lds_all[WPB];
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             mball[j] = __ballot(mbyte[j] != 0);
-            if (P.counters) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball[j]); }
+            if (COUNT) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball[j]); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P)
     n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }   // bundle queue
-    if (P.counters && lane == 0) {
+    if (COUNT && P.counters && lane == 0) {
         atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
         atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade);
     }
@@ -1305,11 +1307,12 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         static const int wpb = getenv("K4_GEOM_WPB") ? atoi(getenv("K4_GEOM_WPB")) : 4;
         static const int split = getenv("K4_GEOM_SPLIT") ? atoi(getenv("K4_GEOM_SPLIT")) : 1;
         static const int ldspad = getenv("K4_GEOM_LDSPAD") ? atoi(getenv("K4_GEOM_LDSPAD")) : 0;      // occupancy experiments
-        if (P.geom_persist) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false>), dim3((unsigned)min(nwg, n_cu * per_cu)), block, 0, st, P);
-        else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else if (wpb == 1) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
-        else if (wpb == 2) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 2, false>), dim3((unsigned)nwg * 2), dim3(128), 0, st, P);
-        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false>), grid, block, 0, st, P);
+        if (P.geom_persist) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false, true>), dim3((unsigned)min(nwg, n_cu * per_cu)), block, 0, st, P);
+        else if (split && P.counters) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, false>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        else if (wpb == 1) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false, true>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
+        else if (wpb == 2) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 2, false, true>), dim3((unsigned)nwg * 2), dim3(128), 0, st, P);
+        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false, true>), grid, block, 0, st, P);
     }
     int rc = k4_check_launch();
     if (rc) return rc;
