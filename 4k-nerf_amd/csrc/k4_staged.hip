@@ -248,6 +248,48 @@ __global__ void k_segment_sum(const float* __restrict__ src, const int64_t* __re
     out[seg * C + ch] += acc;
 }
 
+// ---------------------------------------------------------------- d(DenseGrid.forward)/d(grid)  
+// What autograd runs for lib/grid.py:124 in the reference: grid_sampler_3d_backward's grad_input, i.e. every sample adds
+// grad_out[i][ch] * w[c] to its 8 corners (zero padding: corners outside the grid receive nothing).  One thread per
+// (sample, channel-quad): the corner indices / weights are recomputed (same setup as the forward), the scatter uses the
+// hardware fp32 atomic add (global_atomic_add_f32, no return) -- order-nondeterministic like the reference's
+// fastAtomicAdd.  d/d(xyz) is never needed (sample points come from rays, lib/dvgo.py:350).
+__global__ void k_grid_sample_bwd(const float* __restrict__ gout, int C, int X, int Y, int Z,
+                                  const float* __restrict__ xyz, const float* __restrict__ mn, const float* __restrict__ mx,
+                                  int64_t n, float* __restrict__ ggrid) {
+    const int cq = (C + 3) >> 2;                          // channel quads per sample
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * cq) return;
+    const int64_t i = t / cq;
+    const int ch0 = (int)(t % cq) * 4;
+    const float nx = k4_norm_coord(xyz[i * 3 + 0], mn[0], mx[0]);
+    const float ny = k4_norm_coord(xyz[i * 3 + 1], mn[1], mx[1]);
+    const float nz = k4_norm_coord(xyz[i * 3 + 2], mn[2], mx[2]);
+    const K4Tri tr = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
+    const size_t plane = (size_t)X * Y * Z;
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = ch0 + q < C ? gout[i * C + ch0 + q] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int x = tr.x0 + K4_CX(c), y = tr.y0 + K4_CY(c), z = tr.z0 + K4_CZ(c);
+        if (!((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z)) continue;
+        const size_t idx = ((size_t)x * Y + y) * Z + z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ch0 + q < C) unsafeAtomicAdd(ggrid + plane * (ch0 + q) + idx, g[q] * tr.w[c]);
+    }
+}
+
+// ---------------------------------------------------------------- d(segment_coo sum)/d(src): grad_src[i] = grad_out[index[i]]
+__global__ void k_segment_gather(const float* __restrict__ gout, const int64_t* __restrict__ index, int64_t n, int C,
+                                 float* __restrict__ gsrc) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    const int64_t i = t / C;
+    gsrc[t] = gout[index[i] * C + (t - i * C)];
+}
+
 // ---------------------------------------------------------------- k0 repack [C][V] -> [V][CP]
 __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t nvox, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,6 +415,22 @@ extern "C" int k4_segment_sum(const float* src, const int64_t* index, int64_t n,
     if (n == 0) return K4_OK;
     REQ(src && index);
     hipLaunchKernelGGL(k_segment_sum, dim3(k4_blocks(n * C)), dim3(K4_THREADS), 0, ST, src, index, n, C, out);
+    return k4_check_launch();
+}
+extern "C" int k4_grid_sample_3d_backward(const float* grad_out, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
+                                          const float* mn, const float* mx, int64_t n, float* grad_grid, void* stream) {
+    REQ(C > 0 && X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && grad_grid);
+    if (n == 0) return K4_OK;
+    REQ(xyz && grad_out);
+    hipLaunchKernelGGL(k_grid_sample_bwd, dim3(k4_blocks(n * ((C + 3) / 4))), dim3(K4_THREADS), 0, ST, grad_out, C, X, Y, Z, xyz, mn, mx, n, grad_grid);
+    return k4_check_launch();
+}
+extern "C" int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n, int32_t C, float* grad_src,
+                                       void* stream) {
+    REQ(C > 0 && n >= 0);
+    if (n == 0) return K4_OK;
+    REQ(grad_out && index && grad_src);
+    hipLaunchKernelGGL(k_segment_gather, dim3(k4_blocks(n * C)), dim3(K4_THREADS), 0, ST, grad_out, index, n, C, grad_src);
     return k4_check_launch();
 }
 extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {

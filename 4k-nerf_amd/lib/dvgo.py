@@ -481,13 +481,38 @@ def segment_sum(src, index, n):
     """torch_scatter.segment_coo(src, index, out=zeros([n,...]), reduce='sum') for a sorted index
     (lib/dvgo.py:415-419).  Inference: k4_segment_sum; under autograd: differentiable index_add."""
     if torch.is_grad_enabled() and src.requires_grad:
-        return torch.zeros([n] + list(src.shape[1:]), dtype=src.dtype, device=src.device).index_add_(0, index, src)
+        return SegmentSum.apply(src, index, n)
+    return _segment_sum_fwd(src, index, n)
+
+
+def _segment_sum_fwd(src, index, n):
     C_ = 1 if src.dim() == 1 else src.shape[1]
     out = torch.empty([n] + list(src.shape[1:]), dtype=torch.float32, device=src.device)
     srcc = src.detach().float().contiguous()
     N.check(N.lib().k4_segment_sum(N.f32(srcc), N.ptr(index.contiguous()), srcc.shape[0], C_, n, N.f32(out), N.stream()),
             'segment_sum')
     return out
+
+
+class SegmentSum(torch.autograd.Function):
+    """segment_coo(sum) with its HIP backward: grad_src[i] = grad_out[index[i]] (k4_segment_sum_backward)."""
+
+    @staticmethod
+    def forward(ctx, src, index, n):
+        ctx.save_for_backward(index)
+        ctx.src_shape = tuple(src.shape)
+        return _segment_sum_fwd(src.detach(), index, n)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        index, = ctx.saved_tensors
+        C_ = 1 if len(ctx.src_shape) == 1 else ctx.src_shape[1]
+        gs = torch.empty(ctx.src_shape, dtype=torch.float32, device=grad_out.device)
+        go = grad_out.float().contiguous()
+        N.check(N.lib().k4_segment_sum_backward(N.f32(go), N.ptr(index.contiguous()), ctx.src_shape[0], C_, N.f32(gs), N.stream()),
+                'segment_sum_backward')
+        return gs, None, None
 
 
 ''' Misc

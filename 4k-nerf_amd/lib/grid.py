@@ -14,6 +14,37 @@ from .. import _native as N
 from . import render_utils_cuda
 
 
+def _grid_sample_fwd(grid, pts, xyz_min, xyz_max):
+    C_ = grid.shape[1]
+    out = torch.empty([pts.shape[0], C_], dtype=torch.float32, device=pts.device)
+    N.check(N.lib().k4_grid_sample_3d(N.f32(grid), C_, grid.shape[2], grid.shape[3], grid.shape[4],
+                                      N.f32(pts), N.f32(xyz_min), N.f32(xyz_max),
+                                      pts.shape[0], N.f32(out), N.stream()), 'grid_sample_3d')
+    return out
+
+
+class GridSample3D(torch.autograd.Function):
+    """DenseGrid lookup with a HIP backward: d/d(grid) by fp32 atomic scatter-add (what grid_sampler_3d_backward does for
+    lib/grid.py:124 in the reference's training step).  No gradient w.r.t. the sample points (they come from rays)."""
+
+    @staticmethod
+    def forward(ctx, grid, pts, xyz_min, xyz_max):
+        ctx.save_for_backward(pts, xyz_min, xyz_max)
+        ctx.grid_shape = tuple(grid.shape)
+        return _grid_sample_fwd(grid.detach().contiguous(), pts, xyz_min, xyz_max)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        pts, xyz_min, xyz_max = ctx.saved_tensors
+        _, C_, X, Y, Z = ctx.grid_shape
+        gg = torch.zeros(ctx.grid_shape, dtype=torch.float32, device=grad_out.device)
+        go = grad_out.float().contiguous()
+        N.check(N.lib().k4_grid_sample_3d_backward(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max),
+                                                   pts.shape[0], N.f32(gg), N.stream()), 'grid_sample_3d_backward')
+        return gg, None, None, None
+
+
 def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
     """total_variation_cuda.total_variation_add_grad (lib/cuda/total_variation.cpp:16-20): grad += TV gradient of param,
     in place.  param, grad: [1, C, X, Y, Z] contiguous fp32 device tensors (CHECK_INPUT upstream)."""
@@ -44,22 +75,15 @@ class DenseGrid(nn.Module):
         self.grid = nn.Parameter(torch.zeros([1, channels, *world_size]))
 
     def forward(self, xyz):
-        """Trilinear lookup == F.grid_sample(bilinear, align_corners=True, zero pad) of lib/grid.py:117-128.
-        Inference: HIP kernel (k4_grid_sample_3d).  When autograd needs d/dgrid the PyTorch-ROCm op is
-        used (native backward is a 'next' row)."""
+        """Trilinear lookup == F.grid_sample(bilinear, align_corners=True, zero pad) of lib/grid.py:117-128: HIP kernel
+        k4_grid_sample_3d; under autograd its backward is k4_grid_sample_3d_backward (gradient w.r.t. the grid)."""
         shape = xyz.shape[:-1]
+        pts = xyz.reshape(-1, 3).contiguous()
         if torch.is_grad_enabled() and self.grid.requires_grad:
-            ind = ((xyz.reshape(1, 1, 1, -1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
-            out = F.grid_sample(self.grid, ind, mode='bilinear', align_corners=True)
-            out = out.reshape(self.channels, -1).T.reshape(*shape, self.channels)
+            out = GridSample3D.apply(self.grid, pts.detach(), self.xyz_min, self.xyz_max)
         else:
-            pts = xyz.reshape(-1, 3).contiguous()
-            out = torch.empty([pts.shape[0], self.channels], dtype=torch.float32, device=pts.device)
-            g = self.grid.detach()
-            N.check(N.lib().k4_grid_sample_3d(N.f32(g), self.channels, g.shape[2], g.shape[3], g.shape[4],
-                                              N.f32(pts), N.f32(self.xyz_min), N.f32(self.xyz_max),
-                                              pts.shape[0], N.f32(out), N.stream()), 'grid_sample_3d')
-            out = out.reshape(*shape, self.channels)
+            out = _grid_sample_fwd(self.grid.detach(), pts, self.xyz_min, self.xyz_max)
+        out = out.reshape(*shape, self.channels)
         if self.channels == 1:
             out = out.squeeze(-1)
         return out

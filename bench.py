@@ -329,6 +329,19 @@ def training_step_kernels(dev, reps=5):
         gbs = n * bpe / (ms * 1e-3) / 1e9
         out[name] = {'ms': round(ms, 3), 'algorithmic_bytes_per_voxel': round(bpe, 2), 'achieved_GBs': round(gbs, 1),
                      'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
+    # marcher backward scatter (8f rank 1): d(DenseGrid lookup)/d(grid) for one training batch of 8192 rays x 256 samples,
+    # 12 channels, fp32 hardware atomics into the same grid; bytes = grad_out + xyz read + 8 corners x 12 ch x 4 B RMW
+    npts = 8192 * 256
+    pts = torch.rand([npts, 3], device=dev, generator=gen) * 2 - 1
+    gout = torch.randn([npts, 12], device=dev, generator=gen)
+    mn, mx = torch.tensor([-1., -1., -1.], device=dev), torch.tensor([1., 1., 1.], device=dev)
+    from nerf4k_amd import _native as N_
+    ms = timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
+                                                                    npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
+    bpp = 12 * 4 + 12 + 8 * 12 * 4 * 2
+    out['grid_sample_3d_backward_2M_random_points'] = {'ms': round(ms, 3), 'Mpoints_per_s': round(npts / ms / 1e3, 1),
+                                                       'algorithmic_bytes_per_point': bpp,
+                                                       'achieved_GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
     return out
 
 

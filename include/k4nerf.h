@@ -176,6 +176,14 @@ int k4_grid_sample_3d(const float* grid, int32_t channels, int32_t X, int32_t Y,
 /* segment_coo(src, index, out=zeros, reduce='sum') for a SORTED index (lib/dmpigo.py:382-386): out [n_seg][C] */
 int k4_segment_sum(const float* src, const int64_t* index, int64_t n_pts, int32_t channels, int64_t n_seg,
                    float* out, void* stream);
+/* Backward of the two library ops above, as autograd runs them in the reference's training step:
+ * grad_grid [C][X][Y][Z] += scatter of grad_out [n_pts][C] with the forward's trilinear weights (grid_sampler_3d_backward,
+ * grad wrt input; fp32 hardware atomics, caller zero-fills or accumulates); grad_src [n_pts][C] = grad_out[index[i]]. */
+int k4_grid_sample_3d_backward(const float* grad_out, int32_t channels, int32_t X, int32_t Y, int32_t Z,
+                               const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
+                               float* grad_grid, void* stream);
+int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n_pts, int32_t channels,
+                            float* grad_src, void* stream);
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
 

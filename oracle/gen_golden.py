@@ -162,12 +162,53 @@ def gen_sr(ref):
         print(name, tuple(y.shape), float(y.abs().mean()))
 
 
+def gen_grad(ref):
+    """Training-step gradients of the reference's own modules (autograd through Raw2Alpha / Alphas2Weights with the restated
+    backward kernels, torch's grid_sample backward, index_add): d(mse(rgb_marched, target))/d(parameters)."""
+    poses = scene.llff_spiral_poses()
+    cases = [('grad_mpi', scene.make_llff_checkpoint(seed=15, num_voxels=14 * 14 * 12, mpi_depth=12), None),
+             ('grad_dvgo', scene.make_lego_checkpoint(seed=25, num_voxels=12 ** 3), 20)]
+    for name, ck, hw in cases:
+        if hw is None:
+            rays = _llff_rays(ref, 24, 32, poses[5], subsample=3)
+        else:
+            ro, rd, vd = ref.dvgo.get_rays_of_a_view(hw, hw, scene.lego_K(hw, hw), torch.Tensor(scene.lego_pose()),
+                                                     False, inverse_y=False, flip_x=False, flip_y=False)
+            rays = [x.flatten(0, -2)[::2].contiguous() for x in (ro, rd, vd)]
+        model = _ref_model(ref, ck)
+        g = torch.Generator().manual_seed(77)
+        target = torch.rand([rays[0].shape[0], 3], generator=g)
+        out = model(*rays, global_step=0, **ck['render_kwargs'])
+        loss = torch.nn.functional.mse_loss(out['rgb_marched'], target)
+        loss.backward()
+        arrs = {'model_class': np.array(ck['model_class']),
+                'model_kwargs_json': np.array(_kwargs_json(ck['model_kwargs'])),
+                'render_kwargs_json': np.array(json.dumps(ck['render_kwargs'])),
+                'target': _np(target), 'loss': _np(loss.detach())}
+        for k, v in ck['model_state_dict'].items():
+            arrs['sd/' + k] = _np(v)
+        for k, v in zip(('rays_o', 'rays_d', 'viewdirs'), rays):
+            arrs['in/' + k] = _np(v)
+        ng = 0
+        for k, prm in model.named_parameters():
+            if prm.grad is not None:
+                arrs['grad/' + k] = _np(prm.grad)
+                ng += 1
+        path = os.path.join(GOLDEN, name + '.npz')
+        np.savez_compressed(path, **arrs)
+        print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {float(loss):.6f}, {ng} parameter gradients')
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ref = ref_import.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'grad':
+        gen_grad(ref)
+        return
     gen_rays(ref)
     gen_march(ref)
     gen_sr(ref)
+    gen_grad(ref)
 
 
 if __name__ == '__main__':
