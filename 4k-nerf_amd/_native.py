@@ -53,6 +53,8 @@ _SIGS = {
     'k4_segment_sum': [_P, _P, _I64, _I32, _I64, _P, _P],
     'k4_grid_sample_3d_backward': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
     'k4_segment_sum_backward': [_P, _P, _I64, _I32, _P, _P],
+    'k4_get_rays_of_a_view': [_I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P],
+    'k4_to8b': [_P, _I64, _P, _P],
     'k4_repack_k0': [_P, _I32, _I32, _I64, _P, _P],
 }
 _lib = None

@@ -290,6 +290,58 @@ __global__ void k_segment_gather(const float* __restrict__ gout, const int64_t* 
     gsrc[t] = gout[index[i] * C + (t - i * C)];
 }
 
+// ---------------------------------------------------------------- get_rays_of_a_view (lib/dvgo.py:516-582), SURVEY.md 8f rank 4
+// One thread per pixel, no intermediate [H,W,3] tensors: pixel -> camera direction -> world ray -> unit view direction
+// (BEFORE the NDC warp) -> optional NDC warp (near = 1, focal = K[0][0]).  The arithmetic restates the reference's torch
+// op sequence one rounding at a time (__fmul_rn/__fadd_rn/__fdiv_rn: no contraction), so the rays equal the torch-built
+// ones to the last bit wherever torch itself is deterministic (its norm reduction may differ in the last bit).
+__global__ void k_rays_of_view(int H, int W, const float* __restrict__ Kd, const float* __restrict__ c2w, int ndc,
+                               int inverse_y, int flip_x, int flip_y, float pix_off, float c_w, float c_h,
+                               float* __restrict__ ro, float* __restrict__ rd, float* __restrict__ vd) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int row = (int)(p / W), col = (int)(p - (int64_t)row * W);
+    const k4_cptr K = k4_const(Kd), M = k4_const(c2w);          // uniform: scalar loads
+    const float i = (float)(flip_x ? W - 1 - col : col) + pix_off;
+    const float j = (float)(flip_y ? H - 1 - row : row) + pix_off;
+    float d[3];
+    d[0] = __fdiv_rn(__fsub_rn(i, K[2]), K[0]);
+    d[1] = __fdiv_rn(__fsub_rn(j, K[5]), K[4]);
+    d[2] = 1.f;
+    if (!inverse_y) { d[1] = -d[1]; d[2] = -1.f; }
+    float v[3], o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                                // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1)
+        v[a] = __fadd_rn(__fadd_rn(__fmul_rn(d[0], M[a * 4 + 0]), __fmul_rn(d[1], M[a * 4 + 1])), __fmul_rn(d[2], M[a * 4 + 2]));
+        o[a] = M[a * 4 + 3];
+    }
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) vd[p * 3 + a] = __fdiv_rn(v[a], nrm);
+    if (ndc) {                                                   // ndc_rays, near = 1 (lib/dvgo.py:557-574)
+        const float t = __fdiv_rn(-__fadd_rn(1.f, o[2]), v[2]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) o[a] = __fadd_rn(o[a], __fmul_rn(t, v[a]));
+        const float o0 = __fdiv_rn(__fmul_rn(c_w, o[0]), o[2]);
+        const float o1 = __fdiv_rn(__fmul_rn(c_h, o[1]), o[2]);
+        const float o2 = __fadd_rn(1.f, __fdiv_rn(2.f, o[2]));
+        const float d0 = __fmul_rn(c_w, __fsub_rn(__fdiv_rn(v[0], v[2]), __fdiv_rn(o[0], o[2])));
+        const float d1 = __fmul_rn(c_h, __fsub_rn(__fdiv_rn(v[1], v[2]), __fdiv_rn(o[1], o[2])));
+        const float d2 = __fdiv_rn(-2.f, o[2]);
+        o[0] = o0; o[1] = o1; o[2] = o2; v[0] = d0; v[1] = d1; v[2] = d2;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ro[p * 3 + a] = o[a]; rd[p * 3 + a] = v[a]; }
+}
+
+// ---------------------------------------------------------------- utils.to8b (lib/utils.py:19): (255*clip(x,0,1)).astype(uint8)
+__global__ void k_to8b(const float* __restrict__ x, int64_t n, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = fminf(fmaxf(x[i], 0.f), 1.f);               // np.clip: NaN propagates in numpy; maps to 0 here
+    out[i] = (uint8_t)(int)__fmul_rn(255.f, c);                  // astype(uint8): truncation
+}
+
 // ---------------------------------------------------------------- k0 repack [C][V] -> [V][CP]
 __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t nvox, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,6 +483,24 @@ extern "C" int k4_segment_sum_backward(const float* grad_out, const int64_t* ind
     if (n == 0) return K4_OK;
     REQ(grad_out && index && grad_src);
     hipLaunchKernelGGL(k_segment_gather, dim3(k4_blocks(n * C)), dim3(K4_THREADS), 0, ST, grad_out, index, n, C, grad_src);
+    return k4_check_launch();
+}
+extern "C" int k4_get_rays_of_a_view(int32_t H, int32_t W, const float* K_dev, const float* c2w_dev, int32_t ndc,
+                                     int32_t inverse_y, int32_t flip_x, int32_t flip_y, int32_t mode_center,
+                                     float focal, float* rays_o, float* rays_d, float* viewdirs, void* stream) {
+    REQ(H > 0 && W > 0 && K_dev && c2w_dev && rays_o && rays_d && viewdirs);
+    // -1./(W/(2.*focal)) as the reference evaluates it: Python double arithmetic, cast to fp32 by the tensor multiply
+    const float c_w = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
+    const float c_h = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
+    hipLaunchKernelGGL(k_rays_of_view, dim3(k4_blocks((int64_t)H * W)), dim3(K4_THREADS), 0, ST, H, W, K_dev, c2w_dev, ndc, inverse_y,
+                       flip_x, flip_y, mode_center ? 0.5f : 0.f, c_w, c_h, rays_o, rays_d, viewdirs);
+    return k4_check_launch();
+}
+extern "C" int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream) {
+    REQ(n >= 0);
+    if (n == 0) return K4_OK;
+    REQ(x && out);
+    hipLaunchKernelGGL(k_to8b, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, x, n, out);
     return k4_check_launch();
 }
 extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {

@@ -612,7 +612,21 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 
 def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='center'):
-    """viewdirs normalised BEFORE the NDC warp (lib/dvgo.py:577-582)."""
+    """viewdirs normalised BEFORE the NDC warp (lib/dvgo.py:577-582).  On a GPU pose: one HIP launch
+    (k4_get_rays_of_a_view) instead of ~25 elementwise kernels and their [H,W,3] temporaries."""
+    if torch.is_tensor(c2w) and c2w.is_cuda and mode in ('center', 'lefttop'):
+        dev = c2w.device
+        Kt = (torch.as_tensor(np.asarray(K), dtype=torch.float32) if not torch.is_tensor(K) else K.detach().float().cpu())
+        focal = float(Kt[0][0])
+        Kd = Kt.contiguous().to(dev)
+        M = c2w.detach().float().contiguous()
+        if M.shape[-1] != 4 or M.shape[0] < 3:
+            raise ValueError('c2w must be [3,4] or [4,4]')
+        ro, rd, vd = (torch.empty([H, W, 3], dtype=torch.float32, device=dev) for _ in range(3))
+        N.check(N.lib().k4_get_rays_of_a_view(int(H), int(W), N.f32(Kd), N.f32(M), int(bool(ndc)), int(bool(inverse_y)),
+                                              int(bool(flip_x)), int(bool(flip_y)), 1 if mode == 'center' else 0, focal,
+                                              N.f32(ro), N.f32(rd), N.f32(vd), N.stream()), 'k4_get_rays_of_a_view')
+        return ro, rd, vd
     rays_o, rays_d = get_rays(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y, mode=mode)
     viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
     if ndc:

@@ -14,6 +14,16 @@ to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)     # lib/utils.py:19
 mse2psnr = lambda x: -10. * torch.log10(x)
 
 
+def to8b_device(x):
+    """to8b for a device tensor: uint8 tensor of the same shape, packed on the GPU (k4_to8b) -- a 4K frame leaves the device
+    as 36.6 MB instead of 146 MB of fp32."""
+    from .. import _native as N
+    xc = x.detach().float().contiguous()
+    out = torch.empty(xc.shape, dtype=torch.uint8, device=xc.device)
+    N.check(N.lib().k4_to8b(N.f32(xc), xc.numel(), N.ptr(out), N.stream()), 'k4_to8b')
+    return out
+
+
 def create_optimizer_or_freeze_model(model, cfg_train, global_step):
     """lib/utils.py:21-48: one param group per `lrate_<name>` entry of cfg_train whose attribute exists on the model;
     lr decays by 0.1 every `lrate_decay` k-steps; lr == 0 freezes the parameter.  cfg_train: attribute-style mapping

@@ -184,6 +184,14 @@ int k4_grid_sample_3d_backward(const float* grad_out, int32_t channels, int32_t 
                                float* grad_grid, void* stream);
 int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n_pts, int32_t channels,
                             float* grad_src, void* stream);
+/* get_rays_of_a_view (lib/dvgo.py:516-582: get_rays + viewdirs + ndc_rays with near = 1) in one launch.  K_dev: [3][3]
+ * intrinsics, c2w_dev: [3][4] (or the top of a [4][4]) camera-to-world, both fp32 ON THE DEVICE; focal = K[0][0] as a
+ * host value (the reference passes it as a Python scalar); mode_center: 1 = pixel centres (+0.5), 0 = 'lefttop'.
+ * Outputs [H*W][3] each.  k4_to8b: utils.to8b (lib/utils.py:19), n floats -> n bytes. */
+int k4_get_rays_of_a_view(int32_t H, int32_t W, const float* K_dev, const float* c2w_dev, int32_t ndc,
+                          int32_t inverse_y, int32_t flip_x, int32_t flip_y, int32_t mode_center, float focal,
+                          float* rays_o, float* rays_d, float* viewdirs, void* stream);
+int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream);
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
 

@@ -8,15 +8,17 @@ Tolerances (fp32; stated here as the contract):
   * mask-decision agreement: device counters (in-bbox / mask / alpha / shaded samples) within 1e-4 relative
     of the oracle's counts.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import scene, render
-from nerf4k_amd.lib import utils, render_utils_cuda as ruc, grid as kgrid
+from nerf4k_amd.lib import utils, dvgo, render_utils_cuda as ruc, grid as kgrid
 from oracle import marcher, native_cpu as nat
-from helpers import load_march_golden, psnr
+from helpers import GOLDEN, load_march_golden, psnr
 
 pytestmark = pytest.mark.gpu
 
@@ -261,3 +263,35 @@ def test_full_size_llff_properties():
     import nerf4k_amd.lib.dvgo as kd
     gro, grd, gvd = kd.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(pose).cuda(), True, False, False, False)
     assert torch.allclose(gro.cpu(), ro, atol=1e-6) and torch.allclose(grd.cpu(), rd, atol=1e-6)
+
+
+def test_device_ray_generation_matches_reference_goldens_and_torch_path():
+    """k4_get_rays_of_a_view (one launch) against rays produced by the reference (tests/golden/rays_views.npz) and against the
+    elementwise torch formulation on the same device.  Tolerance 2e-6 absolute on O(1) values: one rounding per op is
+    reproduced, only torch's norm reduction may differ in the last bit."""
+    z = np.load(os.path.join(GOLDEN, 'rays_views.npz'))
+    H, W = int(z['H']), int(z['W'])
+    for tag, ndc in (('ndc', True), ('persp', False)):
+        K, c2w = z[f'{tag}/K'], torch.from_numpy(z[f'{tag}/c2w']).float()
+        got = dvgo.get_rays_of_a_view(H, W, K, c2w.cuda(), ndc, False, False, False)
+        for g, key in zip(got, ('rays_o', 'rays_d', 'viewdirs')):
+            want = torch.from_numpy(z[f'{tag}/{key}'])
+            assert g.shape == want.shape
+            assert float((g.cpu() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (tag, key)
+        for flags in ((True, False, False), (False, True, True)):
+            a = dvgo.get_rays_of_a_view(H, W, K, c2w.cuda(), ndc, *flags)
+            ro, rd = dvgo.get_rays(H, W, K, c2w.cuda(), inverse_y=flags[0], flip_x=flags[1], flip_y=flags[2])
+            vd = rd / rd.norm(dim=-1, keepdim=True)
+            if ndc:
+                ro, rd = dvgo.ndc_rays(H, W, float(K[0][0]), 1., ro, rd)
+            for g, w_ in zip(a, (ro, rd, vd)):
+                assert float((g - w_).abs().max()) <= 2e-6 * max(1.0, float(w_.abs().max())), (tag, flags)
+
+
+def test_device_to8b_is_exact():
+    from nerf4k_amd.lib.utils import to8b, to8b_device
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand([3, 37, 53], generator=g) * 1.4 - 0.2
+    x.view(-1)[:512] = torch.arange(512, dtype=torch.float32) / 255.0 - 0.5          # exact k/255 boundaries, < 0 and > 1
+    got = to8b_device(x.cuda()).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, to8b(x.numpy()))
