@@ -17,6 +17,7 @@
 // fp32 MFMA issues at the fp32 vector rate (157 TFLOP/s peak), so LDS/HBM are far from limiting: the kernel is
 // matrix-pipe bound; bf16 would be 16x faster but breaks the fp32 parity contract.
 #include "k4_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -393,17 +394,21 @@ __device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4
     t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
 }
 
-template <int KS, int NT>
-__global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
+// NW = waves per workgroup (tile = 2*NW rows x 32 columns).  NW = 8 for 64 output channels (one 114 KB workgroup per CU);
+// NW = 4 for 32 output channels: 60 KB, two workgroups per CU whose staging / MFMA phases interleave.
+template <int KS, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvParams P) {
+    constexpr int THREADS = 64 * NW;
+    constexpr int TILE_ROWS = 2 * NW;
     constexpr int TAPS = KS * KS;
     constexpr int PADW = KS / 2;
-    constexpr int ROWS = TILE_HB + 2 * PADW;
+    constexpr int ROWS = TILE_ROWS + 2 * PADW;
     constexpr int COLS = TILE_W + 2 * PADW;
     constexpr int NOUT = NT * 32;
     constexpr int IN_ITEMS = ROWS * COLS * 2;                 // (pixel, channel group of 8)
-    constexpr int IN_PER = (IN_ITEMS + 511) / 512;
+    constexpr int IN_PER = (IN_ITEMS + THREADS - 1) / THREADS;
     constexpr int W_ITEMS = 3 * TAPS * 2 * NOUT;              // 16-byte units of one chunk's split weights
-    constexpr int W_PER = (W_ITEMS + 511) / 512;
+    constexpr int W_PER = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr int IN_PLANE = 2 * ROWS * COLS;                 // uint4 per term
     extern __shared__ uint4 k4_b6_smem[];
     uint4* const in_s = k4_b6_smem;                           // [term][channel group][row][col] x 8 bf16
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
     const int half = lane >> 5, l31 = lane & 31;
     const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_HB;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_ROWS;
     const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
 
     f32x16 acc[2][NT];
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
     int ikg[IN_PER], idst[IN_PER];
 #pragma unroll
     for (int i = 0; i < IN_PER; ++i) {
-        const int it = tid + i * 512;
+        const int it = tid + i * THREADS;
         const int itc = it < IN_ITEMS ? it : 0;
         const int kg = itc & 1, pp = itc >> 1;
         const int py = pp / COLS, px = pp - py * COLS;
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
         } \
         const uint4* wsrc_ = wsrc_all + (size_t)(CH) * W_ITEMS; \
         _Pragma("unroll") for (int j = 0; j < W_PER; ++j) { \
-            const int it = tid + j * 512; \
+            const int it = tid + j * THREADS; \
             wr[j] = wsrc_[it < W_ITEMS ? it : 0]; \
         } } while (0)
 #define K4_B6_STORE() do { \
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
             if (idst[i] >= 0) { in_s[idst[i]] = t0; in_s[IN_PLANE + idst[i]] = t1; in_s[2 * IN_PLANE + idst[i]] = t2; } \
         } \
         _Pragma("unroll") for (int j = 0; j < W_PER; ++j) { \
-            const int it = tid + j * 512; \
+            const int it = tid + j * THREADS; \
             if (it < W_ITEMS) w_s[it] = wr[j]; \
         } } while (0)
 
@@ -529,19 +534,20 @@ __global__ __launch_bounds__(512) void k4_conv_b6_kernel(const ConvParams P) {
     k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
 }
 
-template <int KS, int NT>
-static int launch_conv_b6(const ConvParams& P, hipStream_t st) {
+template <int KS, int NT, int NW>
+static int launch_conv_b6(ConvParams P, hipStream_t st) {
     constexpr int TAPS = KS * KS, PADW = KS / 2;
-    constexpr size_t lds = ((size_t)3 * 2 * (TILE_HB + 2 * PADW) * (TILE_W + 2 * PADW) + (size_t)3 * TAPS * 2 * NT * 32) * sizeof(uint4);
+    constexpr size_t lds = ((size_t)3 * 2 * (2 * NW + 2 * PADW) * (TILE_W + 2 * PADW) + (size_t)3 * TAPS * 2 * NT * 32) * sizeof(uint4);
+    P.tiles_y = (P.H + 2 * NW - 1) / (2 * NW);
     static_assert(lds <= 160 * 1024, "split chunk must fit the CU's LDS");
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_b6_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_b6_kernel<KS, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(512);
-    hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT>), grid, block, lds, st, P);
+    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(64 * NW);
+    hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT, NW>), grid, block, lds, st, P);
     return k4_check_launch();
 }
 
@@ -575,13 +581,14 @@ extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_st
     P.modx = mod_x; P.mod_stride = mod_stride;
     P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_HB - 1) / TILE_HB;
     hipStream_t st = (hipStream_t)stream;
+    static const int nw1 = getenv("K4_B6_NW1") ? atoi(getenv("K4_B6_NW1")) : 8;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
     if (ksize == 3) {
-        if (nt == 1) return launch_conv_b6<3, 1>(P, st);
-        if (nt == 2) return launch_conv_b6<3, 2>(P, st);
+        if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(P, st) : launch_conv_b6<3, 1, 8>(P, st);
+        if (nt == 2) return launch_conv_b6<3, 2, 8>(P, st);
     } else {
-        if (nt == 1) return launch_conv_b6<1, 1>(P, st);
-        if (nt == 2) return launch_conv_b6<1, 2>(P, st);
-        if (nt == 4) return launch_conv_b6<1, 4>(P, st);
+        if (nt == 1) return launch_conv_b6<1, 1, 8>(P, st);
+        if (nt == 2) return launch_conv_b6<1, 2, 8>(P, st);
+        if (nt == 4) return launch_conv_b6<1, 4, 8>(P, st);
     }
     return K4_ERR_UNSUPPORTED;
 }

@@ -47,6 +47,10 @@ def parse():
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams frames alternate on (2: the geometry kernel of frame '
                     'i+1 overlaps the matrix-core shading kernel of frame i)')
+    ap.add_argument('--shard', choices=['frames', 'rows'], default='frames',
+                    help='N>1, marcher metric: "frames" = every rank renders its own frames of the pose sequence (independent '
+                         'units, no collective, weak scaling); "rows" = every frame split in row bands + all_gather of the final '
+                         'pixels (strong scaling; the 4K pipeline always shards tiles of one frame, see four_k)')
     ap.add_argument('--no-extras', action='store_true', help='marcher line only: skip the reference-pipeline and training-step '
                     'side measurements (profiling runs)')
     ap.add_argument('--backend', default='nccl', help=argparse.SUPPRESS)          # gloo + --same-device: 1-GPU logic smoke test
@@ -99,7 +103,10 @@ def main():
 
     # band of pixel rows owned by this rank (multiples of 8 rows -> whole 8x8 wave tiles)
     from nerf4k_amd import tile_parallel as tp
-    r0, r1, rows_per = tp.shard_rows(H, world, rank)
+    by_rows = world > 1 and args.shard == 'rows'
+    r0, r1, rows_per = tp.shard_rows(H, world, rank) if by_rows else (0, H, H)
+    if world > 1 and not by_rows:          # rank r renders frames r, r+N, r+2N, ... of the pose sequence
+        poses = [poses[(rank + i * world) % len(poses)] for i in range(len(poses))]
     rays = []
     with torch.no_grad():
         for p in poses:
@@ -109,7 +116,7 @@ def main():
     slot = rows_per * W
     # all-gather buffers (double buffered): [rgb n x 3 | depth n | alphainv n] -- the marcher writes straight into them
     send = [torch.zeros([5 * slot], dtype=torch.float32, device=dev) for _ in range(2)]
-    recv = [torch.empty([world * 5 * slot], dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    recv = [torch.empty([world * 5 * slot], dtype=torch.float32, device=dev) for _ in range(2)] if by_rows else None
     outs = [(b[:3 * n_band].view(n_band, 3), b[3 * slot:3 * slot + n_band], b[4 * slot:4 * slot + n_band]) for b in send]
     works = [None, None]
 
@@ -130,7 +137,7 @@ def main():
             out = model(ro, rd, vd, k4_img_w=W, k4_counters=counters, k4_out=outs[b], k4_ws_slot=i % len(streams), **rk)
             if timed is not None:
                 timed[1].record(st)
-            if world > 1:                        # final pixels only; asynchronous, overlaps the next frame's march
+            if by_rows:                          # final pixels only; asynchronous, overlaps the next frame's march
                 works[b] = dist.all_gather_into_tensor(recv[b], send[b], async_op=True)
         return out
 
@@ -181,7 +188,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        rays_per_step = H * W
+        rays_per_step = H * W * (1 if (world == 1 or by_rows) else world)     # frames mode: every rank renders a frame per step
         value = rays_per_step * args.steps / elapsed / 1e6
         eff_ms = elapsed / args.steps * 1e3            # per-frame time of the timed region (frames overlap on the streams)
         b_alg = n_band * 56 + n_inb * 1 + n_mask * 32 + n_shade * 8 * model.k0_dim * 4
@@ -190,13 +197,16 @@ def main():
             'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
             'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(eff_ms, 4), 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong' if by_rows or world == 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: LLFF fern_lg_pretrain render_test 1008x756, DirectMPIGO '
                                    '417x353x256 grid, 256 samples/ray, rgbnet 15->64->64->3, marcher only (no SR)'
                                    + (' [REDUCED --small scene]' if args.small else ''),
-                       'rays_per_frame': rays_per_step, 'frames': args.steps, 'streams': len(streams),
-                       'parallelism': f'row-bands x{world} + all_gather of final pixels' if world > 1 else 'single GPU'},
-            'frames_per_s_lr': round(args.steps / elapsed, 2),
+                       'rays_per_frame': H * W, 'frames': args.steps * (1 if (world == 1 or by_rows) else world),
+                       'streams': len(streams),
+                       'parallelism': ('single GPU' if world == 1 else
+                                       f'row-bands x{world} + all_gather of final pixels' if by_rows else
+                                       f'frames of the pose sequence sharded over {world} GPUs (full model replica each, no collective)')},
+            'frames_per_s_lr': round(rays_per_step * args.steps / (H * W) / elapsed, 2),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                          'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>',
