@@ -193,6 +193,11 @@ def main():
         eff_ms = elapsed / args.steps * 1e3            # per-frame time of the timed region (frames overlap on the streams)
         b_alg = n_band * 56 + n_inb * 1 + n_mask * 32 + n_shade * 8 * model.k0_dim * 4
         achieved = b_alg / (iso_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None            # HBM-side bytes per launch: PMC passes of this command, committed under profiles/
+        tp_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_marcher_traffic.json')
+        if os.path.exists(tp_) and not args.small:
+            tj = json.load(open(tp_))
+            traffic, traffic_src = int(tj['fabric_bytes_per_launch']), tj['source']
         res = {
             'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
             'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -208,7 +213,7 @@ def main():
                                        f'frames of the pose sequence sharded over {world} GPUs (full model replica each, no collective)')},
             'frames_per_s_lr': round(rays_per_step * args.steps / (H * W) / elapsed, 2),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>',
                          'kernel_ms': round(iso_ms, 4),
                          'kernel_ms_note': 'isolated launch duration (1 stream, HIP events on the launch stream); in the '

@@ -5,10 +5,10 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 f=$(find $R/gpurun_out/prof_m -name "*kernel_stats.csv" | head -1); head -14 "$f" > $R/gpurun_out/final_marcher_stats.csv
 grep '"metric"' $R/gpurun_out/prof_m.log | tail -1 > $R/gpurun_out/final_marcher_bench_line.json
 rm -rf $R/gpurun_out/prof_m
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_s -o run -- python $R/scratch/sr_bench.py bf16x6 > $R/gpurun_out/prof_s.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_s -o run -- python $R/tools/sr_frame_time.py bf16x6 > $R/gpurun_out/prof_s.log 2>&1
 f=$(find $R/gpurun_out/prof_s -name "*kernel_stats.csv" | head -1); head -14 "$f" > $R/gpurun_out/final_sr_stats.csv
-tail -2 $R/gpurun_out/prof_s.log > $R/gpurun_out/final_sr_line.txt
+grep "ms/frame" $R/gpurun_out/prof_s.log > $R/gpurun_out/final_sr_line.txt
 rm -rf $R/gpurun_out/prof_s
 cd $R
-PMC_GROUPS="2 3" tools/pmc_run.sh final --steps 3 --warmup 1 --sr-frames 0 --no-cpu-baseline --no-extras --streams 1 > /dev/null 2>&1
+PMC_GROUPS="3 4" tools/pmc_run.sh final --steps 3 --warmup 1 --sr-frames 0 --no-cpu-baseline --no-extras --streams 1 > /dev/null 2>&1
 ls $R/gpurun_out

@@ -1,5 +1,5 @@
 import sys, time, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))    # repo root
 import nerf4k_amd
 from nerf4k_amd.lib import sr_esrnet
 torch.manual_seed(777)
