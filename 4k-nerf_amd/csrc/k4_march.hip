@@ -1319,7 +1319,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const int width = mlp->width, nh = mlp->n_hidden;
     // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; K4_MLP=fp32 selects the
     // fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
-    static const bool mlp_fp32 = getenv("K4_MLP") && !strcmp(getenv("K4_MLP"), "fp32");
+    const char* const mlp_env = getenv("K4_MLP");              // read per launch (tests toggle it within one process)
+    const bool mlp_fp32 = mlp_env && !strcmp(mlp_env, "fp32");
     const bool b3 = width != 0 && width <= 64 && !mlp_fp32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
     const size_t lds_pipe = lds_base + sizeof(float) * 4 * (64 * 12 + 24 * 64 * 4);       // + ray table + 24 KB staging per wave

@@ -295,3 +295,23 @@ def test_device_to8b_is_exact():
     x.view(-1)[:512] = torch.arange(512, dtype=torch.float32) / 255.0 - 0.5          # exact k/255 boundaries, < 0 and > 1
     got = to8b_device(x.cuda()).cpu().numpy()
     assert got.dtype == np.uint8 and np.array_equal(got, to8b(x.numpy()))
+
+
+def test_rgbnet_split_bf16_agrees_with_exact_fp32_mfma(monkeypatch):
+    """The default rgbnet arithmetic (exact 3-term bf16 splits, 6 partial products, fp32 accumulation) against the
+    fp32-input MFMA form (bit-exact fp32 FMA chains, K4_MLP=fp32) on a whole frame: the two differ like two fp32 summation
+    orders -- max |rgb| difference <= 2e-6, alphainv/depth paths untouched (bit-equal alphainv)."""
+    ck = scene.make_llff_checkpoint(seed=51, num_voxels=64 * 64 * 48, mpi_depth=48)
+    model = _model(ck)
+    H, W = 64, 96
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    rays = [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[2], ndc=True)]
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    a = model(*rays, k4_img_w=W, **rk)
+    monkeypatch.setenv('K4_MLP', 'fp32')
+    b = model(*rays, k4_img_w=W, **rk)
+    monkeypatch.delenv('K4_MLP')
+    assert torch.equal(a['alphainv_last'], b['alphainv_last'])
+    d = float((a['rgb_marched'] - b['rgb_marched']).abs().max())
+    assert 0 < d <= 2e-6, d                                   # > 0: the two paths really are different kernels
