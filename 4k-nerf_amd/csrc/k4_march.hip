@@ -10,28 +10,29 @@
 //   (lib/dmpigo.py:336-379, lib/dvgo.py:372-412) -> sum_w rgb, sum_w s, alphainv_last*bg
 //   (lib/dmpigo.py:382-398,418-424).
 //
-// K1  k4_geom_kernel   (HBM/latency bound, <=64 VGPR -> 8 waves/SIMD, no LDS)
-//     a wavefront owns a bundle of 64 rays (an 8x8 pixel tile when the caller says the rays are an image,
-//     else 64 consecutive rays; workgroups are XCD-banded so neighbouring tiles share an L2) and walks
-//     ONE ray at a time with lanes = 64 consecutive samples.  NDC/MPI rays advance mostly along Z, the
-//     contiguous axis of the [X][Y][Z] grids, so the occupancy byte and the 8 density gathers of a wave
-//     coalesce into a few 256-B lines.  Transmittance is the reference's exact sequential product over
-//     the (few) alpha-passing lanes (ballot + readlane).  Survivors (w > thres) are compacted
-//     (ballot/mbcnt) straight into the bundle's slice of a workspace as 8-byte {ray,step | weight}
-//     records -- ~9 per ray instead of the reference's 256 x 60 B of per-sample intermediates.
-// K2  k4_shade_kernel  (matrix-core bound)
-//     the same wave->bundle map; 64 records at a time, lane = sample: 8-corner k0 gather from the
-//     channel-last repack, features to LDS, then the rgbnet MLP on the matrix cores as
-//     C^T[neuron][sample] = W . X with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  Weights are
-//     pre-arranged in operand order and LDS resident, so every A operand is one conflict-free
-//     ds_read_b32; the C layout of layer n IS the B-operand layout of layer n+1 (K is walked in
-//     accumulator-register order), so activations never leave registers and there is no cross-lane
-//     traffic between layers.  A segmented wave scan folds w*rgb / w*s into per-ray LDS accumulators;
-//     5 floats per ray are the only other global writes.
-// Deterministic: no atomics on the data path, fixed summation order.
+// K1  k4_geom2_kernel  (VALU-issue / latency bound; HBM traffic ~0.2 GB per frame)
+//     a WORKGROUP owns a bundle of 64 rays (an 8x8 pixel tile when the caller says the rays are an image, else 64
+//     consecutive rays; workgroups are XCD-banded so neighbouring tiles share an L2); its 4 waves take one depth quarter of
+//     every ray each and walk ONE ray at a time with lanes = 64 consecutive samples.  NDC/MPI rays advance mostly along Z,
+//     the contiguous axis of the [X][Y][Z] grids, so the occupancy byte and the density gathers of a wave coalesce into a
+//     few 128-B lines that the neighbouring ray re-uses from L1/L2.  Mask-passing samples are compacted across rays
+//     before the density stage (all lanes busy); transmittance is the reference's exact sequential product, run
+//     transposed (lane = ray) by wave 0 after a workgroup barrier.  Survivors (w > thres) are compacted straight into the
+//     bundle's slice of a workspace as 8-byte {ray,step | weight} records -- ~9 per ray instead of the reference's
+//     256 x 60 B of per-sample intermediates.
+// K2  k4_shade_kernel  (VALU / gather bound)
+//     persistent waves pull bundles from a queue; 64 records at a time, lane = sample: 8-corner k0 gather from the
+//     channel-last repack, features to LDS, then the rgbnet MLP on the matrix cores as C^T[neuron][sample] = W . X --
+//     by default with exact 3-term bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-equivalent), optionally with
+//     v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  Weights are pre-arranged in operand order and LDS resident; the C
+//     layout of layer n IS the B-operand layout of layer n+1 (K is walked in accumulator-register order), so activations
+//     never leave registers and there is no cross-lane traffic between layers.  A segmented wave scan folds w*rgb / w*s
+//     into per-ray LDS accumulators; 5 floats per ray are the only other global writes.
+// Superseded variants (a per-ray K1 with every stage on the same lanes, a K1 with global / per-XCD work queues, a K2 with
+// LDS-DMA prefetch of the next batch's gathers at one workgroup per CU) were measured and dropped: DESIGN.md 5, profiles/.
+// Deterministic: no global atomics on the data path, fixed summation order.
 #include "k4_common.h"
 #include <string.h>
-#include <stdlib.h>
 #include <stdlib.h>
 
 #define MODE_MPI  0
@@ -56,11 +57,9 @@ struct MarchParams {
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
-    int* ghead;                                    // geometry work-queue head (zeroed by the launcher)
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     int serp;               // 1: serpentine ray order inside a tile (default)
-    int geom_persist;       // 0: one bundle per wave, static XCD-banded map (default, fastest measured); 1: per-XCD work queues
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
 
@@ -127,126 +126,9 @@ __device__ __forceinline__ void ray_setup(const MarchParams& P, float ox, float 
 // =====================================================================================================
 // K1: geometry
 // =====================================================================================================
-template <int MODE>
-__global__ __launch_bounds__(256) void k4_geom_kernel(const MarchParams P) {
-    const int lane = k4_lane();
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const Bundle B = bundle_of(P, wv);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.qhead = 0;            // work queue of the shading kernel that follows
-    uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-    const k4_cptr c_o = k4_const(P.rays_o), c_d = k4_const(P.rays_d);
-    const bool unit_interval = P.interval == 1.f;
-    const bool use_thres = P.thres > 0.f;
-    unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0;
-    int cnt = 0;
-    float my_ainv = 1.f;
-    const float tk0 = step_t<MODE>(P, lane), tk1 = step_t<MODE>(P, 64 + lane), tk2 = step_t<MODE>(P, 128 + lane),
-                tk3 = step_t<MODE>(P, 192 + lane);
-
-    for (int r = 0; r < 64; ++r) {
-        const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, r));
-        if (ray < 0) continue;
-        float sx, sy, sz, dx, dy, dz;
-        int nsteps;
-        ray_setup<MODE>(P, c_o[ray * 3 + 0], c_o[ray * 3 + 1], c_o[ray * 3 + 2],
-                        c_d[ray * 3 + 0], c_d[ray * 3 + 1], c_d[ray * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
-        nsteps = __builtin_amdgcn_readfirstlane(nsteps);
-        float T = 1.f;
-        for (int base = 0; base < nsteps; base += 64) {
-            // ------------------ 64 consecutive samples of ray r ------------------
-            const int k = base + lane;
-            float tk;
-            if (MODE == MODE_MPI && base < 256) {       // t_k = k/(Ns-1) does not depend on the ray: the division is hoisted
-                tk = base == 0 ? tk0 : (base == 64 ? tk1 : (base == 128 ? tk2 : tk3));
-            } else tk = step_t<MODE>(P, k);
-            const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
-            const bool inb = (k < nsteps) &&
-                !((P.minx > px) | (P.miny > py) | (P.minz > pz) | (P.maxx < px) | (P.maxy < py) | (P.maxz < pz));
-            bool m = false;
-            if (inb) {
-                const int mi = k4_round_half_away(fmaf(px, P.msx, P.mtx));
-                const int mj = k4_round_half_away(fmaf(py, P.msy, P.mty));
-                const int mk = k4_round_half_away(fmaf(pz, P.msz, P.mtz));
-                if ((unsigned)mi < (unsigned)P.MX && (unsigned)mj < (unsigned)P.MY && (unsigned)mk < (unsigned)P.MZ)
-                    m = P.mask[((size_t)mi * P.MY + mj) * P.MZ + mk] != 0;
-            }
-            const uint64_t mball = __ballot(m);
-            if (P.counters) { n_inb += __popcll(__ballot(inb)); n_mask += __popcll(mball); }
-            if (!mball) continue;
-            float alpha = 0.f;
-            bool act = false;
-            if (m) {
-                const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
-                const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
-                const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
-                const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
-                // The point is inside the closed bbox, so 0 <= u <= dim-1: only the "+1" corner can leave the grid and
-                // then its weight (u - floor u) is exactly 0 -> clamp the index instead of branching (zero padding of
-                // grid_sample contributes the same +0).
-                float sigma = 0.f;
-                const int x1 = min(t.x0 + 1, P.X - 1), y1 = min(t.y0 + 1, P.Y - 1), z1 = min(t.z0 + 1, P.Z - 1);
-                const unsigned r00 = (unsigned)(t.x0 * P.Y + t.y0) * (unsigned)P.Z, r01 = (unsigned)(t.x0 * P.Y + y1) * (unsigned)P.Z;
-                const unsigned r10 = (unsigned)(x1 * P.Y + t.y0) * (unsigned)P.Z, r11 = (unsigned)(x1 * P.Y + y1) * (unsigned)P.Z;
-                float d0, d1, d2, d3, d4, d5, d6, d7;
-                if (P.debug & 16) { d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = -3.f + t.w[0]; }
-                else {
-                d0 = P.density[r00 + t.z0]; d1 = P.density[r00 + z1]; d2 = P.density[r01 + t.z0]; d3 = P.density[r01 + z1];
-                d4 = P.density[r10 + t.z0]; d5 = P.density[r10 + z1]; d6 = P.density[r11 + t.z0]; d7 = P.density[r11 + z1];
-                }
-                sigma += d0 * t.w[0]; sigma += d1 * t.w[1]; sigma += d2 * t.w[2]; sigma += d3 * t.w[3];
-                sigma += d4 * t.w[4]; sigma += d5 * t.w[5]; sigma += d6 * t.w[6]; sigma += d7 * t.w[7];
-                if (MODE == MODE_MPI) {
-                    // act_shift grid [1,1,D]: x/y sizes are 1 -> only z interpolates (lib/dmpigo.py:48-58,316)
-                    const float ua = k4_unnorm(nz, P.act_d);
-                    const float fa = floorf(ua);
-                    const int a0 = (int)fa;
-                    const float lo = P.act_shift[a0];
-                    const float hi = P.act_shift[min(a0 + 1, P.act_d - 1)];
-                    sigma += lo * ((fa + 1.f) - ua) + hi * (ua - fa);
-                }
-                // raw2alpha: e = exp(d+shift); alpha = 1 - (1+e)^(-interval)   render_utils_kernel.cu:439-441
-                const float e = expf(sigma + P.shift);
-                if (unit_interval) alpha = 1.f - 1.f / (1.f + e);         // wave-uniform branch: powf is ~100 VALU
-                else alpha = 1.f - powf(1.f + e, -P.interval);
-                act = use_thres ? (alpha > P.thres) : true;
-            }
-            // ---- alpha2weight: exact sequential scan over the active lanes (render_utils_kernel.cu:591-603) ----
-            uint64_t bm = __ballot(act);
-            if (P.counters) n_alpha += __popcll(bm);
-            float w = 0.f;
-            bool proc = false, stop = false;
-            if (P.debug & 32) { w = alpha * 0.01f; proc = act; bm = 0; }
-            while (bm) {
-                const int l = __builtin_ctzll(bm);
-                const float a = k4_readlane(alpha, l);
-                if (lane == l) { w = T * a; proc = true; }
-                // `T_cum *= (1. - alpha[i])` is evaluated in double by the CUDA source and rounded to float:
-                // round(T*(1-a)) with an exact (1-a).  fmaf(-T,a,T) = round(T - T*a) is the same single rounding of the
-                // same real number (the double route differs only by double rounding, p ~ 2^-29 per step), at a third of the cost.
-                T = fmaf(-T, a, T);
-                bm &= bm - 1;
-                if (T < 1e-3f) { stop = true; break; }                    // == (double)T < 1e-3 for every float T; sample l is still counted (:597-600)
-            }
-            const bool shade = proc && (use_thres ? (w > P.thres) : true);
-            const uint64_t sm = __ballot(shade);
-            if (shade) ent[cnt + k4_prefix(sm)] = make_uint2(((unsigned)r << 24) | (unsigned)k, __float_as_uint(w));
-            cnt += __popcll(sm);
-            if (stop) break;
-        }
-        if (lane == r) my_ainv = T;                                       // alphainv_last (:603)
-    }
-    if (lane == 0) P.counts[B.id] = cnt;
-    const int myray = ray_index(P, B, lane);
-    if (myray >= 0) P.out_ainv[myray] = my_ainv;
-    if (P.counters && lane == 0) {
-        atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
-        atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], (unsigned long long)cnt);
-    }
-}
-
-
 // -----------------------------------------------------------------------------------------------------
-// K1, compacting form (default).  Profiling of the per-ray form above (profiles/r01_marcher_split_v1_pmc.md):
+// K1.  Profiling of the first, per-ray form of this kernel (one wave walks a ray, every stage on the same 64 lanes;
+// profiles/r01_marcher_split_v1_pmc.md):
 // VALU-issue bound, and two thirds of the issue slots were spent with most lanes idle -- the density stage ran on
 // the ~35 % of lanes that pass the occupancy mask, the transmittance scan on one lane at a time.  Here
 //   A. the occupancy stage still walks a ray with lanes = 64 consecutive samples, but mask-passing samples are
@@ -294,29 +176,11 @@ __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P)
           tk3 = step_t<MODE>(P, 192 + lane);
     asm volatile("" : "+v"(tk0), "+v"(tk1), "+v"(tk2), "+v"(tk3));   // keep the hoisted divisions in registers (no rematerialisation)
 
-    // persistent waves pull bundles from a global queue: tiles differ ~10x in occupied samples and a static
-    // wave->tile map left 40 % of the wave slots empty behind the slow ones (SQ_WAVE_CYCLES, profiles/)
-    // (one queue per XCD over a contiguous band of tiles keeps the band's grid columns in that XCD's L2 -- a single
-    //  global queue cost +25 % kernel time; a drained XCD steals from the others)
-    const int my_xcd = (int)(blockIdx.x & 7);
-    int steal = 0;
-    bool first = true;
-    for (;;) {
-    int bid = -1;
-    if (!P.geom_persist) {                       // static map: measured 6-15 % faster than either queue form
-        if (first) bid = SPLIT ? k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) : k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * WPB + wv;
-        first = false;
-    } else
-    while (steal < 8) {
-        const int q = (my_xcd + steal) & 7;
-        const int lo = (int)(((long long)P.n_bundles * q) >> 3), hi = (int)(((long long)P.n_bundles * (q + 1)) >> 3);
-        int got = 0;
-        if (lane == 0) got = atomicAdd(&P.ghead[q], 1);
-        got = __builtin_amdgcn_readfirstlane(got);
-        if (lo + got < hi) { bid = lo + got; break; }
-        steal += 1;
-    }
-    if (bid < 0) break;
+    // static, XCD-banded bundle map (one bundle per workgroup when SPLIT, per wave otherwise): per-XCD or global work
+    // queues measured 6-25 % slower -- the hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2
+    for (bool once = true; once; once = false) {
+    const int bid = SPLIT ? k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) : k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * WPB + wv;
+    if (bid >= P.n_bundles) break;
     const Bundle B = bundle_from_id(P, bid);
     uint2* const ent_base = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int quarter = P.ent_stride >> 2;
@@ -544,7 +408,7 @@ __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P)
                     float wgt = -1.f;                                  // behind the early stop: never shaded
                     if (!stopped) {
                         wgt = T * a[u];
-                        T = fmaf(-T, a[u], T);                         // == (float)((double)T*(1.-a)), see k4_geom_kernel
+                        T = fmaf(-T, a[u], T);                         // == (float)((double)T*(1.-a)): the CUDA source's fp64 product, one rounding
                         if (T < 1e-3f) stopped = true;                 // the crossing sample is still counted (:597-600)
                     }
                     run[seg + j0 + u].y = __float_as_uint(wgt);
@@ -579,7 +443,7 @@ __global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P)
     if (myray >= 0) P.out_ainv[myray] = my_ainv;
     n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }   // bundle queue
+    }   // bundle
     if (COUNT && P.counters && lane == 0) {
         atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
         atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade);
@@ -1053,218 +917,10 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
         P.out_depth[ray] = acc[lane * 4 + 3];
     }
     __builtin_amdgcn_wave_barrier();
-    }   // bundle queue
+    }   // bundle
 }
 
 
-// -----------------------------------------------------------------------------------------------------
-// K2, software-pipelined form (k0 channel-last with CP == 12, i.e. 9..12 feature channels -- both BASELINE models).
-// Measured on the plain form: gather phase (dependent loads, ~14 us per 64-sample batch per wave) and MFMA phase
-// (164 x 64 cycles) simply ADD, the waves of a SIMD do not hide each other.  Here each wave hides its own latency:
-// the 24 x 16-B corner gathers of batch i+1 are issued BEFORE the MFMAs of batch i and consumed after them, the
-// 8-byte records are fetched two batches ahead, and the per-ray setup (start, dir, viewdir) of the bundle's 64 rays
-// sits in LDS so the only global dependency chain left is record -> gather.
-// -----------------------------------------------------------------------------------------------------
-struct ShadePrep {
-    float w; int rl; int k; bool lact;
-    float nx, ny, nz;
-    float cw[8];
-};
-
-__device__ __forceinline__ unsigned k4_lds_addr(const void* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
-// async global -> LDS copy of 16 B per lane (LDS-DMA, no VGPR round trip): lands at lds_dst + lane*16.  hipcc does not
-// count it in its vmcnt bookkeeping: the consumer waits explicitly (shade_wait_stage).
-__device__ __forceinline__ void k4_glds16(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void shade_wait_stage() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Decode one record, look the ray up in the bundle table, and put the 8 x 48-B corner reads of the sample in flight
-// towards the wave's LDS staging area stage[c*3+q][lane] (float4).
-template <int MODE>
-__device__ __forceinline__ void shade_issue(const MarchParams& P, const float* raytab, uint2 en, bool lact,
-                                            ShadePrep& S, unsigned stage_lds) {
-    S.lact = lact;
-    S.w = lact ? __uint_as_float(en.y) : 0.f;
-    S.rl = (int)(en.x >> 24);
-    S.k = (int)(en.x & 0xffffffu);
-    const float* rt = raytab + S.rl * 12;
-    const float tk = step_t<MODE>(P, S.k);
-    const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
-    S.nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
-    S.ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
-    S.nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
-    const K4Tri t = k4_tri_setup(k4_unnorm(S.nx, P.X), k4_unnorm(S.ny, P.Y), k4_unnorm(S.nz, P.Z));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous batch's reads of the staging area are done
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
-        const bool ok = (unsigned)x < (unsigned)P.X && (unsigned)y < (unsigned)P.Y && (unsigned)z < (unsigned)P.Z;
-        const unsigned idx = ok ? (unsigned)(x * P.Y + y) * (unsigned)P.Z + (unsigned)z : 0u;
-        S.cw[c] = ok ? t.w[c] : 0.f;
-        const float* src = P.k0 + (size_t)idx * 12;
-        k4_glds16(src, stage_lds + (unsigned)((c * 3 + 0) * 1024));
-        k4_glds16(src + 4, stage_lds + (unsigned)((c * 3 + 1) * 1024));
-        k4_glds16(src + 8, stage_lds + (unsigned)((c * 3 + 2) * 1024));
-    }
-}
-
-template <int MODE, int WIDTH, int NHID>
-__global__ __launch_bounds__(256, 2) void k4_shade_pipe_kernel(const MarchParams P) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int W = WIDTH;
-    const int lane = k4_lane();
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int mlp_pad = (P.mlp_floats + 3) & ~3;
-    float* const wl = smem;
-    const int per_wave = 64 * 4 + P.k1p * 64 + 64 * 12 + 24 * 64 * 4;
-    float* const acc = smem + mlp_pad + wv * per_wave;        // [64][4]  r,g,b,depth
-    float* const feat = acc + 64 * 4;                          // [K1P][64]
-    float* const raytab = feat + P.k1p * 64;                   // [64][12] start xyz, dir xyz, viewdir xyz
-    const float4* const stage = reinterpret_cast<const float4*>(raytab + 64 * 12);   // [24][64] float4: gathered corners
-    const unsigned stage_lds = __builtin_amdgcn_readfirstlane(k4_lds_addr(stage));
-    for (int i = threadIdx.x; i < P.mlp_floats; i += 256) wl[i] = P.mlp[i];
-    __syncthreads();
-    const int half = lane >> 5;
-
-    for (;;) {
-        int bid = 0;
-        if (lane == 0) bid = atomicAdd(P.qhead, 1);
-        bid = __builtin_amdgcn_readfirstlane(bid);
-        if (bid >= P.n_bundles) break;
-        const Bundle B = bundle_from_id(P, bid);
-        const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-        const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
-        const int myray = ray_index(P, B, lane);
-        acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
-        if (total > 0) {
-            // per-ray table of the bundle (lane = ray)
-            const int rs = myray < 0 ? 0 : myray;
-            float sx, sy, sz, dx, dy, dz;
-            int nsteps_unused;
-            ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
-                            P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps_unused);
-            float* rt = raytab + lane * 12;
-            rt[0] = sx; rt[1] = sy; rt[2] = sz; rt[3] = dx; rt[4] = dy; rt[5] = dz;
-            rt[6] = P.viewdirs[rs * 3 + 0]; rt[7] = P.viewdirs[rs * 3 + 1]; rt[8] = P.viewdirs[rs * 3 + 2];
-            __builtin_amdgcn_wave_barrier();
-
-            const int nb = (total + 63) >> 6;
-            ShadePrep cur;
-            uint2 e_next = ent[lane < total ? lane : 0];
-            shade_issue<MODE>(P, raytab, e_next, lane < total, cur, stage_lds);
-            e_next = ent[(64 + lane) < total ? (64 + lane) : 0];
-
-            for (int i = 0; i < nb; ++i) {
-                // ---- 1. features of batch i from the corners staged in LDS (the only wait on the gathers) ----
-                shade_wait_stage();
-                float v[12];
-#pragma unroll
-                for (int q = 0; q < 12; ++q) v[q] = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float wc = cur.cw[c];
-                    const float4 g0 = stage[(c * 3 + 0) * 64 + lane], g1 = stage[(c * 3 + 1) * 64 + lane], g2 = stage[(c * 3 + 2) * 64 + lane];
-                    v[0] += g0.x * wc; v[1] += g0.y * wc; v[2] += g0.z * wc; v[3] += g0.w * wc;
-                    v[4] += g1.x * wc; v[5] += g1.y * wc; v[6] += g1.z * wc; v[7] += g1.w * wc;
-                    v[8] += g2.x * wc; v[9] += g2.y * wc; v[10] += g2.z * wc; v[11] += g2.w * wc;
-                }
-                float dif0 = 0.f, dif1 = 0.f, dif2 = 0.f;
-                if (P.k0_skip) { dif0 = v[0]; dif1 = v[1]; dif2 = v[2]; }
-#pragma unroll
-                for (int q = 0; q < 12; ++q)
-                    if (q >= P.k0_skip && q < P.C) feat[(q - P.k0_skip) * 64 + lane] = v[q];
-                int fi = P.C - P.k0_skip;
-                if (MODE == MODE_MPI) {
-                    const float pe[3] = {cur.nz, cur.ny, cur.nx};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) feat[(fi + c) * 64 + lane] = pe[c];
-                    fi += 3;
-                    for (int f = 0; f < P.spe; ++f) {
-                        const float fr = (float)(1 << f);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            feat[(fi + c * P.spe + f) * 64 + lane] = sinf(pe[c] * fr);
-                            feat[(fi + 3 * P.spe + c * P.spe + f) * 64 + lane] = cosf(pe[c] * fr);
-                        }
-                    }
-                    fi += 6 * P.spe;
-                }
-                {
-                    const float* rt2 = raytab + cur.rl * 12;
-                    const float vd[3] = {rt2[6], rt2[7], rt2[8]};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) feat[(fi + c) * 64 + lane] = vd[c];
-                    fi += 3;
-                    for (int f = 0; f < P.vpe; ++f) {
-                        const float fr = (float)(1 << f);
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            feat[(fi + c * P.vpe + f) * 64 + lane] = sinf(vd[c] * fr);
-                            feat[(fi + 3 * P.vpe + c * P.vpe + f) * 64 + lane] = cosf(vd[c] * fr);
-                        }
-                    }
-                    fi += 6 * P.vpe;
-                }
-                feat[fi * 64 + lane] = 1.f;
-                for (int kx = fi + 1; kx < P.k1p; ++kx) feat[kx * 64 + lane] = 0.f;
-                const float w_i = cur.w;
-                const int k_i = cur.k, rl_i = cur.rl;
-                const bool lact_i = cur.lact;
-                __builtin_amdgcn_wave_barrier();
-
-                // ---- 2. put batch i+1 in flight: gathers now, its record was fetched one iteration ago ----
-                // (unconditional: a branch here makes hipcc drain vmcnt at the join, i.e. before the MFMAs; past the last
-                //  batch the lanes are inactive and re-read record 0 of the bundle -- harmless, cache resident)
-                {
-                    const int b1 = (i + 1) * 64;
-                    shade_issue<MODE>(P, raytab, e_next, (b1 + lane) < total, cur, stage_lds);
-                    const int b2 = b1 + 64 + lane;
-                    e_next = ent[b2 < total ? b2 : 0];
-                }
-
-                // ---- 3. MLP of batch i on the matrix cores (the gathers of batch i+1 fly meanwhile) ----
-                float l0, l1, l2;
-                mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
-                const float o0 = l0 + dif0, o1 = l1 + dif1, o2 = l2 + dif2;
-
-                // ---- 4. sigmoid, blend, segmented scan per ray ----
-                float v0 = w_i * (1.f / (1.f + expf(-o0)));
-                float v1 = w_i * (1.f / (1.f + expf(-o1)));
-                float v2 = w_i * (1.f / (1.f + expf(-o2)));
-                float v3 = w_i * (((float)k_i + 0.5f) / (float)P.depth_n);
-                const int keyr = k4_run_id(lact_i ? rl_i : (256 + lane), lane);
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int ok_ = __shfl_up(keyr, off);
-                    const float u0 = __shfl_up(v0, off), u1 = __shfl_up(v1, off), u2 = __shfl_up(v2, off), u3 = __shfl_up(v3, off);
-                    if (lane >= off && ok_ == keyr) { v0 += u0; v1 += u1; v2 += u2; v3 += u3; }
-                }
-                const int nextk = __shfl_down(keyr, 1);
-                if (lact_i && (lane == 63 || nextk != keyr)) {
-                    k4_lds_add(&acc[rl_i * 4 + 0], v0); k4_lds_add(&acc[rl_i * 4 + 1], v1); k4_lds_add(&acc[rl_i * 4 + 2], v2); k4_lds_add(&acc[rl_i * 4 + 3], v3);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (myray >= 0) {
-            const float ab = P.out_ainv[myray] * P.bg;
-            P.out_rgb[(size_t)myray * 3 + 0] = acc[lane * 4 + 0] + ab;
-            P.out_rgb[(size_t)myray * 3 + 1] = acc[lane * 4 + 1] + ab;
-            P.out_rgb[(size_t)myray * 3 + 2] = acc[lane * 4 + 2] + ab;
-            P.out_depth[myray] = acc[lane * 4 + 3];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
 static int n_workgroups(int64_t n_rays, int img_w) {
     if (img_w > 0) return (int)(((img_w + 15) / 16) * (((n_rays / img_w) + 15) / 16));
     return (int)((n_rays + 255) / 256);
@@ -1299,20 +955,14 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    if (getenv("K4_GEOM_V1")) hipLaunchKernelGGL((k4_geom_kernel<MODE>), grid, block, 0, st, P);
-    else {
-        hipError_t e0 = hipMemsetAsync(P.ghead, 0, 8 * sizeof(int), st);
-        if (e0 != hipSuccess) return (int)e0;
-        const int per_cu = 7;                                      // 7 waves/SIMD (SGPR bound)
-        static const int wpb = getenv("K4_GEOM_WPB") ? atoi(getenv("K4_GEOM_WPB")) : 4;
+    {
+        // one workgroup (4 waves = 4 depth quarters) per bundle; K4_GEOM_SPLIT=0 keeps the unsplit form (one wave = one bundle,
+        // all depths) and K4_GEOM_LDSPAD pads LDS to cap occupancy -- the baselines of profiles/r01_final_pmc.md
         static const int split = getenv("K4_GEOM_SPLIT") ? atoi(getenv("K4_GEOM_SPLIT")) : 1;
-        static const int ldspad = getenv("K4_GEOM_LDSPAD") ? atoi(getenv("K4_GEOM_LDSPAD")) : 0;      // occupancy experiments
-        if (P.geom_persist) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false, true>), dim3((unsigned)min(nwg, n_cu * per_cu)), block, 0, st, P);
-        else if (split && P.counters) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        static const int ldspad = getenv("K4_GEOM_LDSPAD") ? atoi(getenv("K4_GEOM_LDSPAD")) : 0;
+        if (split && P.counters) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
         else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, false>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else if (wpb == 1) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false, true>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
-        else if (wpb == 2) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 2, false, true>), dim3((unsigned)nwg * 2), dim3(128), 0, st, P);
-        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, false, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false, true>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
     }
     int rc = k4_check_launch();
     if (rc) return rc;
@@ -1323,22 +973,15 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const bool mlp_fp32 = mlp_env && !strcmp(mlp_env, "fp32");
     const bool b3 = width != 0 && width <= 64 && !mlp_fp32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
-    const size_t lds_pipe = lds_base + sizeof(float) * 4 * (64 * 12 + 24 * 64 * 4);       // + ray table + 24 KB staging per wave
-    // pipelined kernel (opt-in, K4_PIPE=1): 10 % faster in isolation, but its 150 KB of LDS per workgroup keeps the geometry
-    // kernel of the next frame off the CU, and overlapped frames are what the render loop runs (bench.py --streams)
-    const bool pipe = !b3 && width != 0 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && lds_pipe <= 160 * 1024 &&
-                      getenv("K4_PIPE");
-    const int wg_per_cu = pipe ? 1 : K4_SHADE_WG_PER_CU;             // the pipelined kernel runs ONE self-overlapping wave per SIMD
-    const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
-    const size_t lds = pipe ? lds_pipe : lds_base;
+    const dim3 sgrid((unsigned)min(nwg, n_cu * K4_SHADE_WG_PER_CU));
+    const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
         if (lds > 64 * 1024) { \
             hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
         hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)
-#define K4_LAUNCH(WD, NH) do { if (pipe && WD > 0) K4_LAUNCH_K((k4_shade_pipe_kernel<MODE, (WD > 0 ? WD : 32), NH>)); \
-                               else if (b3 && WD > 0 && WD <= 64) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD > 0 && WD <= 64 ? WD : 32), NH, true>)); \
+#define K4_LAUNCH(WD, NH) do { if (b3 && WD > 0 && WD <= 64) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD > 0 && WD <= 64 ? WD : 32), NH, true>)); \
                                else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, false>)); } while (0)
     if (width == 0) K4_LAUNCH(0, 0);
     else if (width == 32 && nh == 0) K4_LAUNCH(32, 0);
@@ -1399,9 +1042,8 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
-    P.ghead = P.qhead + 1;
     P.n_bundles = (int)nb;
-    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0; P.geom_persist = getenv("K4_GEOM_PERSIST") ? 1 : 0;
+    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0;
       P.serp = getenv("K4_SERP") ? atoi(getenv("K4_SERP")) : 1; }
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;

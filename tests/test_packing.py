@@ -1,0 +1,119 @@
+"""CPU tests of the host-side weight packers against the layouts documented in include/k4nerf.h / csrc/*.hip: every packed
+buffer must reproduce the original fp32 weights EXACTLY when read back through the documented index maps (the 3-term bf16
+split is exact: w == t0 + t1 + t2).  Needs lib4k_hip.so only for its size functions (no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd import _native as N
+from nerf4k_amd.lib import dvgo
+from nerf4k_amd.lib.sr_esrnet import _Packed
+
+
+def _row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def _bf16_terms(raw_f32_view, shape):
+    """fp32-typed raw bytes -> bf16 tensor of `shape` -> float"""
+    return raw_f32_view.contiguous().view(torch.int16).view(torch.bfloat16).reshape(shape).float()
+
+
+def test_three_term_split_is_exact_and_ordered():
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4096, generator=g) * 10.0 ** torch.randint(-6, 6, [4096], generator=g).float(),
+                   torch.tensor([0.0, 1.0, -1.0, 1.0e-30, 65504.0, 1e30])])      # (exact down to ~2^-110: bf16 shares fp32's exponent range)
+    t0, t1, t2 = dvgo._split3_bf16(x)
+    assert torch.equal(t0.float() + t1.float() + t2.float(), x)                       # exact (fp32 adds of nested terms)
+    assert bool((t1.float().abs() <= t0.float().abs() * 2 ** -7 + 1e-45).all())
+    assert bool((t2.float().abs() <= t0.float().abs() * 2 ** -15 + 1e-45).all())
+
+
+@pytest.mark.parametrize('dim0,W,depth', [(15, 64, 3), (27, 32, 3), (39, 128, 2), (6, 32, 2)])
+def test_pack_mlp_sections_reproduce_the_weights(dim0, W, depth):
+    torch.manual_seed(dim0 + W)
+    lins = [torch.nn.Linear(dim0, W)] + [torch.nn.Linear(W, W) for _ in range(depth - 2)] + [torch.nn.Linear(W, 3)]
+    buf = dvgo.pack_mlp_mfma(lins)
+    nh = depth - 2
+    assert buf.numel() == N.lib().k4_mlp_packed_floats(dim0, W, nh)
+    NB, k1p = W // 32, (dim0 + 2) & ~1
+    w1ext = torch.zeros([W, k1p])
+    w1ext[:, :dim0] = lins[0].weight.detach()
+    w1ext[:, dim0] = lins[0].bias.detach()
+    # ---- fp32 section (v_mfma_f32_32x32x2_f32 order)
+    off = 0
+    w1a = buf[off:off + NB * (k1p // 2) * 64].reshape(NB, k1p // 2, 64); off += w1a.numel()
+    for mb in range(NB):
+        for kk in range(k1p // 2):
+            for l in (0, 17, 31, 32, 63):
+                assert w1a[mb, kk, l] == w1ext[mb * 32 + (l & 31), 2 * kk + (l >> 5)]
+    if nh:
+        w2 = lins[1].weight.detach()
+        w2a = buf[off:off + NB * NB * 16 * 64].reshape(NB, NB, 16, 64); off += w2a.numel()
+        for mb2 in range(NB):
+            for mb in range(NB):
+                for r in (0, 5, 15):
+                    for l in (0, 31, 32, 63):
+                        assert w2a[mb2, mb, r, l] == w2[mb2 * 32 + (l & 31), mb * 32 + _row(r, l >> 5)]
+        off += NB * 64
+    off += NB * 16 * 2 * 4 + 4
+    # ---- split-bf16 section (v_mfma_f32_32x32x16_bf16 order): terms must sum back to the weights exactly
+    KB1, KB2 = (k1p + 15) // 16, W // 16
+    n1 = NB * KB1 * 3 * 64 * 4
+    w1s = _bf16_terms(buf[off:off + n1], [NB, KB1, 3, 64, 8]).sum(2); off += n1
+    for mb in range(NB):
+        for kb in range(KB1):
+            for l in (0, 9, 31, 32, 50, 63):
+                for e in range(8):
+                    k = kb * 16 + 8 * (l >> 5) + e
+                    want = w1ext[mb * 32 + (l & 31), k] if k < k1p else 0.0
+                    assert w1s[mb, kb, l, e] == want
+    if nh:
+        n2 = NB * KB2 * 3 * 64 * 4
+        w2s = _bf16_terms(buf[off:off + n2], [NB, KB2, 3, 64, 8]).sum(2); off += n2
+        for mb2 in range(NB):
+            for kb in range(KB2):
+                for l in (0, 31, 32, 63):
+                    for e in range(8):
+                        h = l >> 5
+                        n = (kb >> 1) * 32 + (e & 3) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * h
+                        assert w2s[mb2, kb, l, e] == w2[mb2 * 32 + (l & 31), n]
+        b2s = buf[off:off + NB * 2 * 16].reshape(NB, 2, 16); off += b2s.numel()
+        b2 = lins[1].bias.detach()
+        for mb2 in range(NB):
+            for h in range(2):
+                for r in range(16):
+                    assert b2s[mb2, h, r] == b2[mb2 * 32 + _row(r, h)]
+    wot = buf[off:off + NB * 16 * 2 * 4].reshape(NB, 16, 2, 4); off += wot.numel()
+    wo = lins[-1].weight.detach()
+    for mb in range(NB):
+        for r in (0, 7, 15):
+            for h in range(2):
+                assert torch.equal(wot[mb, r, h, :3], wo[:, mb * 32 + _row(r, h)]) and wot[mb, r, h, 3] == 0
+    assert torch.equal(buf[off:off + 3], lins[-1].bias.detach()) and off + 4 == buf.numel()
+
+
+@pytest.mark.parametrize('cout,cin,k', [(32, 160, 3), (64, 192, 3), (64, 3, 3), (3, 64, 3), (128, 64, 1), (64, 1, 3)])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16x6'])
+def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w = torch.randn([cout, cin, k, k], generator=g)
+    b = torch.randn([cout], generator=g)
+    pk = _Packed(w, b, mode)
+    nt = (cout + 31) // 32
+    assert torch.equal(pk.b[:cout], b) and float(pk.b[cout:].abs().sum()) == 0
+    if mode == 'fp32':
+        nch = (cin + 7) // 8
+        got = pk.w.reshape(nch, k * k, 8, nt * 32).permute(1, 0, 2, 3).reshape(k * k, nch * 8, nt * 32)
+    else:
+        nterm = 3 if mode == 'bf16x6' else 2
+        nch = (cin + 15) // 16
+        terms = pk.w.view(torch.bfloat16).reshape(nch, nterm, k * k, 2, nt * 32, 8).float()
+        got = terms.sum(1).permute(1, 0, 2, 4, 3).reshape(k * k, nch * 16, nt * 32)         # [tap][channel][cout]
+    want = torch.zeros_like(got)
+    want[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+    if mode == 'bf16x3':                                  # 2-term split: 16 significant bits
+        assert float((got - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
+    else:
+        assert torch.equal(got, want)

@@ -83,7 +83,7 @@ def test_training_step_gradients_match_the_reference(name):
         out = model(rays['rays_o'].cuda(), rays['rays_d'].cuda(), rays['viewdirs'].cuda(), global_step=0, **rk)
         loss = F.mse_loss(out['rgb_marched'], target.cuda())
         loss.backward()
-    assert abs(float(loss) - loss_ref) <= 2e-6 * max(1.0, abs(loss_ref)), (float(loss), loss_ref)
+    assert abs(float(loss.detach()) - loss_ref) <= 2e-6 * max(1.0, abs(loss_ref)), (float(loss.detach()), loss_ref)
     named = dict(model.named_parameters())
     assert set(grads) <= set(named), set(grads) - set(named)
     for k, want in grads.items():
