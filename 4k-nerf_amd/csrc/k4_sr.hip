@@ -609,6 +609,7 @@ struct SftParams {
     float* y; int y_stride;
     const float* res; int res_stride; float res_scale;
     int n_pix; float slope;
+    int vec4;                                  // all of x / y / res rows are 16-byte aligned (strides % 4 == 0, bases % 16 == 0)
 };
 
 template <int CB>
@@ -681,12 +682,38 @@ __global__ __launch_bounds__(256) void k4_sft_kernel(const SftParams P) {
         for (int t = 0; t < 2; ++t) {
             const int pix = base + t * 32 + l31;
             if (pix >= P.n_pix) continue;
+            // accumulator registers 4q..4q+3 are 4 CONSECUTIVE channels (co = 8q + 4*half + 0..3): 16-byte accesses
+            const bool vec = P.vec4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = mb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = P.x[(size_t)pix * P.x_stride + co] * (cs[t][r] + 1.f) + ch[t][r];      // x*(scale+1)+shift
-                if (P.res) v = v * P.res_scale + P.res[(size_t)pix * P.res_stride + co];
-                P.y[(size_t)pix * P.y_stride + co] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int co = mb2 * 32 + 8 * q + 4 * half;
+                float xv[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(P.x + (size_t)pix * P.x_stride + co);
+                    xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    if (P.res) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(P.res + (size_t)pix * P.res_stride + co);
+                        rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xv[e] = P.x[(size_t)pix * P.x_stride + co + e];
+                        if (P.res) rv[e] = P.res[(size_t)pix * P.res_stride + co + e];
+                    }
+                }
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = xv[e] * (cs[t][4 * q + e] + 1.f) + ch[t][4 * q + e];               // x*(scale+1)+shift
+                    if (P.res) v = v * P.res_scale + rv[e];
+                    ov[e] = v;
+                }
+                if (vec) *reinterpret_cast<float4*>(P.y + (size_t)pix * P.y_stride + co) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) P.y[(size_t)pix * P.y_stride + co + e] = ov[e];
+                }
             }
         }
     }
@@ -707,6 +734,8 @@ extern "C" int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* 
     SftParams P{};
     P.cond = cond; P.cond_stride = cond_stride; P.w = w_packed; P.x = x; P.x_stride = x_stride; P.y = y; P.y_stride = y_stride;
     P.res = res; P.res_stride = res_stride; P.res_scale = res_scale; P.n_pix = (int)n_pix; P.slope = slope;
+    P.vec4 = ((x_stride | y_stride | (res ? res_stride : 0)) & 3) == 0 &&
+             ((((size_t)x) | ((size_t)y) | ((size_t)(res ? res : x))) & 15) == 0;
     const dim3 grid((unsigned)((n_pix + 255) / 256)), block(256);
     if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, P);
