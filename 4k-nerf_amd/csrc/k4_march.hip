@@ -973,7 +973,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const bool mlp_fp32 = mlp_env && !strcmp(mlp_env, "fp32");
     const bool b3 = width != 0 && width <= 64 && !mlp_fp32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
-    const dim3 sgrid((unsigned)min(nwg, n_cu * K4_SHADE_WG_PER_CU));
+    static const int shade_wg = getenv("K4_SHADE_GRID_WG") ? atoi(getenv("K4_SHADE_GRID_WG")) : K4_SHADE_WG_PER_CU;   // experiment knob
+    const dim3 sgrid((unsigned)min(nwg, n_cu * shade_wg));
     const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
