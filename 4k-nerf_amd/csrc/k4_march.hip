@@ -141,6 +141,9 @@ __device__ __forceinline__ void ray_setup(const MarchParams& P, float ox, float 
 // The early stop therefore no longer saves density fetches behind it (they were ~13 % of the mask-passing samples);
 // results are unchanged: a sample behind the stop never gets a weight.
 // -----------------------------------------------------------------------------------------------------
+#ifndef K4_GEOM_MIN_WG
+#define K4_GEOM_MIN_WG 1
+#endif
 #ifndef K4_SHADE_WG_PER_CU
 #define K4_SHADE_WG_PER_CU 2      // 256 VGPRs per wave: at 3 (168 VGPRs) the batch loop spilled ~90 dwords and its scratch reloads cost 0.4 ms/frame
 #endif
@@ -160,7 +163,7 @@ struct Geom2Lds {
 // COUNT: the sample counters of bench.py / the tests (k4_march_*_fwd `counters`) are a separate instantiation, so that
 // the render path carries no counting code and a profile lists the two under different names.
 template <int MODE, int WPB, bool SPLIT, bool COUNT>
-__global__ __launch_bounds__(64 * WPB) void k4_geom2_kernel(const MarchParams P) {
+__global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(const MarchParams P) {
     static_assert(!SPLIT || WPB == 4, "depth split uses 4 waves per bundle");
     __shared__ Geom2Lds lds_all[WPB];
     __shared__ int na_sh[WPB];

@@ -239,7 +239,7 @@ def main():
             res['reference_pipeline_baseline']['speedup_of_value'] = round(
                 value / res['reference_pipeline_baseline']['value'], 1)
         if world == 1 and not args.small and not args.no_extras:
-            res['training_step_kernels'] = training_step_kernels(dev)
+            res['training_step_kernels'] = training_step_kernels(dev, rays[0], model)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
         print(json.dumps(res), flush=True)
@@ -305,7 +305,7 @@ def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world, mode='bf16x6'
     return base
 
 
-def training_step_kernels(dev, reps=5):
+def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
     """MaskedAdam + total_variation_add_grad on the LLFF k0 grid (12 x 417 x 353 x 256 fp32 =
     1.81 GB per tensor, far beyond the 256 MB infinity cache), HIP-event timed.  Algorithmic bytes per voxel:
     dense Adam 28 (param/exp_avg/exp_avg_sq read+write, grad read), TV 12 (param read once, grad read+write),
@@ -357,6 +357,16 @@ def training_step_kernels(dev, reps=5):
     out['grid_sample_3d_backward_2M_random_points'] = {'ms': round(ms, 3), 'Mpoints_per_s': round(npts / ms / 1e3, 1),
                                                        'algorithmic_bytes_per_point': bpp,
                                                        'achieved_GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
+    if frame_rays is not None and model is not None:
+        # the coherent case: 8192 rays of the frame x 256 NDC samples each (what a training batch scatters)
+        ro, rd = frame_rays[0][:8192], frame_rays[1][:8192]
+        t = torch.linspace(0, 1, 256, device=dev)
+        pts = (ro[:, None, :] + rd[:, None, :] * t[None, :, None]).reshape(-1, 3).contiguous()
+        mn, mx = model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous()
+        ms = timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
+                                                                        npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
+        out['grid_sample_3d_backward_8192_rays_x_256'] = {'ms': round(ms, 3), 'Mpoints_per_s': round(npts / ms / 1e3, 1),
+                                                          'achieved_GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
     return out
 
 
