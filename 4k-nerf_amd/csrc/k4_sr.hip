@@ -551,6 +551,144 @@ static int launch_conv_b6(ConvParams P, hipStream_t st) {
     return k4_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution with <= 3 output channels (SFTNet.conv_last, 64 -> 3 at 4x resolution).  As an implicit GEMM with
+// N = C_out it would waste 29 of every 32 matrix columns.  Here the nine taps become the N dimension instead:
+//   Y[p][t*3 + co] = sum_c X[p][c] * W[co][c][t]          one 1x1 GEMM, N = 27 (padded to 32), over the HALOED tile,
+//   out[p][co]     = bias[co] + sum_t Y[p + offset(t)][t*3 + co]      a 9-point gather-sum from LDS,
+// 9x fewer matrix instructions than the padded 3x3 form.  Same 3-term split arithmetic as k4_conv_b6_kernel.
+// Workgroup = 8 waves, 16 x 32 output pixels; the haloed tile is 18 x 34 = 612 pixels = 20 row blocks of 32 (the last
+// one partly empty), wave w accumulates row blocks w, w+8, w+16.  Weights: the host packs [27->32][C_in] as a 1x1 layer
+// in the bf16x6 layout (flag K4_W_TAPS_AS_COUT).
+// ------------------------------------------------------------------------------------------------------------------
+#define K4_TAPS_ROWS (TILE_HB + 2)
+#define K4_TAPS_COLS (TILE_W + 2)
+#define K4_TAPS_NPIX (K4_TAPS_ROWS * K4_TAPS_COLS)        /* 612 */
+#define K4_TAPS_PPAD 640                                   /* 20 row blocks */
+#define K4_TAPS_YS 29                                      /* Y row stride in floats (27 used; odd -> conflict-free gathers) */
+
+__global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvParams P) {
+    extern __shared__ uint4 k4_taps_smem[];
+    uint4* const in_s = k4_taps_smem;                                    // [term][channel group][pixel] x 8 bf16
+    uint4* const w_s = k4_taps_smem + 3 * 2 * K4_TAPS_PPAD;              // [term][channel group][n] x 8 bf16
+    float* const y_s = reinterpret_cast<float*>(k4_taps_smem);           // [pixel][29], aliases in_s/w_s after the GEMM
+    const int tid = (int)threadIdx.x;
+    const int lane = k4_lane();
+    const int wv = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int x0 = tx * TILE_W, y0 = ty * TILE_HB;
+    const bool vec_ok = (P.cin_stride & 3) == 0 && (((size_t)P.x) & 15) == 0;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = (f32x16)(0.f);
+
+    const int nchunks = (P.cin + KC2 - 1) / KC2;
+    const uint4* const wsrc_all = reinterpret_cast<const uint4*>(P.w);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * KC2;
+        for (int it = tid; it < K4_TAPS_PPAD * 2; it += 512) {
+            const int kg = it & 1, pp = it >> 1;
+            const int py = pp / K4_TAPS_COLS, px = pp - py * K4_TAPS_COLS;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool inside = pp < K4_TAPS_NPIX && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const int cb = c0 + kg * 8;
+            float v[8];
+            const float* src = inside ? P.x + ((size_t)gy * P.W + gx) * P.cin_stride + cb : P.x;
+            if (vec_ok && c0 + KC2 <= P.cin) {
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 b = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = inside ? v[c] : 0.f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool ok_ = inside && cb + c < P.cin;
+                    const float q_ = *(ok_ ? src + c : P.x);
+                    v[c] = ok_ ? q_ : 0.f;
+                }
+            }
+            uint4 t0, t1, t2;
+            k4s_split3(v, t0, t1, t2);
+            in_s[(0 * 2 + kg) * K4_TAPS_PPAD + pp] = t0;
+            in_s[(1 * 2 + kg) * K4_TAPS_PPAD + pp] = t1;
+            in_s[(2 * 2 + kg) * K4_TAPS_PPAD + pp] = t2;
+        }
+        if (tid < 3 * 2 * 32) w_s[tid] = wsrc_all[(size_t)ch * 3 * 2 * 32 + tid];
+        __syncthreads();
+        bf16x8 b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, w_s[(q * 2 + half) * 32 + l31]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rb = wv + 8 * i;
+            if (rb < K4_TAPS_PPAD / 32) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x8, in_s[(q * 2 + half) * K4_TAPS_PPAD + rb * 32 + l31]);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // Y tile to LDS (aliases the staging buffers: every wave is past its last operand read)
+    if (l31 < 9 * P.cout) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int rb = wv + 8 * i;
+            if (rb < K4_TAPS_PPAD / 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pp = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pp < K4_TAPS_NPIX) y_s[pp * K4_TAPS_YS + l31] = acc[i][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 9-point gather-sum, one output pixel per thread
+    const int oy = tid >> 5, ox = tid & 31;
+    const int gy = y0 + oy, gx = x0 + ox;
+    if (gy < P.H && gx < P.W) {
+        const size_t pix = (size_t)gy * P.W + gx;
+        for (int co = 0; co < P.cout; ++co) {
+            float v = P.bias[co];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t - dy * 3;
+                v += y_s[((oy + dy) * K4_TAPS_COLS + ox + dx) * K4_TAPS_YS + t * P.cout + co];
+            }
+            if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
+            if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
+            P.y[pix * P.cout_stride + co] = v;
+        }
+    }
+}
+
+static int launch_conv_taps_b6(ConvParams P, hipStream_t st) {
+    constexpr size_t lds_gemm = ((size_t)3 * 2 * K4_TAPS_PPAD + 3 * 2 * 32) * sizeof(uint4);
+    constexpr size_t lds_y = (size_t)K4_TAPS_NPIX * K4_TAPS_YS * sizeof(float);
+    constexpr size_t lds = lds_gemm > lds_y ? lds_gemm : lds_y;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_taps_b6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    P.tiles_y = (P.H + TILE_HB - 1) / TILE_HB;
+    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(512);
+    hipLaunchKernelGGL(k4_conv_taps_b6_kernel, grid, block, lds, st, P);
+    return k4_check_launch();
+}
+
 extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
     const int64_t nt = (cout + 31) / 32;
@@ -581,6 +719,10 @@ extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_st
     P.modx = mod_x; P.mod_stride = mod_stride;
     P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_HB - 1) / TILE_HB;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & K4_W_TAPS_AS_COUT) {
+        if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
+        return launch_conv_taps_b6(P, st);
+    }
     static const int nw1 = getenv("K4_B6_NW1") ? atoi(getenv("K4_B6_NW1")) : 8;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
     if (ksize == 3) {
         if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(P, st) : launch_conv_b6<3, 1, 8>(P, st);

@@ -26,7 +26,7 @@ from torch.nn import init as init
 
 from .. import _native as N
 
-EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X = 2, 4, 8, 16
+EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT = 2, 4, 8, 16, 32
 
 
 @torch.no_grad()
@@ -115,7 +115,8 @@ class _Packed:
         nt = (cout + 31) // 32
         dev = weight.device
         wf = weight.detach().float()
-        self.mode = mode
+        self.mode = 'bf16x6' if mode == 'bf16x6_plain' else mode
+        self.flags_extra = 0
         if mode == 'fp32':
             kc = 8
             nch = (cin + kc - 1) // kc
@@ -123,7 +124,14 @@ class _Packed:
             w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
             self.w = w.reshape(k * k, nch, kc, nt * 32).permute(1, 0, 2, 3).contiguous()
             assert self.w.numel() == N.lib().k4_conv_weight_floats(cout, cin, k)
-        elif mode == 'bf16x6':
+        elif mode == 'bf16x6' and k == 3 and cout <= 3 and os.environ.get('K4_CONV_TAPS', '1') != '0':
+            # few output channels (conv_last): the 9 taps become the GEMM's N dimension, packed as a 1x1 layer
+            # [n = tap*cout + co][cin] (k4nerf.h, K4_W_TAPS_AS_COUT)
+            w1 = wf.permute(2, 3, 0, 1).reshape(9 * cout, cin, 1, 1)             # [(dy,dx,co)][cin]
+            inner = _Packed(w1, torch.zeros([9 * cout], dtype=torch.float32, device=dev), 'bf16x6_plain')
+            self.w = inner.w
+            self.flags_extra = W_TAPS_AS_COUT
+        elif mode in ('bf16x6', 'bf16x6_plain'):
             nch = (cin + 15) // 16
             w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)
             w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
@@ -297,7 +305,7 @@ class SFTNet(nn.Module):
               'bf16x6': N.lib().k4_conv2d_nhwc_bf16x6}[pk.mode]
         N.check(fn(
             N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.k,
-            N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags, 0.2,
+            N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags | pk.flags_extra, 0.2,
             rp, rs, rscale, mp, ms, N.stream()), 'k4_conv2d_nhwc')
 
     def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None):

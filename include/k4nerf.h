@@ -204,6 +204,8 @@ int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t
 #define K4_EPI_RES         4u    /* y = y*res_scale + res[pix][co]                 (after the activation)      */
 #define K4_EPI_MODULATE    8u    /* SFTLayer tail: the GEMM yields 2*cout channels [scale | shift];
                                     y[co] = mod_x[pix][co]*(scale[co]+1) + shift[co]   (lib/sr_esrnet.py:123)   */
+#define K4_W_TAPS_AS_COUT 32u    /* k4_conv2d_nhwc_bf16x6 only, 3x3 with cout <= 3: w_split holds the 1x1 layer [9*cout -> 32][cin]
+                                    (n = tap*cout + co) in the bf16x6 layout; the kernel sums the 9 taps from LDS        */
 #define K4_PRE_UPSAMPLE2X 16u    /* the input is read through a nearest x2 upsample (lib/sr_esrnet.py:461-463)  */
 
 /* stride-1 "same" (zero padded) 3x3 or 1x1 convolution, NHWC:

@@ -103,6 +103,18 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
     pk = _Packed(w, b, mode)
     nt = (cout + 31) // 32
     assert torch.equal(pk.b[:cout], b) and float(pk.b[cout:].abs().sum()) == 0
+    if mode == 'bf16x6' and k == 3 and cout <= 3:
+        # few output channels: taps become the N dimension of a 1x1 layer, n = tap*cout + co (K4_W_TAPS_AS_COUT)
+        from nerf4k_amd.lib.sr_esrnet import W_TAPS_AS_COUT
+        assert pk.flags_extra == W_TAPS_AS_COUT
+        nch = (cin + 15) // 16
+        terms = pk.w.view(torch.bfloat16).reshape(nch, 3, 1, 2, 32, 8).float()
+        got1 = terms.sum(1).permute(1, 0, 2, 4, 3).reshape(nch * 16, 32)                    # [channel][n]
+        want1 = torch.zeros_like(got1)
+        want1[:cin, :9 * cout] = w.permute(1, 2, 3, 0).reshape(cin, 9 * cout)               # n = (dy*3+dx)*cout + co
+        assert torch.equal(got1, want1)
+        return
+    assert pk.flags_extra == 0
     if mode == 'fp32':
         nch = (cin + 7) // 8
         got = pk.w.reshape(nch, k * k, 8, nt * 32).permute(1, 0, 2, 3).reshape(k * k, nch * 8, nt * 32)
