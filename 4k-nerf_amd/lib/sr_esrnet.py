@@ -279,7 +279,8 @@ class SFTNet(nn.Module):
         ``slot``: independent buffer set (one per concurrently used stream)."""
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         spec = {'feat': (1, nf), 'cond': (1, g), 'c64a': (1, 64), 'c64b': (1, 64), 'trunk': (1, nf), 'rrdb_in': (1, nf),
-                'blk': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3)}
+                'blk': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3),
+                'xin': (1, self.conv_first.in_channels), 'cnd': (1, self.CondNet[0].in_channels)}
         if s > 1:
             spec['up1'] = (2, nf)
             if s == 4:
@@ -297,57 +298,96 @@ class SFTNet(nn.Module):
         return B
 
     @staticmethod
-    def _conv(pk, x, x_off, x_stride, y, y_off, y_stride, cout, H, W, flags=0, res=None, mod=None):
+    def _conv(pk, x, x_off, x_stride, y, y_off, y_stride, cout, H, W, flags=0, res=None, mod=None, plan=None):
         """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))"""
         rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
         mp, ms = (None, 0) if mod is None else (N.C.c_void_p(mod[0].data_ptr() + 4 * mod[1]), mod[2])
         fn = {'fp32': N.lib().k4_conv2d_nhwc, 'bf16x3': N.lib().k4_conv2d_nhwc_bf16x3,
               'bf16x6': N.lib().k4_conv2d_nhwc_bf16x6}[pk.mode]
-        N.check(fn(
-            N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.k,
-            N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags | pk.flags_extra, 0.2,
-            rp, rs, rscale, mp, ms, N.stream()), 'k4_conv2d_nhwc')
+        args = (N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.k,
+                N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags | pk.flags_extra, 0.2,
+                rp, rs, rscale, mp, ms)
+        if plan is not None:
+            plan.append((fn, args, 'k4_conv2d_nhwc'))
+        N.check(fn(*args, N.stream()), 'k4_conv2d_nhwc')
 
-    def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None):
+    def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None, plan=None):
         """SFTLayer (lib/sr_esrnet.py:120-123) in one launch: y = x*(scale(cond)+1) + shift(cond) [*res_scale + res]."""
         wp = pk[prefix]
         rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
-        N.check(N.lib().k4_sft_nhwc(
-            N.f32(B['cond']), self.num_grow_ch, N.f32(wp),
-            N.C.c_void_p(x.data_ptr() + 4 * x_off), x_stride, N.C.c_void_p(y.data_ptr() + 4 * y_off), y_stride,
-            cfeat, h * w, 0.2, rp, rs, rscale, N.stream()), 'k4_sft_nhwc')
+        args = (N.f32(B['cond']), self.num_grow_ch, N.f32(wp),
+                N.C.c_void_p(x.data_ptr() + 4 * x_off), x_stride, N.C.c_void_p(y.data_ptr() + 4 * y_off), y_stride,
+                cfeat, h * w, 0.2, rp, rs, rscale)
+        if plan is not None:
+            plan.append((N.lib().k4_sft_nhwc, args, 'k4_sft_nhwc'))
+        N.check(N.lib().k4_sft_nhwc(*args, N.stream()), 'k4_sft_nhwc')
 
     @torch.no_grad()
     def _forward_hip(self, x, cond, slot=0):
+        """One window through the decoder on the HIP kernels (111 launches).  The launch sequence of a (slot, window size) is
+        recorded once as a list of (entry point, prepared ctypes arguments) and replayed afterwards: all buffers are
+        capacity-cached at fixed addresses, so a replay costs one prepared foreign call per launch instead of rebuilding ~20
+        ctypes objects (the decoder of a small window -- 8-GPU tile sharding -- is otherwise bound by host launch time)."""
         assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
         _, cin, h, w = x.shape
         dev = x.device
-        nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         pk = self._packed()
         B = self._k4_buffers(h, w, dev, slot)
-        xin = x[0].permute(1, 2, 0).contiguous().float()                 # NHWC [h][w][cin]
-        cnd = cond[0].permute(1, 2, 0).contiguous().float()
-        cv = self._conv
-        cv(pk['conv_first'], xin, 0, cin, B['feat'], 0, nf, nf, h, w)
-        cv(pk['CondNet.0'], cnd, 0, cnd.shape[2], B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
+        B['xin'].copy_(x[0].permute(1, 2, 0))                             # NHWC [h][w][cin], fixed address
+        B['cnd'].copy_(cond[0].permute(1, 2, 0))
+        key = (h, w, self._k4.get('key'), self.k4_mode) + tuple(t.data_ptr() for t in B.values())
+        plans = self._k4.setdefault(('plans', slot), {})
+        plan = plans.get(key)
+        if plan is None or os.environ.get('K4_SR_PLAN', '1') == '0':
+            plan = []
+            self._record_hip(pk, B, h, w, plan)
+            if len(plans) > 16:
+                plans.clear()
+            plans[key] = plan
+        else:
+            st = N.stream()
+            for fn, args, what in plan:
+                if fn is None:
+                    args[0].copy_(args[1])
+                else:
+                    N.check(fn(*args, st), what)
+        return B['out'].permute(2, 0, 1).unsqueeze(0)                     # view [1,3,H,W] of the NHWC result
+
+    def _record_hip(self, pk, B, h, w, plan):
+        """Run the launch sequence of SFTNet.forward (lib/sr_esrnet.py:446-465) once, appending every step to `plan`."""
+        nf, g, s = self.num_feat, self.num_grow_ch, self.scale
+        cin, ccond = B['xin'].shape[2], B['cnd'].shape[2]
+
+        def cv(*a, **k):
+            self._conv(*a, plan=plan, **k)
+
+        def sft(*a, **k):
+            self._sft(*a, plan=plan, **k)
+
+        def copy(dst, src):
+            plan.append((None, (dst, src), 'copy'))
+            dst.copy_(src)
+
+        cv(pk['conv_first'], B['xin'], 0, cin, B['feat'], 0, nf, nf, h, w)
+        cv(pk['CondNet.0'], B['cnd'], 0, ccond, B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
         cv(pk['CondNet.2'], B['c64a'], 0, 64, B['c64b'], 0, 64, 64, h, w, EPI_LRELU)
         cv(pk['CondNet.4'], B['c64b'], 0, 64, B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
         cv(pk['CondNet.6'], B['c64a'], 0, 64, B['cond'], 0, g, g, h, w)
-        B['trunk'].copy_(B['feat'])
+        copy(B['trunk'], B['feat'])
         bw = nf + 4 * g
         for b in range(self.num_block):
-            B['rrdb_in'].copy_(B['trunk'])
+            copy(B['rrdb_in'], B['trunk'])
             for r in (1, 2, 3):
                 p = f'body.{b}.rdb{r}'
-                self._sft(pk, p + '.sft0', B, h, w, B['trunk'], 0, nf, B['blk'], 0, bw, nf)          # xc0
+                sft(pk, p + '.sft0', B, h, w, B['trunk'], 0, nf, B['blk'], 0, bw, nf)                # xc0
                 for k in range(1, 5):                                                               # x1..x4
                     cv(pk[f'{p}.conv{k}'], B['blk'], 0, bw, B['blk'], nf + (k - 1) * g, bw, g, h, w, EPI_LRELU)
-                self._sft(pk, p + '.sft1', B, h, w, B['blk'], nf + 3 * g, bw, B['blk'], nf + 3 * g, bw, g)  # xc1 in place
+                sft(pk, p + '.sft1', B, h, w, B['blk'], nf + 3 * g, bw, B['blk'], nf + 3 * g, bw, g)  # xc1 in place
                 cv(pk[f'{p}.conv5'], B['blk'], 0, bw, B['trunk'], 0, nf, nf, h, w, EPI_RES,
                    res=(B['trunk'], 0, nf, 0.2))                                                    # x5*0.2 + x
-            self._sft(pk, f'body.{b}.sft0', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf,
-                      res=(B['rrdb_in'], 0, nf, 0.2))                                               # sft(out)*0.2 + x
-        self._sft(pk, 'sftbody', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf)
+            sft(pk, f'body.{b}.sft0', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf,
+                res=(B['rrdb_in'], 0, nf, 0.2))                                                     # sft(out)*0.2 + x
+        sft(pk, 'sftbody', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf)
         cv(pk['conv_body'], B['trunk'], 0, nf, B['rrdb_in'], 0, nf, nf, h, w, EPI_RES,
            res=(B['feat'], 0, nf, 1.0))                                                             # body_feat += feat
         cur, hh, ww = B['rrdb_in'], h, w
@@ -359,7 +399,6 @@ class SFTNet(nn.Module):
                 cur, hh, ww = B['up2'], 4 * h, 4 * w
         cv(pk['conv_hr'], cur, 0, nf, B['hr'], 0, nf, nf, hh, ww, EPI_LRELU)
         cv(pk['conv_last'], B['hr'], 0, nf, B['out'], 0, 3, 3, hh, ww)
-        return B['out'].permute(2, 0, 1).unsqueeze(0)                     # view [1,3,H,W] of the NHWC result
 
     def forward(self, x, cond, fea=None):
         if not x.is_cuda:
