@@ -22,6 +22,16 @@ from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, s
 
 
 '''Model'''
+def _mlp(dim_in, width, depth, dim_out):
+    """Linear-ReLU stack with the reference's module nesting (state-dict keys '0', '2.0', ..., lib/dmpigo.py:112-120); the last
+    bias starts at 0."""
+    act = nn.ReLU(inplace=True)
+    hidden = [nn.Sequential(nn.Linear(width, width), act) for _ in range(depth - 2)]
+    net = nn.Sequential(nn.Linear(dim_in, width), act, *hidden, nn.Linear(width, dim_out))
+    nn.init.constant_(net[-1].bias, 0)
+    return net
+
+
 class DirectMPIGO(torch.nn.Module, _FusedMarcher):
     def __init__(self, xyz_min, xyz_max,
                  num_voxels=0, mpi_depth=0,
@@ -34,86 +44,63 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
                  viewbase_pe=0,
                  spatial_pe=0,
                  **kwargs):
-        super(DirectMPIGO, self).__init__()
-        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
-        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        super().__init__()
+        for name, val in (('xyz_min', xyz_min), ('xyz_max', xyz_max)):
+            self.register_buffer(name, torch.Tensor(val))
         self.fast_color_thres = fast_color_thres
         self._set_grid_resolution(num_voxels, mpi_depth)
+        self.density_type, self.density_config = density_type, density_config
+        self.k0_type, self.k0_config = k0_type, k0_config
+        self.rgbnet_kwargs = dict(rgbnet_dim=rgbnet_dim, rgbnet_depth=rgbnet_depth, rgbnet_width=rgbnet_width,
+                                  viewbase_pe=viewbase_pe, spatial_pe=spatial_pe)
+        self.density = self._new_grid(density_type, 1, density_config)
+        self._init_act_shift(xyz_min, xyz_max)
 
-        self.density_type = density_type
-        self.density_config = density_config
-        self.density = grid.create_grid(
-            density_type, channels=1, world_size=self.world_size,
-            xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.density_config)
-
-        # per-plane density bias so that the initial alphas along a ray are equal (lib/dmpigo.py:48-58)
-        self.act_shift = grid.DenseGrid(
-            channels=1, world_size=[1, 1, mpi_depth], xyz_min=xyz_min, xyz_max=xyz_max)
-        self.act_shift.grid.requires_grad = False
-        with torch.no_grad():
-            g = np.full([mpi_depth], 1. / mpi_depth - 1e-6)
-            p = [1 - g[0]]
-            for i in range(1, len(g)):
-                p.append((1 - g[:i + 1].sum()) / (1 - g[:i].sum()))
-            for i in range(len(p)):
-                self.act_shift.grid[..., i].fill_(np.log(p[i] ** (-1 / self.voxel_size_ratio) - 1))
-
-        self.rgbnet_kwargs = {
-            'rgbnet_dim': rgbnet_dim,
-            'rgbnet_depth': rgbnet_depth, 'rgbnet_width': rgbnet_width,
-            'viewbase_pe': viewbase_pe, 'spatial_pe': spatial_pe,
-        }
-        self.k0_type = k0_type
-        self.k0_config = k0_config
+        # colour: feature grid + MLP (lib/dmpigo.py:65-131).  The coarse "colour voxel" branch (rgbnet_dim <= 0) is kept for
+        # state-dict compatibility although upstream cannot run it (forward reads self.dim_rend, set only when rgbnet_dim > 0).
         self.dim_rend = 3
-        self.act_type = kwargs.get('act_type', 'relu')
-        self.mode_type = kwargs.get('mode_type', 'mlp')
-        if rgbnet_dim <= 0:
-            # colour voxel grid (coarse stage).  Upstream this branch cannot run: forward reads
-            # self.dim_rend which is only set when rgbnet_dim>0 (lib/dmpigo.py:69-88,385).
-            self.k0_dim = 3
-            self.k0 = grid.create_grid(
-                k0_type, channels=self.k0_dim, world_size=self.world_size,
-                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
-            self.rgbnet = None
-        else:
-            self.k0_dim = rgbnet_dim
-            self.k0 = grid.create_grid(
-                k0_type, channels=self.k0_dim, world_size=self.world_size,
-                xyz_min=self.xyz_min, xyz_max=self.xyz_max, config=self.k0_config)
-            self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
-            self.register_buffer('posfreq', torch.FloatTensor([(2 ** i) for i in range(spatial_pe)]))
-            self.dim0 = (3 + 3 * viewbase_pe * 2 + 3 + 3 * spatial_pe * 2) + self.k0_dim
-            self.pe_dim = 3 + 3 * viewbase_pe * 2 + 3 + 3 * spatial_pe * 2
-            self.act_type = kwargs['act_type']
-            self.mode_type = kwargs['mode_type']
+        self.act_type, self.mode_type = kwargs.get('act_type', 'relu'), kwargs.get('mode_type', 'mlp')
+        self.k0_dim = rgbnet_dim if rgbnet_dim > 0 else 3
+        self.k0 = self._new_grid(k0_type, self.k0_dim, k0_config)
+        self.rgbnet = None
+        if rgbnet_dim > 0:
+            self.act_type, self.mode_type = kwargs['act_type'], kwargs['mode_type']      # required upstream (lib/dmpigo.py:89)
             if self.act_type != 'relu':
                 raise NotImplementedError(f"act_type={self.act_type!r}: every BASELINE config uses 'relu' "
                                           "(configs/llff/fern_lg_joint_l1.py)")
             if self.mode_type in ('TRANS', 'adain'):
                 raise NotImplementedError(f'mode_type={self.mode_type!r} needs modules the reference never defines '
                                           '(lib/dmpigo.py:124-130)')
-            act = nn.ReLU(inplace=True)
-            self.rgbnet = nn.Sequential(
-                nn.Linear(self.dim0, rgbnet_width), act,
-                *[
-                    nn.Sequential(nn.Linear(rgbnet_width, rgbnet_width), act)
-                    for _ in range(rgbnet_depth - 2)
-                ],
-                nn.Linear(rgbnet_width, self.dim_rend),
-            )
-            nn.init.constant_(self.rgbnet[-1].bias, 0)
+            for name, n in (('viewfreq', viewbase_pe), ('posfreq', spatial_pe)):
+                self.register_buffer(name, torch.FloatTensor([2 ** i for i in range(n)]))
+            self.pe_dim = 3 * (1 + 2 * viewbase_pe) + 3 * (1 + 2 * spatial_pe)           # viewdirs + position embeddings
+            self.dim0 = self.pe_dim + self.k0_dim
+            self.rgbnet = _mlp(self.dim0, rgbnet_width, rgbnet_depth, self.dim_rend)
 
-        self.mask_cache_path = mask_cache_path
-        self.mask_cache_thres = mask_cache_thres
-        if mask_cache_world_size is None:
-            mask_cache_world_size = self.world_size
-        if mask_cache_path is not None and mask_cache_path:
-            mask = coarse_mask_on_grid(mask_cache_path, mask_cache_thres, self.xyz_min, self.xyz_max,
-                                       mask_cache_world_size)
+        # occupancy: from a coarse checkpoint when given, else everything occupied (lib/dmpigo.py:133-152)
+        self.mask_cache_path, self.mask_cache_thres = mask_cache_path, mask_cache_thres
+        mask_ws = self.world_size if mask_cache_world_size is None else mask_cache_world_size
+        if mask_cache_path:
+            mask = coarse_mask_on_grid(mask_cache_path, mask_cache_thres, self.xyz_min, self.xyz_max, mask_ws)
         else:
-            mask = torch.ones(list(mask_cache_world_size), dtype=torch.bool)
+            mask = torch.ones(list(mask_ws), dtype=torch.bool)
         self.mask_cache = grid.MaskGrid(path=None, mask=mask, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
+
+    def _new_grid(self, kind, channels, config):
+        return grid.create_grid(kind, channels=channels, world_size=self.world_size, xyz_min=self.xyz_min,
+                                xyz_max=self.xyz_max, config=config)
+
+    def _init_act_shift(self, xyz_min, xyz_max):
+        """Per-plane density bias chosen so that a ray through an empty volume sees equal alphas on every plane
+        (lib/dmpigo.py:48-58): alpha_i = g = 1/D - 1e-6 of the remaining transmittance."""
+        D = self.mpi_depth
+        self.act_shift = grid.DenseGrid(channels=1, world_size=[1, 1, D], xyz_min=xyz_min, xyz_max=xyz_max)
+        self.act_shift.grid.requires_grad = False
+        g = np.full([D], 1. / D - 1e-6)
+        keep = [1 - g[0]] + [(1 - g[:i + 1].sum()) / (1 - g[:i].sum()) for i in range(1, D)]
+        with torch.no_grad():
+            for i, p_i in enumerate(keep):
+                self.act_shift.grid[..., i].fill_(np.log(p_i ** (-1 / self.voxel_size_ratio) - 1))
 
     def _set_grid_resolution(self, num_voxels, mpi_depth):
         # lib/dmpigo.py:156-164

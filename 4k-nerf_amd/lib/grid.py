@@ -67,12 +67,11 @@ def create_grid(type, **kwargs):
 
 class DenseGrid(nn.Module):
     def __init__(self, channels, world_size, xyz_min, xyz_max, **kwargs):
-        super(DenseGrid, self).__init__()
-        self.channels = channels
-        self.world_size = world_size
-        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
-        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
-        self.grid = nn.Parameter(torch.zeros([1, channels, *world_size]))
+        super().__init__()
+        self.channels, self.world_size = channels, world_size
+        for name, val in (('xyz_min', xyz_min), ('xyz_max', xyz_max)):
+            self.register_buffer(name, torch.Tensor(val))
+        self.grid = nn.Parameter(torch.zeros([1, channels, *world_size]))          # [1, C, X, Y, Z], Z fastest
 
     def forward(self, xyz):
         """Trilinear lookup == F.grid_sample(bilinear, align_corners=True, zero pad) of lib/grid.py:117-128: HIP kernel
@@ -89,11 +88,11 @@ class DenseGrid(nn.Module):
         return out
 
     def scale_volume_grid(self, new_world_size):
-        if self.channels == 0:
-            self.grid = nn.Parameter(torch.zeros([1, self.channels, *new_world_size]))
-        else:
-            self.grid = nn.Parameter(
-                F.interpolate(self.grid.data, size=tuple(new_world_size), mode='trilinear', align_corners=True))
+        """Trilinear resample to a new resolution (progressive growing, lib/grid.py:130-135)."""
+        size = tuple(int(v) for v in new_world_size)
+        data = (torch.zeros([1, 0, *size]) if self.channels == 0 else
+                F.interpolate(self.grid.data, size=size, mode='trilinear', align_corners=True))
+        self.grid = nn.Parameter(data)
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
         '''Add gradients by total variation loss in-place (lib/grid.py:137-140).'''
@@ -112,35 +111,35 @@ class DenseGrid(nn.Module):
         return f'channels={self.channels}, world_size={ws}'
 
 
+def _mask_from_coarse_checkpoint(path, thres):
+    """Occupancy of a coarse-stage DVGO checkpoint (lib/grid.py:277-284): alpha of the 3x3x3 max-pooled density >= thres."""
+    st = torch.load(path, map_location='cpu', weights_only=False)
+    sd, kw = st['model_state_dict'], st['model_kwargs']
+    pooled = F.max_pool3d(sd['density.grid'], kernel_size=3, padding=1, stride=1)
+    alpha = 1 - torch.exp(-F.softplus(pooled + sd['act_shift']) * kw['voxel_size_ratio'])
+    return (alpha >= thres)[0, 0], kw['xyz_min'], kw['xyz_max']
+
+
 class MaskGrid(nn.Module):
+    """Boolean occupancy grid + the affine map world -> voxel index (buffers `mask`, `xyz2ijk_scale`, `xyz2ijk_shift`)."""
+
     def __init__(self, path=None, mask_cache_thres=None, mask=None, xyz_min=None, xyz_max=None):
-        super(MaskGrid, self).__init__()
+        super().__init__()
         if path is not None:
-            # occupancy from a coarse-stage checkpoint (lib/grid.py:277-284)
-            st = torch.load(path, map_location='cpu')
             self.mask_cache_thres = mask_cache_thres
-            density = F.max_pool3d(st['model_state_dict']['density.grid'], kernel_size=3, padding=1, stride=1)
-            alpha = 1 - torch.exp(-F.softplus(density + st['model_state_dict']['act_shift'])
-                                  * st['model_kwargs']['voxel_size_ratio'])
-            mask = (alpha >= self.mask_cache_thres).squeeze(0).squeeze(0)
-            xyz_min = torch.Tensor(st['model_kwargs']['xyz_min'])
-            xyz_max = torch.Tensor(st['model_kwargs']['xyz_max'])
-        else:
-            mask = mask.bool()
-            xyz_min = torch.Tensor(xyz_min)
-            xyz_max = torch.Tensor(xyz_max)
-        self.register_buffer('mask', mask)
-        xyz_len = xyz_max - xyz_min
-        self.register_buffer('xyz2ijk_scale', (torch.Tensor(list(mask.shape)) - 1) / xyz_len)
-        self.register_buffer('xyz2ijk_shift', -xyz_min * self.xyz2ijk_scale)
+            mask, xyz_min, xyz_max = _mask_from_coarse_checkpoint(path, mask_cache_thres)
+        lo, hi = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
+        self.register_buffer('mask', mask.bool())
+        scale = (torch.Tensor(list(mask.shape)) - 1) / (hi - lo)
+        self.register_buffer('xyz2ijk_scale', scale)
+        self.register_buffer('xyz2ijk_shift', -lo * scale)
 
     @torch.no_grad()
     def forward(self, xyz):
-        """Skip known free space: nearest-voxel lookup, C round() (lib/grid.py:295-304)."""
-        shape = xyz.shape[:-1]
-        xyz = xyz.reshape(-1, 3).contiguous()
-        mask = render_utils_cuda.maskcache_lookup(self.mask, xyz, self.xyz2ijk_scale, self.xyz2ijk_shift)
-        return mask.reshape(shape)
+        """Skip known free space: nearest-voxel lookup with C round() (lib/grid.py:295-304) on k4_maskcache_lookup."""
+        pts = xyz.reshape(-1, 3).contiguous()
+        hit = render_utils_cuda.maskcache_lookup(self.mask, pts, self.xyz2ijk_scale, self.xyz2ijk_shift)
+        return hit.reshape(xyz.shape[:-1])
 
     def extra_repr(self):
         return f'mask.shape={list(self.mask.shape)}'

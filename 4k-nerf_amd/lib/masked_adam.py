@@ -42,14 +42,13 @@ class MaskedAdam(torch.optim.Optimizer):
     """Adam with (1) per-voxel learning rate and (2) masked update that skips zero-gradient voxels."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8):
-        if not 0.0 <= lr:
-            raise ValueError("Invalid learning rate: {}".format(lr))
-        if not 0.0 <= eps:
-            raise ValueError("Invalid epsilon value: {}".format(eps))
-        if not 0.0 <= betas[0] < 1.0:
-            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
-        if not 0.0 <= betas[1] < 1.0:
-            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
+        # same argument checks (and messages) as lib/masked_adam.py:21-28
+        checks = ((lr >= 0.0, f'Invalid learning rate: {lr}'), (eps >= 0.0, f'Invalid epsilon value: {eps}'),
+                  (0.0 <= betas[0] < 1.0, f'Invalid beta parameter at index 0: {betas[0]}'),
+                  (0.0 <= betas[1] < 1.0, f'Invalid beta parameter at index 1: {betas[1]}'))
+        for ok, msg in checks:
+            if not ok:
+                raise ValueError(msg)
         self.per_lr = None
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
@@ -60,24 +59,21 @@ class MaskedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self):
         for group in self.param_groups:
-            lr, (beta1, beta2), eps = group['lr'], group['betas'], group['eps']
-            skip_zero_grad = group['skip_zero_grad']           # KeyError without it, as upstream (masked_adam.py:45)
-            for param in group['params']:
-                if param.grad is None:
-                    continue
+            (beta1, beta2), lr, eps = group['betas'], group['lr'], group['eps']
+            masked = group['skip_zero_grad']                   # KeyError without it, as upstream (masked_adam.py:45)
+            for param in (p for p in group['params'] if p.grad is not None):
                 state = self.state[param]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
-                    state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                if not state:                                   # lazy state, zeros in the parameter's memory format
+                    state.update(step=0, exp_avg=torch.zeros_like(param, memory_format=torch.preserve_format),
+                                 exp_avg_sq=torch.zeros_like(param, memory_format=torch.preserve_format))
                 state['step'] += 1
-                grad = param.grad if param.grad.is_contiguous() else param.grad.contiguous()
+                grad = param.grad.contiguous()
+                moments = (state['exp_avg'], state['exp_avg_sq'])
+                hyper = (state['step'], beta1, beta2, lr, eps)
+                # kernel selection order of lib/masked_adam.py:58-71: per-voxel lr first, then the masked update
                 if self.per_lr is not None and param.shape == self.per_lr.shape:
-                    adam_upd_with_perlr(param, grad, state['exp_avg'], state['exp_avg_sq'], self.per_lr,
-                                        state['step'], beta1, beta2, lr, eps)
-                elif skip_zero_grad:
-                    masked_adam_upd(param, grad, state['exp_avg'], state['exp_avg_sq'],
-                                    state['step'], beta1, beta2, lr, eps)
+                    adam_upd_with_perlr(param, grad, *moments, self.per_lr, *hyper)
+                elif masked:
+                    masked_adam_upd(param, grad, *moments, *hyper)
                 else:
-                    adam_upd(param, grad, state['exp_avg'], state['exp_avg_sq'],
-                             state['step'], beta1, beta2, lr, eps)
+                    adam_upd(param, grad, *moments, *hyper)
