@@ -89,3 +89,27 @@ def test_reference_still_importable_and_live_equal():
     got = marcher.mpi_forward(ck['model_kwargs'], ck['model_state_dict'], *rays, **ck['render_kwargs'])
     assert torch.equal(got['ray_id'], want['ray_id'])
     assert torch.allclose(got['rgb_marched'], want['rgb_marched'], atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['grad_mpi', 'grad_dvgo'])
+def test_training_goldens_are_consistent_with_the_forward_oracle(name):
+    """tests/golden/grad_*.npz (reference modules under autograd) record the training loss of their forward pass: the forward
+    oracle on the same checkpoint / rays / target must reproduce it, and every recorded gradient must belong to a parameter of
+    the checkpoint with the parameter's shape."""
+    import json
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    kw = json.loads(str(z['model_kwargs_json']))
+    for k in ('xyz_min', 'xyz_max'):
+        kw[k] = np.asarray(kw[k], dtype=np.float32)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
+    rays = [torch.from_numpy(z['in/' + k]) for k in ('rays_o', 'rays_d', 'viewdirs')]
+    rk = json.loads(str(z['render_kwargs_json']))
+    out = marcher.forward(str(z['model_class']), kw, sd, *rays, **rk)
+    loss = torch.nn.functional.mse_loss(out['rgb_marched'].float(), torch.from_numpy(z['target']))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-6, (float(loss), float(z['loss']))
+    grads = {k[5:]: z[k] for k in z.files if k.startswith('grad/')}
+    assert len(grads) >= 6 and 'density.grid' in grads and 'k0.grid' in grads
+    for k, g in grads.items():
+        assert k in sd and tuple(sd[k].shape) == g.shape, k
+        assert np.isfinite(g).all()
+    assert float(np.abs(grads['k0.grid']).max()) > 0 and float(np.abs(grads['density.grid']).max()) > 0
