@@ -251,33 +251,51 @@ __global__ void k_segment_sum(const float* __restrict__ src, const int64_t* __re
 // ---------------------------------------------------------------- d(DenseGrid.forward)/d(grid)  
 // What autograd runs for lib/grid.py:124 in the reference: grid_sampler_3d_backward's grad_input, i.e. every sample adds
 // grad_out[i][ch] * w[c] to its 8 corners (zero padding: corners outside the grid receive nothing).  One thread per
-// (sample, channel-quad): the corner indices / weights are recomputed (same setup as the forward), the scatter uses the
-// hardware fp32 atomic add (global_atomic_add_f32, no return) -- order-nondeterministic like the reference's
-// fastAtomicAdd.  d/d(xyz) is never needed (sample points come from rays, lib/dvgo.py:350).
+// sample: the corner indices / weights are recomputed (same setup as the forward), the scatter uses the hardware fp32
+// atomic add (global_atomic_add_f32, no return) -- order-nondeterministic like the reference's fastAtomicAdd.  d/d(xyz) is never needed (sample points come from rays, lib/dvgo.py:350).
 __global__ void k_grid_sample_bwd(const float* __restrict__ gout, int C, int X, int Y, int Z,
                                   const float* __restrict__ xyz, const float* __restrict__ mn, const float* __restrict__ mx,
                                   int64_t n, float* __restrict__ ggrid) {
-    const int cq = (C + 3) >> 2;                          // channel quads per sample
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * cq) return;
-    const int64_t i = t / cq;
-    const int ch0 = (int)(t % cq) * 4;
-    const float nx = k4_norm_coord(xyz[i * 3 + 0], mn[0], mx[0]);
-    const float ny = k4_norm_coord(xyz[i * 3 + 1], mn[1], mx[1]);
-    const float nz = k4_norm_coord(xyz[i * 3 + 2], mn[2], mx[2]);
+    // lane = sample (consecutive samples of a ray sit in consecutive lanes).  A sample's corners are 4 (x,y) rows x
+    // {z0, z0+1}; the z0+1 corner of one sample is very often the z0 corner of the next sample of the same ray (same row,
+    // z0 one higher).  Those pairs are merged with one shuffle so that the voxel receives ONE atomic instead of two: the
+    // scatter is bound by atomic throughput (96 per sample at 12 channels), the merge removes up to half of them.
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const int lane = k4_lane();
+    const int64_t ic = valid ? i : 0;
+    const float nx = k4_norm_coord(xyz[ic * 3 + 0], mn[0], mx[0]);
+    const float ny = k4_norm_coord(xyz[ic * 3 + 1], mn[1], mx[1]);
+    const float nz = k4_norm_coord(xyz[ic * 3 + 2], mn[2], mx[2]);
     const K4Tri tr = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
     const size_t plane = (size_t)X * Y * Z;
-    float g[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) g[q] = ch0 + q < C ? gout[i * C + ch0 + q] : 0.f;
+    // rows: c>>1 = (dx,dy); corner c = row*2 + dz.  -1 marks a corner outside the grid (zero padding: no contribution)
+    long long addr[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int x = tr.x0 + K4_CX(c), y = tr.y0 + K4_CY(c), z = tr.z0 + K4_CZ(c);
-        if (!((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z)) continue;
-        const size_t idx = ((size_t)x * Y + y) * Z + z;
+        const bool ok = valid && (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
+        addr[c] = ok ? (long long)(((size_t)x * Y + y) * Z + z) : -1;
+    }
+    // merge pattern (channel independent): my z0+1 corner of row r == the next lane's z0 corner of row r
+    bool take_next[4], skip_lo[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (ch0 + q < C) unsafeAtomicAdd(ggrid + plane * (ch0 + q) + idx, g[q] * tr.w[c]);
+    for (int r = 0; r < 4; ++r) {
+        const long long nxt_lo = __shfl_down(addr[2 * r], 1);
+        take_next[r] = lane < 63 && addr[2 * r + 1] >= 0 && nxt_lo == addr[2 * r + 1];
+        const int prev_took = __shfl_up((int)take_next[r], 1);
+        skip_lo[r] = lane > 0 && prev_took != 0;
+    }
+    for (int ch = 0; ch < C; ++ch) {
+        const float g = valid ? gout[ic * C + ch] : 0.f;
+        float* const gp = ggrid + plane * ch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vlo = g * tr.w[2 * r], vhi = g * tr.w[2 * r + 1];
+            const float nxt = __shfl_down(vlo, 1);
+            if (addr[2 * r + 1] >= 0) unsafeAtomicAdd(gp + addr[2 * r + 1], take_next[r] ? vhi + nxt : vhi);
+            if (addr[2 * r] >= 0 && !skip_lo[r]) unsafeAtomicAdd(gp + addr[2 * r], vlo);
+        }
     }
 }
 
@@ -474,7 +492,7 @@ extern "C" int k4_grid_sample_3d_backward(const float* grad_out, int32_t C, int3
     REQ(C > 0 && X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && grad_grid);
     if (n == 0) return K4_OK;
     REQ(xyz && grad_out);
-    hipLaunchKernelGGL(k_grid_sample_bwd, dim3(k4_blocks(n * ((C + 3) / 4))), dim3(K4_THREADS), 0, ST, grad_out, C, X, Y, Z, xyz, mn, mx, n, grad_grid);
+    hipLaunchKernelGGL(k_grid_sample_bwd, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, grad_out, C, X, Y, Z, xyz, mn, mx, n, grad_grid);
     return k4_check_launch();
 }
 extern "C" int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n, int32_t C, float* grad_src,
