@@ -68,6 +68,12 @@ typedef struct k4_grid_desc {
  *     n_hidden==1:  W2A [NB][NB][16][64] = W2[mb2*32+(l&31)][mb*32+row(r,l>>5)] ;  B2A [NB][64] = l<32 ? b2[mb2*32+l] : 0
  *     WOT [NB][16][2][4]         = Wout[c][mb*32+row(r,h)]  (c = 0..2, 3rd padded with 0)
  *     BO  [4]
+ * followed by the SPLIT section the default arithmetic uses (exact 3-term bf16 split w = t0 + t1 + t2, each term RNE of the
+ * running remainder; v_mfma_f32_32x32x16_bf16 operand order, 16-byte units = 8 bf16; KB1 = ceil(K1P/16)):
+ *     W1S [NB][KB1][3 terms][64]   = W1ext[mb*32+(l&31)][kb*16 + 8*(l>>5) + e]                      e = 0..7
+ *     n_hidden==1:  W2S [NB][width/16][3][64] = W2[mb2*32+(l&31)][(kb>>1)*32 + (e&3) + 8*(2*(kb&1)+(e>>2)) + 4*(l>>5)]
+ *                   B2S [NB][2][16] fp32      = b2[mb2*32 + row(r,h)]
+ *     WOT, BO as above
  * width == 0 means "no rgbnet": rgb = sigmoid(k0) with k0_ch == 3 (lib/dvgo.py:377-379). */
 typedef struct k4_mlp_desc {
     const float* packed;
