@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=80)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-stride', type=int, default=1, help='CPU baseline marches every k-th row and column')
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
