@@ -241,7 +241,9 @@ def main():
         if world == 1 and not args.small and not args.no_extras:
             res['training_step_kernels'] = training_step_kernels(dev, rays[0], model)
         if not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(ck, poses[0], args.cpu_stride)
+            res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
+            if parity is not None:
+                res['parity_vs_oracle'] = parity
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -391,7 +393,7 @@ def reference_pipeline_baseline(model, rays, rk, chunk=8192, frames=2):
             'what': 'reference op sequence, per-op launches, 8192-ray chunks, on the same GPU (k4_staged=True)'}
 
 
-def cpu_baseline(ck, pose, stride):
+def cpu_baseline(ck, pose, stride, model=None):
     """The CPU oracle ("port": oracle/marcher.py on torch CPU kernels) on a bounded sample of the same frame."""
     from oracle import marcher
     from nerf4k_amd import scene
@@ -404,11 +406,26 @@ def cpu_baseline(ck, pose, stride):
     marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro[:8192], rd[:8192], vd[:8192],
                     **ck['render_kwargs'])                                  # warm-up
     t = time.perf_counter()
-    marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
+    want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
     dt = time.perf_counter() - t
-    return {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
+    base = {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
             'sample': f'{len(ro)} rays = every {stride}th row and column of one 1008x756 frame, 8192-ray chunks '
                       f'as run_sr.py:121-124, {dt:.1f}s of CPU work, torch {torch.__version__} CPU kernels'}
+    parity = None
+    if model is not None:
+        # the oracle's output is at hand: use it as the CHECKER of the HIP path on the same (BASELINE-size) rays
+        dev = next(model.parameters()).device
+        with torch.no_grad():
+            got = model(ro.to(dev), rd.to(dev), vd.to(dev), k4_img_w=(W if stride == 1 else 0),
+                        **dict(ck['render_kwargs'], render_depth=True))
+        d = (got['rgb_marched'].cpu().double() - want['rgb_marched'].double())
+        mse = float((d ** 2).mean())
+        parity = {'rays': len(ro), 'psnr_rgb_db': round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1),
+                  'max_abs_rgb': float(d.abs().max()),
+                  'max_abs_depth': float((got['depth'].cpu().double() - want['depth'].double()).abs().max()),
+                  'max_abs_alphainv': float((got['alphainv_last'].cpu().double() - want['alphainv_last'].double()).abs().max()),
+                  'what': 'HIP fused marcher vs the CPU oracle on the same rays (the frame timed for cpu_baseline)'}
+    return base, parity
 
 
 if __name__ == '__main__':
