@@ -10,15 +10,24 @@ LLFF scene (no datasets / checkpoints exist offline), camera poses cycling throu
 Rays are resident in HBM before the timed region (the reference's own timer starts after
 ``get_rays_of_a_view`` too, run_sr.py:104-111).
 
-N>1 (strong scaling, BASELINE configs[3]): every frame is split into N horizontal bands of pixel rows,
-each rank marches its band (full replicas of the grids), one RCCL ``all_gather_into_tensor`` of the final
-per-pixel values (rgb, depth, alphainv: 5 floats/ray) per frame -- final pixels only.
+The timed region pipelines the frames over 3 HIP streams (the geometry kernel of frame i+1 overlaps the shading kernel of
+frame i); ``roofline`` is measured on isolated launches of the same call (one stream, HIP events on the launch stream).
+
+N>1: the frames of the pose sequence are sharded over the ranks (independent units, full model replica per GPU, no data-path
+collective; ``scaling: "weak"``, value = rays of all ranks / max-over-ranks time).  ``--shard rows`` selects the
+one-frame-split-N-ways form instead (row bands + one asynchronous ``all_gather_into_tensor`` of 5 floats per ray, strong).
+The 4K pipeline (``four_k``, BASELINE configs[2]/[3]) always shards the SR tiles of ONE frame over the ranks with one
+all-gather of the final HR pixels.
 
 Extra objects on the JSON line (rank 0):
-  roofline     -- dominant kernel (fused marcher), HBM bound: algorithmic bytes per launch (device
-                  counters, SURVEY.md 8d formula) / mean kernel time from HIP events on the launch stream.
-  cpu_baseline -- the CPU oracle (oracle/marcher.py, kind "port") timed on this host's cores on a bounded
-                  strided subset of the same frame.
+  roofline        -- dominant kernels (fused marcher call), HBM bound: algorithmic bytes per launch (device counters,
+                     SURVEY.md 8d formula) / mean isolated launch time; ``traffic`` = fabric bytes per launch from the
+                     committed rocprofv3 PMC passes (profiles/r01_marcher_traffic.json).
+  cpu_baseline    -- the CPU oracle (oracle/marcher.py, kind "port") timed on this host's cores on one full frame.
+  parity_vs_oracle-- the HIP marcher's output on that frame against the oracle's (PSNR, max errors): the oracle as checker.
+  four_k / four_k_fp32mfma / four_k_bf16x3 -- march + SFTNet x4 (tile 510) to 4032x3024 per decoder arithmetic.
+  reference_pipeline_baseline -- the reference's op-per-launch sequence (staged kernels, 8192-ray chunks) on this GPU.
+  training_step_kernels       -- Adam / masked Adam / TV / grid-sample backward streaming kernels vs the HBM roof.
 """
 import argparse
 import json
