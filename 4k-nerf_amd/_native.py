@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib4k_hip.so')
-K4_ABI_VERSION = 1
+K4_ABI_VERSION = 2
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
@@ -28,7 +28,7 @@ class GridDesc(C.Structure):
 
 class MlpDesc(C.Structure):
     _fields_ = [('packed', C.c_void_p), ('dim0', C.c_int32), ('width', C.c_int32), ('n_hidden', C.c_int32),
-                ('viewbase_pe', C.c_int32), ('spatial_pe', C.c_int32), ('k0_skip', C.c_int32)]
+                ('viewbase_pe', C.c_int32), ('spatial_pe', C.c_int32), ('k0_skip', C.c_int32), ('arith', C.c_int32)]
 
 
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -69,22 +69,24 @@ def lib():
                 f'{LIB_PATH} not found: the HIP extension is not built (python -c "import __graft_entry__ as g; '
                 f'g.build()").  There is no CPU/PyTorch fallback for the 4K-NeRF hot path.')
         l = C.CDLL(LIB_PATH)
+        missing = [name for name in list(_SIGS) + list(_EXTRA_SIGS) if not hasattr(l, name)]
+        if missing:          # a stale library (built before an entry point was added) must not load silently
+            raise RuntimeError(f'lib4k_hip.so lacks {missing}: rebuild (python -c "import __graft_entry__ as g; g.build()")')
         for name, args in _SIGS.items():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_int
         for name, (args, res) in _EXTRA_SIGS.items():
-            if hasattr(l, name):
-                fn = getattr(l, name)
-                fn.argtypes = args
-                fn.restype = res
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
         if l.k4_abi_version() != K4_ABI_VERSION:
             raise RuntimeError('lib4k_hip.so ABI version mismatch: rebuild')
         _lib = l
     return _lib
 
 
-# SR entry points are registered by sr modules (optional symbols are bound when present)
+# entry points with a non-default return type / added after ABI v1 (all REQUIRED: lib() refuses a library lacking any)
 _EXTRA_SIGS = {
     'k4_conv2d_nhwc': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                         _P, _I32, _F, _P, _I32, _P], C.c_int),

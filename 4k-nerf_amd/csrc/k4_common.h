@@ -101,3 +101,34 @@ static inline int k4_check_launch() {
     hipError_t e = hipGetLastError();
     return (int)e;
 }
+
+// ---- host-side process state: none that can change after load --------------------------------------------------------
+// Experiment / profiling knobs are environment variables read ONCE while the library is being loaded (a namespace-scope
+// constant in k4_march.hip); launches never call getenv.  Per-device facts (CU count, "dynamic LDS attribute already raised
+// for kernel F") are cached in fixed arrays indexed by the HIP device ordinal; concurrent first calls write the same values.
+struct K4Env {
+    int geom_split;      // K4_GEOM_SPLIT   (1) 0: one wave per bundle, all depths (baseline of profiles/r01_final_pmc.md)
+    int geom_ldspad;     // K4_GEOM_LDSPAD  (0) extra dynamic LDS bytes for the geometry kernel (occupancy experiments)
+    int geom_skip;       // K4_GEOM_SKIP    (1) 0: do not use the coarse occupancy summary (A/B of the empty-space skipping)
+    int shade_grid_wg;   // K4_SHADE_GRID_WG    persistent shading workgroups per CU
+    int debug;           // K4_DEBUG        (0) ablation bits, profiling only
+    int serp;            // K4_SERP         (1) serpentine ray order inside an 8x8 tile
+    int b6_nw1;          // K4_B6_NW1       (8) waves per workgroup of the 32-output-channel bf16x6 convolution
+    int sr_variant;      // K4_SR_VARIANT   (0) experiment selector of the decoder kernels
+};
+const K4Env& k4_env();
+#define K4_MAX_DEVICES 64
+static inline int k4_device_ordinal() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= K4_MAX_DEVICES) dev = 0;
+    return dev;
+}
+int k4_num_cus();
+// raise hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device)
+#define K4_ENSURE_DYN_LDS(KERN, BYTES) do { \
+        static bool k4_attr_done_[K4_MAX_DEVICES]; \
+        const int k4_dev_ = k4_device_ordinal(); \
+        if ((BYTES) > 64 * 1024 && !k4_attr_done_[k4_dev_]) { \
+            hipError_t k4_e_ = hipFuncSetAttribute((const void*)(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+            if (k4_e_ != hipSuccess) return (int)k4_e_; \
+            k4_attr_done_[k4_dev_] = true; } } while (0)

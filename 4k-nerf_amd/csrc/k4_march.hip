@@ -952,17 +952,11 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const int nwg = n_workgroups(P.n_rays, P.img_w);
     if (nwg <= 0) return K4_OK;
     const dim3 grid(nwg), block(256);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = k4_num_cus();
     {
         // one workgroup (4 waves = 4 depth quarters) per bundle; K4_GEOM_SPLIT=0 keeps the unsplit form (one wave = one bundle,
         // all depths) and K4_GEOM_LDSPAD pads LDS to cap occupancy -- the baselines of profiles/r01_final_pmc.md
-        static const int split = getenv("K4_GEOM_SPLIT") ? atoi(getenv("K4_GEOM_SPLIT")) : 1;
-        static const int ldspad = getenv("K4_GEOM_LDSPAD") ? atoi(getenv("K4_GEOM_LDSPAD")) : 0;
+        const int split = k4_env().geom_split, ldspad = k4_env().geom_ldspad;
         if (split && P.counters) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
         else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, false>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
         else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false, true>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
@@ -970,13 +964,11 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     int rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
-    // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; K4_MLP=fp32 selects the
-    // fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
-    const char* const mlp_env = getenv("K4_MLP");              // read per launch (tests toggle it within one process)
-    const bool mlp_fp32 = mlp_env && !strcmp(mlp_env, "fp32");
-    const bool b3 = width != 0 && width <= 64 && !mlp_fp32;
+    // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; k4_mlp_desc.arith =
+    // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
+    const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
-    static const int shade_wg = getenv("K4_SHADE_GRID_WG") ? atoi(getenv("K4_SHADE_GRID_WG")) : K4_SHADE_WG_PER_CU;   // experiment knob
+    const int shade_wg = k4_env().shade_grid_wg;
     const dim3 sgrid((unsigned)min(nwg, n_cu * shade_wg));
     const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
@@ -984,7 +976,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         if (lds > 64 * 1024) { \
             hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
-        hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)
+        hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)      /* lds varies with the MLP shape: set per launch */
 #define K4_LAUNCH(WD, NH) do { if (b3 && WD > 0 && WD <= 64) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD > 0 && WD <= 64 ? WD : 32), NH, true>)); \
                                else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, false>)); } while (0)
     if (width == 0) K4_LAUNCH(0, 0);
@@ -1047,14 +1039,29 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.counts = (int*)((char*)workspace + nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
     P.n_bundles = (int)nb;
-    { const char* dbg = getenv("K4_DEBUG"); P.debug = dbg ? atoi(dbg) : 0;
-      P.serp = getenv("K4_SERP") ? atoi(getenv("K4_SERP")) : 1; }
+    P.debug = k4_env().debug; P.serp = k4_env().serp;
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
 }
 
 extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
+
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
+    env_int("K4_GEOM_SPLIT", 1), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
+    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_B6_NW1", 8), env_int("K4_SR_VARIANT", 0)};
+const K4Env& k4_env() { return g_k4_env; }
+int k4_num_cus() {
+    static int n_cu[K4_MAX_DEVICES];
+    const int dev = k4_device_ordinal();
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
+    }
+    return n_cu[dev];
+}
 
 extern "C" int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden) {
     if (width == 0) return 0;

@@ -540,12 +540,7 @@ static int launch_conv_b6(ConvParams P, hipStream_t st) {
     constexpr size_t lds = ((size_t)3 * 2 * (2 * NW + 2 * PADW) * (TILE_W + 2 * PADW) + (size_t)3 * TAPS * 2 * NT * 32) * sizeof(uint4);
     P.tiles_y = (P.H + 2 * NW - 1) / (2 * NW);
     static_assert(lds <= 160 * 1024, "split chunk must fit the CU's LDS");
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_b6_kernel<KS, NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    K4_ENSURE_DYN_LDS((k4_conv_b6_kernel<KS, NT, NW>), lds);
     const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(64 * NW);
     hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT, NW>), grid, block, lds, st, P);
     return k4_check_launch();
@@ -677,12 +672,7 @@ static int launch_conv_taps_b6(ConvParams P, hipStream_t st) {
     constexpr size_t lds_gemm = ((size_t)3 * 2 * K4_TAPS_PPAD + 3 * 2 * 32) * sizeof(uint4);
     constexpr size_t lds_y = (size_t)K4_TAPS_NPIX * K4_TAPS_YS * sizeof(float);
     constexpr size_t lds = lds_gemm > lds_y ? lds_gemm : lds_y;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k4_conv_taps_b6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    K4_ENSURE_DYN_LDS(k4_conv_taps_b6_kernel, lds);
     P.tiles_y = (P.H + TILE_HB - 1) / TILE_HB;
     const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(512);
     hipLaunchKernelGGL(k4_conv_taps_b6_kernel, grid, block, lds, st, P);
@@ -723,7 +713,7 @@ extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_st
         if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
         return launch_conv_taps_b6(P, st);
     }
-    static const int nw1 = getenv("K4_B6_NW1") ? atoi(getenv("K4_B6_NW1")) : 8;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
+    const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
     if (ksize == 3) {
         if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(P, st) : launch_conv_b6<3, 1, 8>(P, st);
         if (nt == 2) return launch_conv_b6<3, 2, 8>(P, st);

@@ -15,6 +15,8 @@ What is new is everything inside ``forward``:
     ``raw_alpha``, ``raw_rgb``, ``ray_id``).
 There is no CPU path: CPU tensors raise.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -65,6 +67,7 @@ class _FusedMarcher:
         md.viewbase_pe = int(len(self.viewfreq)) if self.rgbnet is not None else 0
         md.spatial_pe = int(spatial_pe)
         md.k0_skip = int(k0_skip)
+        md.arith = 1 if os.environ.get('K4_MLP') == 'fp32' else 0      # K4_MLP_ARITH_FP32: exact-fp32 MFMA form (tests, A/B runs)
         if self.rgbnet is None:
             md.packed, md.dim0, md.width, md.n_hidden = None, 0, 0, 0
             return md, None
@@ -110,12 +113,22 @@ class _FusedMarcher:
         gd.mask = mc.mask.data_ptr()
         gd.mask_dims = (N.C.c_int32 * 3)(*[int(v) for v in mc.mask.shape])
         c = self._k4_cache()
-        hkey = ('host3', self.xyz_min.data_ptr(), mc.xyz2ijk_scale.data_ptr(), str(dens.device))
+        hkey = ('host3', str(dens.device)) + tuple((t.data_ptr(), t._version) for t in
+                                                   (self.xyz_min, self.xyz_max, mc.xyz2ijk_scale, mc.xyz2ijk_shift))
         if c.get('host_key') != hkey:      # tiny D2H copies, once
             c['host_key'] = hkey
             c['host'] = (N.vec3(self.xyz_min), N.vec3(self.xyz_max), N.vec3(mc.xyz2ijk_scale), N.vec3(mc.xyz2ijk_shift))
         gd.xyz_min, gd.xyz_max, gd.xyz2ijk_scale, gd.xyz2ijk_shift = c['host']
         return gd
+
+    def k4_warm(self):
+        """Build every load-time cache of the fused path (k0 channel-last repack, packed rgbnet, host copies of the bbox) on the
+        current stream.  Callers that fan work out over several HIP streams call this before forking them."""
+        if self._k4_fusable():
+            act = getattr(self, 'act_shift', None)
+            self._k4_grid(act_shift_grid=act.grid if isinstance(act, nn.Module) else None)
+            if self.rgbnet is not None:
+                self._k4_mlp(k0_skip=0, spatial_pe=0)
 
     def _k4_host_scalar(self, name, t):
         """float(t) for a 1-element device buffer without a D2H sync per call (cached per version)."""
@@ -489,7 +502,8 @@ def _segment_sum_fwd(src, index, n):
     C_ = 1 if src.dim() == 1 else src.shape[1]
     out = torch.empty([n] + list(src.shape[1:]), dtype=torch.float32, device=src.device)
     srcc = src.detach().float().contiguous()
-    N.check(N.lib().k4_segment_sum(N.f32(srcc), N.ptr(index.contiguous()), srcc.shape[0], C_, n, N.f32(out), N.stream()),
+    idx = index.contiguous()
+    N.check(N.lib().k4_segment_sum(N.f32(srcc), N.ptr(idx), srcc.shape[0], C_, n, N.f32(out), N.stream()),
             'segment_sum')
     return out
 
@@ -510,7 +524,8 @@ class SegmentSum(torch.autograd.Function):
         C_ = 1 if len(ctx.src_shape) == 1 else ctx.src_shape[1]
         gs = torch.empty(ctx.src_shape, dtype=torch.float32, device=grad_out.device)
         go = grad_out.float().contiguous()
-        N.check(N.lib().k4_segment_sum_backward(N.f32(go), N.ptr(index.contiguous()), ctx.src_shape[0], C_, N.f32(gs), N.stream()),
+        idx = index.contiguous()
+        N.check(N.lib().k4_segment_sum_backward(N.f32(go), N.ptr(idx), ctx.src_shape[0], C_, N.f32(gs), N.stream()),
                 'segment_sum_backward')
         return gs, None, None
 
@@ -616,8 +631,10 @@ def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='cente
     (k4_get_rays_of_a_view) instead of ~25 elementwise kernels and their [H,W,3] temporaries."""
     if torch.is_tensor(c2w) and c2w.is_cuda and mode in ('center', 'lefttop'):
         dev = c2w.device
+        # focal from the caller's K BEFORE any fp32 cast: the reference evaluates -1./(W/(2.*focal)) in Python floats from K[0][0]
+        # (typically float64, lib/dvgo.py:559-563), exactly as the host fallback below does
+        focal = float(K[0][0])
         Kt = (torch.as_tensor(np.asarray(K), dtype=torch.float32) if not torch.is_tensor(K) else K.detach().float().cpu())
-        focal = float(Kt[0][0])
         Kd = Kt.contiguous().to(dev)
         M = c2w.detach().float().contiguous()
         if M.shape[-1] != 4 or M.shape[0] < 3:

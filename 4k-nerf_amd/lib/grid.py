@@ -104,6 +104,7 @@ class DenseGrid(nn.Module):
     @torch.no_grad()
     def __isub__(self, val):
         self.grid.data -= val
+        torch.autograd.graph.increment_version(self.grid)      # `.data` edits bypass the version counter the repack caches key on
         return self
 
     def extra_repr(self):

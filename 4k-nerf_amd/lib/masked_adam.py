@@ -21,6 +21,10 @@ def _launch(name, param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, l
         rc = fn(N.ptr(param), N.ptr(grad), N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(perlr), param.numel(), int(step),
                 float(beta1), float(beta2), float(lr), float(eps), st)
     N.check(rc, name)
+    # the kernels write through raw pointers: tell autograd / every `_version`-keyed cache (the fused marcher's k0 repack and
+    # packed rgbnet, SFTNet's packed convs) that these tensors changed -- a render after an optimizer step must not see stale copies
+    for t in (param, exp_avg, exp_avg_sq):
+        torch.autograd.graph.increment_version(t)
 
 
 def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):

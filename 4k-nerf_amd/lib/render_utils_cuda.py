@@ -146,8 +146,8 @@ def alpha2weight(alpha, ray_id, n_rays):
 
 def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_rays, grad_weights, grad_last):
     grad = torch.empty_like(alpha)
+    gw, gl = grad_weights.contiguous(), grad_last.contiguous()       # named: the copies must outlive the launch
     N.check(N.lib().k4_alpha2weight_backward(N.f32(alpha), N.f32(weight), N.f32(T), N.f32(alphainv_last),
                                              N.ptr(i_start), N.ptr(i_end), int(n_rays), alpha.shape[0],
-                                             N.f32(grad_weights.contiguous()), N.f32(grad_last.contiguous()),
-                                             N.f32(grad), N.stream()), 'alpha2weight_backward')
+                                             N.f32(gw), N.f32(gl), N.f32(grad), N.stream()), 'alpha2weight_backward')
     return grad

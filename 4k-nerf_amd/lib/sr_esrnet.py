@@ -8,11 +8,11 @@ tensor like the reference, lib/sr_esrnet.py:477,526), ``load_network`` / ``save_
 (lib/sr_esrnet.py:529-621: ``params_ema`` -> ``params`` fallback, ``module.`` stripping, size-mismatch skipping
 with ``strict=False``).
 
-Inference (``torch.no_grad``) runs on the fp32-MFMA implicit-GEMM kernel of ``csrc/k4_sr.hip`` through
-``k4_conv2d_nhwc``: NHWC activations, the dense block's ``torch.cat`` is a [H][W][192] buffer written slice by
-slice, bias / LeakyReLU / residual / SFT modulation / nearest-x2 upsampling are fused into the conv.  With autograd
-enabled (training, a "next" row of SURVEY.md 8f) the module evaluates the same graph with PyTorch-ROCm ops.
-No CPU path.
+Inference (``torch.no_grad``) runs on the implicit-GEMM kernels of ``csrc/k4_sr.hip``: by default ``k4_conv2d_nhwc_bf16x6``
+(exact 3-term bf16 splits, 6 partial products on ``v_mfma_f32_32x32x16_bf16``, fp32 accumulation = fp32-equivalent);
+``k4_mode='fp32'`` selects ``k4_conv2d_nhwc`` (``v_mfma_f32_32x32x2_f32``, exact fp32 FMA chains), ``'bf16x3'`` the 2-term
+split.  NHWC activations, the dense block's ``torch.cat`` is a [H][W][192] buffer written slice by slice, bias / LeakyReLU /
+residual / nearest-x2 upsampling are fused into the conv, an SFTLayer is one launch (``k4_sft_nhwc``).  No CPU path.
 """
 import math
 import os
@@ -434,6 +434,7 @@ class SFTNet(nn.Module):
         # flight together the tail of one tile's layer is filled by another tile's
         n_str = max(1, min(len(tiles), int(os.environ.get('K4_SR_STREAMS', '4'))))
         cur = torch.cuda.current_stream(img.device)
+        self._packed()           # cold caches: the weight packing is enqueued on `cur` BEFORE the side streams fork from it
         if n_str > 1:
             pool = self._k4.setdefault(('streams', str(img.device)), [])
             while len(pool) < n_str:

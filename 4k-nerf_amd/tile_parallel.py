@@ -76,6 +76,10 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
     n_str = _n_streams(dev, len(owned[rk]), march_fn, sr_fn)
     pool = _stream_pool(dev, n_str) if n_str > 1 else None
     cur = torch.cuda.current_stream(dev) if n_str > 1 else None
+    for fn in (march_fn, sr_fn):         # cold caches (k0 repack, packed rgbnet / conv weights) are built on the CURRENT stream,
+        warm = getattr(fn, 'k4_warm', None)      # before the side streams fork from it -- never inside one of them
+        if warm is not None:
+            warm()
     if pool:
         for st in pool:
             st.wait_stream(cur)
@@ -139,6 +143,7 @@ def hip_march_fn(model, render_kwargs):
         o = model(ro, rd, vd, k4_img_w=window_w, k4_ws_slot=8 + slot, **kw)
         return o['rgb_feature'], o['depth']
     fn.k4_slots = True
+    fn.k4_warm = model.k4_warm
     return fn
 
 
@@ -146,6 +151,7 @@ def hip_sr_fn(net_sr):
     def fn(img, cond, slot=0):
         return net_sr._forward_hip(img, cond, slot=slot)
     fn.k4_slots = True
+    fn.k4_warm = net_sr._packed
     return fn
 
 

@@ -5,31 +5,35 @@
 
 Metric (BASELINE.json): Mrays/s on LLFF-fern ``render_test``.  A *step* is one full 1008x756 frame
 (762,048 rays x 256 samples) of BASELINE configs[1] -- "LLFF fern_lg_pretrain render_test at 1008x756,
-1xMI355X, HIP ray-marcher only (no SR)" -- marched by the fused HIP kernel on the seeded synthetic
+1xMI355X, HIP ray-marcher only (no SR)" -- marched by the fused HIP kernels on the seeded synthetic
 LLFF scene (no datasets / checkpoints exist offline), camera poses cycling through the 20-pose spiral.
 Rays are resident in HBM before the timed region (the reference's own timer starts after
 ``get_rays_of_a_view`` too, run_sr.py:104-111).
 
-The timed region pipelines the frames over 3 HIP streams (the geometry kernel of frame i+1 overlaps the shading kernel of
-frame i); ``roofline`` is measured on isolated launches of the same call (one stream, HIP events on the launch stream).
+``value`` is whole-job throughput: the frames of the timed region alternate over 3 HIP streams (the geometry kernel of frame
+i+1 overlaps the shading kernel of frame i).  ``mrays_isolated`` is the stream-synchronised per-call rate (one stream, HIP
+events around each call): ``roofline`` is computed on THAT duration, never on the overlapped one.
 
-N>1: the frames of the pose sequence are sharded over the ranks (independent units, full model replica per GPU, no data-path
-collective; ``scaling: "weak"``, value = rays of all ranks / max-over-ranks time).  ``--shard rows`` selects the
-one-frame-split-N-ways form instead (row bands + one asynchronous ``all_gather_into_tensor`` of 5 floats per ray, strong).
-The 4K pipeline (``four_k``, BASELINE configs[2]/[3]) always shards the SR tiles of ONE frame over the ranks with one
-all-gather of the final HR pixels.
+N>1 (strong scaling, the default): every frame is split in N row bands, rank r marches band r of EVERY frame and one
+asynchronous ``all_gather_into_tensor`` (RCCL) per frame moves the final 5 floats per ray -- ``scaling: "strong"``,
+``value`` = rays of one frame x frames / max-over-ranks time.  ``frames_sharded`` (secondary field) is the no-collective
+form: rank r renders frames r, r+N, ... (weak).  The 4K pipeline (``four_k``, BASELINE configs[2]/[3]) shards the SR tiles of
+ONE frame over the ranks with one all-gather of the final HR pixels (strong).
 
-Extra objects on the JSON line (rank 0):
-  roofline        -- dominant kernels (fused marcher call), HBM bound: algorithmic bytes per launch (device counters,
-                     SURVEY.md 8d formula) / mean isolated launch time; ``traffic`` = fabric bytes per launch from the
-                     committed rocprofv3 PMC passes (profiles/r01_marcher_traffic.json).
-  cpu_baseline    -- the CPU oracle (oracle/marcher.py, kind "port") timed on this host's cores on one full frame.
-  parity_vs_oracle-- the HIP marcher's output on that frame against the oracle's (PSNR, max errors): the oracle as checker.
-  four_k / four_k_fp32mfma / four_k_bf16x3 -- march + SFTNet x4 (tile 510) to 4032x3024 per decoder arithmetic.
-  reference_pipeline_baseline -- the reference's op-per-launch sequence (staged kernels, 8192-ray chunks) on this GPU.
-  training_step_kernels       -- Adam / masked Adam / TV / grid-sample backward streaming kernels vs the HBM roof.
+Objects on the JSON line (rank 0):
+  roofline         -- dominant kernels (fused marcher call), HBM bound: algorithmic bytes per launch (device counters,
+                      SURVEY.md 8d formula) / mean ISOLATED launch time; ``traffic`` = fabric bytes per launch from the committed
+                      rocprofv3 PMC passes of this command (profiles/*_marcher_traffic.json, the newest).
+  cpu_baseline     -- the CPU oracle (oracle/marcher.py, kind "port") timed on this host's cores on one full frame.
+  parity_vs_oracle -- the HIP marcher's output on that frame against the oracle's.
+  four_k           -- march + SFTNet x4 (tile 510) to 4032x3024: frames/s, MFMA roofline of the decoder, PSNR of the HR
+                      pixels against the oracle (march + SFTNet on the CPU) on a bounded window, and that window's CPU time
+                      as ``cpu_baseline``; ``four_k_fp32mfma`` / ``four_k_bf16x3`` = the other decoder arithmetics.
+  own_staged_pipeline   -- the reference's op-per-launch sequence on THIS package's staged kernels (8192-ray chunks).
+  training_step_kernels -- Adam / masked Adam / TV / grid-sample backward streaming kernels vs the HBM roof.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -44,6 +48,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CPU_THREAD_CAP = 64            # torch CPU kernels stop scaling (and thrash) far below a 256-thread host
 
 
 def parse():
@@ -54,19 +59,115 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-stride', type=int, default=1, help='CPU baseline marches every k-th row and column')
     ap.add_argument('--small', action='store_true', help='reduced scene (debug only; never a reported number)')
-    ap.add_argument('--streams', type=int, default=3, help='HIP streams frames alternate on (2: the geometry kernel of frame '
-                    'i+1 overlaps the matrix-core shading kernel of frame i)')
-    ap.add_argument('--shard', choices=['frames', 'rows'], default='frames',
-                    help='N>1, marcher metric: "frames" = every rank renders its own frames of the pose sequence (independent '
-                         'units, no collective, weak scaling); "rows" = every frame split in row bands + all_gather of the final '
-                         'pixels (strong scaling; the 4K pipeline always shards tiles of one frame, see four_k)')
-    ap.add_argument('--no-extras', action='store_true', help='marcher line only: skip the reference-pipeline and training-step '
-                    'side measurements (profiling runs)')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams the frames alternate on')
+    ap.add_argument('--shard', choices=['rows', 'frames'], default='rows',
+                    help='N>1 headline: "rows" = every frame split in N row bands + all_gather of the final pixels (strong '
+                         'scaling, default); "frames" = rank r renders frames r, r+N, ... (no collective, weak scaling)')
+    ap.add_argument('--no-extras', action='store_true', help='marcher line only: skip the side measurements (profiling runs)')
     ap.add_argument('--backend', default='nccl', help=argparse.SUPPRESS)          # gloo + --same-device: 1-GPU logic smoke test
     ap.add_argument('--same-device', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--sr-frames', type=int, default=3, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
-                    'secondary frames/s figure (N=1 only; 0 disables)')
+                    'secondary frames/s figure (0 disables)')
     return ap.parse_args()
+
+
+class MarcherRun:
+    """The timed marcher loop for one sharding mode."""
+
+    def __init__(self, model, poses, rk, H, W, K, dev, world, rank, by_rows, n_streams):
+        from nerf4k_amd import tile_parallel as tp
+        from nerf4k_amd.lib import dvgo
+        self.model, self.rk, self.W, self.dev, self.world, self.by_rows = model, rk, W, dev, world, by_rows
+        r0, r1, rows_per = tp.shard_rows(H, world, rank) if by_rows else (0, H, H)
+        if world > 1 and not by_rows:          # rank r renders frames r, r+N, r+2N, ... of the pose sequence
+            poses = [poses[(rank + i * world) % len(poses)] for i in range(len(poses))]
+        self.rays = []
+        with torch.no_grad():
+            for p in poses:
+                ro, rd, vd = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False)
+                self.rays.append(tuple(x[r0:r1].reshape(-1, 3).contiguous() for x in (ro, rd, vd)))
+        self.n_band = n_band = (r1 - r0) * W
+        slot = rows_per * W
+        # all-gather buffers (double buffered): [rgb n x 3 | depth n | alphainv n] -- the marcher writes straight into them
+        self.send = [torch.zeros([5 * slot], dtype=torch.float32, device=dev) for _ in range(2)]
+        self.recv = [torch.empty([world * 5 * slot], dtype=torch.float32, device=dev) for _ in range(2)] if by_rows else None
+        self.outs = [(b[:3 * n_band].view(n_band, 3), b[3 * slot:3 * slot + n_band], b[4 * slot:4 * slot + n_band]) for b in self.send]
+        self.works = [None, None]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_streams))]
+        model.k4_warm()                        # load-time caches on the current stream, before the side streams fork
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream())
+
+    def step(self, i, timed=None):
+        b = i & 1
+        st = self.streams[i % len(self.streams)]
+        with torch.cuda.stream(st):
+            if self.works[b] is not None:
+                self.works[b].wait()                  # the collective that last read send[b] has finished
+                self.works[b] = None
+            ro, rd, vd = self.rays[i % len(self.rays)]
+            if timed is not None:
+                timed[0].record(st)
+            out = self.model(ro, rd, vd, k4_img_w=self.W, k4_out=self.outs[b], k4_ws_slot=i % len(self.streams), **self.rk)
+            if timed is not None:
+                timed[1].record(st)
+            if self.by_rows and self.world > 1:       # final pixels only; asynchronous, overlaps the next frame's march
+                self.works[b] = dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
+        return out
+
+    def sync(self):
+        for b in range(2):
+            if self.works[b] is not None:
+                self.works[b].wait()
+                self.works[b] = None
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()             # all streams
+
+    def run(self, steps, warmup):
+        """-> (elapsed seconds max over ranks, mean launch-to-completion ms of a call inside the overlapped region)"""
+        with torch.no_grad():
+            for i in range(warmup):
+                self.step(i)
+            self.sync()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            t_start = time.perf_counter()
+            for i in range(steps):
+                self.step(i, timed=ev[i])
+            self.sync()
+            elapsed = time.perf_counter() - t_start
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def isolated(self, n):
+        """ISOLATED launch duration (one stream, HIP events around each call on the launch stream) and the device sample
+        counters -- the duration the rocprofv3 --stats summary of `bench.py --streams 1` must agree with."""
+        cnt = torch.zeros(4, dtype=torch.int64, device=self.dev)
+        st0 = self.streams[0]
+        iso = []
+        with torch.no_grad():
+            for i in range(n):
+                with torch.cuda.stream(st0):
+                    ro, rd, vd = self.rays[i % len(self.rays)]
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st0)
+                    self.model(ro, rd, vd, k4_img_w=self.W, k4_out=self.outs[0], k4_ws_slot=0, **self.rk)
+                    e1.record(st0)
+                    iso.append((e0, e1))
+                    self.model(ro, rd, vd, k4_img_w=self.W, k4_counters=cnt, k4_out=self.outs[0], k4_ws_slot=0, **self.rk)
+            self.sync()
+        return float(np.mean([a.elapsed_time(b) for a, b in iso])), [c / n for c in cnt.cpu().tolist()]
+
+
+def newest_traffic_profile():
+    """HBM-side bytes per launch: PMC passes of this command, committed under profiles/ (the newest round's file)."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_marcher_traffic.json')))
+    if not files:
+        return None, None
+    tj = json.load(open(files[-1]))
+    return int(tj['fabric_bytes_per_launch']), os.path.relpath(files[-1], ROOT) + (' @ ' + tj['commit'] if 'commit' in tj else '')
 
 
 def main():
@@ -93,14 +194,11 @@ def main():
         dist.barrier()
     import nerf4k_amd  # noqa: F401
     from nerf4k_amd import scene, _native
-    from nerf4k_amd.lib import utils, dvgo
+    from nerf4k_amd.lib import utils
 
     _native.lib()
     t0 = time.time()
-    if args.small:
-        ck = scene.make_llff_checkpoint(num_voxels=96 * 96 * 64, mpi_depth=64)
-    else:
-        ck = scene.make_llff_checkpoint()
+    ck = scene.make_llff_checkpoint(num_voxels=96 * 96 * 64, mpi_depth=64) if args.small else scene.make_llff_checkpoint()
     model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
     rk = ck['render_kwargs']
     H, W = scene.LLFF_HW
@@ -108,93 +206,22 @@ def main():
     poses = scene.llff_spiral_poses()
     if rank == 0:
         print(f'[bench] scene ready in {time.time() - t0:.1f}s: world_size={model.world_size.tolist()} '
-              f'k0_ch={model.k0_dim} rays/frame={H * W}', file=sys.stderr)
+              f'k0_ch={model.k0_dim} rays/frame={H * W} dist_world={dist.get_world_size() if world > 1 else 1}', file=sys.stderr)
 
-    # band of pixel rows owned by this rank (multiples of 8 rows -> whole 8x8 wave tiles)
-    from nerf4k_amd import tile_parallel as tp
     by_rows = world > 1 and args.shard == 'rows'
-    r0, r1, rows_per = tp.shard_rows(H, world, rank) if by_rows else (0, H, H)
-    if world > 1 and not by_rows:          # rank r renders frames r, r+N, r+2N, ... of the pose sequence
-        poses = [poses[(rank + i * world) % len(poses)] for i in range(len(poses))]
-    rays = []
-    with torch.no_grad():
-        for p in poses:
-            ro, rd, vd = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False)
-            rays.append(tuple(x[r0:r1].reshape(-1, 3).contiguous() for x in (ro, rd, vd)))
-    n_band = (r1 - r0) * W
-    slot = rows_per * W
-    # all-gather buffers (double buffered): [rgb n x 3 | depth n | alphainv n] -- the marcher writes straight into them
-    send = [torch.zeros([5 * slot], dtype=torch.float32, device=dev) for _ in range(2)]
-    recv = [torch.empty([world * 5 * slot], dtype=torch.float32, device=dev) for _ in range(2)] if by_rows else None
-    outs = [(b[:3 * n_band].view(n_band, 3), b[3 * slot:3 * slot + n_band], b[4 * slot:4 * slot + n_band]) for b in send]
-    works = [None, None]
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream())
-
-    def step(i, counters=None, timed=None):
-        b = i & 1
-        st = streams[i % len(streams)]
-        with torch.cuda.stream(st):
-            if works[b] is not None:
-                works[b].wait()                  # the collective that last read send[b] has finished
-                works[b] = None
-            ro, rd, vd = rays[i % len(rays)]
-            if timed is not None:
-                timed[0].record(st)
-            out = model(ro, rd, vd, k4_img_w=W, k4_counters=counters, k4_out=outs[b], k4_ws_slot=i % len(streams), **rk)
-            if timed is not None:
-                timed[1].record(st)
-            if by_rows:                          # final pixels only; asynchronous, overlaps the next frame's march
-                works[b] = dist.all_gather_into_tensor(recv[b], send[b], async_op=True)
-        return out
-
-    def sync():
-        for b in range(2):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()             # all streams
-
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        sync()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        t_start = time.perf_counter()
-        for i in range(args.steps):
-            step(i, timed=ev[i])
-        sync()
-        elapsed = time.perf_counter() - t_start
-        kern_ms = [a.elapsed_time(b) for a, b in ev]
-
-        # untimed: (a) algorithmic bytes per launch from device counters, (b) ISOLATED launch duration (one stream,
-        # HIP events around each marcher call on the launch stream) -- the figure the rocprofv3 --stats summary
-        # of `bench.py --streams 1` must agree with (geom + shade kernel averages)
-        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
-        nf = min(args.steps, len(rays))
-        iso = []
-        st0 = streams[0]
-        for i in range(nf):
-            with torch.cuda.stream(st0):
-                ro, rd, vd = rays[i % len(rays)]
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(st0)
-                model(ro, rd, vd, k4_img_w=W, k4_counters=None, k4_out=outs[0], k4_ws_slot=0, **rk)
-                e1.record(st0)
-                iso.append((e0, e1))
-                model(ro, rd, vd, k4_img_w=W, k4_counters=cnt, k4_out=outs[0], k4_ws_slot=0, **rk)
-        sync()
-        iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso]))
-        n_inb, n_mask, n_alpha, n_shade = [c / nf for c in cnt.cpu().tolist()]
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    run = MarcherRun(model, poses, rk, H, W, K, dev, world, rank, by_rows, args.streams)
+    elapsed, overlapped_ms = run.run(args.steps, args.warmup)
+    nf = min(args.steps, len(run.rays))
+    iso_ms, (n_inb, n_mask, n_alpha, n_shade) = run.isolated(nf)
+    n_band = run.n_band
+    secondary = None
+    if world > 1 and not args.no_extras:       # the other sharding mode, as a secondary field
+        other = MarcherRun(model, poses, rk, H, W, K, dev, world, rank, not by_rows, args.streams)
+        e2, _ = other.run(args.steps, args.warmup)
+        rays2 = H * W * (1 if not by_rows else world)
+        secondary = {'mode': 'rows+all_gather (strong)' if not by_rows else 'frames of the pose sequence per rank, no collective (weak)',
+                     'value': round(rays2 * args.steps / e2 / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_step': round(e2 / args.steps * 1e3, 4)}
+        del other
 
     if rank == 0:
         rays_per_step = H * W * (1 if (world == 1 or by_rows) else world)     # frames mode: every rank renders a frame per step
@@ -202,11 +229,7 @@ def main():
         eff_ms = elapsed / args.steps * 1e3            # per-frame time of the timed region (frames overlap on the streams)
         b_alg = n_band * 56 + n_inb * 1 + n_mask * 32 + n_shade * 8 * model.k0_dim * 4
         achieved = b_alg / (iso_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None            # HBM-side bytes per launch: PMC passes of this command, committed under profiles/
-        tp_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_marcher_traffic.json')
-        if os.path.exists(tp_) and not args.small:
-            tj = json.load(open(tp_))
-            traffic, traffic_src = int(tj['fabric_bytes_per_launch']), tj['source']
+        traffic, traffic_src = (None, None) if args.small else newest_traffic_profile()
         res = {
             'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
             'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -216,39 +239,36 @@ def main():
                                    '417x353x256 grid, 256 samples/ray, rgbnet 15->64->64->3, marcher only (no SR)'
                                    + (' [REDUCED --small scene]' if args.small else ''),
                        'rays_per_frame': H * W, 'frames': args.steps * (1 if (world == 1 or by_rows) else world),
-                       'streams': len(streams),
+                       'streams': len(run.streams), 'dist_world_size': dist.get_world_size() if world > 1 else 1,
                        'parallelism': ('single GPU' if world == 1 else
-                                       f'row-bands x{world} + all_gather of final pixels' if by_rows else
+                                       f'ONE frame split in {world} row bands + RCCL all_gather of the final pixels' if by_rows else
                                        f'frames of the pose sequence sharded over {world} GPUs (full model replica each, no collective)')},
-            'frames_per_s_lr': round(rays_per_step * args.steps / (H * W) / elapsed, 2),
+            'mrays_isolated': round(n_band / (iso_ms * 1e-3) / 1e6, 3),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>',
-                         'kernel_ms': round(iso_ms, 4),
-                         'kernel_ms_note': 'isolated launch duration (1 stream, HIP events on the launch stream); in the '
-                                           'timed region frames overlap on %d streams: %.4f ms/frame effective = %.1f GB/s '
-                                           'algorithmic' % (len(streams), eff_ms, b_alg / (eff_ms * 1e-3) / 1e9),
-                         'overlapped_launch_ms': round(float(np.mean(kern_ms)), 4),
+                         'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>, isolated (1 stream, HIP events)',
+                         'kernel_ms': round(iso_ms, 4), 'overlapped_launch_ms': round(overlapped_ms, 4),
                          'algorithmic_bytes_per_launch': int(b_alg),
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
                                                 'shaded': int(n_shade)}},
         }
+        if secondary is not None:
+            res['frames_sharded' if by_rows else 'rows_sharded'] = secondary
     four_k = four_k_fp32 = four_k_fast = None
     if args.sr_frames > 0 and not args.small:
-        four_k = four_k_frames(model, poses, rk, H, W, K, dev, args.sr_frames, world, mode='bf16x6')
-        four_k_fp32 = four_k_frames(model, poses, rk, H, W, K, dev, args.sr_frames, world, mode='fp32')
-        four_k_fast = four_k_frames(model, poses, rk, H, W, K, dev, args.sr_frames, world, mode='bf16x3')
+        four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x6',
+                               check=not args.no_cpu_baseline)
+        if not args.no_extras:
+            four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32')
+            four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3')
     if rank == 0:
         if four_k is not None:
             res['four_k'] = four_k
-            res['four_k_fp32mfma'] = four_k_fp32
-            res['four_k_bf16x3'] = four_k_fast
+        if four_k_fp32 is not None:
+            res['four_k_fp32mfma'], res['four_k_bf16x3'] = four_k_fp32, four_k_fast
         if world == 1 and not args.small and not args.no_extras:
-            res['reference_pipeline_baseline'] = reference_pipeline_baseline(model, rays[0], rk)
-            res['reference_pipeline_baseline']['speedup_of_value'] = round(
-                value / res['reference_pipeline_baseline']['value'], 1)
-        if world == 1 and not args.small and not args.no_extras:
-            res['training_step_kernels'] = training_step_kernels(dev, rays[0], model)
+            res['own_staged_pipeline'] = own_staged_pipeline(model, run.rays[0], rk)
+            res['training_step_kernels'] = training_step_kernels(dev, run.rays[0], model)
         if not args.no_cpu_baseline:
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
@@ -259,9 +279,16 @@ def main():
         dist.destroy_process_group()
 
 
-def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world, mode='bf16x6'):
+def _cpu_threads():
+    cores = os.cpu_count() or 1
+    used = min(cores, CPU_THREAD_CAP)
+    torch.set_num_threads(used)
+    return cores, used
+
+
+def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mode='bf16x6', check=False):
     """BASELINE configs[2] (N=1) / configs[3] (N>1): LLFF 4K render_test = march 1008x756 + SFTNet x4 to 4032x3024,
-    reference tile geometry (test_tile=510, tile_pad=10; 189 when more than 4 ranks need tiles), tiles sharded over
+    reference tile geometry (test_tile=510, tile_pad=10; 252 / 189 when 4 / 8 ranks need tiles), tiles sharded over
     the ranks, ONE all-gather of the final HR pixels per frame.  SFTNet weights: seeded default init."""
     from nerf4k_amd.lib import sr_esrnet, dvgo
     from nerf4k_amd import tile_parallel as tp
@@ -270,7 +297,8 @@ def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world, mode='bf16x6'
     net.k4_mode = mode
     tile = {1: 510, 2: 510, 4: 252}.get(world, 189)       # balanced tile counts: 4 / 4 / 12 / 24 tiles
     flop_per_px = 10377728
-    px = sum((t[5] - t[4]) * (t[7] - t[6]) for t in tp.tile_geometry(H, W, tile, 10))
+    tiles = tp.tile_geometry(H, W, tile, 10)
+    px = sum((t[5] - t[4]) * (t[7] - t[6]) for t in tiles)
     march_fn, sr_fn = tp.hip_march_fn(model, rk), tp.hip_sr_fn(net)
     frames = []
     with torch.no_grad():
@@ -295,25 +323,99 @@ def four_k_frames(model, poses, rk, H, W, K, dev, n_frames, world, mode='bf16x6'
     base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'n_gpus': world, 'test_tile': tile,
             'effective_tflops': round(tflops, 2)}
     if mode == 'bf16x3':
-        base['arithmetic'] = ('SR convs: 2-term bf16 splits, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; opt-in '
-                              '(K4_SR_MODE=bf16x3), >= 75 dB vs the fp32 oracle (tests/test_sr_gpu.py)')
+        base['arithmetic'] = 'SR convs: 2-term bf16 splits, 3 MFMA products (opt-in K4_SR_MODE=bf16x3, >= 75 dB vs the fp32 oracle)'
         return base
     if mode == 'fp32':
-        base['arithmetic'] = 'SR convs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains; K4_SR_MODE=fp32); peak 157.3 TFLOP/s'
+        base['arithmetic'] = 'SR convs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains; K4_SR_MODE=fp32)'
         base['frac_of_fp32_mfma_peak'] = round(tflops / (157.3 * world), 4)
         return base
     peak = 2500.0 / 6 * world
     base.update({
-        'output': list(hr.shape),
+        'output': list(hr.shape), 'scaling': 'strong',
         'workload': ('configs[2]' if world == 1 else 'configs[3]') + ': march 1008x756 + SFTNet x4 tile_process('
-                    f'{tile}, pad 10) -> 4032x3024' + (f', tiles sharded over {world} GPUs + all-gather of HR pixels' if world > 1 else ''),
+                    f'{tile}, pad 10) -> 4032x3024' + (f', tiles of ONE frame sharded over {world} GPUs + RCCL all_gather of HR pixels' if world > 1 else ''),
         'arithmetic': 'marcher fp32; SR convs: exact 3-term bf16 splits, 6 of 9 partial products on v_mfma_f32_32x32x16_bf16, '
-                      'fp32 accumulation = fp32-equivalent (dropped terms <= 2^-23 per product; >= 115 dB vs the fp32 oracle)',
+                      'fp32 accumulation (fp32-equivalent, dropped terms <= 2^-23 per product)',
         'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
                         'frac': round(tflops / peak, 4), 'flop_per_frame': flop_per_px * px,
-                        'note': 'peak = 2.5 PFLOP/s dense bf16 MFMA / 6 matrix instructions per fp32-equivalent product, x n_gpus; '
-                                'time includes the marcher, layout copies and the all-gather'}})
+                        'note': 'peak = 2.5 PFLOP/s dense bf16 / 6 MFMA per fp32-equivalent product x n_gpus; time includes the '
+                                'marcher, layout copies and the all-gather'}})
+    if world == 1:                               # rank 0's share of the 8-GPU job (3 tiles of tile_size 189), timed on this GPU
+        t189 = tp.tile_geometry(H, W, 189, 10)
+        mine = tp.assign_tiles(t189, 8)[0]
+        sub = _SubsetGeometry(t189, mine)
+        with torch.no_grad():
+            sub.render(frames[0], march_fn, sr_fn)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                sub.render(frames[0], march_fn, sr_fn)
+            torch.cuda.synchronize()
+        share = (time.perf_counter() - t) / 3
+        base['rank_share_8gpu'] = {'ms': round(share * 1e3, 2), 'tiles': len(mine), 'tile_size': 189,
+                                   'projected_speedup_before_gather': round(dt / share, 2)}
+    if check and rank == 0:
+        base.update(four_k_parity_and_cpu(ck, net, poses[(n_frames - 1) % len(frames)], hr, tiles, H, W))
     return base
+
+
+class _SubsetGeometry:
+    """March + decode a subset of tiles on the caller's GPU exactly as tile_parallel does for one rank (no gather)."""
+
+    def __init__(self, tiles, mine):
+        self.tiles = [tiles[i] for i in mine]
+
+    def render(self, rays, march_fn, sr_fn):
+        from nerf4k_amd import tile_parallel as tp
+        dev = rays[0].device
+        pool = tp._stream_pool(dev, min(4, len(self.tiles)))
+        cur = torch.cuda.current_stream(dev)
+        for st in pool:
+            st.wait_stream(cur)
+        outs = []
+        for j, (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in enumerate(self.tiles):
+            with torch.cuda.stream(pool[j % len(pool)]):
+                ro, rd, vd = [r[yp0:yp1, xp0:xp1].reshape(-1, 3).contiguous() for r in rays]
+                rgb, depth = march_fn(ro, rd, vd, xp1 - xp0, slot=j % len(pool))
+                hh, ww = yp1 - yp0, xp1 - xp0
+                outs.append(sr_fn(rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0), depth.reshape(1, 1, hh, ww), slot=j % len(pool)))
+        for st in pool:
+            cur.wait_stream(st)
+        return outs
+
+
+def four_k_parity_and_cpu(ck, net, pose, hr, tiles, H, W):
+    """The oracle as CHECKER of the 4K path and as its CPU baseline, on a bounded sample: the smallest tile window of the frame
+    is marched and decoded by oracle/marcher.py + oracle/sr.py (CPU) and compared with the HIP frame's pixels of that tile."""
+    from oracle import marcher, sr as osr
+    from nerf4k_amd import scene
+    cores, used = _cpu_threads()
+    i = min(range(len(tiles)), key=lambda q: (tiles[q][5] - tiles[q][4]) * (tiles[q][7] - tiles[q][6]))
+    y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
+    hh, ww = yp1 - yp0, xp1 - xp0
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
+    win = [r[yp0:yp1, xp0:xp1].reshape(-1, 3).contiguous() for r in (ro, rd, vd)]
+    t = time.perf_counter()
+    o = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], *win, **dict(ck['render_kwargs'], render_depth=True))
+    t_march = time.perf_counter() - t
+    t = time.perf_counter()
+    want = osr.sftnet_forward(sd, o['rgb_feature'].reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0), o['depth'].reshape(1, 1, hh, ww))
+    t_sr = time.perf_counter() - t
+    s = 4
+    oy, ox = (y0 - yp0) * s, (x0 - xp0) * s
+    want = want[0, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+    got = hr[0, :, y0 * s:y1 * s, x0 * s:x1 * s].cpu()
+    d = (got.double() - want.double())
+    mse = float((d ** 2).mean())
+    px_all = sum((q[5] - q[4]) * (q[7] - q[6]) for q in tiles)
+    frac = hh * ww / px_all
+    return {'psnr_vs_oracle_db': round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1), 'max_abs_vs_oracle': float(d.abs().max()),
+            'parity_sample': f'tile {i} of {len(tiles)} ({ww}x{hh} LR window -> {(x1 - x0) * s}x{(y1 - y0) * s} HR pixels), oracle march + SFTNet on the CPU',
+            'cpu_baseline': {'value': round(frac / (t_march + t_sr), 5), 'unit': '4K frames/s', 'cores': cores, 'threads_used': used,
+                             'kind': 'port',
+                             'sample': f'that window = {frac:.3f} of the frame\'s padded LR pixels: {t_march:.1f}s march + {t_sr:.1f}s SFTNet on the '
+                                       f'CPU, extrapolated to the frame; torch {torch.__version__} CPU kernels'}}
 
 
 def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
@@ -345,48 +447,46 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
         torch.cuda.synchronize()
         return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
-    out = {'grid': list(shape), 'voxels': n}
+    out = {'grid': list(shape)}
     for name, fn, bpe in (
             ('adam_upd', lambda: MA.adam_upd(p, g, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 28.0),
             ('masked_adam_upd_1pct', lambda: MA.masked_adam_upd(p, gs, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 4.0 + 24.0 * frac_touched),
-            ('total_variation_add_grad_dense', lambda: G.total_variation_add_grad(p, g, 1e-3, 1e-3, 1e-3, True), 12.0),
-            ('total_variation_add_grad_sparse_1pct', lambda: G.total_variation_add_grad(p, gs, 1e-3, 1e-3, 1e-3, False), 4.0 + 8.0 * frac_touched)):
+            ('tv_add_grad_dense', lambda: G.total_variation_add_grad(p, g, 1e-3, 1e-3, 1e-3, True), 12.0),
+            ('tv_add_grad_sparse_1pct', lambda: G.total_variation_add_grad(p, gs, 1e-3, 1e-3, 1e-3, False), 4.0 + 8.0 * frac_touched)):
         ms = timed(fn)
         gbs = n * bpe / (ms * 1e-3) / 1e9
-        out[name] = {'ms': round(ms, 3), 'algorithmic_bytes_per_voxel': round(bpe, 2), 'achieved_GBs': round(gbs, 1),
-                     'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
+        out[name] = {'ms': round(ms, 3), 'B_per_voxel': round(bpe, 2), 'GBs': round(gbs, 1), 'frac_hbm': round(gbs / HBM_PEAK_GBS, 3)}
     # marcher backward scatter (8f rank 1): d(DenseGrid lookup)/d(grid) for one training batch of 8192 rays x 256 samples,
-    # 12 channels, fp32 hardware atomics into the same grid; bytes = grad_out + xyz read + 8 corners x 12 ch x 4 B RMW
+    # 12 channels, into the same grid; bytes = grad_out + xyz read + 8 corners x 12 ch x 4 B RMW
     npts = 8192 * 256
-    pts = torch.rand([npts, 3], device=dev, generator=gen) * 2 - 1
     gout = torch.randn([npts, 12], device=dev, generator=gen)
-    mn, mx = torch.tensor([-1., -1., -1.], device=dev), torch.tensor([1., 1., 1.], device=dev)
     from nerf4k_amd import _native as N_
-    ms = timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
-                                                                    npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
     bpp = 12 * 4 + 12 + 8 * 12 * 4 * 2
-    out['grid_sample_3d_backward_2M_random_points'] = {'ms': round(ms, 3), 'Mpoints_per_s': round(npts / ms / 1e3, 1),
-                                                       'algorithmic_bytes_per_point': bpp,
-                                                       'achieved_GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
+
+    def scatter(pts, mn, mx):
+        g.zero_()
+        return timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
+                                                                          npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
+    pts = torch.rand([npts, 3], device=dev, generator=gen) * 2 - 1
+    one = torch.tensor([1., 1., 1.], device=dev)
+    ms = scatter(pts, -one, one)
+    out['grid_sample_bwd_2M_random_points'] = {'ms': round(ms, 3), 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
     if frame_rays is not None and model is not None:
         # the coherent case: 8192 rays of the frame x 256 NDC samples each (what a training batch scatters)
         ro, rd = frame_rays[0][:8192], frame_rays[1][:8192]
         t = torch.linspace(0, 1, 256, device=dev)
         pts = (ro[:, None, :] + rd[:, None, :] * t[None, :, None]).reshape(-1, 3).contiguous()
-        mn, mx = model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous()
-        ms = timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
-                                                                        npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
-        out['grid_sample_3d_backward_8192_rays_x_256'] = {'ms': round(ms, 3), 'Mpoints_per_s': round(npts / ms / 1e3, 1),
-                                                          'achieved_GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
+        ms = scatter(pts, model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous())
+        out['grid_sample_bwd_8192_rays_x_256'] = {'ms': round(ms, 3), 'B_per_point': bpp, 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
     return out
 
 
-def reference_pipeline_baseline(model, rays, rk, chunk=8192, frames=2):
-    """the REFERENCE's pipeline structure on this MI355X -- 8192-ray chunks (run_sr.py:121-124), one
-    launch per op (sampler, maskcache_lookup, grid_sample, raw2alpha, alpha2weight, segment sum: the staged gfx950
-    kernels of this package; rgbnet on rocBLAS), boolean-mask compactions with their host syncs, exactly the op
-    sequence of lib/dmpigo.py:300-427.  It is what `k4_staged=True` runs; same outputs as the fused path."""
+def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):
+    """The reference's pipeline STRUCTURE on this MI355X -- 8192-ray chunks (run_sr.py:121-124), one launch per op, boolean-mask
+    compactions with their host syncs, the op sequence of lib/dmpigo.py:300-427 -- on THIS package's staged gfx950 kernels
+    (`k4_staged=True`; rgbnet on rocBLAS).  Context only: it is our own slow path, not the reference's kernels."""
     ro, rd, vd = rays
+
     def frame():
         outs = [model(a, b, c, k4_staged=True, **rk) for a, b, c in zip(ro.split(chunk, 0), rd.split(chunk, 0), vd.split(chunk, 0))]
         return torch.cat([o['rgb_marched'] for o in outs])
@@ -399,7 +499,7 @@ def reference_pipeline_baseline(model, rays, rk, chunk=8192, frames=2):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / frames
     return {'value': round(ro.shape[0] / dt / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(dt * 1e3, 2),
-            'what': 'reference op sequence, per-op launches, 8192-ray chunks, on the same GPU (k4_staged=True)'}
+            'what': 'reference op sequence, per-op launches of our own staged kernels, 8192-ray chunks, same GPU'}
 
 
 def cpu_baseline(ck, pose, stride, model=None):
@@ -407,8 +507,7 @@ def cpu_baseline(ck, pose, stride, model=None):
     from oracle import marcher
     from nerf4k_amd import scene
     H, W = scene.LLFF_HW
-    cores = min(os.cpu_count() or 1, 32)       # torch CPU kernels stop scaling (and thrash) far below 256 threads
-    torch.set_num_threads(cores)
+    cores, used = _cpu_threads()
     ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
     sel = (slice(None, None, stride), slice(None, None, stride))
     ro, rd, vd = [x[sel].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
@@ -417,7 +516,7 @@ def cpu_baseline(ck, pose, stride, model=None):
     t = time.perf_counter()
     want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
     dt = time.perf_counter() - t
-    base = {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
+    base = {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'threads_used': used, 'kind': 'port',
             'sample': f'{len(ro)} rays = every {stride}th row and column of one 1008x756 frame, 8192-ray chunks '
                       f'as run_sr.py:121-124, {dt:.1f}s of CPU work, torch {torch.__version__} CPU kernels'}
     parity = None
@@ -433,7 +532,7 @@ def cpu_baseline(ck, pose, stride, model=None):
                   'max_abs_rgb': float(d.abs().max()),
                   'max_abs_depth': float((got['depth'].cpu().double() - want['depth'].double()).abs().max()),
                   'max_abs_alphainv': float((got['alphainv_last'].cpu().double() - want['alphainv_last'].double()).abs().max()),
-                  'what': 'HIP fused marcher vs the CPU oracle on the same rays (the frame timed for cpu_baseline)'}
+                  'what': 'HIP fused marcher vs the CPU oracle on the frame timed for cpu_baseline'}
     return base, parity
 
 

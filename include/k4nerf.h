@@ -20,7 +20,8 @@
  *   - the last argument is the HIP stream to launch on (`hipStream_t` passed as void*); the
  *     reference launches on the legacy default stream (render_utils_kernel.cu:93,230,283...).
  *   - all floating point is fp32; index tensors are int64 as in the reference.
- *   - thread-safe / re-entrant: no globals.
+ *   - thread-safe / re-entrant: no mutable globals (experiment knobs are environment variables read once at load time;
+ *     per-device facts such as the CU count are cached in write-once tables).
  */
 #ifndef K4NERF_H
 #define K4NERF_H
@@ -35,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      1
+#define K4_ABI_VERSION      2       /* 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -83,7 +84,10 @@ typedef struct k4_mlp_desc {
     int32_t viewbase_pe;             /* #frequencies 2^0..2^(n-1) on viewdirs                            */
     int32_t spatial_pe;              /* MPI only: #frequencies on the normalised position                */
     int32_t k0_skip;                 /* DVGO rgbnet_direct=False: 3 (first 3 k0 channels are added to the logits, lib/dvgo.py:385-386,412), else 0 */
+    int32_t arith;                   /* K4_MLP_ARITH_*: matrix-pipe arithmetic of the rgbnet                */
 } k4_mlp_desc;
+#define K4_MLP_ARITH_DEFAULT 0      /* width <= 64: exact 3-term bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-equivalent); else fp32 */
+#define K4_MLP_ARITH_FP32    1      /* v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains (2.7x the matrix-pipe time)                  */
 int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden);   /* <0: unsupported shape */
 
 /* ---------------------------------------------------------------------------------------------
