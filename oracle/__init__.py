@@ -14,8 +14,10 @@ Parity pin status (see DESIGN.md "Oracle"):
     ``DenseGrid`` / ``MaskGrid`` / ``get_rays_of_a_view`` executed in the build
     container with their three un-importable dependencies stubbed
     (``oracle/ref_import.py``); golden vectors in ``tests/golden/march_*.npz``.
-  * The 13 native CUDA entry points (``oracle/native_cpu.py``): the reference ships
-    no CPU path, no tests and no golden vectors for them and its ``.cu`` sources
-    cannot be compiled without nvcc / source rewriting -- this layer is a
-    restatement and is "parity unpinned" by the reference itself.
+  * The 13 native CUDA entry points (``oracle/native_cpu.py``) and the optimizer / TV
+    kernels (``oracle/optim.py``): pinned against the reference's own ``lib/cuda``
+    sources compiled for gfx950 (``oracle/build_ref.py`` -> ``oracle/_ref/*.so``, test-only,
+    git-ignored) and run on an MI355X (``oracle/gen_native_golden.py``); vectors in
+    ``tests/golden/native_*.npz`` / ``optim_ref.npz``.  ``native_march_*.npz`` re-evaluate the
+    march fixtures with those compiled kernels serving every native step.
 """

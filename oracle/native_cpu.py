@@ -11,8 +11,13 @@ nvcc contracts ``a*b+c`` into one FMA by default (``-fmad=true``); the kernels'
 that through fp64 (the 24x24-bit product is exact in fp64; the residual
 double-rounding case has probability ~2^-29 per op).
 
-PARITY UNPINNED by the reference: it has no CPU path, tests or golden vectors for
-these kernels.
+Pin: the reference ships no CPU path, tests or golden vectors for these kernels (SURVEY.md
+section 4 / 8c), so the pin is made from the reference ITSELF: its ``lib/cuda/render_utils*.cu|.cpp``
+are compiled for gfx950 by ``oracle/build_ref.py`` (-> ``oracle/_ref/``, the same
+``torch.utils.cpp_extension.load`` call the reference makes), run on an MI355X by
+``oracle/gen_native_golden.py`` and the outputs committed as ``tests/golden/native_*.npz``;
+``tests/test_oracle_golden.py::test_native_cpu_matches_reference_compiled_kernels`` holds this file to
+them (integer / boolean outputs and the transmittance scan bit-exact, a few ulp elsewhere).
 """
 import torch
 

@@ -11,8 +11,9 @@ nvcc contracts ``a*b + c`` to one FMA; the products of two floats are exact in f
 ``float32(float64(a)*float64(b) + float64(c))`` (double rounding can differ from a true FMA in the last bit with
 probability ~2^-29 per op; the tests use a 2-ulp tolerance).
 
-Pinning: the reference holds no golden vectors for these ops.  tests/test_optim_oracle.py pins the restatement against
-independent PyTorch formulations: torch.optim.Adam (identical up to where eps enters the denominator, so compared with
+Pinning: tests/golden/optim_ref.npz holds outputs of the reference's own adam_upd_cuda / total_variation_cuda extensions compiled
+for gfx950 (oracle/build_ref.py) and run on an MI355X (oracle/gen_native_golden.py); tests/test_oracle_golden.py checks this file
+against them.  tests/test_optim_oracle.py additionally pins the restatement against independent PyTorch formulations: torch.optim.Adam (identical up to where eps enters the denominator, so compared with
 eps -> 0) and autograd of a Huber (smooth-L1, beta=1) neighbour loss whose gradient the TV kernel is.
 """
 import numpy as np

@@ -28,3 +28,96 @@ def load_march_golden(name):
 def psnr(a, b):
     mse = float(((a.double() - b.double()) ** 2).mean())
     return 200.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reference-made vectors of the native kernels (tests/golden/native_*.npz, optim_ref.npz): outputs of the reference's OWN
+# lib/cuda/*.cu compiled for gfx950 (oracle/build_ref.py) and run on an MI355X (oracle/gen_native_golden.py).
+# Contract: integer / boolean outputs and everything that feeds a mask decision are BIT-EXACT; floating-point values that pass
+# through compiler-chosen FMA contraction, division or libm (the reference was built with hipcc's defaults, nvcc would choose
+# its own) agree to a few ulp -- the tolerance of each key is spelled out below.
+# ---------------------------------------------------------------------------------------------------------------------
+NATIVE_EXACT = ['t_min', 't_max', 'n_samples', 'rays_start', 'aabb/mask_outbbox', 'aabb/ray_id', 'aabb/step_id', 'aabb/N_steps',
+                'aabb/sp_t_min', 'aabb/sp_t_max', 'ndc37/pts', 'ndc37/mask_outbbox', 'ndc256/pts', 'ndc256/mask_outbbox', 'mask/hit',
+                'a2w/weight', 'a2w/T', 'a2w/alphainv_last', 'a2w/i_start', 'a2w/i_end']
+NATIVE_TOL = {  # key -> (atol, rtol)
+    'rays_dir': (2.5e-7, 0.0),                 # d / |d|: 2 ulp (contraction of dx*dx+dy*dy+dz*dz is the compiler's choice)
+    'aabb/pts': (6e-7, 0.0),                   # start + dir * (stepdist * k) with that dir
+    'r2a_a/exp': (0.0, 1.3e-7), 'r2a_b/exp': (0.0, 1.3e-7), 'r2a_c/exp': (0.0, 1.3e-7), 'r2a_nonuni/exp': (0.0, 1.3e-7),   # expf: 1 ulp
+    'r2a_a/alpha': (2.4e-7, 0.0), 'r2a_b/alpha': (2.4e-7, 0.0), 'r2a_c/alpha': (2.4e-7, 0.0), 'r2a_nonuni/alpha': (2.4e-7, 0.0),
+    'r2a_a/grad': (2.4e-7, 1e-6), 'r2a_b/grad': (2.4e-7, 1e-6), 'r2a_c/grad': (2.4e-7, 1e-6), 'r2a_nonuni/grad': (2.4e-7, 1e-6),
+    'a2w/grad': (1e-6, 1e-5),                  # reverse scan with a division by (1 - alpha + 1e-10)
+}
+
+
+def load_native_golden():
+    out = {}
+    for name in ('native_sampler', 'native_mask', 'native_alpha'):
+        z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+        out[name] = {k: z[k] for k in z.files}
+    return out
+
+
+def replay_native(impl, G, device):
+    """Feed the fixtures' inputs to `impl` (an object with the 13 render_utils_cuda entry points) -> {key: numpy array}."""
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    N_ = lambda v: v.detach().cpu().numpy()
+    S, M, A = G['native_sampler'], G['native_mask'], G['native_alpha']
+    near, far, sd = float(S['in/near']), float(S['in/far']), float(S['in/stepdist'])
+    ro, rd, lo, hi = T(S['in/rays_o']), T(S['in/rays_d']), T(S['in/xyz_min']), T(S['in/xyz_max'])
+    r = {}
+    t_min, t_max = impl.infer_t_minmax(ro, rd, lo, hi, near, far)
+    r['t_min'], r['t_max'] = N_(t_min), N_(t_max)
+    r['n_samples'] = N_(impl.infer_n_samples(rd, T(S['t_min']), T(S['t_max']), sd))
+    st, di = impl.infer_ray_start_dir(ro, rd, T(S['t_min']))
+    r['rays_start'], r['rays_dir'] = N_(st), N_(di)
+    for k, v in zip(['pts', 'mask_outbbox', 'ray_id', 'step_id', 'N_steps', 'sp_t_min', 'sp_t_max'],
+                    impl.sample_pts_on_rays(ro, rd, lo, hi, near, far, sd)):
+        r['aabb/' + k] = N_(v)
+    for ns in (37, 256):
+        pts, m = impl.sample_ndc_pts_on_rays(T(S['in/ndc_o']), T(S['in/ndc_d']), lo, hi, ns)
+        r[f'ndc{ns}/pts'], r[f'ndc{ns}/mask_outbbox'] = N_(pts), N_(m)
+    r['mask/hit'] = N_(impl.maskcache_lookup(T(M['in/world']), T(M['in/xyz']), T(M['in/scale']), T(M['in/shift'])))
+    d, gb = T(A['in/density']), T(A['in/grad_back'])
+    for tag in ('a', 'b', 'c'):
+        sh, iv = float(A[f'r2a_{tag}/shift']), float(A[f'r2a_{tag}/interval'])
+        e, a = impl.raw2alpha(d, sh, iv)
+        r[f'r2a_{tag}/exp'], r[f'r2a_{tag}/alpha'] = N_(e), N_(a)
+        r[f'r2a_{tag}/grad'] = N_(impl.raw2alpha_backward(T(A[f'r2a_{tag}/exp']), gb, iv))
+    ipp = T(A['in/interval_pp'])
+    e, a = impl.raw2alpha_nonuni(d, -2.0, ipp)
+    r['r2a_nonuni/exp'], r['r2a_nonuni/alpha'] = N_(e), N_(a)
+    r['r2a_nonuni/grad'] = N_(impl.raw2alpha_nonuni_backward(T(A['r2a_nonuni/exp']), gb, ipp))
+    al, rid, nr = T(A['in/alpha']), T(A['in/ray_id']), int(A['in/n_rays'])
+    for k, v in zip(('weight', 'T', 'alphainv_last', 'i_start', 'i_end'), impl.alpha2weight(al, rid, nr)):
+        r['a2w/' + k] = N_(v)
+    r['a2w/grad'] = N_(impl.alpha2weight_backward(al, T(A['a2w/weight']), T(A['a2w/T']), T(A['a2w/alphainv_last']), T(A['a2w/i_start']),
+                                                  T(A['a2w/i_end']), nr, T(A['in/grad_weights']), T(A['in/grad_last'])))
+    return r
+
+
+def native_reference_value(G, key):
+    if key == 'mask/hit':
+        return G['native_mask']['hit']
+    for name in ('native_sampler', 'native_alpha'):
+        if key in G[name]:
+            return G[name][key]
+    raise KeyError(key)
+
+
+def check_native(got, G, what):
+    """Assert the replayed outputs against the reference-made values with the tolerances of NATIVE_EXACT / NATIVE_TOL."""
+    assert set(got) == set(NATIVE_EXACT) | set(NATIVE_TOL), sorted(set(got) ^ (set(NATIVE_EXACT) | set(NATIVE_TOL)))
+    for key in NATIVE_EXACT:
+        want = native_reference_value(G, key)
+        assert got[key].shape == want.shape, (what, key, got[key].shape, want.shape)
+        assert np.array_equal(got[key], want, equal_nan=True), (what, key, 'must be bit-exact', int((got[key] != want).sum()))
+    for key, (atol, rtol) in NATIVE_TOL.items():
+        want = native_reference_value(G, key)
+        g = got[key]
+        assert g.shape == want.shape, (what, key)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(g), fin) and np.array_equal(g[~fin], want[~fin], equal_nan=True), (what, key, 'non-finite pattern')
+        err = np.abs(g[fin].astype(np.float64) - want[fin].astype(np.float64))
+        bound = atol + rtol * np.abs(want[fin].astype(np.float64))
+        assert (err <= bound).all(), (what, key, float(err.max()), float((err - bound).max()))

@@ -37,6 +37,13 @@ def _close(got, want, min_psnr=90.0, tol=1e-4, frac=0.999):
     return p
 
 
+def _assert_same_frame(single, tiled):
+    """Whole-frame march -> tile_process_device against per-window marches.  Every per-sample value is independent of how rays
+    are grouped; the per-ray accumulation in the shading kernel is carried in fp64 (one rounding to fp32 at the end), which makes
+    the marched colours -- and therefore the decoded pixels -- independent of the grouping: exact equality."""
+    assert torch.equal(single, tiled), float((single - tiled).abs().max())
+
+
 def _small_scene():
     ck = scene.make_llff_checkpoint(seed=11, num_voxels=48 * 48 * 32, mpi_depth=32)
     H, W = 44, 60
@@ -80,7 +87,7 @@ def test_tile_parallel_hip_path_vs_oracle(tile, n_tiles, monkeypatch):
     res = render.render_frame(model, H, W, K, pose, True, ck['render_kwargs'])
     img = res['rgb_feature'].permute(2, 0, 1).unsqueeze(0).contiguous()
     single = net.tile_process_device(img, res['depth'].unsqueeze(0), tile)
-    assert torch.equal(single, got), float((single - got).abs().max())
+    _assert_same_frame(single, got)
 
 
 @pytest.fixture(scope='module')
@@ -126,13 +133,15 @@ def test_full_frame_tile_parallel_equals_tile_process_device(full_scene):
     got = tp.render_frame_tiles(rays, H, W, tp.hip_march_fn(model, ck['render_kwargs']), tp.hip_sr_fn(net), 510)
     res = render.render_frame(model, H, W, scene.LLFF_K, pose, True, ck['render_kwargs'], rays=rays)
     single = net.tile_process_device(res['rgb_feature'].permute(2, 0, 1).unsqueeze(0).contiguous(), res['depth'].unsqueeze(0), 510)
-    assert got.shape == (1, 3, 3024, 4032) and torch.equal(got, single)
+    assert got.shape == (1, 3, 3024, 4032)
+    _assert_same_frame(single, got)
 
 
 def test_render_viewpoints_contract():
     """run_sr.py:75-182: return tuple (rgbs, depths, bgmaps, psnrs, viewdirs_all, rgb_features), shapes, clamped rgb vs UNclamped
     feature (:130-131), psnr against gt, render_factor, flipy / rot90, values against the oracle."""
     ck, H, W, K, _ = _small_scene()
+    ck['model_state_dict']['density.grid'] -= 4.0                       # thin the scene: ~20 % of the rays keep alphainv_last > 0.3
     model = utils.model_from_checkpoint_dict(ck).cuda().eval()
     poses = scene.llff_spiral_poses()[[2, 9]]
     rk = dict(ck['render_kwargs'], bg=1.5, render_depth=True)           # bg > 1: marched colours leave [0,1] where rays escape

@@ -168,3 +168,28 @@ def test_full_size_llff_grid_properties():
     MA.adam_upd(p, grad, m, v, 1, 0.9, 0.99, 0.1, 1e-8)
     MA.masked_adam_upd(p2, grad, m2, v2, 1, 0.9, 0.99, 0.1, 1e-8)
     assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+
+
+def test_optimizer_kernels_vs_reference_compiled_kernels():
+    """k4_opt.hip against tests/golden/optim_ref.npz = the reference's adam_upd_cuda / total_variation_cuda compiled for gfx950 and
+    run on an MI355X (oracle/gen_native_golden.py).  Same compiler family on both sides: atol 5e-7 covers contraction order."""
+    import json
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'optim_ref.npz'))
+    hyp = json.loads(str(z['hyper_json']))
+    args = (hyp['beta1'], hyp['beta2'], hyp['lr'], hyp['eps'])
+    T = lambda k: torch.from_numpy(z[k].copy()).cuda()
+    for name in ('adam_upd', 'masked_adam_upd', 'adam_upd_with_perlr'):
+        for step in (1, 7):
+            p, g, m, v = T('in/param'), T('in/grad'), T('in/exp_avg'), T('in/exp_avg_sq')
+            if name == 'adam_upd_with_perlr':
+                MA.adam_upd_with_perlr(p, g, m, v, T('in/perlr'), step, *args)
+            else:
+                getattr(MA, name)(p, g, m, v, step, *args)
+            for got, key in ((p, 'param'), (m, 'exp_avg'), (v, 'exp_avg_sq')):
+                np.testing.assert_allclose(got.cpu().numpy(), z[f'{name}/{step}/{key}'], rtol=0, atol=5e-7, err_msg=f'{name}/{step}/{key}')
+    for dense in (True, False):
+        p, g = T('in/param'), T('in/grad')
+        G.total_variation_add_grad(p, g, 0.3, 0.2, 0.7, dense)
+        np.testing.assert_allclose(g.cpu().numpy(), z[f'tv/{"dense" if dense else "sparse"}/grad'], rtol=0, atol=5e-7)
