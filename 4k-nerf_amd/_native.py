@@ -23,7 +23,7 @@ class GridDesc(C.Structure):
                 ('dims', C.c_int32 * 3), ('k0_ch', C.c_int32), ('k0_cpad', C.c_int32), ('k0_layout', C.c_int32),
                 ('act_depth', C.c_int32), ('mask_dims', C.c_int32 * 3),
                 ('xyz_min', C.c_float * 3), ('xyz_max', C.c_float * 3),
-                ('xyz2ijk_scale', C.c_float * 3), ('xyz2ijk_shift', C.c_float * 3)]
+                ('xyz2ijk_scale', C.c_float * 3), ('xyz2ijk_shift', C.c_float * 3), ('occ_summary', C.c_void_p)]
 
 
 class MlpDesc(C.Structure):
@@ -105,6 +105,8 @@ _EXTRA_SIGS = {
                                _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
+    'k4_occupancy_summary_bytes': ([_I32, _I32, _I32], C.c_int64),
+    'k4_build_occupancy_summary': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
 }
 
 

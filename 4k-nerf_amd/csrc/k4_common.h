@@ -28,8 +28,11 @@ __device__ __forceinline__ int k4_run_id(int key, int lane) {
     return __popcll(heads & (~0ull >> (63 - lane)));
 }
 
-// LDS float accumulate (ds_add_f32, no return value)
+// LDS accumulate (ds_add_f32 / ds_add_f64, no return value)
 __device__ __forceinline__ void k4_lds_add(float* p, float v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void k4_lds_add(double* p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -75,6 +78,16 @@ __device__ __forceinline__ float k4_unnorm(float n, int size) {
     return ((n + 1.f) / 2.f) * (float)(size - 1);
 }
 
+// Same, with the logical range cut in bands of `band` blocks dealt round-robin to the XCDs (band r*8+x -> XCD x): every XCD gets a
+// sample of the whole range instead of one contiguous eighth (load balance) while `band` consecutive blocks still share an L2.
+__device__ __forceinline__ int k4_xcd_remap_banded(int b, int nwg, int band) {
+    if (band <= 0) return k4_xcd_remap(b, nwg);
+    const int full = nwg / (8 * band) * (8 * band);
+    if (b >= full) return full + k4_xcd_remap(b - full, nwg - full);
+    const int xcd = b & 7, idx = b >> 3;
+    return ((idx / band) * 8 + xcd) * band + idx % band;
+}
+
 // The 8 trilinear corner weights in PyTorch's naming/order (tnw,tne,tsw,tse,bnw,bne,bsw,bse) with
 // torch's ix<->our z (W axis), iy<->y (H), iz<->x (D):  t/b = x lo/hi, n/s = y lo/hi, w/e = z lo/hi.
 struct K4Tri {
@@ -107,7 +120,7 @@ static inline int k4_check_launch() {
 // constant in k4_march.hip); launches never call getenv.  Per-device facts (CU count, "dynamic LDS attribute already raised
 // for kernel F") are cached in fixed arrays indexed by the HIP device ordinal; concurrent first calls write the same values.
 struct K4Env {
-    int geom_split;      // K4_GEOM_SPLIT   (1) 0: one wave per bundle, all depths (baseline of profiles/r01_final_pmc.md)
+    int geom_occ;        // K4_GEOM_OCC     (5) waves per SIMD the geometry kernel's register allocation is bounded for (5 | 6)
     int geom_ldspad;     // K4_GEOM_LDSPAD  (0) extra dynamic LDS bytes for the geometry kernel (occupancy experiments)
     int geom_skip;       // K4_GEOM_SKIP    (1) 0: do not use the coarse occupancy summary (A/B of the empty-space skipping)
     int shade_grid_wg;   // K4_SHADE_GRID_WG    persistent shading workgroups per CU
@@ -115,6 +128,7 @@ struct K4Env {
     int serp;            // K4_SERP         (1) serpentine ray order inside an 8x8 tile
     int b6_nw1;          // K4_B6_NW1       (8) waves per workgroup of the 32-output-channel bf16x6 convolution
     int sr_variant;      // K4_SR_VARIANT   (0) experiment selector of the decoder kernels
+    int geom_band;       // K4_GEOM_BAND    (1) rows of workgroup tiles per XCD band of the geometry kernel (0: one contiguous band per XCD)
 };
 const K4Env& k4_env();
 #define K4_MAX_DEVICES 64

@@ -10,7 +10,7 @@
 //   (lib/dmpigo.py:336-379, lib/dvgo.py:372-412) -> sum_w rgb, sum_w s, alphainv_last*bg
 //   (lib/dmpigo.py:382-398,418-424).
 //
-// K1  k4_geom2_kernel  (VALU-issue / latency bound; HBM traffic ~0.2 GB per frame)
+// K1  k4_geom3_kernel  (VALU-issue / latency bound; HBM traffic ~0.2 GB per frame)
 //     a WORKGROUP owns a bundle of 64 rays (an 8x8 pixel tile when the caller says the rays are an image, else 64
 //     consecutive rays; workgroups are XCD-banded so neighbouring tiles share an L2); its 4 waves take one depth quarter of
 //     every ray each and walk ONE ray at a time with lanes = 64 consecutive samples.  NDC/MPI rays advance mostly along Z,
@@ -44,6 +44,7 @@ struct MarchParams {
     const float* rays_o; const float* rays_d; const float* viewdirs;
     int n_rays; int img_w; int img_h;
     const float* density; const float* k0; const float* act_shift; const uint8_t* mask;
+    const uint32_t* occ;      // coarse occupancy summary (k4_build_occupancy_summary) or NULL
     int X, Y, Z; int C; int CP; int k0_layout; int act_d;
     int MX, MY, MZ;
     float minx, miny, minz, maxx, maxy, maxz;
@@ -60,6 +61,7 @@ struct MarchParams {
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     int serp;               // 1: serpentine ray order inside a tile (default)
+    int band_blocks;        // geometry kernel: blocks per XCD band (0: one contiguous band per XCD)
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
 };
 
@@ -127,19 +129,25 @@ __device__ __forceinline__ void ray_setup(const MarchParams& P, float ox, float 
 // K1: geometry
 // =====================================================================================================
 // -----------------------------------------------------------------------------------------------------
-// K1.  Profiling of the first, per-ray form of this kernel (one wave walks a ray, every stage on the same 64 lanes;
-// profiles/r01_marcher_split_v1_pmc.md):
-// VALU-issue bound, and two thirds of the issue slots were spent with most lanes idle -- the density stage ran on
-// the ~35 % of lanes that pass the occupancy mask, the transmittance scan on one lane at a time.  Here
-//   A. the occupancy stage still walks a ray with lanes = 64 consecutive samples, but mask-passing samples are
-//      compacted (ballot/mbcnt) ACROSS blocks and rays into a 128-entry LDS ring;
-//   B. the density / act_shift / raw2alpha stage runs on 64 ring entries at a time: all lanes busy;
-//      alpha-passing samples are appended to the bundle's workspace slice as {ray,step | alpha};
-//   C. the transmittance scan is transposed: lane = RAY, all 64 rays of the bundle advance their exact
-//      sequential products in parallel (fmaf chain, identical rounding to the reference's loop), writing w over alpha;
-//   D. a last pass compacts the w > thres survivors in place -> the records the shading kernel consumes.
-// The early stop therefore no longer saves density fetches behind it (they were ~13 % of the mask-passing samples);
-// results are unchanged: a sample behind the stop never gets a weight.
+// K1.  History (profiles/r01_*): the first, per-ray form (one wave walks a ray, every stage on the same 64 lanes) was
+// VALU-issue bound with most lanes idle; v2 compacted mask-passing samples across rays before the density stage and ran
+// the transmittance scan transposed; v3 split a bundle's depth range over the 4 waves of a workgroup (L2 hit 75 -> 96 %).
+// In v3 the occupancy stage alone was ~0.6 of 1.0 ms although only 27 % of the in-bbox samples pass the mask: 141 M samples
+// per frame paid 3 FMAs + 3 round() + bounds + a byte load to be dropped.  v4 (this kernel) does not visit them:
+//   P. probe, lane = RAY: for each group of 16 consecutive samples of the wave's depth quarter the two END samples' occupancy
+//      indices are computed exactly as the per-sample code would; the index map is monotone along a ray, so every sample of the
+//      group lies in the per-axis interval they span.  The box is tested against a coarse summary of the mask (one bit per
+//      8x8 (x,y) cell and z plane, k4_build_occupancy_summary, 76 KB for the LLFF grid, L2 resident; on the LLFF scene 41 % of the
+//      groups are kept where 36 % hold an occupied sample; 4x4 cells would need 3x3 of them for 39 %): all bits clear => no sample of the group
+//      can pass MaskGrid.forward => the group is never enumerated.  Boxes wider than 2x2 cells / 32 planes are kept unseen.
+//      Skipping is conservative by construction: results are bit-identical with and without the summary (tests).
+//   A. occupancy, lanes = 4 kept groups x 16 consecutive samples (ray-major, depth-ascending order as before): sample point,
+//      closed-bbox test, MaskGrid index with C round(), occupancy byte; 4 items' bytes are fetched together (one round trip per
+//      256 samples); mask-passing samples are compacted (ballot/mbcnt) into an LDS ring;
+//   B. density / act_shift / raw2alpha on 64 ring entries at a time, 2 per lane, issued one group early (fetches fly under the
+//      next group's occupancy round trip); alpha-passing samples are appended to the bundle's workspace slice as {ray,step|alpha};
+//   C. transposed transmittance scan, lane = RAY: the reference's exact sequential product, writing w over alpha;
+//   D. in-place compaction of the w > thres survivors -> the records the shading kernel consumes.
 // -----------------------------------------------------------------------------------------------------
 #ifndef K4_GEOM_MIN_WG
 #define K4_GEOM_MIN_WG 1
@@ -148,47 +156,119 @@ __device__ __forceinline__ void ray_setup(const MarchParams& P, float ox, float 
 #define K4_SHADE_WG_PER_CU 2      // 256 VGPRs per wave: at 3 (168 VGPRs) the batch loop spilled ~90 dwords and its scratch reloads cost 0.4 ms/frame
 #endif
 #define K4_RING 512
+#define K4_TKTAB 256              // MPI: k/(Ns-1) for k < K4_TKTAB is tabulated once per workgroup (an IEEE division costs ~10 VALU per sample)
+#define K4_ELIST 512              // kept (ray, group) entries enumerated at a time (ray sub-batches when 64 rays x groups exceed it)
+#define K4_GRP 16                 // samples per skip group
 struct Geom2Lds {
-    float raytab[64][6];     // start xyz, dir xyz of the bundle's rays
+    float raytab[64][8];     // [0..2] start xyz, [3] bits(kq0) | [4..6] dir xyz, [7] bits(kq1): the bundle's rays and THIS wave's depth range [kq0,kq1) of each
     unsigned qk[K4_RING];    // ring of mask-passing samples: ray_local<<24 | step (residual < 64 + one group of 256)
     int acnt[64];            // alpha-passing samples per ray
+    unsigned short elist[K4_ELIST];   // kept entries, ray-major / depth-ascending: ray_local<<10 | group
 };
 
-// SPLIT (default): the 4 waves of a workgroup share ONE bundle, wave w taking depth quarter w of every ray.  A wave's
-// footprint between two neighbouring rays drops from 4 rows x 1 KB to 4 rows x 256 B, which turns the row reuse of
-// adjacent rays into L1/L2 hits (rocprofv3 PMC on the unsplit form: 116 M L1-miss requests and 2 GB of fabric reads per
-// frame for 190 MB of unique grid data; the kernel ran as fast at 3 waves/SIMD as at 6 -- cache-throughput bound).
-// Records of quarter w go to quarter w of the bundle's workspace slice; after a workgroup barrier wave 0 runs the
-// transmittance scan over the four runs of each ray in depth order and compacts the survivors.
-// COUNT: the sample counters of bench.py / the tests (k4_march_*_fwd `counters`) are a separate instantiation, so that
-// the render path carries no counting code and a profile lists the two under different names.
-template <int MODE, int WPB, bool SPLIT, bool COUNT>
-__global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(const MarchParams P) {
-    static_assert(!SPLIT || WPB == 4, "depth split uses 4 waves per bundle");
-    __shared__ Geom2Lds lds_all[WPB];
-    __shared__ int na_sh[WPB];
+template <int MODE>
+__device__ __forceinline__ float tk_of(const MarchParams& P, const float* tktab, int k) {
+    if (MODE == MODE_MPI) return k < K4_TKTAB ? tktab[k] : (float)k / P.nsm1;         // render_utils_kernel.cu:260
+    return P.stepdist * (float)k;                                                      // render_utils_kernel.cu:184
+}
+
+// The 4 waves of a workgroup share ONE bundle of 64 rays, wave w taking depth quarter w of every ray (a wave's footprint between
+// two neighbouring rays is 4 rows x 256 B: the row reuse of adjacent rays hits L1/L2).  Records of quarter w go to quarter w of
+// the bundle's workspace slice; after a workgroup barrier wave 0 runs the transmittance scan over the four runs of each ray in
+// depth order and compacts the survivors.  (Since v4 there is no barrier: the last wave to finish its quarter does this.)
+// COUNT: the sample counters of bench.py / the tests (k4_march_*_fwd `counters`) are a separate instantiation that visits EVERY
+// sample (no skipping), so that the counters are the algorithm's sample counts and the render path carries no
+// counting code.
+template <int MODE, bool COUNT, int MINW>
+__global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P) {
+    __shared__ Geom2Lds lds_all[4];
+    __shared__ int na_sh[4];
+    __shared__ int arrived;                                            // waves of this workgroup that have finished their depth quarter
+    __shared__ float tktab[MODE == MODE_MPI ? K4_TKTAB : 1];
     const int lane = k4_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     Geom2Lds& L = lds_all[wv];
     if (blockIdx.x == 0 && threadIdx.x == 0) *P.qhead = 0;            // work queue of the shading kernel that follows
-    const k4_cptr c_o = k4_const(P.rays_o), c_d = k4_const(P.rays_d);
+    if (threadIdx.x == 0) arrived = 0;
+    if (MODE == MODE_MPI) {
+        for (int i = (int)threadIdx.x; i < K4_TKTAB; i += 256) tktab[i] = (float)i / P.nsm1;
+    }
+    __syncthreads();
     const bool unit_interval = P.interval == 1.f;
     const bool use_thres = P.thres > 0.f;
     unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0, n_shade = 0;
-    float tk0 = step_t<MODE>(P, lane), tk1 = step_t<MODE>(P, 64 + lane), tk2 = step_t<MODE>(P, 128 + lane),
-          tk3 = step_t<MODE>(P, 192 + lane);
-    asm volatile("" : "+v"(tk0), "+v"(tk1), "+v"(tk2), "+v"(tk3));   // keep the hoisted divisions in registers (no rematerialisation)
 
-    // static, XCD-banded bundle map (one bundle per workgroup when SPLIT, per wave otherwise): per-XCD or global work
-    // queues measured 6-25 % slower -- the hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2
+    // static, XCD-banded bundle map, one bundle per workgroup: per-XCD or global work queues measured 6-25 % slower -- the
+    // hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2
     for (bool once = true; once; once = false) {
-    const int bid = SPLIT ? k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) : k4_xcd_remap((int)blockIdx.x, (int)gridDim.x) * WPB + wv;
+    const int bid = k4_xcd_remap_banded((int)blockIdx.x, (int)gridDim.x, P.band_blocks);
     if (bid >= P.n_bundles) break;
     const Bundle B = bundle_from_id(P, bid);
     uint2* const ent_base = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int quarter = P.ent_stride >> 2;
-    uint2* const ent = SPLIT ? ent_base + (size_t)wv * quarter : ent_base;       // this wave's run of records
-    L.acnt[lane] = 0;
+    uint2* const ent = ent_base + (size_t)wv * quarter;                          // this wave's run of records
+
+    // ---- ray setup, lane = ray of the bundle ----
+    const int myray = ray_index(P, B, lane);
+    int ngrp;                                                                    // 16-sample groups of this wave's depth range of ray `lane`
+    {
+        const int rs = myray < 0 ? 0 : myray;
+        float sx, sy, sz, dx, dy, dz;
+        int nsteps;
+        ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
+                        P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
+        if (myray < 0) nsteps = 0;
+        const int nb4 = (((nsteps + 63) >> 6) + 3) >> 2;                         // 64-sample blocks per depth quarter of this ray
+        const int kq0 = wv * nb4 * 64, kq1 = min((wv + 1) * nb4 * 64, nsteps);
+        ngrp = kq1 > kq0 ? (kq1 - kq0 + K4_GRP - 1) / K4_GRP : 0;
+        *reinterpret_cast<float4*>(&L.raytab[lane][0]) = make_float4(sx, sy, sz, __int_as_float(kq0));
+        *reinterpret_cast<float4*>(&L.raytab[lane][4]) = make_float4(dx, dy, dz, __int_as_float(kq1));
+        L.acnt[lane] = 0;
+    }
+    int gq = ngrp;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gq = max(gq, __shfl_xor(gq, off));
+    gq = __builtin_amdgcn_readfirstlane(gq);
+    const bool big = gq > 64;                                                    // more groups than mask bits: enumerate every group (g < 1024: host check)
+
+    // ---- stage P: which 16-sample groups of my ray can touch an occupied voxel? ----
+    unsigned long long keep = ngrp >= 64 ? ~0ull : ((1ull << ngrp) - 1ull);
+    if (!COUNT && P.occ != nullptr && !big) {
+        keep = 0ull;
+        const float4 ra = *reinterpret_cast<const float4*>(&L.raytab[lane][0]);
+        const float4 rb = *reinterpret_cast<const float4*>(&L.raytab[lane][4]);
+        const int kq0 = __float_as_int(ra.w), kq1 = __float_as_int(rb.w);
+        const int ncy = (P.MY + K4_OCC_CELL - 1) >> K4_OCC_SHIFT, zw = (P.MZ + 31) >> 5;
+#pragma unroll 4
+        for (int j = 0; j < gq; ++j) {                                            // (unrolled: the summary fetches of 4 groups fly together)
+            const int ka = kq0 + K4_GRP * j, kb = min(ka + K4_GRP - 1, kq1 - 1);
+            const float ta = tk_of<MODE>(P, tktab, j < ngrp ? ka : 0), tb = tk_of<MODE>(P, tktab, j < ngrp ? kb : 0);
+            // the two end samples, with the arithmetic of stage A (same fmaf chain, same round())
+            const int iax = k4_round_half_away(fmaf(fmaf(rb.x, ta, ra.x), P.msx, P.mtx)), ibx = k4_round_half_away(fmaf(fmaf(rb.x, tb, ra.x), P.msx, P.mtx));
+            const int iay = k4_round_half_away(fmaf(fmaf(rb.y, ta, ra.y), P.msy, P.mty)), iby = k4_round_half_away(fmaf(fmaf(rb.y, tb, ra.y), P.msy, P.mty));
+            const int iaz = k4_round_half_away(fmaf(fmaf(rb.z, ta, ra.z), P.msz, P.mtz)), ibz = k4_round_half_away(fmaf(fmaf(rb.z, tb, ra.z), P.msz, P.mtz));
+            const int x0 = max(min(iax, ibx), 0), x1 = min(max(iax, ibx), P.MX - 1);
+            const int y0 = max(min(iay, iby), 0), y1 = min(max(iay, iby), P.MY - 1);
+            const int z0 = max(min(iaz, ibz), 0), z1 = min(max(iaz, ibz), P.MZ - 1);
+            const bool empty = (x0 > x1) | (y0 > y1) | (z0 > z1);                // every sample's index is out of range on some axis
+            const int cx0 = x0 >> K4_OCC_SHIFT, cy0 = y0 >> K4_OCC_SHIFT;
+            const int cx1 = min(x1 >> K4_OCC_SHIFT, cx0 + 1), cy1 = min(y1 >> K4_OCC_SHIFT, cy0 + 1);
+            const bool wide = ((x1 >> K4_OCC_SHIFT) - cx0 > 1) | ((y1 >> K4_OCC_SHIFT) - cy0 > 1) | (z1 - z0 >= 32);     // box beyond 2x2 cells / one 64-bit window: keep unseen
+            const int w0 = z0 >> 5, w1 = min(z1 >> 5, zw - 1);
+            unsigned lo = 0u, hi = 0u;
+            if (!empty) {
+                const unsigned b00 = (unsigned)(cx0 * ncy + cy0) * (unsigned)zw, b01 = (unsigned)(cx0 * ncy + cy1) * (unsigned)zw;
+                const unsigned b10 = (unsigned)(cx1 * ncy + cy0) * (unsigned)zw, b11 = (unsigned)(cx1 * ncy + cy1) * (unsigned)zw;
+                lo = P.occ[b00 + w0] | P.occ[b01 + w0] | P.occ[b10 + w0] | P.occ[b11 + w0];
+                hi = P.occ[b00 + w1] | P.occ[b01 + w1] | P.occ[b10 + w1] | P.occ[b11 + w1];
+            }
+            const unsigned long long win = w1 != w0 ? ((unsigned long long)hi << 32) | lo : (unsigned long long)lo;
+            const int len = z1 - z0 + 1;
+            const unsigned long long bits = (len >= 64 ? ~0ull : ((1ull << (len & 63)) - 1ull)) << (z0 & 31);
+            const bool hit = !empty && (wide || (win & bits) != 0ull);
+            if (j < ngrp && hit) keep |= 1ull << j;
+        }
+    }
     int qn = 0, qh = 0;          // ring fill / head (wave-uniform)
     int na = 0;                  // alpha-passing records written so far (wave-uniform)
 
@@ -209,8 +289,8 @@ __global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(cons
             const int rl = (int)(key >> 24);
             const int k = (int)(key & 0xffffffu);
             const float* rt = L.raytab[rl];
-            const float tk = step_t<MODE>(P, k);
-            const float px = fmaf(rt[3], tk, rt[0]), py = fmaf(rt[4], tk, rt[1]), pz = fmaf(rt[5], tk, rt[2]);
+            const float tk = tk_of<MODE>(P, tktab, k);
+            const float px = fmaf(rt[4], tk, rt[0]), py = fmaf(rt[5], tk, rt[1]), pz = fmaf(rt[6], tk, rt[2]);
             const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
             const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
             const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
@@ -295,55 +375,52 @@ __global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(cons
         }
     };
 
-    // ---- stage A: occupancy, lanes = 64 consecutive samples of one ray.  Work items = (ray, block of 64 samples) in
-    // ray-major order over this wave's depth range of each ray (SPLIT: quarter wv of the ray's blocks; else all of them).
-    int it_r = -1, it_k = 0, it_kend = 0;
-    float sx = 0.f, sy = 0.f, sz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;      // the current ray (wave-uniform values)
-    auto next_item = [&](int& r_out, int& base_out, int& kend_out) -> bool {
-        while (it_k >= it_kend) {
-            ++it_r;
-            if (it_r >= 64) return false;
-            const int ray = __builtin_amdgcn_readfirstlane(ray_index(P, B, it_r));
-            if (ray < 0) continue;
-            int nsteps;
-            ray_setup<MODE>(P, c_o[ray * 3 + 0], c_o[ray * 3 + 1], c_o[ray * 3 + 2],
-                            c_d[ray * 3 + 0], c_d[ray * 3 + 1], c_d[ray * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
-            nsteps = __builtin_amdgcn_readfirstlane(nsteps);
-            if (lane == 0) {
-                L.raytab[it_r][0] = sx; L.raytab[it_r][1] = sy; L.raytab[it_r][2] = sz;
-                L.raytab[it_r][3] = dx; L.raytab[it_r][4] = dy; L.raytab[it_r][5] = dz;
-            }
-            if (SPLIT) {
-                const int nb4 = (((nsteps + 63) >> 6) + 3) >> 2;               // blocks per depth quarter of this ray
-                it_k = wv * nb4 * 64;
-                it_kend = min((wv + 1) * nb4 * 64, nsteps);
-            } else { it_k = 0; it_kend = nsteps; }
-        }
-        r_out = it_r; base_out = it_k; kend_out = it_kend;
-        it_k += 64;
-        return true;
-    };
-    // groups of 4 items: the 4 occupancy bytes are fetched together (one memory round trip per 256 samples), branch-free
-    // (clamped index, validity folded into the predicate); all 4 are consumed (ballots) before any density batch is
-    // issued, so the only fetches in flight across the next group's wait are that batch's
-    for (bool more = true; more;) {
-        unsigned mbyte[4];
-        bool inbv[4];
-        unsigned ikey[4];
-        int nitems = 0;
+    // ---- stage A: occupancy.  Work entries = kept (ray, group) pairs in ray-major, depth-ascending order, written to an LDS list
+    // by their rays' lanes (prefix sum of the per-ray counts); an item = 4 consecutive entries, lanes 16q..16q+15 = the 16
+    // consecutive samples of entry q.  Rays are taken in sub-batches of `rb` so that rb x groups-per-ray fits the list (one
+    // batch of 64 rays for the LLFF configuration: 4 groups per ray and quarter).
+    const int q16 = lane >> 4, l15 = lane & 15;
+    int rb = 64;
+    while (rb > 1 && rb * gq > K4_ELIST) rb >>= 1;
+    for (int r0 = 0; r0 < 64; r0 += rb) {
+        int total;
+        {
+            const bool mine = lane >= r0 && lane < r0 + rb;
+            int c = mine ? (big ? ngrp : __popcll(keep)) : 0;
+            int incl = c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int r_ = 0, base_ = 0, kend_ = 0;
-            mbyte[j] = 0u; inbv[j] = false; ikey[j] = 0u;
-            if (more) more = next_item(r_, base_, kend_);
-            if (more) {
-                nitems = j + 1;
-                const int k = base_ + lane;
-                float tk;
-                if (MODE == MODE_MPI && base_ < 256) tk = base_ == 0 ? tk0 : (base_ == 64 ? tk1 : (base_ == 128 ? tk2 : tk3));   // hoisted k/(Ns-1)
-                else tk = step_t<MODE>(P, k);
-                const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
-                const bool inb = (k < kend_) &&
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            total = __builtin_amdgcn_readlane(incl, 63);
+            int o = incl - c;
+            if (big) { for (int g = 0; g < c; ++g) L.elist[o + g] = (unsigned short)((lane << 10) | g); }
+            else {
+                unsigned long long m = mine ? keep : 0ull;
+                for (int j = 0; j < gq; ++j)                                  // wave-uniform trip count, <= 64
+                    if ((m >> j) & 1ull) L.elist[o++] = (unsigned short)((lane << 10) | j);
+            }
+        }
+        // groups of 4 items: the 4 occupancy bytes are fetched together (one memory round trip per 256 samples), branch-free
+        // (clamped index, validity folded into the predicate); all 4 are consumed (ballots) before any density batch is
+        // issued, so the only fetches in flight across the next group's wait are that batch's
+        for (int e0 = 0; e0 < total; e0 += 16) {
+            unsigned mbyte[4];
+            bool inbv[4];
+            unsigned ikey[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ei = e0 + 4 * j + q16;
+                const bool ev = ei < total;
+                const unsigned e = ev ? (unsigned)L.elist[ei] : 0u;
+                const int r_ = (int)(e >> 10), g_ = (int)(e & 1023u);
+                const float4 ra = *reinterpret_cast<const float4*>(&L.raytab[r_][0]);
+                const float4 rbv = *reinterpret_cast<const float4*>(&L.raytab[r_][4]);
+                const int k = __float_as_int(ra.w) + g_ * K4_GRP + l15;
+                const float tk = tk_of<MODE>(P, tktab, k);
+                const float px = fmaf(rbv.x, tk, ra.x), py = fmaf(rbv.y, tk, ra.y), pz = fmaf(rbv.z, tk, ra.z);
+                const bool inb = ev && (k < __float_as_int(rbv.w)) &&
                     !((P.minx > px) | (P.miny > py) | (P.minz > pz) | (P.maxx < px) | (P.maxy < py) | (P.maxz < pz));
                 const int mi = k4_round_half_away(fmaf(px, P.msx, P.mtx));
                 const int mj = k4_round_half_away(fmaf(py, P.msy, P.mty));
@@ -354,41 +431,40 @@ __global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(cons
                 inbv[j] = inb;
                 ikey[j] = ((unsigned)r_ << 24) | (unsigned)k;
             }
-        }
-        if (nitems == 0) break;
-        uint64_t mball[4];
+            uint64_t mball[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mball[j] = __ballot(mbyte[j] != 0);
-            if (COUNT) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball[j]); }
-        }
+            for (int j = 0; j < 4; ++j) {
+                mball[j] = __ballot(mbyte[j] != 0);
+                if (COUNT) { n_inb += __popcll(__ballot(inbv[j])); n_mask += __popcll(mball[j]); }
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!mball[j]) continue;
-            if (mbyte[j] != 0) L.qk[(qh + qn + k4_prefix(mball[j])) & (K4_RING - 1)] = ikey[j];
-            qn += __popcll(mball[j]);
+            for (int j = 0; j < 4; ++j) {
+                if (mbyte[j] != 0) L.qk[(qh + qn + k4_prefix(mball[j])) & (K4_RING - 1)] = ikey[j];
+                qn += __popcll(mball[j]);
+            }
+            pump_b();
         }
-        pump_b();
     }
     if (pend_n) finish_b();
     while (qn > 0) { issue_b(min(qn, 128)); finish_b(); }
 
-    // the scan re-reads records other lanes (SPLIT: other waves) stored: drain the stores first
+    // No barrier: a wave whose quarter is done leaves at once (depth quarters are very unequal -- waves parked at a barrier held 1/3
+    // of the wave slots); the LAST wave to arrive finishes the bundle.  It re-reads records the other waves stored: every wave drains
+    // its stores (vmcnt) before it counts itself in, the records go through this CU's L1 write-through and were never read before.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    constexpr int NRUN = SPLIT ? 4 : 1;
-    if (SPLIT) {
-        if (lane == 0) na_sh[wv] = na;
-        __syncthreads();
-        if (wv != 0) break;                                            // quarters 1..3 are done; wave 0 finishes the bundle
-    }
+    int prev = 0;
+    if (lane == 0) { na_sh[wv] = na; prev = __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    prev = __builtin_amdgcn_readfirstlane(prev);
+    if (prev != 3) break;                                              // not the last: done
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // ---- stage C: transposed transmittance scan, lane = ray (render_utils_kernel.cu:591-603); a ray's records are
-    // NRUN runs (one per depth quarter), visited in depth order ----
+    // 4 runs (one per depth quarter), visited in depth order ----
     float T = 1.f;
     bool stopped = false;
 #pragma unroll
-    for (int w = 0; w < NRUN; ++w) {
+    for (int w = 0; w < 4; ++w) {
         uint2* const run = ent_base + (size_t)w * quarter;
-        const int c = lds_all[SPLIT ? w : wv].acnt[lane];
+        const int c = lds_all[w].acnt[lane];
         int incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -425,9 +501,9 @@ __global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(cons
     // ---- stage D: keep w > thres, compacted to the front of the bundle's slice, run order preserved ----
     int cnt = 0, na_all = 0;
 #pragma unroll
-    for (int w = 0; w < NRUN; ++w) {
+    for (int w = 0; w < 4; ++w) {
         const uint2* const run = ent_base + (size_t)w * quarter;
-        int naw = SPLIT ? na_sh[w] : na;
+        int naw = na_sh[w];
         na_all += naw;
         if (P.debug & 128) naw = 0;                                    // ablation: no survivor compaction (nothing shaded)
         for (int base = 0; base < naw; base += 64) {
@@ -442,7 +518,6 @@ __global__ __launch_bounds__(64 * WPB, K4_GEOM_MIN_WG) void k4_geom2_kernel(cons
         }
     }
     if (lane == 0) P.counts[B.id] = cnt;
-    const int myray = ray_index(P, B, lane);
     if (myray >= 0) P.out_ainv[myray] = my_ainv;
     n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -718,9 +793,9 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     const int mlp_floats = WIDTH > 0 ? (B3 ? P.mlp_floats_b3 : P.mlp_floats) : 0;
     const int mlp_pad = (mlp_floats + 3) & ~3;
     float* const wl = smem;
-    const int per_wave = 64 * 4 + (WIDTH > 0 ? P.k1p * 64 : 0);
-    float* const acc = smem + mlp_pad + wv * per_wave;        // [64][4]  r,g,b,depth
-    float* const feat = acc + 64 * 4;                          // [K1P][64]
+    const int per_wave = 64 * 8 + (WIDTH > 0 ? P.k1p * 64 : 0);
+    double* const acc = reinterpret_cast<double*>(smem + mlp_pad + wv * per_wave);     // [64][4]  r,g,b,depth  (fp64, see the blend below)
+    float* const feat = reinterpret_cast<float*>(acc + 64 * 4);                        // [K1P][64]
     if (WIDTH > 0) {
         const float* const src = P.mlp + (B3 ? P.mlp_floats : 0);
         for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = src[i];
@@ -736,7 +811,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     bid = __builtin_amdgcn_readfirstlane(bid);
     if (bid >= P.n_bundles) break;
     const Bundle B = bundle_from_id(P, bid);
-    acc[lane * 4 + 0] = 0.f; acc[lane * 4 + 1] = 0.f; acc[lane * 4 + 2] = 0.f; acc[lane * 4 + 3] = 0.f;
+    acc[lane * 4 + 0] = 0.; acc[lane * 4 + 1] = 0.; acc[lane * 4 + 2] = 0.; acc[lane * 4 + 3] = 0.;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
     // the bundle's 64 rays live in registers, lane = ray slot; a record reads its ray's with ds_bpermute (__shfl).
@@ -888,23 +963,28 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
         }
-        // sigmoid, blend
-        float v0 = w * (1.f / (1.f + expf(-o0)));
-        float v1 = w * (1.f / (1.f + expf(-o1)));
-        float v2 = w * (1.f / (1.f + expf(-o2)));
-        float v3 = w * (((float)k + 0.5f) / (float)P.depth_n);       // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
+        // sigmoid, blend.  The per-ray sums (segment_coo, lib/dmpigo.py:382-386,418-424) are carried in fp64 with every fp32 term first
+        // rounded to a multiple of 2^-40 (the (x + 2^12) - 2^12 pair): terms <= 1, at most a few hundred per ray -> every fp64 addition is
+        // EXACT, so the sum does not depend on how records fall into batches, scan trees or LDS-atomic order.  A ray's colour is therefore
+        // independent of which other rays were marched with it (whole frame vs tile window vs row band: bit-identical pixels); the
+        // 2^-41 quantisation is 5 orders below an fp32 ulp of the result.
+        const double QC = 4096.0;
+        double v0 = ((double)(w * (1.f / (1.f + expf(-o0)))) + QC) - QC;
+        double v1 = ((double)(w * (1.f / (1.f + expf(-o1)))) + QC) - QC;
+        double v2 = ((double)(w * (1.f / (1.f + expf(-o2)))) + QC) - QC;
+        double v3 = ((double)(w * (((float)k + 0.5f) / (float)P.depth_n)) + QC) - QC;       // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
         // segmented inclusive scan over RUNS of equal ray (a ray's records are contiguous within a depth quarter, so
         // one batch can hold two runs of the same ray: key = index of the run, not the ray)
         const int keyr = k4_run_id(lact ? rl : (256 + lane), lane);
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int ok_ = __shfl_up(keyr, off);
-            const float u0 = __shfl_up(v0, off), u1 = __shfl_up(v1, off), u2 = __shfl_up(v2, off), u3 = __shfl_up(v3, off);
+            const double u0 = __shfl_up(v0, off), u1 = __shfl_up(v1, off), u2 = __shfl_up(v2, off), u3 = __shfl_up(v3, off);
             if (lane >= off && ok_ == keyr) { v0 += u0; v1 += u1; v2 += u2; v3 += u3; }
         }
         const int nextk = __shfl_down(keyr, 1);
         if (lact && (lane == 63 || nextk != keyr)) {
-            // ds_add_f32: two runs of one ray can end in the same batch (sparse bundles), a plain read-modify-write would lose one
+            // ds_add_f64: two runs of one ray can end in the same batch (sparse bundles), a plain read-modify-write would lose one
             k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
         }
         __builtin_amdgcn_wave_barrier();
@@ -914,10 +994,10 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     const int ray = ray_index(P, B, lane);
     if (ray >= 0) {
         const float ab = P.out_ainv[ray] * P.bg;
-        P.out_rgb[(size_t)ray * 3 + 0] = acc[lane * 4 + 0] + ab;
-        P.out_rgb[(size_t)ray * 3 + 1] = acc[lane * 4 + 1] + ab;
-        P.out_rgb[(size_t)ray * 3 + 2] = acc[lane * 4 + 2] + ab;
-        P.out_depth[ray] = acc[lane * 4 + 3];
+        P.out_rgb[(size_t)ray * 3 + 0] = (float)acc[lane * 4 + 0] + ab;
+        P.out_rgb[(size_t)ray * 3 + 1] = (float)acc[lane * 4 + 1] + ab;
+        P.out_rgb[(size_t)ray * 3 + 2] = (float)acc[lane * 4 + 2] + ab;
+        P.out_depth[ray] = (float)acc[lane * 4 + 3];
     }
     __builtin_amdgcn_wave_barrier();
     }   // bundle
@@ -954,12 +1034,12 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const dim3 grid(nwg), block(256);
     const int n_cu = k4_num_cus();
     {
-        // one workgroup (4 waves = 4 depth quarters) per bundle; K4_GEOM_SPLIT=0 keeps the unsplit form (one wave = one bundle,
-        // all depths) and K4_GEOM_LDSPAD pads LDS to cap occupancy -- the baselines of profiles/r01_final_pmc.md
-        const int split = k4_env().geom_split, ldspad = k4_env().geom_ldspad;
-        if (split && P.counters) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, true>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else if (split) hipLaunchKernelGGL((k4_geom2_kernel<MODE, 4, true, false>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else hipLaunchKernelGGL((k4_geom2_kernel<MODE, 1, false, true>), dim3((unsigned)nwg * 4), dim3(64), ldspad, st, P);
+        // one workgroup (4 waves = 4 depth quarters) per bundle; K4_GEOM_LDSPAD pads LDS to cap occupancy (experiments)
+        // MINW = waves per SIMD the register allocation is bounded for: 5 (85 VGPRs, no spills) or 6 (80 VGPRs, 6 spilled) -- K4_GEOM_OCC
+        const int ldspad = k4_env().geom_ldspad;
+        if (P.counters) hipLaunchKernelGGL((k4_geom3_kernel<MODE, true, 5>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        else if (k4_env().geom_occ >= 6) hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 6>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        else hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
     }
     int rc = k4_check_launch();
     if (rc) return rc;
@@ -967,7 +1047,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; k4_mlp_desc.arith =
     // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
     const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
-    const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 8 + (width ? (size_t)P.k1p * 64 : 0)));
     const int shade_wg = k4_env().shade_grid_wg;
     const dim3 sgrid((unsigned)min(nwg, n_cu * shade_wg));
     const size_t lds = lds_base;
@@ -1018,6 +1098,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs;
     P.n_rays = (int)n_rays; P.img_w = img_w; P.img_h = img_w > 0 ? (int)(n_rays / img_w) : 0;
     P.density = g->density; P.k0 = g->k0; P.act_shift = g->act_shift; P.mask = g->mask;
+    P.occ = k4_env().geom_skip ? g->occ_summary : nullptr;
     P.X = g->dims[0]; P.Y = g->dims[1]; P.Z = g->dims[2];
     P.C = g->k0_ch; P.CP = g->k0_cpad; P.k0_layout = g->k0_layout; P.act_d = g->act_depth;
     P.MX = g->mask_dims[0]; P.MY = g->mask_dims[1]; P.MZ = g->mask_dims[2];
@@ -1040,6 +1121,11 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.qhead = P.counts + nb;
     P.n_bundles = (int)nb;
     P.debug = k4_env().debug; P.serp = k4_env().serp;
+    // XCD bands of the geometry kernel: K4_GEOM_BAND rows of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to
+    // the 8 XCDs.  One contiguous band per XCD (0) left the XCDs 0.61..1.31 of the mean work on the LLFF frames -- the kernel ran at
+    // the pace of the heaviest eighth of the image.
+    P.band_blocks = img_w > 0 ? k4_env().geom_band * ((img_w + 15) / 16) * 4 : k4_env().geom_band * 64;
+    if (max_steps > 65536) return K4_ERR_UNSUPPORTED;                                   // group index of the skip list is 10 bits per depth quarter
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
@@ -1049,8 +1135,8 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
-    env_int("K4_GEOM_SPLIT", 1), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
-    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_B6_NW1", 8), env_int("K4_SR_VARIANT", 0)};
+    env_int("K4_GEOM_OCC", 5), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
+    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_B6_NW1", 8), env_int("K4_SR_VARIANT", 0), env_int("K4_GEOM_BAND", 1)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

@@ -369,6 +369,24 @@ __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t
     out[t] = ch < C ? in[(size_t)ch * nvox + v] : 0.f;
 }
 
+// coarse occupancy summary (k4nerf.h): one thread per (cell, z word)
+__global__ void k_occ_summary(const uint8_t* __restrict__ mask, int MX, int MY, int MZ, int ncx, int ncy, int zw, uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)ncx * ncy * zw) return;
+    const int w = (int)(t % zw);
+    const int cy = (int)((t / zw) % ncy), cx = (int)(t / ((int64_t)zw * ncy));
+    uint32_t bits = 0u;
+    for (int x = cx * K4_OCC_CELL; x < min((cx + 1) * K4_OCC_CELL, MX); ++x)
+        for (int y = cy * K4_OCC_CELL; y < min((cy + 1) * K4_OCC_CELL, MY); ++y) {
+            const uint8_t* col = mask + ((size_t)x * MY + y) * MZ;
+            for (int b = 0; b < 32; ++b) {
+                const int z = w * 32 + b;
+                if (z < MZ && col[z]) bits |= 1u << b;
+            }
+        }
+    out[t] = bits;
+}
+
 // ================================================================ C ABI
 #define ST ((hipStream_t)stream)
 #define REQ(c) do { if (!(c)) return K4_ERR_BAD_ARG; } while (0)
@@ -519,6 +537,16 @@ extern "C" int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream) {
     if (n == 0) return K4_OK;
     REQ(x && out);
     hipLaunchKernelGGL(k_to8b, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, x, n, out);
+    return k4_check_launch();
+}
+extern "C" int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz) {
+    if (mx <= 0 || my <= 0 || mz <= 0) return -1;
+    return (int64_t)((mx + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((my + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((mz + 31) / 32) * 4;
+}
+extern "C" int k4_build_occupancy_summary(const uint8_t* mask, int32_t mx, int32_t my, int32_t mz, uint32_t* out, void* stream) {
+    REQ(mask && out && mx > 0 && my > 0 && mz > 0);
+    const int ncx = (mx + K4_OCC_CELL - 1) / K4_OCC_CELL, ncy = (my + K4_OCC_CELL - 1) / K4_OCC_CELL, zw = (mz + 31) / 32;
+    hipLaunchKernelGGL(k_occ_summary, dim3(k4_blocks((int64_t)ncx * ncy * zw)), dim3(K4_THREADS), 0, ST, mask, mx, my, mz, ncx, ncy, zw, out);
     return k4_check_launch();
 }
 extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {

@@ -62,6 +62,20 @@ class _FusedMarcher:
             c['k0_key'], c['k0_cl'], c['k0_cpad'] = key, out, CP
         return c['k0_cl'], c['k0_cpad']
 
+    def _k4_occ_summary(self):
+        """Load-time coarse occupancy summary of mask_cache.mask (k4_build_occupancy_summary), cached per mask version: lets the
+        geometry kernel skip 16-sample groups of a ray that cannot touch an occupied voxel (identical results)."""
+        m = self.mask_cache.mask
+        key = ('occ', m.data_ptr(), m._version, str(m.device))
+        c = self._k4_cache()
+        if c.get('occ_key') != key:
+            mx, my, mz = (int(v) for v in m.shape)
+            nbytes = int(N.lib().k4_occupancy_summary_bytes(mx, my, mz))
+            out = torch.empty([nbytes // 4], dtype=torch.int32, device=m.device)
+            N.check(N.lib().k4_build_occupancy_summary(N.ptr(m), mx, my, mz, N.ptr(out), N.stream()), 'k4_build_occupancy_summary')
+            c['occ_key'], c['occ'] = key, out
+        return c['occ']
+
     def _k4_mlp(self, k0_skip, spatial_pe):
         md = N.MlpDesc()
         md.viewbase_pe = int(len(self.viewfreq)) if self.rgbnet is not None else 0
@@ -112,6 +126,7 @@ class _FusedMarcher:
         mc = self.mask_cache
         gd.mask = mc.mask.data_ptr()
         gd.mask_dims = (N.C.c_int32 * 3)(*[int(v) for v in mc.mask.shape])
+        gd.occ_summary = self._k4_occ_summary().data_ptr()
         c = self._k4_cache()
         hkey = ('host3', str(dens.device)) + tuple((t.data_ptr(), t._version) for t in
                                                    (self.xyz_min, self.xyz_max, mc.xyz2ijk_scale, mc.xyz2ijk_shift))

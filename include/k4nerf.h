@@ -58,7 +58,19 @@ typedef struct k4_grid_desc {
     int32_t mask_dims[3];
     float   xyz_min[3], xyz_max[3];
     float   xyz2ijk_scale[3], xyz2ijk_shift[3];   /* lib/grid.py:291-293 */
+    const uint32_t* occ_summary;     /* optional (NULL = none): coarse occupancy summary of `mask` built by
+                                        k4_build_occupancy_summary(); lets the geometry kernel skip 16-sample groups of a ray
+                                        that cannot touch an occupied voxel.  Results are identical with and without it. */
 } k4_grid_desc;
+
+/* Coarse occupancy summary of a MaskGrid (load-time, like the k0 repack): [ceil(MX/8)][ceil(MY/8)][ceil(MZ/32)] dwords, bit z of
+ * cell (cx,cy) = OR of mask[x][y][z] over the 8x8 (x,y) voxels of the cell (K4_OCC_CELL).  A group of consecutive samples of a ray touches only
+ * voxels inside the per-axis index interval of its two end samples (the index map is monotone along a ray); when every summary
+ * bit of that box is clear no sample of the group can pass MaskGrid.forward (lib/grid.py:295-304) and the group is skipped. */
+#define K4_OCC_CELL  8
+#define K4_OCC_SHIFT 3
+int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz);
+int k4_build_occupancy_summary(const uint8_t* mask, int32_t mx, int32_t my, int32_t mz, uint32_t* out, void* stream);
 
 /* Colour MLP `Sequential(Linear, ReLU, [Sequential(Linear, ReLU)] x n_hidden, Linear)`
  * (lib/dmpigo.py:112-120, lib/dvgo.py:116-124), repacked by the host into ONE contiguous fp32 buffer in
