@@ -31,6 +31,15 @@ class MlpDesc(C.Structure):
                 ('viewbase_pe', C.c_int32), ('spatial_pe', C.c_int32), ('k0_skip', C.c_int32), ('arith', C.c_int32)]
 
 
+class ConvJob(C.Structure):          # k4_conv_job
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('res', C.c_void_p), ('mod_x', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
+
+
+class SftJob(C.Structure):           # k4_sft_job
+    _fields_ = [('cond', C.c_void_p), ('x', C.c_void_p), ('y', C.c_void_p), ('res', C.c_void_p), ('n_pix', C.c_int64)]
+
+
+K4_MAX_JOBS = 8
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     'k4_abi_version': [],
@@ -105,6 +114,8 @@ _EXTRA_SIGS = {
                                _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
+    'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P, _P], C.c_int),
+    'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _P], C.c_int),
     'k4_occupancy_summary_bytes': ([_I32, _I32, _I32], C.c_int64),
     'k4_build_occupancy_summary': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
 }

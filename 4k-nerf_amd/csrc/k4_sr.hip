@@ -37,6 +37,35 @@ struct ConvParams {
     int tiles_x, tiles_y;
 };
 
+// Grouped launch: one grid covers up to K4_MAX_JOBS windows (the tiles of SFTNet.tile_process are independent images that share every
+// weight): a layer of all windows is ONE launch, its workgroups fill the chip together (a 520x520 window alone is 561 workgroups on
+// 256 CUs = 73 % tail efficiency; the four windows of a frame together are 1649 = 92 %) and the launch count per frame drops 4x.
+struct ConvMulti {
+    ConvParams base;                       // everything the windows share (x / y / res / modx / H / W / srcH / srcW / tiles_* are per job)
+    int n;
+    int blk_end[K4_MAX_JOBS];              // exclusive prefix of the jobs' workgroup counts
+    const float* x[K4_MAX_JOBS]; float* y[K4_MAX_JOBS]; const float* res[K4_MAX_JOBS]; const float* modx[K4_MAX_JOBS];
+    int H[K4_MAX_JOBS], W[K4_MAX_JOBS], tiles_x[K4_MAX_JOBS];
+    int* queue;                            // persistent form: {next ticket, workgroups done}, zero at launch, reset by the last workgroup; NULL: one workgroup per tile
+    int total;                             // workgroup-tiles of the launch
+};
+// -> this workgroup's window parameters and its tile index inside that window (workgroup-uniform)
+__device__ __forceinline__ ConvParams k4_select_job_of(const ConvMulti& M, int b, int& local);
+__device__ __forceinline__ ConvParams k4_select_job(const ConvMulti& M, int& local) {
+    return k4_select_job_of(M, k4_xcd_remap((int)blockIdx.x, (int)gridDim.x), local);
+}
+__device__ __forceinline__ ConvParams k4_select_job_of(const ConvMulti& M, int b, int& local) {
+    int g = 0;
+    while (g + 1 < M.n && b >= M.blk_end[g]) ++g;
+    local = b - (g ? M.blk_end[g - 1] : 0);
+    ConvParams P = M.base;
+    P.x = M.x[g]; P.y = M.y[g]; P.res = M.res[g]; P.modx = M.modx[g];
+    P.H = M.H[g]; P.W = M.W[g]; P.tiles_x = M.tiles_x[g];
+    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
+    P.srcH = ups ? P.H / 2 : P.H; P.srcW = ups ? P.W / 2 : P.W;
+    return P;
+}
+
 // shared epilogue: lane holds output channel n*32+l31 of pixels x0 + row(r,half), rows y0 + wv*2 + m
 template <int NT>
 __device__ __forceinline__ void k4_conv_epilogue(const ConvParams& P, f32x16 (&acc)[2][NT], int x0, int y0, int wv, int half, int l31) {
@@ -397,7 +426,9 @@ __device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4
 // NW = waves per workgroup (tile = 2*NW rows x 32 columns).  NW = 8 for 64 output channels (one 114 KB workgroup per CU);
 // NW = 4 for 32 output channels: 60 KB, two workgroups per CU whose staging / MFMA phases interleave.
 template <int KS, int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvParams P) {
+__global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) {
+    int tile;
+    const ConvParams P = k4_select_job(M, tile);
     constexpr int THREADS = 64 * NW;
     constexpr int TILE_ROWS = 2 * NW;
     constexpr int TAPS = KS * KS;
@@ -418,7 +449,6 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvParams P)
     const int lane = k4_lane();
     const int wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const int x0 = tx * TILE_W, y0 = ty * TILE_ROWS;
     const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
@@ -534,15 +564,304 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvParams P)
     k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2 of the 3x3 bf16x6 convolution (default).  rocprofv3 + the ISA of the kernel above showed why it sat at 0.22-0.35 of its
+// matrix floor: hipcc waited lgkmcnt(0) in front of nearly every group of 1-4 MFMAs (no operand prefetch distance), spilled the
+// prefetched next-chunk weights to scratch (134 VGPRs chosen for an occupancy the 114 KB of LDS forbids anyway), and the 8 waves
+// of the single workgroup per CU staged and computed in lock step, so the matrix pipe idled through every staging phase.
+// Here:
+//   * a workgroup = 4 waves, 16 rows x 32 columns x 32 OUTPUT CHANNELS (layers with 64 output channels run two workgroups per
+//     tile, adjacent in launch order: the second finds the tile in L2); LDS holds only the split input tile (58.7 KB) -> TWO
+//     workgroups per CU whose staging and MFMA phases interleave;
+//   * weights never touch LDS: a wave loads the 3 pre-split fragments of one tap straight from L1/L2 into registers, a ring of
+//     3 filled two taps ahead (across the chunk boundary too); activations are fetched with the non-temporal hint so that they do
+//     not evict the 28 KB of weight fragments from the 32 KB L1;
+//   * a wave owns 4 output rows; the chunk is 36 sub-stages (tap x output row r) of 6 MFMAs; the 3 A fragments of sub-stage u+1
+//     are read from LDS while the MFMAs of sub-stage u run (explicit software pipeline, order pinned with sched_barrier);
+//   * 2 waves per SIMD, nothing spills.
+// Same arithmetic, same operand order per accumulator as above: results are bit-identical to the v1 kernel (tests).
+// ------------------------------------------------------------------------------------------------------------------
+#define K4_V2_ROWS 16
+#ifndef K4_V2_ARING
+#define K4_V2_ARING 3      // A-fragment ring: filled ARING-1 sub-stages ahead
+#endif
+#ifndef K4_V2_BRING
+#define K4_V2_BRING 2      // weight-fragment ring: filled BRING-1 taps ahead
+#endif
+#ifndef K4_V2_NT
+#define K4_V2_NT 0         // 1: non-temporal activation loads
+#endif
+typedef float k4_f4 __attribute__((ext_vector_type(4)));
+// per-tile scalars (workgroup-uniform)
+struct V2Tile { const float* x; float* y; const float* res; int H, W, srcW, x0, y0, nb; };
+__device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_count, bool ups) {
+    int g = 0;
+    while (g + 1 < M.n && b >= M.blk_end[g]) ++g;
+    const int local = b - (g ? M.blk_end[g - 1] : 0);
+    const int tile = local / nb_count;
+    V2Tile T;
+    T.nb = local - tile * nb_count;
+    T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.H = M.H[g]; T.W = M.W[g];
+    T.srcW = ups ? T.W / 2 : T.W;
+    const int tiles_x = M.tiles_x[g];
+    T.x0 = (tile % tiles_x) * TILE_W; T.y0 = (tile / tiles_x) * K4_V2_ROWS;
+    return T;
+}
+
+// PERSIST: 2 workgroups per CU pull tiles from a ticket counter until it runs out, and the chunk pipeline runs ACROSS tiles: the
+// raw activations of the next tile's first chunk are fetched under the MFMAs of the current tile's last chunk, the epilogue's
+// stores drain under the next tile's staging.  (Ablation on the 2080x2080 64->64 layer: of 1.9 ms, 0.58 ms were per-workgroup
+// prologue / epilogue latency that nothing overlapped -- the two workgroups of a CU run in phase -- and a static grid of 1649
+// tiles runs in 3.2 "rounds" of 512 and pays for 4.)
+template <bool PERSIST>
+__global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M) {
+    constexpr int THREADS = 256;
+    constexpr int ROWS = K4_V2_ROWS + 2, COLS = TILE_W + 2;
+    constexpr int IN_ITEMS = ROWS * COLS * 2;                 // (pixel, channel group of 8)
+    constexpr int IN_PER = (IN_ITEMS + THREADS - 1) / THREADS;
+    constexpr int IN_PLANE = 2 * ROWS * COLS;                 // uint4 per term
+    __shared__ uint4 in_s[3 * IN_PLANE];                      // [term][channel group][row][col] x 8 bf16
+    __shared__ int ticket_sh;
+    const ConvParams& P = M.base;                             // shared by every window: cin, strides, weights, bias, cout, flags ...
+    const int nb_count = (P.cout + 31) >> 5;
+    const int NOUT = nb_count * 32;
+    const int tid = (int)threadIdx.x;
+    const int lane = k4_lane();
+    const int wv = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
+    const int nchunks = (P.cin + KC2 - 1) / KC2;
+    const int W_ITEMS = 3 * 9 * 2 * NOUT;                                    // 16-byte units of one chunk's split weights
+    const bool vec_base = (P.cin_stride & 3) == 0;
+
+    int bcur;
+    if (PERSIST) {
+        if (tid == 0) ticket_sh = atomicAdd(&M.queue[0], 1);
+        __syncthreads();
+        bcur = ticket_sh;
+        __syncthreads();
+    } else bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (bcur < M.total) {
+    V2Tile T = k4_v2_tile(M, bcur, nb_count, ups);
+
+    // per-thread source of each staged item of the tile being STAGED (chunk independent part)
+    const float* isrc[IN_PER];
+    bool iin[IN_PER];
+    int ikg[IN_PER], idst[IN_PER];
+    bool vec_ok;
+    const float* dummy;
+#define K4_V2_SETUP(TT) do { \
+        _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+            const int it = tid + i * THREADS; \
+            const int itc = it < IN_ITEMS ? it : 0; \
+            const int kg = itc & 1, pp = itc >> 1; \
+            const int py = pp / COLS, px = pp - py * COLS; \
+            const int gy = (TT).y0 - 1 + py, gx = (TT).x0 - 1 + px; \
+            const bool inside = it < IN_ITEMS && gy >= 0 && gy < (TT).H && gx >= 0 && gx < (TT).W; \
+            const int sy = inside ? (ups ? (gy >> 1) : gy) : 0, sx = inside ? (ups ? (gx >> 1) : gx) : 0; \
+            isrc[i] = (TT).x + ((size_t)sy * (TT).srcW + sx) * P.cin_stride + kg * 8; \
+            iin[i] = inside; ikg[i] = kg; \
+            idst[i] = it < IN_ITEMS ? (kg * ROWS + py) * COLS + px : -1; \
+        } \
+        vec_ok = vec_base && (((size_t)(TT).x) & 15) == 0; dummy = (TT).x; } while (0)
+    K4_V2_SETUP(T);
+
+    // raw fp32 of the NEXT chunk's tile items: fetched before the MFMA phase of the current chunk, split + stored after it, so that
+    // the HBM/L2 latency of the staging is hidden (the two workgroups of a CU start in phase and stay in phase: a synchronous
+    // staging phase was fully exposed -- SQ_VALU_MFMA_BUSY_CYCLES showed the matrix pipe 48 % busy)
+    float4 rva[IN_PER], rvb[IN_PER];
+#define K4_V2_LOADRAW(CH) do { \
+        const int c0_ = (CH) * KC2; \
+        if (vec_ok && c0_ + KC2 <= P.cin) { \
+            _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+                const k4_f4* src = reinterpret_cast<const k4_f4*>(iin[i] ? isrc[i] + c0_ : dummy); \
+                const k4_f4 va = K4_V2_NT ? __builtin_nontemporal_load(src) : *src; \
+                const k4_f4 vb = K4_V2_NT ? __builtin_nontemporal_load(src + 1) : src[1]; \
+                rva[i] = iin[i] ? make_float4(va.x, va.y, va.z, va.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                rvb[i] = iin[i] ? make_float4(vb.x, vb.y, vb.z, vb.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            } \
+        } else { \
+            _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
+                const int cb = c0_ + ikg[i] * 8; \
+                const float* src = isrc[i] + c0_; \
+                float e8[8]; \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c) { \
+                    const bool ok_ = iin[i] && cb + c < P.cin; \
+                    const float q_ = *(ok_ ? src + c : dummy); \
+                    e8[c] = ok_ ? q_ : 0.f; \
+                } \
+                rva[i] = make_float4(e8[0], e8[1], e8[2], e8[3]); rvb[i] = make_float4(e8[4], e8[5], e8[6], e8[7]); \
+            } \
+        } } while (0)
+    K4_V2_LOADRAW(0);
+
+    // operand registers: B = the 3 split terms of ONE tap, a ring filled BRING-1 taps ahead (over chunk and tile boundaries: the
+    // weights do not depend on the tile);  A = the 3 split terms of one (input row, dx), a ring filled ARING-1 sub-stages ahead
+    uint4 bbuf[K4_V2_BRING][3];
+    const uint4* wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 + l31;
+#define K4_V2_LOADB(DST, CH, TAP) do { \
+        const uint4* wp_ = wlane + (size_t)(CH) * W_ITEMS; \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) DST[q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT]; } while (0)
+    K4_V2_LOADB(bbuf[0], 0, 0);
+    if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
+
+    const uint4* const arow = in_s + (half * ROWS + wv * 4) * COLS + l31;   // A fragment of (term q, input row i, dx): arow[q*IN_PLANE + i*COLS + dx]
+#define K4_V2_READA(DST, U) do { \
+        const int t_ = (U) >> 2, r_ = (U) & 3; \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
+
+    bool first = true;
+    for (;;) {                                                               // tiles
+        int bnext = M.total;
+        V2Tile Tn = T;
+        if (PERSIST && tid == 0) ticket_sh = atomicAdd(&M.queue[0], 1);      // read by everyone after the first barrier below
+        f32x16 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (f32x16)(0.f);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (K4_V2_BRING == 2 && !first) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bbuf[0][q] = bbuf[1][q];
+            }
+            first = false;
+            // ---- split + store this chunk's haloed input tile ----
+#ifdef K4_V2_NOSTAGE      /* timing experiment only (WRONG results): stage the first chunk only */
+            if (ch == 0)
+#endif
+#pragma unroll
+            for (int i = 0; i < IN_PER; ++i) {
+                const float v8[8] = {rva[i].x, rva[i].y, rva[i].z, rva[i].w, rvb[i].x, rvb[i].y, rvb[i].z, rvb[i].w};
+                uint4 t0, t1, t2;
+                k4s_split3(v8, t0, t1, t2);
+                if (idst[i] >= 0) { in_s[idst[i]] = t0; in_s[IN_PLANE + idst[i]] = t1; in_s[2 * IN_PLANE + idst[i]] = t2; }
+            }
+            __syncthreads();
+            if (PERSIST && ch == 0) bnext = ticket_sh;
+            // next staging unit: the next chunk of this tile, or the first chunk of the next tile (its loads fly during the MFMAs below)
+            if (ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
+            else if (PERSIST && bnext < M.total) {
+                Tn = k4_v2_tile(M, bnext, nb_count, ups);
+                K4_V2_SETUP(Tn);
+                K4_V2_LOADRAW(0);
+            }
+            // ---- 36 sub-stages u = tap*4 + r: 6 MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
+            constexpr int AD = K4_V2_ARING - 1, BD = K4_V2_BRING - 1;
+            const bool last_chunk = ch + 1 == nchunks;
+            // the tap ring runs over the chunk boundary; at a tile boundary the next tile may use another output-channel block
+            const uint4* const wnext = last_chunk ? reinterpret_cast<const uint4*>(P.w) + half * NOUT + Tn.nb * 32 + l31 : wlane;
+            const int chn = last_chunk ? 0 : ch + 1;
+            uint4 abuf[K4_V2_ARING][3];
+            K4_V2_READA(abuf[0], 0);
+            if (AD == 2) K4_V2_READA(abuf[1], 1);
+#ifdef K4_V2_NOMFMA       /* timing experiment only (WRONG results): staging and barriers without the MFMA phase */
+            if (ch < 0)
+#endif
+#pragma unroll
+            for (int u = 0; u < 36; ++u) {
+                const int t = u >> 2, r = u & 3;
+                if (r == 0) {                                                // weights of tap t+BD
+                    if (t + BD < 9) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], ch, t + BD);
+                    else {
+                        const uint4* wp_ = wnext + (size_t)chn * W_ITEMS;
+#pragma unroll
+                        for (int q_ = 0; q_ < 3; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
+                    }
+                }
+                if (u + AD < 36) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
+                                 a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][2]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][1]),
+                                 b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][2]);
+#ifdef K4_V2_DEPTEST      /* timing experiment only (WRONG results): consecutive MFMAs on different accumulators */
+#define K4_ACC(k) acc[(r + (k)) & 3]
+#else
+#define K4_ACC(k) acc[r]
+#endif
+                    K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, K4_ACC(0), 0, 0, 0);
+                    K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, K4_ACC(1), 0, 0, 0);
+                    K4_ACC(2) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, K4_ACC(2), 0, 0, 0);
+                    K4_ACC(3) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, K4_ACC(3), 0, 0, 0);
+                    K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, K4_ACC(0), 0, 0, 0);
+                    K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, K4_ACC(1), 0, 0, 0);
+#undef K4_ACC
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue of tile T: lane holds output channel nb*32 + l31 of pixels x0 + row(reg, half) in rows y0 + wv*4 + r ----
+        {
+            const int co = T.nb * 32 + l31;
+            if (co < P.cout) {
+                const float bias = P.bias[co];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = T.y0 + wv * 4 + r;
+                    if (gy >= T.H) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int gx = T.x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                        if (gx >= T.W) continue;
+                        const size_t pix = (size_t)gy * T.W + gx;
+                        float v = acc[r][e] + bias;
+                        if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
+                        if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
+                        T.y[pix * P.cout_stride + co] = v;
+                    }
+                }
+            }
+        }
+        if (!PERSIST || bnext >= M.total) break;
+        T = Tn;
+        wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 + l31;
+    }   // tiles
+    }
+#undef K4_V2_LOADB
+#undef K4_V2_READA
+#undef K4_V2_LOADRAW
+#undef K4_V2_SETUP
+    if (PERSIST && threadIdx.x == 0) {
+        // the last workgroup to leave re-arms the counters for the next launch that is handed this queue (same stream: ordered)
+        if (atomicAdd(&M.queue[1], 1) == (int)gridDim.x - 1) { M.queue[0] = 0; M.queue[1] = 0; }
+    }
+}
+
+static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
+    const int nbc = (M.base.cout + 31) / 32;
+    int total = 0;
+    for (int g = 0; g < M.n; ++g) {
+        M.tiles_x[g] = (M.W[g] + TILE_W - 1) / TILE_W;
+        total += M.tiles_x[g] * ((M.H[g] + K4_V2_ROWS - 1) / K4_V2_ROWS) * nbc;
+        M.blk_end[g] = total;
+    }
+    M.total = total;
+    const int slots = 2 * k4_num_cus();
+    if (M.queue && total > slots && !k4_env().sr_static) hipLaunchKernelGGL(k4_conv_b6v2_kernel<true>, dim3((unsigned)slots), dim3(256), 0, st, M);
+    else hipLaunchKernelGGL(k4_conv_b6v2_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, M);
+    return k4_check_launch();
+}
+
+// fills blk_end / tiles_x of the jobs for a kernel whose workgroup covers tile_rows x TILE_W output pixels -> total workgroups
+static int k4_multi_grid(ConvMulti& M, int tile_rows) {
+    int total = 0;
+    for (int g = 0; g < M.n; ++g) {
+        M.tiles_x[g] = (M.W[g] + TILE_W - 1) / TILE_W;
+        total += M.tiles_x[g] * ((M.H[g] + tile_rows - 1) / tile_rows);
+        M.blk_end[g] = total;
+    }
+    return total;
+}
+
 template <int KS, int NT, int NW>
-static int launch_conv_b6(ConvParams P, hipStream_t st) {
+static int launch_conv_b6(ConvMulti& M, hipStream_t st) {
     constexpr int TAPS = KS * KS, PADW = KS / 2;
     constexpr size_t lds = ((size_t)3 * 2 * (2 * NW + 2 * PADW) * (TILE_W + 2 * PADW) + (size_t)3 * TAPS * 2 * NT * 32) * sizeof(uint4);
-    P.tiles_y = (P.H + 2 * NW - 1) / (2 * NW);
     static_assert(lds <= 160 * 1024, "split chunk must fit the CU's LDS");
     K4_ENSURE_DYN_LDS((k4_conv_b6_kernel<KS, NT, NW>), lds);
-    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(64 * NW);
-    hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT, NW>), grid, block, lds, st, P);
+    const dim3 grid((unsigned)k4_multi_grid(M, 2 * NW)), block(64 * NW);
+    hipLaunchKernelGGL((k4_conv_b6_kernel<KS, NT, NW>), grid, block, lds, st, M);
     return k4_check_launch();
 }
 
@@ -562,7 +881,9 @@ static int launch_conv_b6(ConvParams P, hipStream_t st) {
 #define K4_TAPS_PPAD 640                                   /* 20 row blocks */
 #define K4_TAPS_YS 29                                      /* Y row stride in floats (27 used; odd -> conflict-free gathers) */
 
-__global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvParams P) {
+__global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvMulti M) {
+    int tile;
+    const ConvParams P = k4_select_job(M, tile);
     extern __shared__ uint4 k4_taps_smem[];
     uint4* const in_s = k4_taps_smem;                                    // [term][channel group][pixel] x 8 bf16
     uint4* const w_s = k4_taps_smem + 3 * 2 * K4_TAPS_PPAD;              // [term][channel group][n] x 8 bf16
@@ -571,7 +892,6 @@ __global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvParams P
     const int lane = k4_lane();
     const int wv = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const int x0 = tx * TILE_W, y0 = ty * TILE_HB;
     const bool vec_ok = (P.cin_stride & 3) == 0 && (((size_t)P.x) & 15) == 0;
@@ -668,14 +988,13 @@ __global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvParams P
     }
 }
 
-static int launch_conv_taps_b6(ConvParams P, hipStream_t st) {
+static int launch_conv_taps_b6(ConvMulti& M, hipStream_t st) {
     constexpr size_t lds_gemm = ((size_t)3 * 2 * K4_TAPS_PPAD + 3 * 2 * 32) * sizeof(uint4);
     constexpr size_t lds_y = (size_t)K4_TAPS_NPIX * K4_TAPS_YS * sizeof(float);
     constexpr size_t lds = lds_gemm > lds_y ? lds_gemm : lds_y;
     K4_ENSURE_DYN_LDS(k4_conv_taps_b6_kernel, lds);
-    P.tiles_y = (P.H + TILE_HB - 1) / TILE_HB;
-    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(512);
-    hipLaunchKernelGGL(k4_conv_taps_b6_kernel, grid, block, lds, st, P);
+    const dim3 grid((unsigned)k4_multi_grid(M, TILE_HB)), block(512);
+    hipLaunchKernelGGL(k4_conv_taps_b6_kernel, grid, block, lds, st, M);
     return k4_check_launch();
 }
 
@@ -686,43 +1005,68 @@ extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_
     return (int64_t)((cin + KC2 - 1) / KC2) * 3 * ksize * ksize * 2 * nt * 32 * 16;
 }
 
+static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                         const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
+                         uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride, int32_t* tile_queue,
+                         void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_split || !bias || cin <= 0 || cout <= 0) return K4_ERR_BAD_ARG;
+    if (cin_stride < cin || (ksize != 1 && ksize != 3) || cout_stride < cout) return K4_ERR_BAD_ARG;
+    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
+    if (modulate && (mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
+    if ((flags & K4_EPI_RES) && res_stride <= 0) return K4_ERR_BAD_ARG;
+    const int gemm_n = modulate ? 2 * cout : cout;
+    const int nt = (gemm_n + 31) / 32;
+    ConvMulti M{};
+    ConvParams& P = M.base;
+    P.cin = cin; P.cin_stride = cin_stride; P.w = (const float*)w_split; P.bias = bias;
+    P.cout = cout; P.cout_stride = cout_stride;
+    P.flags = flags; P.slope = slope; P.res_stride = res_stride; P.res_scale = res_scale; P.mod_stride = mod_stride;
+    M.n = n_jobs;
+    M.queue = tile_queue;
+    for (int g = 0; g < n_jobs; ++g) {
+        const k4_conv_job& j = jobs[g];
+        if (!j.x || !j.y || j.H <= 0 || j.W <= 0) return K4_ERR_BAD_ARG;
+        if ((flags & K4_EPI_RES) && !j.res) return K4_ERR_BAD_ARG;
+        if (modulate && !j.mod_x) return K4_ERR_BAD_ARG;
+        if ((flags & K4_PRE_UPSAMPLE2X) && ((j.H & 1) || (j.W & 1))) return K4_ERR_BAD_ARG;
+        M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.modx[g] = j.mod_x; M.H[g] = j.H; M.W[g] = j.W;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & K4_W_TAPS_AS_COUT) {
+        if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
+        return launch_conv_taps_b6(M, st);
+    }
+    if (ksize == 3 && !modulate && nt <= 2 && k4_env().sr_variant == 0) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel
+    const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
+    if (ksize == 3) {
+        if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(M, st) : launch_conv_b6<3, 1, 8>(M, st);
+        if (nt == 2) return launch_conv_b6<3, 2, 8>(M, st);
+    } else {
+        if (nt == 1) return launch_conv_b6<1, 1, 8>(M, st);
+        if (nt == 2) return launch_conv_b6<1, 2, 8>(M, st);
+        if (nt == 4) return launch_conv_b6<1, 4, 8>(M, st);
+    }
+    return K4_ERR_UNSUPPORTED;
+}
+
+extern "C" int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                                           const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
+                                           uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
+                                           int32_t* tile_queue, void* stream) {
+    return conv_b6_multi(jobs, n_jobs, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale,
+                         mod_stride, tile_queue, stream);
+}
+
 extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
                                      const void* w_split, const float* bias, int32_t ksize,
                                      float* y, int32_t cout, int32_t cout_stride,
                                      int32_t H, int32_t W, uint32_t flags, float slope,
                                      const float* res, int32_t res_stride, float res_scale,
                                      const float* mod_x, int32_t mod_stride, void* stream) {
-    if (!x || !w_split || !bias || !y || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return K4_ERR_BAD_ARG;
-    if (cin_stride < cin || (ksize != 1 && ksize != 3)) return K4_ERR_BAD_ARG;
-    if ((flags & K4_EPI_RES) && (!res || res_stride <= 0)) return K4_ERR_BAD_ARG;
-    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
-    if (modulate && (!mod_x || mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
-    if ((flags & K4_PRE_UPSAMPLE2X) && ((H & 1) || (W & 1))) return K4_ERR_BAD_ARG;
-    const int gemm_n = modulate ? 2 * cout : cout;
-    const int nt = (gemm_n + 31) / 32;
-    if (cout_stride < cout) return K4_ERR_BAD_ARG;
-    ConvParams P{};
-    P.x = x; P.cin = cin; P.cin_stride = cin_stride; P.w = (const float*)w_split; P.bias = bias;
-    P.y = y; P.cout = cout; P.cout_stride = cout_stride; P.H = H; P.W = W;
-    P.srcH = (flags & K4_PRE_UPSAMPLE2X) ? H / 2 : H; P.srcW = (flags & K4_PRE_UPSAMPLE2X) ? W / 2 : W;
-    P.flags = flags; P.slope = slope; P.res = res; P.res_stride = res_stride; P.res_scale = res_scale;
-    P.modx = mod_x; P.mod_stride = mod_stride;
-    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_HB - 1) / TILE_HB;
-    hipStream_t st = (hipStream_t)stream;
-    if (flags & K4_W_TAPS_AS_COUT) {
-        if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
-        return launch_conv_taps_b6(P, st);
-    }
-    const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
-    if (ksize == 3) {
-        if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(P, st) : launch_conv_b6<3, 1, 8>(P, st);
-        if (nt == 2) return launch_conv_b6<3, 2, 8>(P, st);
-    } else {
-        if (nt == 1) return launch_conv_b6<1, 1, 8>(P, st);
-        if (nt == 2) return launch_conv_b6<1, 2, 8>(P, st);
-        if (nt == 4) return launch_conv_b6<1, 4, 8>(P, st);
-    }
-    return K4_ERR_UNSUPPORTED;
+    k4_conv_job j{};
+    j.x = x; j.y = y; j.res = res; j.mod_x = mod_x; j.H = H; j.W = W;
+    return conv_b6_multi(&j, 1, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale, mod_stride,
+                         nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -743,9 +1087,24 @@ struct SftParams {
     int n_pix; float slope;
     int vec4;                                  // all of x / y / res rows are 16-byte aligned (strides % 4 == 0, bases % 16 == 0)
 };
+struct SftMulti {                              // grouped launch over the windows of a frame (see ConvMulti)
+    SftParams base;
+    int n;
+    int blk_end[K4_MAX_JOBS];
+    const float* cond[K4_MAX_JOBS]; const float* x[K4_MAX_JOBS]; float* y[K4_MAX_JOBS]; const float* res[K4_MAX_JOBS];
+    int n_pix[K4_MAX_JOBS];
+};
 
 template <int CB>
-__global__ __launch_bounds__(256) void k4_sft_kernel(const SftParams P) {
+__global__ __launch_bounds__(256) void k4_sft_kernel(const SftMulti M) {
+    SftParams P = M.base;
+    int blk = (int)blockIdx.x;
+    {
+        int g = 0;
+        while (g + 1 < M.n && blk >= M.blk_end[g]) ++g;
+        blk -= g ? M.blk_end[g - 1] : 0;
+        P.cond = M.cond[g]; P.x = M.x[g]; P.y = M.y[g]; P.res = M.res[g]; P.n_pix = M.n_pix[g];
+    }
     constexpr int NW = (2 + 2 * CB) * 17 * 64;
     __shared__ float wl[NW];
     __shared__ float ct[4][32][64];               // per wave: cond^T [channel][pixel]
@@ -753,7 +1112,7 @@ __global__ __launch_bounds__(256) void k4_sft_kernel(const SftParams P) {
     const int wv = (int)(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     for (int i = (int)threadIdx.x; i < NW; i += 256) wl[i] = P.w[i];
-    const int base = ((int)blockIdx.x * 4 + wv) * 64;
+    const int base = (blk * 4 + wv) * 64;
     {
         const int pix = base + lane;
         float4 c4[8];
@@ -856,20 +1215,45 @@ extern "C" int64_t k4_sft_weight_floats(int32_t channels) {
     return (int64_t)(2 + 2 * (channels / 32)) * 17 * 64;
 }
 
+static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
+                     int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_packed || cond_stride < 32 || (cond_stride & 3)) return K4_ERR_BAD_ARG;
+    if ((channels != 32 && channels != 64) || x_stride < channels || y_stride < channels) return K4_ERR_BAD_ARG;
+    SftMulti M{};
+    SftParams& P = M.base;
+    P.cond_stride = cond_stride; P.w = w_packed; P.x_stride = x_stride; P.y_stride = y_stride;
+    P.res_stride = res_stride; P.res_scale = res_scale; P.slope = slope;
+    M.n = n_jobs;
+    int total = 0;
+    bool any_res = false, all_res = true;
+    size_t align = 0;
+    for (int g = 0; g < n_jobs; ++g) {
+        const k4_sft_job& j = jobs[g];
+        if (!j.cond || !j.x || !j.y || j.n_pix <= 0 || j.n_pix > 0x7fffffff || (((size_t)j.cond) & 15) != 0) return K4_ERR_BAD_ARG;
+        any_res |= j.res != nullptr; all_res &= j.res != nullptr;
+        align |= (size_t)j.x | (size_t)j.y | (size_t)(j.res ? j.res : j.x);
+        M.cond[g] = j.cond; M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.n_pix[g] = (int)j.n_pix;
+        total += (int)((j.n_pix + 255) / 256);
+        M.blk_end[g] = total;
+    }
+    if (any_res != all_res || (any_res && res_stride < channels)) return K4_ERR_BAD_ARG;
+    P.res = any_res ? jobs[0].res : nullptr;                         // the kernel tests P.res for "has residual"; the job's pointer is used
+    P.vec4 = ((x_stride | y_stride | (any_res ? res_stride : 0)) & 3) == 0 && (align & 15) == 0;
+    const dim3 grid((unsigned)total), block(256);
+    if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
+    else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
+    return k4_check_launch();
+}
+
+extern "C" int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
+                                 int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream) {
+    return sft_multi(jobs, n_jobs, cond_stride, w_packed, x_stride, y_stride, channels, slope, res_stride, res_scale, stream);
+}
+
 extern "C" int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
                            const float* x, int32_t x_stride, float* y, int32_t y_stride, int32_t channels,
                            int64_t n_pix, float slope, const float* res, int32_t res_stride, float res_scale, void* stream) {
-    if (!cond || !w_packed || !x || !y || n_pix <= 0 || n_pix > 0x7fffffff || cond_stride < 32 || (cond_stride & 3)) return K4_ERR_BAD_ARG;
-    if ((((size_t)cond) & 15) != 0) return K4_ERR_BAD_ARG;
-    if ((channels != 32 && channels != 64) || x_stride < channels || y_stride < channels) return K4_ERR_BAD_ARG;
-    if (res && res_stride < channels) return K4_ERR_BAD_ARG;
-    SftParams P{};
-    P.cond = cond; P.cond_stride = cond_stride; P.w = w_packed; P.x = x; P.x_stride = x_stride; P.y = y; P.y_stride = y_stride;
-    P.res = res; P.res_stride = res_stride; P.res_scale = res_scale; P.n_pix = (int)n_pix; P.slope = slope;
-    P.vec4 = ((x_stride | y_stride | (res ? res_stride : 0)) & 3) == 0 &&
-             ((((size_t)x) | ((size_t)y) | ((size_t)(res ? res : x))) & 15) == 0;
-    const dim3 grid((unsigned)((n_pix + 255) / 256)), block(256);
-    if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, P);
-    return k4_check_launch();
+    k4_sft_job j{};
+    j.cond = cond; j.x = x; j.y = y; j.res = res; j.n_pix = n_pix;
+    return sft_multi(&j, 1, cond_stride, w_packed, x_stride, y_stride, channels, slope, res ? res_stride : 0, res_scale, stream);
 }

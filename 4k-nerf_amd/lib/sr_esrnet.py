@@ -299,7 +299,7 @@ class SFTNet(nn.Module):
 
     @staticmethod
     def _conv(pk, x, x_off, x_stride, y, y_off, y_stride, cout, H, W, flags=0, res=None, mod=None, plan=None):
-        """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))"""
+        """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))   (one window)"""
         rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
         mp, ms = (None, 0) if mod is None else (N.C.c_void_p(mod[0].data_ptr() + 4 * mod[1]), mod[2])
         fn = {'fp32': N.lib().k4_conv2d_nhwc, 'bf16x3': N.lib().k4_conv2d_nhwc_bf16x3,
@@ -311,36 +311,82 @@ class SFTNet(nn.Module):
             plan.append((fn, args, 'k4_conv2d_nhwc'))
         N.check(fn(*args, N.stream()), 'k4_conv2d_nhwc')
 
-    def _sft(self, pk, prefix, B, h, w, x, x_off, x_stride, y, y_off, y_stride, cfeat, res=None, plan=None):
-        """SFTLayer (lib/sr_esrnet.py:120-123) in one launch: y = x*(scale(cond)+1) + shift(cond) [*res_scale + res]."""
-        wp = pk[prefix]
-        rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
-        args = (N.f32(B['cond']), self.num_grow_ch, N.f32(wp),
-                N.C.c_void_p(x.data_ptr() + 4 * x_off), x_stride, N.C.c_void_p(y.data_ptr() + 4 * y_off), y_stride,
-                cfeat, h * w, 0.2, rp, rs, rscale)
+    def _conv_multi(self, pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags=0, res=None, plan=None):
+        """One layer of every window.  bf16x6: ONE grouped launch (k4_conv2d_nhwc_bf16x6_multi); other arithmetics: one launch per
+        window.  `up`: output size = window size x up.  res = (buffer name, channel offset, stride, scale)."""
+        if pkc.mode != 'bf16x6':
+            for B, (h, w) in zip(Bs, hws):
+                self._conv(pkc, B[xname], x_off, x_stride, B[yname], y_off, y_stride, cout, h * up, w * up, flags,
+                           res=None if res is None else (B[res[0]], res[1], res[2], res[3]), plan=plan)
+            return
+        jobs = (N.ConvJob * len(Bs))()
+        for j, (B, (h, w)) in enumerate(zip(Bs, hws)):
+            jobs[j].x = B[xname].data_ptr() + 4 * x_off
+            jobs[j].y = B[yname].data_ptr() + 4 * y_off
+            jobs[j].res = None if res is None else B[res[0]].data_ptr() + 4 * res[1]
+            jobs[j].mod_x = None
+            jobs[j].H, jobs[j].W = h * up, w * up
+        rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
+        fn = N.lib().k4_conv2d_nhwc_bf16x6_multi
+        # K4_SR_PERSIST=1 (opt-in, measured 3-20 % slower than the static grid): every recorded launch owns a ticket counter (2 ints,
+        # self-resetting) for the persistent, cross-tile pipelined form of the 3x3 kernel
+        queue = None
+        if plan is not None and os.environ.get('K4_SR_PERSIST', '0') == '1':
+            q = torch.zeros([2], dtype=torch.int32, device=Bs[0][xname].device)
+            plan.append((None, (q, q), 'keepalive'))
+            queue = N.ptr(q)
+        args = (jobs, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), pkc.k, cout, y_stride, flags | pkc.flags_extra, 0.2,
+                rs, rscale, 0, queue)
         if plan is not None:
-            plan.append((N.lib().k4_sft_nhwc, args, 'k4_sft_nhwc'))
-        N.check(N.lib().k4_sft_nhwc(*args, N.stream()), 'k4_sft_nhwc')
+            plan.append((fn, args, 'k4_conv2d_nhwc_bf16x6_multi'))
+        N.check(fn(*args, N.stream()), 'k4_conv2d_nhwc_bf16x6_multi')
+
+    def _sft_multi(self, pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=None, plan=None):
+        """SFTLayer (lib/sr_esrnet.py:120-123) of every window in one launch: y = x*(scale(cond)+1) + shift(cond) [*res_scale + res]."""
+        wp = pk[prefix]
+        jobs = (N.SftJob * len(Bs))()
+        for j, (B, (h, w)) in enumerate(zip(Bs, hws)):
+            jobs[j].cond = B['cond'].data_ptr()
+            jobs[j].x = B[xname].data_ptr() + 4 * x_off
+            jobs[j].y = B[yname].data_ptr() + 4 * y_off
+            jobs[j].res = None if res is None else B[res[0]].data_ptr() + 4 * res[1]
+            jobs[j].n_pix = h * w
+        rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
+        fn = N.lib().k4_sft_nhwc_multi
+        args = (jobs, len(Bs), self.num_grow_ch, N.f32(wp), x_stride, y_stride, cfeat, 0.2, rs, rscale)
+        if plan is not None:
+            plan.append((fn, args, 'k4_sft_nhwc_multi'))
+        N.check(fn(*args, N.stream()), 'k4_sft_nhwc_multi')
 
     @torch.no_grad()
     def _forward_hip(self, x, cond, slot=0):
-        """One window through the decoder on the HIP kernels (111 launches).  The launch sequence of a (slot, window size) is
-        recorded once as a list of (entry point, prepared ctypes arguments) and replayed afterwards: all buffers are
-        capacity-cached at fixed addresses, so a replay costs one prepared foreign call per launch instead of rebuilding ~20
-        ctypes objects (the decoder of a small window -- 8-GPU tile sharding -- is otherwise bound by host launch time)."""
-        assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
-        _, cin, h, w = x.shape
-        dev = x.device
+        """One window through the decoder on the HIP kernels (see _forward_hip_multi)."""
+        return self._forward_hip_multi([x], [cond], slot0=slot)[0]
+
+    @torch.no_grad()
+    def _forward_hip_multi(self, xs, conds, slot0=0):
+        """Up to K4_MAX_JOBS windows through the decoder TOGETHER: every layer is one grouped launch over all windows (111 launches
+        for the whole set; a window alone leaves a quarter of the CUs idle in its last round of workgroups).  The launch sequence
+        of a window set is recorded once as a list of (entry point, prepared ctypes arguments) and replayed afterwards: all
+        buffers are capacity-cached at fixed addresses.  Returns views [1,3,s*h,s*w] of the windows' NHWC results."""
+        assert len(xs) == len(conds) and 0 < len(xs) <= N.K4_MAX_JOBS
+        dev = xs[0].device
         pk = self._packed()
-        B = self._k4_buffers(h, w, dev, slot)
-        B['xin'].copy_(x[0].permute(1, 2, 0))                             # NHWC [h][w][cin], fixed address
-        B['cnd'].copy_(cond[0].permute(1, 2, 0))
-        key = (h, w, self._k4.get('key'), self.k4_mode) + tuple(t.data_ptr() for t in B.values())
-        plans = self._k4.setdefault(('plans', slot), {})
+        Bs, hws = [], []
+        for j, (x, cond) in enumerate(zip(xs, conds)):
+            assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
+            h, w = int(x.shape[2]), int(x.shape[3])
+            B = self._k4_buffers(h, w, dev, slot0 + j)
+            B['xin'].copy_(x[0].permute(1, 2, 0))                         # NHWC [h][w][cin], fixed address
+            B['cnd'].copy_(cond[0].permute(1, 2, 0))
+            Bs.append(B)
+            hws.append((h, w))
+        key = (tuple(hws), self._k4.get('key'), self.k4_mode) + tuple(t.data_ptr() for B in Bs for t in B.values())
+        plans = self._k4.setdefault(('plans', slot0), {})
         plan = plans.get(key)
         if plan is None or os.environ.get('K4_SR_PLAN', '1') == '0':
             plan = []
-            self._record_hip(pk, B, h, w, plan)
+            self._record_hip(pk, Bs, hws, plan)
             if len(plans) > 16:
                 plans.clear()
             plans[key] = plan
@@ -348,57 +394,56 @@ class SFTNet(nn.Module):
             st = N.stream()
             for fn, args, what in plan:
                 if fn is None:
-                    args[0].copy_(args[1])
+                    if what == 'copy':
+                        args[0].copy_(args[1])
                 else:
                     N.check(fn(*args, st), what)
-        return B['out'].permute(2, 0, 1).unsqueeze(0)                     # view [1,3,H,W] of the NHWC result
+        return [B['out'].permute(2, 0, 1).unsqueeze(0) for B in Bs]       # views [1,3,H,W] of the NHWC results
 
-    def _record_hip(self, pk, B, h, w, plan):
-        """Run the launch sequence of SFTNet.forward (lib/sr_esrnet.py:446-465) once, appending every step to `plan`."""
+    def _record_hip(self, pk, Bs, hws, plan):
+        """Run the launch sequence of SFTNet.forward (lib/sr_esrnet.py:446-465) once for the window set, appending every step to `plan`."""
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
-        cin, ccond = B['xin'].shape[2], B['cnd'].shape[2]
+        cin, ccond = Bs[0]['xin'].shape[2], Bs[0]['cnd'].shape[2]
 
-        def cv(*a, **k):
-            self._conv(*a, plan=plan, **k)
+        def cv(pkc, xname, x_off, x_stride, yname, y_off, y_stride, cout, up=1, flags=0, res=None):
+            self._conv_multi(pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags, res=res, plan=plan)
 
-        def sft(*a, **k):
-            self._sft(*a, plan=plan, **k)
+        def sft(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=None):
+            self._sft_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=res, plan=plan)
 
-        def copy(dst, src):
-            plan.append((None, (dst, src), 'copy'))
-            dst.copy_(src)
+        def copy(dname, sname):
+            for B in Bs:
+                plan.append((None, (B[dname], B[sname]), 'copy'))
+                B[dname].copy_(B[sname])
 
-        cv(pk['conv_first'], B['xin'], 0, cin, B['feat'], 0, nf, nf, h, w)
-        cv(pk['CondNet.0'], B['cnd'], 0, ccond, B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
-        cv(pk['CondNet.2'], B['c64a'], 0, 64, B['c64b'], 0, 64, 64, h, w, EPI_LRELU)
-        cv(pk['CondNet.4'], B['c64b'], 0, 64, B['c64a'], 0, 64, 64, h, w, EPI_LRELU)
-        cv(pk['CondNet.6'], B['c64a'], 0, 64, B['cond'], 0, g, g, h, w)
-        copy(B['trunk'], B['feat'])
+        cv(pk['conv_first'], 'xin', 0, cin, 'feat', 0, nf, nf)
+        cv(pk['CondNet.0'], 'cnd', 0, ccond, 'c64a', 0, 64, 64, flags=EPI_LRELU)
+        cv(pk['CondNet.2'], 'c64a', 0, 64, 'c64b', 0, 64, 64, flags=EPI_LRELU)
+        cv(pk['CondNet.4'], 'c64b', 0, 64, 'c64a', 0, 64, 64, flags=EPI_LRELU)
+        cv(pk['CondNet.6'], 'c64a', 0, 64, 'cond', 0, g, g)
+        copy('trunk', 'feat')
         bw = nf + 4 * g
         for b in range(self.num_block):
-            copy(B['rrdb_in'], B['trunk'])
+            copy('rrdb_in', 'trunk')
             for r in (1, 2, 3):
                 p = f'body.{b}.rdb{r}'
-                sft(pk, p + '.sft0', B, h, w, B['trunk'], 0, nf, B['blk'], 0, bw, nf)                # xc0
+                sft(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf)                                    # xc0
                 for k in range(1, 5):                                                               # x1..x4
-                    cv(pk[f'{p}.conv{k}'], B['blk'], 0, bw, B['blk'], nf + (k - 1) * g, bw, g, h, w, EPI_LRELU)
-                sft(pk, p + '.sft1', B, h, w, B['blk'], nf + 3 * g, bw, B['blk'], nf + 3 * g, bw, g)  # xc1 in place
-                cv(pk[f'{p}.conv5'], B['blk'], 0, bw, B['trunk'], 0, nf, nf, h, w, EPI_RES,
-                   res=(B['trunk'], 0, nf, 0.2))                                                    # x5*0.2 + x
-            sft(pk, f'body.{b}.sft0', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf,
-                res=(B['rrdb_in'], 0, nf, 0.2))                                                     # sft(out)*0.2 + x
-        sft(pk, 'sftbody', B, h, w, B['trunk'], 0, nf, B['trunk'], 0, nf, nf)
-        cv(pk['conv_body'], B['trunk'], 0, nf, B['rrdb_in'], 0, nf, nf, h, w, EPI_RES,
-           res=(B['feat'], 0, nf, 1.0))                                                             # body_feat += feat
-        cur, hh, ww = B['rrdb_in'], h, w
+                    cv(pk[f'{p}.conv{k}'], 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
+                sft(p + '.sft1', 'blk', nf + 3 * g, bw, 'blk', nf + 3 * g, bw, g)                     # xc1 in place
+                cv(pk[f'{p}.conv5'], 'blk', 0, bw, 'trunk', 0, nf, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))      # x5*0.2 + x
+            sft(f'body.{b}.sft0', 'trunk', 0, nf, 'trunk', 0, nf, nf, res=('rrdb_in', 0, nf, 0.2))  # sft(out)*0.2 + x
+        sft('sftbody', 'trunk', 0, nf, 'trunk', 0, nf, nf)
+        cv(pk['conv_body'], 'trunk', 0, nf, 'rrdb_in', 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))            # body_feat += feat
+        cur, up = 'rrdb_in', 1
         if s > 1:
-            cv(pk['conv_up1'], cur, 0, nf, B['up1'], 0, nf, nf, 2 * h, 2 * w, EPI_LRELU | PRE_UP2X)
-            cur, hh, ww = B['up1'], 2 * h, 2 * w
+            cv(pk['conv_up1'], cur, 0, nf, 'up1', 0, nf, nf, up=2, flags=EPI_LRELU | PRE_UP2X)
+            cur, up = 'up1', 2
             if s == 4:
-                cv(pk['conv_up2'], cur, 0, nf, B['up2'], 0, nf, nf, 4 * h, 4 * w, EPI_LRELU | PRE_UP2X)
-                cur, hh, ww = B['up2'], 4 * h, 4 * w
-        cv(pk['conv_hr'], cur, 0, nf, B['hr'], 0, nf, nf, hh, ww, EPI_LRELU)
-        cv(pk['conv_last'], B['hr'], 0, nf, B['out'], 0, 3, 3, hh, ww)
+                cv(pk['conv_up2'], cur, 0, nf, 'up2', 0, nf, nf, up=4, flags=EPI_LRELU | PRE_UP2X)
+                cur, up = 'up2', 4
+        cv(pk['conv_hr'], cur, 0, nf, 'hr', 0, nf, nf, up=up, flags=EPI_LRELU)
+        cv(pk['conv_last'], 'hr', 0, nf, 'out', 0, 3, 3, up=up)
 
     def forward(self, x, cond, fea=None):
         if not x.is_cuda:
@@ -429,27 +474,17 @@ class SFTNet(nn.Module):
         if out is None:
             out = img.new_zeros((1, ch, height * s, width * s))
         tiles = tiles if tiles is not None else self.tile_geometry(height, width, tile_size, tile_pad)
-        # tiles are independent: each runs on its own HIP stream (own activation buffers).  A decoder layer launches only
-        # 256..561 workgroups on 256 CUs, so alone it leaves up to half of the last round of CUs idle; with the tiles in
-        # flight together the tail of one tile's layer is filled by another tile's
-        n_str = max(1, min(len(tiles), int(os.environ.get('K4_SR_STREAMS', '4'))))
-        cur = torch.cuda.current_stream(img.device)
-        self._packed()           # cold caches: the weight packing is enqueued on `cur` BEFORE the side streams fork from it
-        if n_str > 1:
-            pool = self._k4.setdefault(('streams', str(img.device)), [])
-            while len(pool) < n_str:
-                pool.append(torch.cuda.Stream(device=img.device))
-            for st in pool[:n_str]:
-                st.wait_stream(cur)
-        for i, (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in enumerate(tiles):
-            st = pool[i % n_str] if n_str > 1 else cur
-            with torch.cuda.stream(st):
-                o = self._forward_hip(img[:, :, yp0:yp1, xp0:xp1], cond[:, :, yp0:yp1, xp0:xp1], slot=i % n_str)
+        # tiles are independent images that share every weight: up to K4_MAX_JOBS of them go through the decoder TOGETHER, one
+        # grouped launch per layer (a 520x520 window alone launches 561 workgroups on 256 CUs = 73 % tail efficiency; the four
+        # windows of a 1008x756 frame together 1649 = 92 %).  K4_SR_GROUP=1 processes them one by one.
+        grp = max(1, min(N.K4_MAX_JOBS, int(os.environ.get('K4_SR_GROUP', str(N.K4_MAX_JOBS)))))
+        for t0 in range(0, len(tiles), grp):
+            part = tiles[t0:t0 + grp]
+            outs = self._forward_hip_multi([img[:, :, yp0:yp1, xp0:xp1] for (_, _, _, _, yp0, yp1, xp0, xp1) in part],
+                                           [cond[:, :, yp0:yp1, xp0:xp1] for (_, _, _, _, yp0, yp1, xp0, xp1) in part])
+            for o, (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in zip(outs, part):
                 oy, ox = (y0 - yp0) * s, (x0 - xp0) * s
                 out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
-        if n_str > 1:
-            for st in pool[:n_str]:
-                cur.wait_stream(st)
         return out
 
     def tile_process(self, img, cond, tile_size, tile_pad=10):

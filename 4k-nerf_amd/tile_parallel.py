@@ -83,6 +83,8 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
     if pool:
         for st in pool:
             st.wait_stream(cur)
+    multi = getattr(sr_fn, 'k4_multi', None)            # HIP decoder: all of this rank's windows per layer in ONE grouped launch
+    pending = []
     for j, i in enumerate(owned[rk]):
         y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
         th, tw = (y1 - y0) * scale, (x1 - x0) * scale
@@ -93,13 +95,24 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
             hh, ww = yp1 - yp0, xp1 - xp0
             img = rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0)
             cond = depth.reshape(1, 1, hh, ww)
-            hr = sr_fn(img, cond, **kw)
-            oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
-            send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
+            if multi is not None:
+                if pool:                                   # produced on a side stream, consumed on the current one after the join
+                    rgb.record_stream(cur)
+                    depth.record_stream(cur)
+                pending.append((img, cond, off, th, tw, (y0 - yp0) * scale, (x0 - xp0) * scale))
+            else:
+                hr = sr_fn(img, cond, **kw)
+                oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
+                send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
         off += th * tw
     if pool:
         for st in pool:
             cur.wait_stream(st)
+    if multi is not None:
+        for p0 in range(0, len(pending), multi.max_jobs):
+            part = pending[p0:p0 + multi.max_jobs]
+            for hr, (_, _, o, th, tw, oy, ox) in zip(multi([p[0] for p in part], [p[1] for p in part]), part):
+                send[:, o:o + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
     if ws > 1:
         recv = torch.empty([ws, 3, slot], dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(recv.view(ws * 3, slot), send, group=group)      # final pixels only
@@ -148,10 +161,17 @@ def hip_march_fn(model, render_kwargs):
 
 
 def hip_sr_fn(net_sr):
+    from . import _native as N
+
     def fn(img, cond, slot=0):
         return net_sr._forward_hip(img, cond, slot=slot)
+
+    def multi(imgs, conds):
+        return net_sr._forward_hip_multi(imgs, conds)
+    multi.max_jobs = N.K4_MAX_JOBS
     fn.k4_slots = True
     fn.k4_warm = net_sr._packed
+    fn.k4_multi = multi
     return fn
 
 

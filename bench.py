@@ -372,16 +372,19 @@ class _SubsetGeometry:
         cur = torch.cuda.current_stream(dev)
         for st in pool:
             st.wait_stream(cur)
-        outs = []
+        imgs, conds = [], []
         for j, (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in enumerate(self.tiles):
             with torch.cuda.stream(pool[j % len(pool)]):
                 ro, rd, vd = [r[yp0:yp1, xp0:xp1].reshape(-1, 3).contiguous() for r in rays]
                 rgb, depth = march_fn(ro, rd, vd, xp1 - xp0, slot=j % len(pool))
+                rgb.record_stream(cur)
+                depth.record_stream(cur)
                 hh, ww = yp1 - yp0, xp1 - xp0
-                outs.append(sr_fn(rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0), depth.reshape(1, 1, hh, ww), slot=j % len(pool)))
+                imgs.append(rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0))
+                conds.append(depth.reshape(1, 1, hh, ww))
         for st in pool:
             cur.wait_stream(st)
-        return outs
+        return sr_fn.k4_multi(imgs, conds)            # one grouped launch per layer over this rank's windows
 
 
 def four_k_parity_and_cpu(ck, net, pose, hr, tiles, H, W):

@@ -273,6 +273,23 @@ int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
                           const float* res, int32_t res_stride, float res_scale,
                           const float* mod_x, int32_t mod_stride, void* stream);
 
+/* Grouped launches: the windows (tiles) of SFTNet.tile_process (lib/sr_esrnet.py:482-526) are independent images sharing every
+ * weight; `_multi` runs one layer of up to K4_MAX_JOBS windows as ONE launch (their workgroups fill the chip together).  `jobs` is
+ * a HOST array; everything not in the job struct is shared and has the meaning documented for the single-window entry points,
+ * which are the n_jobs == 1 case of these. */
+#define K4_MAX_JOBS 8
+typedef struct k4_conv_job { const float* x; float* y; const float* res; const float* mod_x; int32_t H, W; } k4_conv_job;
+int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                                const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
+                                uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
+                                int32_t* tile_queue, void* stream);
+/* tile_queue: NULL, or 2 device ints that are ZERO when the launch starts (the kernel leaves them zero again): 3x3 layers with more
+ * tiles than the chip holds at once then run as persistent workgroups pulling tiles from this counter (no partly filled last round).
+ * Launches that may run concurrently must not share a queue. */
+typedef struct k4_sft_job { const float* cond; const float* x; float* y; const float* res; int64_t n_pix; } k4_sft_job;
+int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
+                      int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream);
+
 /* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then
  * *res_scale + res if res != NULL), scale/shift = conv1x1(lrelu(conv1x1(cond))) evaluated in one launch, the hidden
  * activations stay in registers.  cond: [n_pix][cond_stride] (32 channels, 16-B aligned rows); channels = 32 or 64;

@@ -204,20 +204,24 @@ def test_fused_sft_layer(C):
     assert torch.equal(buf[:, :, :16], keep[:, :, :16]) and torch.equal(buf[:, :, 16 + C:], keep[:, :, 16 + C:])
 
 
-def test_full_size_tile_process_is_stream_invariant_and_fp32_equivalent(monkeypatch):
-    """BASELINE-size frame (1008x756 -> 4032x3024, test_tile=510): (1) the 4-stream tile schedule returns bit-identical pixels to
-    the sequential one (tiles are independent); (2) the default 3-term split arithmetic stays within 110 dB of the exact-fp32
-    MFMA arithmetic on the whole frame."""
+def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkeypatch):
+    """BASELINE-size frame (1008x756 -> 4032x3024, test_tile=510): (1) the grouped schedule (all 4 windows per layer in one launch)
+    returns bit-identical pixels to the window-by-window one (tiles are independent); (2) the default 3-term split arithmetic
+    stays within 110 dB of the exact-fp32 MFMA arithmetic on the whole frame."""
     torch.manual_seed(777)
     net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).cuda().eval()
     g = torch.Generator().manual_seed(9)
     x = torch.rand([1, 3, 756, 1008], generator=g).cuda()
     c = torch.rand([1, 756, 1008], generator=g).cuda()
     net.k4_mode = 'bf16x6'
-    monkeypatch.setenv('K4_SR_STREAMS', '4')
-    a = net.tile_process_device(x, c, 510, 10)
-    monkeypatch.setenv('K4_SR_STREAMS', '1')
-    b = net.tile_process_device(x, c, 510, 10)
+    monkeypatch.setenv('K4_SR_GROUP', '8')
+    a = net.tile_process_device(x, c, 510, 10).clone()
+    monkeypatch.setenv('K4_SR_GROUP', '1')
+    b = net.tile_process_device(x, c, 510, 10).clone()
+    monkeypatch.setenv('K4_SR_GROUP', '3')               # ragged grouping: 3 + 1 windows
+    b3 = net.tile_process_device(x, c, 510, 10)
+    assert torch.equal(a, b3)
+    monkeypatch.delenv('K4_SR_GROUP')
     assert a.shape == (1, 3, 3024, 4032) and torch.equal(a, b)
     net.k4_mode = 'fp32'
     f = net.tile_process_device(x, c, 510, 10)
