@@ -369,6 +369,43 @@ __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t
     out[t] = ch < C ? in[(size_t)ch * nvox + v] : 0.f;
 }
 
+// DenseGrid.scale_volume_grid (lib/grid.py:130-135): F.interpolate(mode='trilinear', align_corners=True) of a [C][X][Y][Z] grid.
+// One thread per output voxel and channel; source index = dst * (in-1)/(out-1) (PyTorch's area_pixel_compute_scale / _source_index
+// with align_corners), upper neighbour clamped, weights (1-l, l) per axis, products accumulated as upsample_trilinear3d does.
+__global__ void k_resample_trilinear(const float* __restrict__ in, int C, int X, int Y, int Z, float* __restrict__ out, int X2, int Y2, int Z2) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n2 = (int64_t)X2 * Y2 * Z2;
+    if (t >= n2 * C) return;
+    const int c = (int)(t / n2);
+    const int64_t v = t - (int64_t)c * n2;
+    const int z2 = (int)(v % Z2), y2 = (int)((v / Z2) % Y2), x2 = (int)(v / ((int64_t)Z2 * Y2));
+    const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f, sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f,
+                sz = Z2 > 1 ? (float)(Z - 1) / (float)(Z2 - 1) : 0.f;
+    const float fx = sx * (float)x2, fy = sy * (float)y2, fz = sz * (float)z2;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = x0 + (x0 < X - 1 ? 1 : 0), y1 = y0 + (y0 < Y - 1 ? 1 : 0), z1 = z0 + (z0 < Z - 1 ? 1 : 0);
+    const float lx = fx - (float)x0, ly = fy - (float)y0, lz = fz - (float)z0;
+    const float mx = 1.f - lx, my = 1.f - ly, mz = 1.f - lz;
+    const float* g = in + (size_t)c * X * Y * Z;
+#define K4_G(a, b, d) g[((size_t)(a) * Y + (b)) * Z + (d)]
+    out[t] = mx * (my * (mz * K4_G(x0, y0, z0) + lz * K4_G(x0, y0, z1)) + ly * (mz * K4_G(x0, y1, z0) + lz * K4_G(x0, y1, z1))) +
+             lx * (my * (mz * K4_G(x1, y0, z0) + lz * K4_G(x1, y0, z1)) + ly * (mz * K4_G(x1, y1, z0) + lz * K4_G(x1, y1, z1)));
+#undef K4_G
+}
+
+// F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1) > thres as one byte per voxel (lib/dmpigo.py:208-209,221-224,
+// lib/dvgo.py:217-219,231-233): a voxel stays occupied iff any of its <= 27 in-grid neighbours has alpha > thres.
+__global__ void k_alpha_pool3_gt(const float* __restrict__ alpha, int X, int Y, int Z, float thres, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)X * Y * Z) return;
+    const int z = (int)(t % Z), y = (int)((t / Z) % Y), x = (int)(t / ((int64_t)Z * Y));
+    float m = -INFINITY;
+    for (int a = max(x - 1, 0); a <= min(x + 1, X - 1); ++a)
+        for (int b = max(y - 1, 0); b <= min(y + 1, Y - 1); ++b)
+            for (int d = max(z - 1, 0); d <= min(z + 1, Z - 1); ++d) m = fmaxf(m, alpha[((size_t)a * Y + b) * Z + d]);
+    out[t] = m > thres ? 1 : 0;
+}
+
 // coarse occupancy summary (k4nerf.h): one thread per (cell, z word)
 __global__ void k_occ_summary(const uint8_t* __restrict__ mask, int MX, int MY, int MZ, int ncx, int ncy, int zw, uint32_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -537,6 +574,17 @@ extern "C" int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream) {
     if (n == 0) return K4_OK;
     REQ(x && out);
     hipLaunchKernelGGL(k_to8b, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, x, n, out);
+    return k4_check_launch();
+}
+extern "C" int k4_resample_trilinear(const float* in, int32_t channels, int32_t x, int32_t y, int32_t z,
+                                     float* out, int32_t x2, int32_t y2, int32_t z2, void* stream) {
+    REQ(in && out && channels > 0 && x > 0 && y > 0 && z > 0 && x2 > 0 && y2 > 0 && z2 > 0);
+    hipLaunchKernelGGL(k_resample_trilinear, dim3(k4_blocks((int64_t)channels * x2 * y2 * z2)), dim3(K4_THREADS), 0, ST, in, channels, x, y, z, out, x2, y2, z2);
+    return k4_check_launch();
+}
+extern "C" int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, float thres, uint8_t* out, void* stream) {
+    REQ(alpha && out && x > 0 && y > 0 && z > 0);
+    hipLaunchKernelGGL(k_alpha_pool3_gt, dim3(k4_blocks((int64_t)x * y * z)), dim3(K4_THREADS), 0, ST, alpha, x, y, z, thres, out);
     return k4_check_launch();
 }
 extern "C" int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz) {

@@ -133,6 +133,45 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             **self.rgbnet_kwargs,
         }
 
+    # ------------------------------------------------------------------ resolution / occupancy maintenance (training loop)
+    @torch.no_grad()
+    def scale_volume_grid(self, num_voxels, mpi_depth):
+        """Progressive growing (lib/dmpigo.py:189-212): resample density / k0 to the new resolution (k4_resample_trilinear) and, while
+        the grid is small enough (<= 256^3), refresh the occupancy: old mask looked up at the new nodes AND max-pooled alpha > thres."""
+        self._set_grid_resolution(num_voxels, mpi_depth)
+        self.density.scale_volume_grid(self.world_size)
+        self.k0.scale_volume_grid(self.world_size)
+        if int(np.prod(self.world_size.tolist())) <= 256 ** 3:
+            nodes = grid.grid_nodes(self.xyz_min, self.xyz_max, self.world_size.tolist())
+            dens = self.density.get_dense_grid() + self.act_shift.grid        # [1,1,X,Y,Z] + [1,1,1,1,D] (D == Z here)
+            occupied = grid.occupancy_from_alpha(self.activate_density(dens)[0, 0], self.fast_color_thres)
+            self.mask_cache = grid.MaskGrid(path=None, mask=self.mask_cache(nodes) & occupied,
+                                            xyz_min=self.xyz_min, xyz_max=self.xyz_max).to(nodes.device)
+
+    @torch.no_grad()
+    def update_occupancy_cache(self):
+        """lib/dmpigo.py:214-226: mask &= maxpool3(alpha(density at the mask's nodes)) > fast_color_thres.  The density lookup
+        (k4_grid_sample_3d), the activation (k4_raw2alpha) and the pooled threshold (k4_alpha_maxpool3_gt) are HIP kernels; the mask
+        tensor is updated in place, its version bump re-keys the fused marcher's occupancy summary."""
+        nodes = grid.grid_nodes(self.xyz_min, self.xyz_max, list(self.mask_cache.mask.shape))
+        alpha = self.activate_density(self.density(nodes))
+        self.mask_cache.mask &= grid.occupancy_from_alpha(alpha, self.fast_color_thres)
+
+    def update_occupancy_cache_lt_nviews(self, rays_o_tr, rays_d_tr, imsz, render_kwargs, maskout_lt_nviews):
+        """lib/dmpigo.py:228-246: drop voxels seen by fewer than `maskout_lt_nviews` training views.  A view "sees" a voxel when the
+        gradient of sum(ones(ray_pts)) w.r.t. an all-ones grid exceeds 1 there (k4_grid_sample_3d_backward scatter)."""
+        count = torch.zeros_like(self.density.get_dense_grid()).long()
+        dev = count.device
+        for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+            ones = grid.DenseGrid(1, self.world_size, self.xyz_min, self.xyz_max).to(dev)
+            for rays_o, rays_d in zip(rays_o_.split(8192), rays_d_.split(8192)):
+                ray_pts = self.sample_ray(rays_o=rays_o.to(dev), rays_d=rays_d.to(dev), **render_kwargs)[0]
+                with torch.enable_grad():
+                    ones(ray_pts).sum().backward()
+            count += (ones.grid.grad > 1)
+        with torch.no_grad():
+            self.mask_cache.mask &= (count >= maskout_lt_nviews)[0, 0]
+
     def density_total_variation_add_grad(self, weight, dense_mode):
         '''lib/dmpigo.py:248-251: separate in-plane / depth weights (the reference passes them as wx=wy=wxy, wz).'''
         wxy = weight * self.world_size[:2].max() / 128

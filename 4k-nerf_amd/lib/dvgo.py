@@ -277,6 +277,64 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             **self.rgbnet_kwargs,
         }
 
+    # ------------------------------------------------------------------ resolution / occupancy maintenance (training loop)
+    @torch.no_grad()
+    def maskout_near_cam_vox(self, cam_o, near_clip):
+        """lib/dvgo.py:186-198: density = -100 at grid nodes closer than `near_clip` to any camera centre."""
+        nodes = grid.grid_nodes(self.xyz_min, self.xyz_max, self.world_size.tolist())
+        cam_o = cam_o.to(nodes.device)
+        nearest = torch.stack([(nodes.unsqueeze(-2) - co).pow(2).sum(-1).sqrt().amin(-1) for co in cam_o.split(100)]).amin(0)
+        self.density.grid.data[nearest[None, None] <= near_clip] = -100
+        torch.autograd.graph.increment_version(self.density.grid)
+
+    @torch.no_grad()
+    def scale_volume_grid(self, num_voxels):
+        """Progressive growing (lib/dvgo.py:200-221): resample density / k0 (k4_resample_trilinear); refresh the occupancy while the
+        grid is <= 256^3: old mask at the new nodes AND max-pooled alpha > fast_color_thres."""
+        self._set_grid_resolution(num_voxels)
+        self.density.scale_volume_grid(self.world_size)
+        self.k0.scale_volume_grid(self.world_size)
+        if int(np.prod(self.world_size.tolist())) <= 256 ** 3:
+            nodes = grid.grid_nodes(self.xyz_min, self.xyz_max, self.world_size.tolist())
+            occupied = grid.occupancy_from_alpha(self.activate_density(self.density.get_dense_grid())[0, 0], self.fast_color_thres)
+            self.mask_cache = grid.MaskGrid(path=None, mask=self.mask_cache(nodes) & occupied,
+                                            xyz_min=self.xyz_min, xyz_max=self.xyz_max).to(nodes.device)
+
+    @torch.no_grad()
+    def update_occupancy_cache(self):
+        """lib/dvgo.py:223-233: mask &= maxpool3(alpha(density at the mask's nodes)) > fast_color_thres, on HIP kernels."""
+        nodes = grid.grid_nodes(self.xyz_min, self.xyz_max, list(self.mask_cache.mask.shape))
+        alpha = self.activate_density(self.density(nodes))
+        self.mask_cache.mask &= grid.occupancy_from_alpha(alpha, self.fast_color_thres)
+
+    def voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
+        """lib/dvgo.py:235-268: per voxel, the number of training views whose rays pass it (gradient of an all-ones grid > 1)."""
+        far = 1e9
+        n_samples = int(np.linalg.norm(np.array(self.world_size.cpu()) + 1) / stepsize) + 1
+        count = torch.zeros_like(self.density.get_dense_grid())
+        dev = count.device
+        rng = torch.arange(n_samples, device=dev)[None].float()
+        for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+            ones = grid.DenseGrid(1, self.world_size, self.xyz_min, self.xyz_max).to(dev)
+            if irregular_shape:
+                chunks_o, chunks_d = rays_o_.split(10000), rays_d_.split(10000)
+            else:
+                chunks_o = rays_o_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+                chunks_d = rays_d_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+            for rays_o, rays_d in zip(chunks_o, chunks_d):
+                rays_o, rays_d = rays_o.to(dev), rays_d.to(dev)
+                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+                rate_a, rate_b = (self.xyz_max - rays_o) / vec, (self.xyz_min - rays_o) / vec
+                t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+                step = stepsize * self.voxel_size * rng
+                interpx = t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True)
+                rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+                with torch.enable_grad():
+                    ones(rays_pts).sum().backward()
+            with torch.no_grad():
+                count += (ones.grid.grad > 1)
+        return count
+
     def density_total_variation_add_grad(self, weight, dense_mode):
         '''lib/dvgo.py:268-270: isotropic TV weight scaled by max(world_size)/128.'''
         w = weight * self.world_size.max() / 128

@@ -59,6 +59,14 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
             'k4_total_variation_add_grad')
 
 
+def _vec3(v):
+    """float32 CPU copy of a bbox corner given as list / numpy / tensor on any device (the reference's torch.Tensor(v) needs its
+    global CUDA default tensor type for device inputs)."""
+    if torch.is_tensor(v):
+        return v.detach().float().cpu().clone()
+    return torch.Tensor(v)
+
+
 def create_grid(type, **kwargs):
     if type == 'DenseGrid':
         return DenseGrid(**kwargs)
@@ -70,8 +78,8 @@ class DenseGrid(nn.Module):
         super().__init__()
         self.channels, self.world_size = channels, world_size
         for name, val in (('xyz_min', xyz_min), ('xyz_max', xyz_max)):
-            self.register_buffer(name, torch.Tensor(val))
-        self.grid = nn.Parameter(torch.zeros([1, channels, *world_size]))          # [1, C, X, Y, Z], Z fastest
+            self.register_buffer(name, _vec3(val))
+        self.grid = nn.Parameter(torch.zeros([1, channels, *[int(v) for v in world_size]]))          # [1, C, X, Y, Z], Z fastest
 
     def forward(self, xyz):
         """Trilinear lookup == F.grid_sample(bilinear, align_corners=True, zero pad) of lib/grid.py:117-128: HIP kernel
@@ -88,11 +96,21 @@ class DenseGrid(nn.Module):
         return out
 
     def scale_volume_grid(self, new_world_size):
-        """Trilinear resample to a new resolution (progressive growing, lib/grid.py:130-135)."""
+        """Trilinear resample to a new resolution (progressive growing, lib/grid.py:130-135): F.interpolate(trilinear,
+        align_corners=True) on the HIP kernel k4_resample_trilinear.  The new tensor replaces the parameter, as upstream."""
         size = tuple(int(v) for v in new_world_size)
-        data = (torch.zeros([1, 0, *size]) if self.channels == 0 else
-                F.interpolate(self.grid.data, size=size, mode='trilinear', align_corners=True))
+        old = self.grid.data
+        if self.channels == 0:
+            data = torch.zeros([1, 0, *size], device=old.device)
+        else:
+            if not old.is_cuda:
+                raise N.K4Error('scale_volume_grid: the grid must be on the GPU (no CPU path)')
+            src = old.float().contiguous()
+            data = torch.empty([1, self.channels, *size], dtype=torch.float32, device=old.device)
+            N.check(N.lib().k4_resample_trilinear(N.f32(src), self.channels, src.shape[2], src.shape[3], src.shape[4],
+                                                  N.f32(data), size[0], size[1], size[2], N.stream()), 'k4_resample_trilinear')
         self.grid = nn.Parameter(data)
+        self.world_size = new_world_size
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
         '''Add gradients by total variation loss in-place (lib/grid.py:137-140).'''
@@ -121,6 +139,25 @@ def _mask_from_coarse_checkpoint(path, thres):
     return (alpha >= thres)[0, 0], kw['xyz_min'], kw['xyz_max']
 
 
+def occupancy_from_alpha(alpha, thres):
+    """(F.max_pool3d(alpha[None,None], kernel_size=3, padding=1, stride=1)[0,0] > thres) for an [X,Y,Z] fp32 device tensor, on
+    the HIP kernel k4_alpha_maxpool3_gt -> bool tensor [X,Y,Z]."""
+    a = alpha.detach().float().contiguous()
+    if a.dim() != 3 or not a.is_cuda:
+        raise N.K4Error('occupancy_from_alpha: [X,Y,Z] device tensor expected')
+    out = torch.empty(a.shape, dtype=torch.bool, device=a.device)
+    N.check(N.lib().k4_alpha_maxpool3_gt(N.f32(a), a.shape[0], a.shape[1], a.shape[2], float(thres), N.ptr(out), N.stream()),
+            'k4_alpha_maxpool3_gt')
+    return out
+
+
+def grid_nodes(xyz_min, xyz_max, shape):
+    """World positions of the nodes of an [X,Y,Z] grid spanning the bbox (the meshgrid of linspaces of lib/dmpigo.py:199-203)."""
+    dev = xyz_min.device
+    axes = [torch.linspace(float(xyz_min[i]), float(xyz_max[i]), int(shape[i]), device=dev) for i in range(3)]
+    return torch.stack(torch.meshgrid(*axes, indexing='ij'), -1)
+
+
 class MaskGrid(nn.Module):
     """Boolean occupancy grid + the affine map world -> voxel index (buffers `mask`, `xyz2ijk_scale`, `xyz2ijk_shift`)."""
 
@@ -129,7 +166,7 @@ class MaskGrid(nn.Module):
         if path is not None:
             self.mask_cache_thres = mask_cache_thres
             mask, xyz_min, xyz_max = _mask_from_coarse_checkpoint(path, mask_cache_thres)
-        lo, hi = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
+        lo, hi = _vec3(xyz_min), _vec3(xyz_max)
         self.register_buffer('mask', mask.bool())
         scale = (torch.Tensor(list(mask.shape)) - 1) / (hi - lo)
         self.register_buffer('xyz2ijk_scale', scale)

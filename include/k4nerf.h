@@ -217,6 +217,15 @@ int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream);
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
 
+/* Occupancy / resolution maintenance of the training loop (lib/dmpigo.py:189-226, lib/dvgo.py:200-233):
+ *   k4_resample_trilinear : DenseGrid.scale_volume_grid (lib/grid.py:130-135) = F.interpolate(trilinear, align_corners=True) of a
+ *                           [C][X][Y][Z] grid to [C][X2][Y2][Z2]
+ *   k4_alpha_maxpool3_gt  : (F.max_pool3d(alpha, 3, padding=1, stride=1) > thres) as one byte per voxel -- the occupancy refresh of
+ *                           update_occupancy_cache / scale_volume_grid */
+int k4_resample_trilinear(const float* in, int32_t channels, int32_t x, int32_t y, int32_t z,
+                          float* out, int32_t x2, int32_t y2, int32_t z2, void* stream);
+int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, float thres, uint8_t* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Super-resolution decoder (SFTNet "VC-Decoder", lib/sr_esrnet.py:400-465): NHWC fp32 activations, fp32 MFMA
  * implicit GEMM (csrc/k4_sr.hip).  Replaces the conv2d / leaky_relu / torch.cat / F.interpolate chain of

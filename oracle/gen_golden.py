@@ -199,16 +199,67 @@ def gen_grad(ref):
         print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {float(loss):.6f}, {ng} parameter gradients')
 
 
+def gen_occ(ref):
+    """Occupancy / resolution maintenance of the training loop, run on the reference's own classes: update_occupancy_cache,
+    scale_volume_grid (lib/dmpigo.py:189-226, lib/dvgo.py:200-233), update_occupancy_cache_lt_nviews / voxel_count_views."""
+    poses = scene.llff_spiral_poses()
+    for name, ck, new_res in (('occ_mpi', scene.make_llff_checkpoint(seed=16, num_voxels=14 * 14 * 12, mpi_depth=12), (18 * 18 * 12, 12)),       # mpi_depth stays fixed upstream (act_shift is per plane)
+                              ('occ_dvgo', scene.make_lego_checkpoint(seed=26, num_voxels=12 ** 3), (15 ** 3,))):
+        arrs = {'model_class': np.array(ck['model_class']), 'model_kwargs_json': np.array(_kwargs_json(ck['model_kwargs'])),
+                'render_kwargs_json': np.array(json.dumps(ck['render_kwargs'])), 'new_res': np.array(new_res)}
+        for k, v in ck['model_state_dict'].items():
+            arrs['sd/' + k] = _np(v)
+        model = _ref_model(ref, ck)
+        with torch.no_grad():
+            model.density.grid += (0.0 if ck['model_class'] == 'DirectMPIGO' else -4.0)   # make the density disagree with the stored mask: the update must prune
+        arrs['density_plus'] = np.array(0.0 if ck['model_class'] == 'DirectMPIGO' else -4.0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.update_occupancy_cache()
+        arrs['upd/mask'] = _np(model.mask_cache.mask).copy()
+        # views-per-voxel utilities on a handful of rays per "image"
+        if ck['model_class'] == 'DirectMPIGO':
+            rays = _llff_rays(ref, 24, 32, poses[5], subsample=1)
+            ro, rd = rays[0], rays[1]
+            with contextlib.redirect_stdout(io.StringIO()):
+                model.update_occupancy_cache_lt_nviews(ro, rd, [384, 384], dict(near=0, far=1, stepsize=ck['render_kwargs']['stepsize']), 1)
+            arrs['lt/rays_o'], arrs['lt/rays_d'] = _np(ro), _np(rd)
+            arrs['lt/mask'] = _np(model.mask_cache.mask).copy()
+        else:
+            H = W = 20
+            ro, rd, _ = ref.dvgo.get_rays_of_a_view(H, W, scene.lego_K(H, W), torch.Tensor(scene.lego_pose()), False,
+                                                    inverse_y=False, flip_x=False, flip_y=False)
+            ro2 = torch.stack([ro, ro]); rd2 = torch.stack([rd, rd * torch.tensor([1.0, 0.9, 1.1])])
+            with contextlib.redirect_stdout(io.StringIO()):
+                cnt = model.voxel_count_views(ro2, rd2, [1, 1], near=ck['render_kwargs']['near'], far=ck['render_kwargs']['far'],
+                                              stepsize=ck['render_kwargs']['stepsize'], downrate=1)
+            arrs['cnt/rays_o'], arrs['cnt/rays_d'], arrs['cnt/count'] = _np(ro2), _np(rd2), _np(cnt)
+            with torch.no_grad():
+                model.maskout_near_cam_vox(torch.tensor([[0.4, 0.3, 0.2], [-0.5, 0.1, 0.0]]), 0.35)
+            arrs['near/density'] = _np(model.density.grid).copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.scale_volume_grid(*new_res)
+        arrs['scale/world_size'] = _np(model.world_size)
+        arrs['scale/density'], arrs['scale/k0'], arrs['scale/mask'] = _np(model.density.grid), _np(model.k0.grid), _np(model.mask_cache.mask)
+        path = os.path.join(GOLDEN, name + '.npz')
+        np.savez_compressed(path, **arrs)
+        print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, mask {float(arrs["upd/mask"].mean()):.3f} -> scale {arrs["scale/world_size"].tolist()} '
+              f'mask {float(arrs["scale/mask"].mean()):.3f}')
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ref = ref_import.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'grad':
         gen_grad(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'occ':
+        gen_occ(ref)
+        return
     gen_rays(ref)
     gen_march(ref)
     gen_sr(ref)
     gen_grad(ref)
+    gen_occ(ref)
 
 
 if __name__ == '__main__':
