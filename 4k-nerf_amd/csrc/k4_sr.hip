@@ -1001,7 +1001,7 @@ static int launch_conv_taps_b6(ConvMulti& M, hipStream_t st) {
 extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
     const int64_t nt = (cout + 31) / 32;
-    if (nt != 1 && nt != 2 && nt != 4) return -1;
+    if (ksize == 1 ? (nt != 1 && nt != 2 && nt != 4) : nt > 8) return -1;      // 3x3 (v2 kernel): any number of 32-channel blocks up to 256 channels
     return (int64_t)((cin + KC2 - 1) / KC2) * 3 * ksize * ksize * 2 * nt * 32 * 16;
 }
 
@@ -1036,7 +1036,7 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
         if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
         return launch_conv_taps_b6(M, st);
     }
-    if (ksize == 3 && !modulate && nt <= 2 && k4_env().sr_variant == 0) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel
+    if (ksize == 3 && !modulate && (nt > 2 || k4_env().sr_variant == 0)) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel (<= 64 channels)
     const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
     if (ksize == 3) {
         if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(M, st) : launch_conv_b6<3, 1, 8>(M, st);

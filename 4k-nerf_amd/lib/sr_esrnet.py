@@ -12,7 +12,9 @@ Inference (``torch.no_grad``) runs on the implicit-GEMM kernels of ``csrc/k4_sr.
 (exact 3-term bf16 splits, 6 partial products on ``v_mfma_f32_32x32x16_bf16``, fp32 accumulation = fp32-equivalent);
 ``k4_mode='fp32'`` selects ``k4_conv2d_nhwc`` (``v_mfma_f32_32x32x2_f32``, exact fp32 FMA chains), ``'bf16x3'`` the 2-term
 split.  NHWC activations, the dense block's ``torch.cat`` is a [H][W][192] buffer written slice by slice, bias / LeakyReLU /
-residual / nearest-x2 upsampling are fused into the conv, an SFTLayer is one launch (``k4_sft_nhwc``).  No CPU path.
+residual / nearest-x2 upsampling are fused into the conv, an SFTLayer is one launch (``k4_sft_nhwc``).  With autograd enabled
+(joint training, run_sr.py:869-1014) ``forward`` evaluates the graph of ``lib/sr_train.py``: every convolution forward, dgrad and
+wgrad on the MFMA kernels.  No CPU path.
 """
 import math
 import os
@@ -449,6 +451,9 @@ class SFTNet(nn.Module):
         if not x.is_cuda:
             raise N.K4Error('SFTNet input must be on the GPU: the MI355X-native decoder has no CPU path')
         if torch.is_grad_enabled() or fea is not None or self.dswise:
+            if fea is None and not self.dswise and os.environ.get('K4_SR_TRAIN', 'hip') != 'torch':
+                from . import sr_train                     # autograd graph with every convolution (fwd, dgrad, wgrad) on the HIP kernels
+                return sr_train.forward_train(self, x, cond)
             return self._forward_torch(x, cond, fea)
         return self._forward_hip(x, cond).clone()
 

@@ -309,6 +309,17 @@ int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
                 const float* x, int32_t x_stride, float* y, int32_t y_stride, int32_t channels,
                 int64_t n_pix, float slope, const float* res, int32_t res_stride, float res_scale, void* stream);
 
+/* ---- decoder backward (run_sr.py:869-1014 back-propagates through SFTNet) ----------------------------------
+ * dgrad needs no entry point of its own: dX = conv(dY, W') with W'[ci][co][2-dy][2-dx] = W[co][ci][dy][dx] runs on
+ * k4_conv2d_nhwc_bf16x6 with the host-packed W' (3x3: any number of 32-channel output blocks).
+ *   k4_conv2d_wgrad_bf16x6 : dW[co][ci][dy][dx] += sum_p dY[p][co] * X[p + (dy-pad, dx-pad)][ci]  (zero padded), MFMA GEMM over the
+ *                            pixels with exact 3-term bf16 splits of both operands; `dw` ([cout][cin][k][k], PyTorch layout) must
+ *                            be zero-initialised (split-K partial sums are added with fp32 atomics)
+ *   k4_conv2d_bias_grad    : dbias[co] = sum_p dY[p][co] */
+int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                           int32_t ksize, int32_t H, int32_t W, float* dw, void* stream);
+int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream);
+
 /* ---- training-step streaming kernels --------------------------------------------------------
  * Replace the reference extension `adam_upd_cuda` (lib/cuda/adam_upd.cpp:10-67 -> adam_upd_kernel.cu:60-133) that
  * MaskedAdam.step calls (lib/masked_adam.py:39-71).  fp32, n contiguous elements, updated in place; `step` >= 1 is

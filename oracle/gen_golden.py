@@ -199,6 +199,41 @@ def gen_grad(ref):
         print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {float(loss):.6f}, {ng} parameter gradients')
 
 
+def gen_grad_sr(ref):
+    """Training-step gradients of the UNMODIFIED reference SFTNet (lib/sr_esrnet.py, PyTorch CPU autograd): L1 loss against a
+    random target (run_sr.py trains the decoder with an L1 term), gradients w.r.t. every parameter and w.r.t. the inputs (the joint
+    loop back-propagates into the marcher).  Full tensors are stored for a selection of parameters, (sum, L2 norm) for all."""
+    nb = 2
+    sd = osr.make_state_dict(seed=300, num_block=nb)
+    net = ref.sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=nb, num_grow_ch=32, num_cond=1)
+    net.load_state_dict(sd)
+    net.train()
+    g = torch.Generator().manual_seed(9)
+    h, w = 17, 22
+    x = torch.rand([1, 3, h, w], generator=g, requires_grad=True)
+    cond = torch.rand([1, 1, h, w], generator=g, requires_grad=True)
+    target = torch.rand([1, 3, 4 * h, 4 * w], generator=g)
+    out = net(x, cond)
+    loss = torch.nn.functional.l1_loss(out, target)
+    loss.backward()
+    full = ['conv_first.weight', 'conv_first.bias', 'CondNet.0.weight', 'CondNet.6.weight', 'CondNet.6.bias', 'conv_last.weight',
+            'conv_last.bias', 'conv_hr.bias', 'conv_up1.bias', 'body.0.rdb1.conv1.weight', 'body.1.rdb3.conv5.bias',
+            'body.0.rdb2.sft1.SFT_shift_conv1.weight', 'body.1.sft0.SFT_scale_conv0.weight', 'sftbody.SFT_scale_conv1.bias']
+    arrs = {'seed': np.array(300), 'num_block': np.array(nb), 'x': _np(x), 'cond': _np(cond), 'target': _np(target), 'loss': _np(loss.detach()),
+            'out': _np(out.detach()), 'grad_x': _np(x.grad), 'grad_cond': _np(cond.grad)}
+    names, stats = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        stats.append([float(p.grad.double().sum()), float(p.grad.double().norm())])
+        if k in full:
+            arrs['grad/' + k] = _np(p.grad)
+    arrs['names'] = np.array(names)
+    arrs['stats'] = np.array(stats, dtype=np.float64)
+    path = os.path.join(GOLDEN, 'grad_sr.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'grad_sr: {os.path.getsize(path) / 1024:.1f} KiB, loss {float(loss):.6f}, {len(names)} parameters, |grad_x| {float(x.grad.abs().max()):.3e}')
+
+
 def gen_occ(ref):
     """Occupancy / resolution maintenance of the training loop, run on the reference's own classes: update_occupancy_cache,
     scale_volume_grid (lib/dmpigo.py:189-226, lib/dvgo.py:200-233), update_occupancy_cache_lt_nviews / voxel_count_views."""
@@ -255,11 +290,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'occ':
         gen_occ(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'grad_sr':
+        gen_grad_sr(ref)
+        return
     gen_rays(ref)
     gen_march(ref)
     gen_sr(ref)
     gen_grad(ref)
     gen_occ(ref)
+    gen_grad_sr(ref)
 
 
 if __name__ == '__main__':
