@@ -128,6 +128,7 @@ struct K4Env {
     int serp;            // K4_SERP         (1) serpentine ray order inside an 8x8 tile
     int b6_nw1;          // K4_B6_NW1       (8) waves per workgroup of the 32-output-channel bf16x6 convolution
     int sr_variant;      // K4_SR_VARIANT   (0) experiment selector of the decoder kernels
+    int sr_small;        // K4_SR_SMALL     (1) 0: never use the 8-row tile form of the 3x3 convolution for small launches
     int sr_static;       // K4_SR_STATIC    (0) 1: never use the persistent tile loop of the 3x3 convolution
     int geom_band;       // K4_GEOM_BAND    (1) rows of workgroup tiles per XCD band of the geometry kernel (0: one contiguous band per XCD)
 };

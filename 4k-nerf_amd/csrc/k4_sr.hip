@@ -581,7 +581,6 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) 
 //   * 2 waves per SIMD, nothing spills.
 // Same arithmetic, same operand order per accumulator as above: results are bit-identical to the v1 kernel (tests).
 // ------------------------------------------------------------------------------------------------------------------
-#define K4_V2_ROWS 16
 #ifndef K4_V2_ARING
 #define K4_V2_ARING 3      // A-fragment ring: filled ARING-1 sub-stages ahead
 #endif
@@ -594,6 +593,7 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) 
 typedef float k4_f4 __attribute__((ext_vector_type(4)));
 // per-tile scalars (workgroup-uniform)
 struct V2Tile { const float* x; float* y; const float* res; int H, W, srcW, x0, y0, nb; };
+template <int TROWS>
 __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_count, bool ups) {
     int g = 0;
     while (g + 1 < M.n && b >= M.blk_end[g]) ++g;
@@ -604,7 +604,7 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
     T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.H = M.H[g]; T.W = M.W[g];
     T.srcW = ups ? T.W / 2 : T.W;
     const int tiles_x = M.tiles_x[g];
-    T.x0 = (tile % tiles_x) * TILE_W; T.y0 = (tile / tiles_x) * K4_V2_ROWS;
+    T.x0 = (tile % tiles_x) * TILE_W; T.y0 = (tile / tiles_x) * TROWS;
     return T;
 }
 
@@ -613,10 +613,14 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 // stores drain under the next tile's staging.  (Ablation on the 2080x2080 64->64 layer: of 1.9 ms, 0.58 ms were per-workgroup
 // prologue / epilogue latency that nothing overlapped -- the two workgroups of a CU run in phase -- and a static grid of 1649
 // tiles runs in 3.2 "rounds" of 512 and pays for 4.)
-template <bool PERSIST>
+// RPW = output rows per wave: 4 (16-row tiles) by default; 2 (8-row tiles, half the serial work per workgroup) for launches too
+// small to fill the chip with 16-row tiles -- the 209x209 windows of the 8-GPU job are 98 tiles per layer each.
+template <bool PERSIST, int RPW>
 __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M) {
     constexpr int THREADS = 256;
-    constexpr int ROWS = K4_V2_ROWS + 2, COLS = TILE_W + 2;
+    constexpr int TROWS = 4 * RPW;
+    constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
+    constexpr int ROWS = TROWS + 2, COLS = TILE_W + 2;
     constexpr int IN_ITEMS = ROWS * COLS * 2;                 // (pixel, channel group of 8)
     constexpr int IN_PER = (IN_ITEMS + THREADS - 1) / THREADS;
     constexpr int IN_PLANE = 2 * ROWS * COLS;                 // uint4 per term
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
         __syncthreads();
     } else bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (bcur < M.total) {
-    V2Tile T = k4_v2_tile(M, bcur, nb_count, ups);
+    V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count, ups);
 
     // per-thread source of each staged item of the tile being STAGED (chunk independent part)
     const float* isrc[IN_PER];
@@ -705,9 +709,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     K4_V2_LOADB(bbuf[0], 0, 0);
     if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
 
-    const uint4* const arow = in_s + (half * ROWS + wv * 4) * COLS + l31;   // A fragment of (term q, input row i, dx): arow[q*IN_PLANE + i*COLS + dx]
+    const uint4* const arow = in_s + (half * ROWS + wv * RPW) * COLS + l31;   // A fragment of (term q, input row i, dx): arow[q*IN_PLANE + i*COLS + dx]
 #define K4_V2_READA(DST, U) do { \
-        const int t_ = (U) >> 2, r_ = (U) & 3; \
+        const int t_ = (U) / RPW, r_ = (U) % RPW; \
         _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
 
     bool first = true;
@@ -715,9 +719,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
         int bnext = M.total;
         V2Tile Tn = T;
         if (PERSIST && tid == 0) ticket_sh = atomicAdd(&M.queue[0], 1);      // read by everyone after the first barrier below
-        f32x16 acc[4];
+        f32x16 acc[RPW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (f32x16)(0.f);
+        for (int r = 0; r < RPW; ++r) acc[r] = (f32x16)(0.f);
         for (int ch = 0; ch < nchunks; ++ch) {
             if (K4_V2_BRING == 2 && !first) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
@@ -740,11 +744,11 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
             // next staging unit: the next chunk of this tile, or the first chunk of the next tile (its loads fly during the MFMAs below)
             if (ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
             else if (PERSIST && bnext < M.total) {
-                Tn = k4_v2_tile(M, bnext, nb_count, ups);
+                Tn = k4_v2_tile<TROWS>(M, bnext, nb_count, ups);
                 K4_V2_SETUP(Tn);
                 K4_V2_LOADRAW(0);
             }
-            // ---- 36 sub-stages u = tap*4 + r: 6 MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
+            // ---- 9*RPW sub-stages u = tap*RPW + r: 6 MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
             constexpr int AD = K4_V2_ARING - 1, BD = K4_V2_BRING - 1;
             const bool last_chunk = ch + 1 == nchunks;
             // the tap ring runs over the chunk boundary; at a tile boundary the next tile may use another output-channel block
@@ -757,8 +761,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
             if (ch < 0)
 #endif
 #pragma unroll
-            for (int u = 0; u < 36; ++u) {
-                const int t = u >> 2, r = u & 3;
+            for (int u = 0; u < NSUB; ++u) {
+                const int t = u / RPW, r = u % RPW;
                 if (r == 0) {                                                // weights of tap t+BD
                     if (t + BD < 9) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], ch, t + BD);
                     else {
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                         for (int q_ = 0; q_ < 3; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
                     }
                 }
-                if (u + AD < 36) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
+                if (u + AD < NSUB) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][1]),
                                  b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][2]);
 #ifdef K4_V2_DEPTEST      /* timing experiment only (WRONG results): consecutive MFMAs on different accumulators */
-#define K4_ACC(k) acc[(r + (k)) & 3]
+#define K4_ACC(k) acc[(r + (k)) % RPW]
 #else
 #define K4_ACC(k) acc[r]
 #endif
@@ -797,8 +801,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
             if (co < P.cout) {
                 const float bias = P.bias[co];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gy = T.y0 + wv * 4 + r;
+                for (int r = 0; r < RPW; ++r) {
+                    const int gy = T.y0 + wv * RPW + r;
                     if (gy >= T.H) continue;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -830,16 +834,34 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
 
 static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     const int nbc = (M.base.cout + 31) / 32;
-    int total = 0;
-    for (int g = 0; g < M.n; ++g) {
-        M.tiles_x[g] = (M.W[g] + TILE_W - 1) / TILE_W;
-        total += M.tiles_x[g] * ((M.H[g] + K4_V2_ROWS - 1) / K4_V2_ROWS) * nbc;
-        M.blk_end[g] = total;
+    const int slots = 2 * k4_num_cus();
+    auto count = [&](int trows) {
+        int total = 0;
+        for (int g = 0; g < M.n; ++g) {
+            M.tiles_x[g] = (M.W[g] + TILE_W - 1) / TILE_W;
+            total += M.tiles_x[g] * ((M.H[g] + trows - 1) / trows) * nbc;
+            M.blk_end[g] = total;
+        }
+        return total;
+    };
+    int total = count(16);
+    // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
+    // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead); K4_SR_SMALL=0 disables
+    int rpw = 4;
+    if (total <= 2 * slots && k4_env().sr_small) {
+        float best = 1e30f;
+        for (int cand = 4; cand >= 2; --cand) {
+            const int c = count(4 * cand);
+            const float cost = (float)((c + slots - 1) / slots) * ((float)cand + 0.6f);
+            if (cost < best - 1e-3f) { best = cost; rpw = cand; }
+        }
+        total = count(4 * rpw);
     }
     M.total = total;
-    const int slots = 2 * k4_num_cus();
-    if (M.queue && total > slots && !k4_env().sr_static) hipLaunchKernelGGL(k4_conv_b6v2_kernel<true>, dim3((unsigned)slots), dim3(256), 0, st, M);
-    else hipLaunchKernelGGL(k4_conv_b6v2_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, M);
+    if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
+    else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3>), dim3((unsigned)total), dim3(256), 0, st, M);
+    else if (M.queue && total > slots && !k4_env().sr_static) hipLaunchKernelGGL((k4_conv_b6v2_kernel<true, 4>), dim3((unsigned)slots), dim3(256), 0, st, M);
+    else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4>), dim3((unsigned)total), dim3(256), 0, st, M);
     return k4_check_launch();
 }
 

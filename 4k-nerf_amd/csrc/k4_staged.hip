@@ -191,18 +191,31 @@ __global__ void k_fill_i64(int64_t* __restrict__ a, int64_t* __restrict__ b, int
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = 0; b[i] = 0; }
 }
-// alpha2weight_backward (.cu:654-677): reverse sequential scan, one thread per ray (training path, "next")
+// alpha2weight_backward (.cu:654-677): grad[i] = gw[i]*T[i] - back_i / (1 - alpha[i] + 1e-10), back_i = gl*ainv + sum_{j>i} gw[j]*w[j].
+// One WAVE per ray (the reference walks a ray's samples with one thread: uncoalesced, 8192 threads per batch): the segment is
+// taken in chunks of 64 from its far end, lane = sample, the suffix sums are a wave scan plus the carry of the chunks behind.
 __global__ void k_alpha2weight_bwd(const float* __restrict__ alpha, const float* __restrict__ weight,
                                    const float* __restrict__ T, const float* __restrict__ ainv,
                                    const int64_t* __restrict__ i_start, const int64_t* __restrict__ i_end,
                                    int64_t n_rays, const float* __restrict__ gw, const float* __restrict__ gl,
                                    float* __restrict__ grad) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= n_rays) return;
-    float back = gl[r] * ainv[r];
-    for (int64_t i = i_end[r] - 1; i >= i_start[r]; --i) {
-        grad[i] = gw[i] * T[i] - back / (1.f - alpha[i] + 1e-10f);
-        back += gw[i] * weight[i];
+    const int lane = k4_lane();
+    const int64_t s0 = i_start[r], s1 = i_end[r];
+    float carry = gl[r] * ainv[r];                                   // back behind the chunk being processed (wave-uniform)
+    for (int64_t hi = s1; hi > s0; hi -= 64) {
+        const int64_t i = hi - 1 - lane;                             // lane 0 = farthest sample of the chunk
+        const bool ok = i >= s0;
+        const float p = ok ? gw[i] * weight[i] : 0.f;
+        float incl = p;                                              // inclusive sum over lanes 0..lane = samples i .. hi-1
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (ok) grad[i] = gw[i] * T[i] - (carry + (incl - p)) / (1.f - alpha[i] + 1e-10f);
+        carry += __shfl(incl, 63);
     }
 }
 
@@ -519,7 +532,7 @@ extern "C" int k4_alpha2weight_backward(const float* alpha, const float* weight,
     if (n_pts == 0 || n_rays == 0) return K4_OK;
     REQ(alpha && weight && T && ainv && i_start && i_end && gw && gl && grad);
     hipLaunchKernelGGL(k_fill2, dim3(k4_blocks(n_pts)), dim3(K4_THREADS), 0, ST, grad, 0.f, (float*)nullptr, 0.f, n_pts);
-    hipLaunchKernelGGL(k_alpha2weight_bwd, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, alpha, weight, T, ainv, i_start, i_end, n_rays, gw, gl, grad);
+    hipLaunchKernelGGL(k_alpha2weight_bwd, dim3(k4_blocks(n_rays * 64)), dim3(K4_THREADS), 0, ST, alpha, weight, T, ainv, i_start, i_end, n_rays, gw, gl, grad);
     return k4_check_launch();
 }
 extern "C" int k4_grid_sample_3d(const float* grid, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
