@@ -115,7 +115,7 @@ _EXTRA_SIGS = {
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P, _P], C.c_int),
-    'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _P], C.c_int),
+    'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_bias_grad': ([_P, _I32, _I32, _I64, _P, _P], C.c_int),
     'k4_resample_trilinear': ([_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P], C.c_int),

@@ -423,6 +423,21 @@ __device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4
     t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
 }
 
+__device__ __forceinline__ void k4s_split3x4(const float4& v, uint2& t0, uint2& t1, uint2& t2) {   // 4 channels -> 3 terms x 4 bf16
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned p0[2], p1[2], p2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = f[2 * i], b = f[2 * i + 1];
+        p0[i] = k4s_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(p0[i] << 16), rb = b - __uint_as_float(p0[i] & 0xffff0000u);
+        p1[i] = k4s_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(p1[i] << 16), sb = rb - __uint_as_float(p1[i] & 0xffff0000u);
+        p2[i] = k4s_pk_bf16(sa, sb);
+    }
+    t0 = make_uint2(p0[0], p0[1]); t1 = make_uint2(p1[0], p1[1]); t2 = make_uint2(p2[0], p2[1]);
+}
+
 // NW = waves per workgroup (tile = 2*NW rows x 32 columns).  NW = 8 for 64 output channels (one 114 KB workgroup per CU);
 // NW = 4 for 32 output channels: 60 KB, two workgroups per CU whose staging / MFMA phases interleave.
 template <int KS, int NT, int NW>
@@ -621,9 +636,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     constexpr int TROWS = 4 * RPW;
     constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
     constexpr int ROWS = TROWS + 2, COLS = TILE_W + 2;
-    constexpr int IN_ITEMS = ROWS * COLS * 2;                 // (pixel, channel group of 8)
-    constexpr int IN_PER = (IN_ITEMS + THREADS - 1) / THREADS;
-    constexpr int IN_PLANE = 2 * ROWS * COLS;                 // uint4 per term
+    constexpr int NPIX = ROWS * COLS;                         // haloed input tile
+    constexpr int IN_PER = (NPIX * 4 + THREADS - 1) / THREADS;   // staged items per thread: (pixel, QUARTER of the 16-channel chunk)
+    constexpr int IN_PLANE = 2 * NPIX;                        // uint4 per term
     __shared__ uint4 in_s[3 * IN_PLANE];                      // [term][channel group][row][col] x 8 bf16
     __shared__ int ticket_sh;
     const ConvParams& P = M.base;                             // shared by every window: cin, strides, weights, bias, cout, flags ...
@@ -648,53 +663,55 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     if (bcur < M.total) {
     V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count, ups);
 
-    // per-thread source of each staged item of the tile being STAGED (chunk independent part)
-    const float* isrc[IN_PER];
-    bool iin[IN_PER];
-    int ikg[IN_PER], idst[IN_PER];
+    // Staging map: thread -> quarter q = tid&3 (4 channels = 16 bytes) of pixels pp = (tid>>2) + 64*i.  Four adjacent lanes read the
+    // 64 contiguous bytes of one pixel's chunk, so a wave's load instruction touches 16 cache lines with 64 bytes each (the
+    // (pixel, 8-channel) map of the v1 kernel touched 64 pieces of 16 bytes: the L1 tag rate, not bytes, bounded the staging --
+    // TCP_TOTAL_CACHE_ACCESSES 2.2e8 per 2080x2080 launch, 0.7 per CU-cycle with the MFMA phase compiled out).
+    // Per-thread state of the tile being STAGED (chunk independent): element offsets from the image base, an inside-the-image mask.
+    int ioff[IN_PER];
+    unsigned imask;
     bool vec_ok;
-    const float* dummy;
+    const float* xbase;
+    const int sq = tid & 3, sp0 = tid >> 2;
 #define K4_V2_SETUP(TT) do { \
+        imask = 0u; \
         _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
-            const int it = tid + i * THREADS; \
-            const int itc = it < IN_ITEMS ? it : 0; \
-            const int kg = itc & 1, pp = itc >> 1; \
-            const int py = pp / COLS, px = pp - py * COLS; \
+            const int pp = sp0 + 64 * i; \
+            const int ppc = pp < NPIX ? pp : 0; \
+            const int py = ppc / COLS, px = ppc - py * COLS; \
             const int gy = (TT).y0 - 1 + py, gx = (TT).x0 - 1 + px; \
-            const bool inside = it < IN_ITEMS && gy >= 0 && gy < (TT).H && gx >= 0 && gx < (TT).W; \
-            const int sy = inside ? (ups ? (gy >> 1) : gy) : 0, sx = inside ? (ups ? (gx >> 1) : gx) : 0; \
-            isrc[i] = (TT).x + ((size_t)sy * (TT).srcW + sx) * P.cin_stride + kg * 8; \
-            iin[i] = inside; ikg[i] = kg; \
-            idst[i] = it < IN_ITEMS ? (kg * ROWS + py) * COLS + px : -1; \
+            const bool inside = pp < NPIX && gy >= 0 && gy < (TT).H && gx >= 0 && gx < (TT).W; \
+            const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx; \
+            ioff[i] = inside ? (sy * (TT).srcW + sx) * P.cin_stride + sq * 4 : 0; \
+            imask |= inside ? (1u << i) : 0u; \
         } \
-        vec_ok = vec_base && (((size_t)(TT).x) & 15) == 0; dummy = (TT).x; } while (0)
+        vec_ok = vec_base && (((size_t)(TT).x) & 15) == 0; xbase = (TT).x; } while (0)
     K4_V2_SETUP(T);
 
     // raw fp32 of the NEXT chunk's tile items: fetched before the MFMA phase of the current chunk, split + stored after it, so that
     // the HBM/L2 latency of the staging is hidden (the two workgroups of a CU start in phase and stay in phase: a synchronous
     // staging phase was fully exposed -- SQ_VALU_MFMA_BUSY_CYCLES showed the matrix pipe 48 % busy)
-    float4 rva[IN_PER], rvb[IN_PER];
+    float4 rv[IN_PER];
 #define K4_V2_LOADRAW(CH) do { \
         const int c0_ = (CH) * KC2; \
         if (vec_ok && c0_ + KC2 <= P.cin) { \
             _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
-                const k4_f4* src = reinterpret_cast<const k4_f4*>(iin[i] ? isrc[i] + c0_ : dummy); \
+                const k4_f4* src = reinterpret_cast<const k4_f4*>(xbase + ioff[i] + c0_); \
                 const k4_f4 va = K4_V2_NT ? __builtin_nontemporal_load(src) : *src; \
-                const k4_f4 vb = K4_V2_NT ? __builtin_nontemporal_load(src + 1) : src[1]; \
-                rva[i] = iin[i] ? make_float4(va.x, va.y, va.z, va.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
-                rvb[i] = iin[i] ? make_float4(vb.x, vb.y, vb.z, vb.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                rv[i] = (imask >> i) & 1u ? make_float4(va.x, va.y, va.z, va.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
             } \
         } else { \
             _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
-                const int cb = c0_ + ikg[i] * 8; \
-                const float* src = isrc[i] + c0_; \
-                float e8[8]; \
-                _Pragma("unroll") for (int c = 0; c < 8; ++c) { \
-                    const bool ok_ = iin[i] && cb + c < P.cin; \
-                    const float q_ = *(ok_ ? src + c : dummy); \
-                    e8[c] = ok_ ? q_ : 0.f; \
+                const bool in_ = (imask >> i) & 1u; \
+                const int cb = c0_ + sq * 4; \
+                const float* src = xbase + ioff[i] + c0_; \
+                float e4[4]; \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
+                    const bool ok_ = in_ && cb + c < P.cin; \
+                    const float q_ = *(ok_ ? src + c : xbase); \
+                    e4[c] = ok_ ? q_ : 0.f; \
                 } \
-                rva[i] = make_float4(e8[0], e8[1], e8[2], e8[3]); rvb[i] = make_float4(e8[4], e8[5], e8[6], e8[7]); \
+                rv[i] = make_float4(e4[0], e4[1], e4[2], e4[3]); \
             } \
         } } while (0)
     K4_V2_LOADRAW(0);
@@ -709,6 +726,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     K4_V2_LOADB(bbuf[0], 0, 0);
     if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
 
+    uint2* const in2 = reinterpret_cast<uint2*>(in_s);
+    const int sdst = ((sq >> 1) * NPIX + sp0) * 2 + (sq & 1);
     const uint4* const arow = in_s + (half * ROWS + wv * RPW) * COLS + l31;   // A fragment of (term q, input row i, dx): arow[q*IN_PLANE + i*COLS + dx]
 #define K4_V2_READA(DST, U) do { \
         const int t_ = (U) / RPW, r_ = (U) % RPW; \
@@ -723,7 +742,12 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
 #pragma unroll
         for (int r = 0; r < RPW; ++r) acc[r] = (f32x16)(0.f);
         for (int ch = 0; ch < nchunks; ++ch) {
-            if (K4_V2_BRING == 2 && !first) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
+#ifndef K4_V2_WONCE
+            if (K4_V2_BRING == 2 && !first)
+#else
+            if (false)
+#endif
+            {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
                 for (int q = 0; q < 3; ++q) bbuf[0][q] = bbuf[1][q];
             }
@@ -734,16 +758,21 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
 #endif
 #pragma unroll
             for (int i = 0; i < IN_PER; ++i) {
-                const float v8[8] = {rva[i].x, rva[i].y, rva[i].z, rva[i].w, rvb[i].x, rvb[i].y, rvb[i].z, rvb[i].w};
-                uint4 t0, t1, t2;
-                k4s_split3(v8, t0, t1, t2);
-                if (idst[i] >= 0) { in_s[idst[i]] = t0; in_s[IN_PLANE + idst[i]] = t1; in_s[2 * IN_PLANE + idst[i]] = t2; }
+                uint2 t0, t1, t2;
+                k4s_split3x4(rv[i], t0, t1, t2);
+                if (sp0 + 64 * i < NPIX) {           // 8-byte unit of (term, channel group kg = q>>1, pixel, q&1); i*128 is a constant offset
+                    uint2* const d = in2 + sdst + i * 128;
+                    d[0] = t0; d[2 * IN_PLANE] = t1; d[4 * IN_PLANE] = t2;
+                }
             }
             __syncthreads();
             if (PERSIST && ch == 0) bnext = ticket_sh;
             // next staging unit: the next chunk of this tile, or the first chunk of the next tile (its loads fly during the MFMAs below)
+#if !defined(K4_V2_LATEPF) && !defined(K4_V2_NOLOAD)       /* NOLOAD: timing experiment only (WRONG results) */
             if (ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
-            else if (PERSIST && bnext < M.total) {
+            else
+#endif
+            if (PERSIST && bnext < M.total) {
                 Tn = k4_v2_tile<TROWS>(M, bnext, nb_count, ups);
                 K4_V2_SETUP(Tn);
                 K4_V2_LOADRAW(0);
@@ -763,7 +792,11 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
 #pragma unroll
             for (int u = 0; u < NSUB; ++u) {
                 const int t = u / RPW, r = u % RPW;
+#ifdef K4_V2_WONCE        /* timing experiment only (WRONG results): no weight loads inside the MFMA phase */
+                if (false) {
+#else
                 if (r == 0) {                                                // weights of tap t+BD
+#endif
                     if (t + BD < 9) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], ch, t + BD);
                     else {
                         const uint4* wp_ = wnext + (size_t)chn * W_ITEMS;
@@ -771,13 +804,24 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                         for (int q_ = 0; q_ < 3; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
                     }
                 }
+#ifdef K4_V2_LATEPF       /* timing experiment only: the activation prefetch issued after the chunk's last weight load */
+                if (u == K4_V2_LATEPF * RPW && ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
+#endif
+#ifndef K4_V2_NOAREAD     /* timing experiment only (WRONG results): no A-fragment reads inside the MFMA phase */
                 if (u + AD < NSUB) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
                                  a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][2]);
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][1]),
-                                 b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][2]);
+#ifdef K4_V2_WONCE
+#define K4_BSLOT 0
+#else
+#define K4_BSLOT (t % K4_V2_BRING)
+#endif
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][1]),
+                                 b2 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][2]);
+#undef K4_BSLOT
 #ifdef K4_V2_DEPTEST      /* timing experiment only (WRONG results): consecutive MFMAs on different accumulators */
 #define K4_ACC(k) acc[(r + (k)) % RPW]
 #else
@@ -793,7 +837,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef K4_V2_NOBAR       /* timing experiment only (WRONG results) */
             __syncthreads();
+#endif
         }
         // ---- epilogue of tile T: lane holds output channel nb*32 + l31 of pixels x0 + row(reg, half) in rows y0 + wv*4 + r ----
         {
@@ -844,11 +890,14 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         }
         return total;
     };
+    for (int g = 0; g < M.n; ++g)                       // the kernel addresses the image with 32-bit element offsets
+        if ((int64_t)M.H[g] * M.W[g] * M.base.cin_stride > 0x7fffffffLL) return K4_ERR_UNSUPPORTED;
     int total = count(16);
     // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
     // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead); K4_SR_SMALL=0 disables
     int rpw = 4;
-    if (total <= 2 * slots && k4_env().sr_small) {
+    const int small_rounds = k4_env().sr_small == 1 ? 2 : k4_env().sr_small;      // experiment knob: K4_SR_SMALL=N applies the choice up to N rounds
+    if (total <= small_rounds * slots && k4_env().sr_small) {
         float best = 1e30f;
         for (int cand = 4; cand >= 2; --cand) {
             const int c = count(4 * cand);
@@ -1232,13 +1281,159 @@ __global__ __launch_bounds__(256) void k4_sft_kernel(const SftMulti M) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same fused SFTLayer on the bf16 matrix pipe with the exact 3-term split (the decoder's default arithmetic): the fp32-input
+// MFMA form above runs the layer's 6 % of the decoder FLOPs at 1/16 of the bf16 rate (12 % of the frame time).  Per 32-pixel
+// tile: GEMM 1 hidden^T[64][pix] = lrelu(WA . cond^T + ba) -- B operand = 8 consecutive condition channels of the lane's pixel,
+// split in registers; GEMM 2 scale / shift = WS . h[0..31] + bs, WH . h[32..63] + bh -- the accumulator layout of GEMM 1 is the
+// B-operand layout of GEMM 2 when K is walked in accumulator-register order (as in the marcher's rgbnet), so the hidden
+// activations never leave registers; the biases are the accumulators' initial values.
+// Split section of the packed buffer (after the fp32 section; host: sr_esrnet.SFTNet._pack_sft), 16-byte units = 8 bf16, lane l:
+//   WA6 [2][2][3][64]   WA[mb*32 + (l&31)][kb*16 + 8*(l>>5) + e]
+//   WS6 [CB][2][3][64]  WS[mb2*32 + (l&31)][n(kb, l>>5, e)],  n = (e&3) + 8*(2*kb + (e>>2)) + 4*(l>>5);   WH6 likewise
+//   BA [2][2][16], BS [CB][2][16], BH [CB][2][16]  fp32: bias[blk*32 + (r&3) + 8*(r>>2) + 4*half]
+// ------------------------------------------------------------------------------------------------------------------
+#define K4_SFT6_FLOATS(CB) ((2 + 2 * (CB)) * 2 * 3 * 64 * 4 + (2 + 2 * (CB)) * 2 * 16)
+#define K4_B6(ACC, A0, A1, A2, B0, B1, B2) do { \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2), __builtin_bit_cast(bf16x8, B0), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B2), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, B1), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A1), __builtin_bit_cast(bf16x8, B0), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B1), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A0), __builtin_bit_cast(bf16x8, B0), ACC, 0, 0, 0); } while (0)
+
+template <int CB>
+__global__ __launch_bounds__(256) void k4_sft_b6_kernel(const SftMulti M) {
+    constexpr int NW6 = K4_SFT6_FLOATS(CB);
+    constexpr int NW32 = (2 + 2 * CB) * 17 * 64;
+    __shared__ __attribute__((aligned(16))) float wl[NW6];
+    SftParams P = M.base;
+    int blk = (int)blockIdx.x;
+    {
+        int g = 0;
+        while (g + 1 < M.n && blk >= M.blk_end[g]) ++g;
+        blk -= g ? M.blk_end[g - 1] : 0;
+        P.cond = M.cond[g]; P.x = M.x[g]; P.y = M.y[g]; P.res = M.res[g]; P.n_pix = M.n_pix[g];
+    }
+    const int lane = k4_lane();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.w + NW32);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = (int)threadIdx.x; i < NW6 / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint4* const wa6 = reinterpret_cast<const uint4*>(wl);
+    const uint4* const ws6 = wa6 + 2 * 2 * 3 * 64;
+    const uint4* const wh6 = ws6 + CB * 2 * 3 * 64;
+    const float* const ba = wl + (2 + 2 * CB) * 2 * 3 * 64 * 4;
+    const float* const bs = ba + 2 * 2 * 16;
+    const float* const bh = bs + CB * 2 * 16;
+    const int base = (blk * 4 + wv) * 64;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int pix = base + t * 32 + l31;
+        const bool pok = pix < P.n_pix;
+        // ---- GEMM 1: hidden^T = lrelu(WA . cond^T + ba) ----
+        f32x16 h[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[mb][r] = ba[(mb * 2 + half) * 16 + r];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float v[8];
+            if (pok) {
+                const float4* src = reinterpret_cast<const float4*>(P.cond + (size_t)pix * P.cond_stride + kb * 16 + 8 * half);
+                const float4 c0 = src[0], c1 = src[1];
+                v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            uint4 x0, x1, x2;
+            k4s_split3(v, x0, x1, x2);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const uint4* wp = wa6 + ((mb * 2 + kb) * 3) * 64 + lane;
+                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                K4_B6(h[mb], a0, a1, a2, x0, x1, x2);
+            }
+        }
+        // lrelu + split of the hidden activations: K chunk kb = accumulator registers 8*kb .. 8*kb+7
+        uint4 hs[2][2][3];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float q = h[mb][8 * kb + e]; v[e] = q > 0.f ? q : q * P.slope; }
+                k4s_split3(v, hs[mb][kb][0], hs[mb][kb][1], hs[mb][kb][2]);
+            }
+        // ---- GEMM 2 + modulation, 32 output channels at a time ----
+#pragma unroll 1
+        for (int mb2 = 0; mb2 < CB; ++mb2) {
+            f32x16 cs, ch;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cs[r] = bs[(mb2 * 2 + half) * 16 + r]; ch[r] = bh[(mb2 * 2 + half) * 16 + r]; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint4* wps = ws6 + ((mb2 * 2 + kb) * 3) * 64 + lane;
+                const uint4* wph = wh6 + ((mb2 * 2 + kb) * 3) * 64 + lane;
+                const uint4 s0 = wps[0], s1 = wps[64], s2 = wps[128];
+                const uint4 g0 = wph[0], g1 = wph[64], g2 = wph[128];
+                K4_B6(cs, s0, s1, s2, hs[0][kb][0], hs[0][kb][1], hs[0][kb][2]);
+                K4_B6(ch, g0, g1, g2, hs[1][kb][0], hs[1][kb][1], hs[1][kb][2]);
+            }
+            if (!pok) continue;
+            // accumulator registers 4q..4q+3 are 4 CONSECUTIVE channels (co = 8q + 4*half + 0..3): 16-byte accesses
+            const bool vec = P.vec4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = mb2 * 32 + 8 * q + 4 * half;
+                float xv[4], rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(P.x + (size_t)pix * P.x_stride + co);
+                    xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                    if (P.res) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(P.res + (size_t)pix * P.res_stride + co);
+                        rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xv[e] = P.x[(size_t)pix * P.x_stride + co + e];
+                        if (P.res) rv[e] = P.res[(size_t)pix * P.res_stride + co + e];
+                    }
+                }
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = xv[e] * (cs[4 * q + e] + 1.f) + ch[4 * q + e];               // x*(scale+1)+shift
+                    if (P.res) v = v * P.res_scale + rv[e];
+                    ov[e] = v;
+                }
+                if (vec) *reinterpret_cast<float4*>(P.y + (size_t)pix * P.y_stride + co) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) P.y[(size_t)pix * P.y_stride + co + e] = ov[e];
+                }
+            }
+        }
+    }
+}
+
 extern "C" int64_t k4_sft_weight_floats(int32_t channels) {
     if (channels != 32 && channels != 64) return -1;
-    return (int64_t)(2 + 2 * (channels / 32)) * 17 * 64;
+    const int cb = channels / 32;
+    return (int64_t)(2 + 2 * cb) * 17 * 64 + (cb == 2 ? K4_SFT6_FLOATS(2) : K4_SFT6_FLOATS(1));
 }
 
 static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
-                     int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream) {
+                     int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith, void* stream) {
+    if (arith != K4_SFT_ARITH_FP32 && arith != K4_SFT_ARITH_BF16X6) return K4_ERR_BAD_ARG;
     if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_packed || cond_stride < 32 || (cond_stride & 3)) return K4_ERR_BAD_ARG;
     if ((channels != 32 && channels != 64) || x_stride < channels || y_stride < channels) return K4_ERR_BAD_ARG;
     SftMulti M{};
@@ -1262,14 +1457,20 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
     P.res = any_res ? jobs[0].res : nullptr;                         // the kernel tests P.res for "has residual"; the job's pointer is used
     P.vec4 = ((x_stride | y_stride | (any_res ? res_stride : 0)) & 3) == 0 && (align & 15) == 0;
     const dim3 grid((unsigned)total), block(256);
-    if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
-    else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
+    if (arith == K4_SFT_ARITH_BF16X6) {
+        if (channels == 64) hipLaunchKernelGGL((k4_sft_b6_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
+        else hipLaunchKernelGGL((k4_sft_b6_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
+    } else {
+        if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
+        else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
+    }
     return k4_check_launch();
 }
 
 extern "C" int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
-                                 int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream) {
-    return sft_multi(jobs, n_jobs, cond_stride, w_packed, x_stride, y_stride, channels, slope, res_stride, res_scale, stream);
+                                 int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith,
+                                 void* stream) {
+    return sft_multi(jobs, n_jobs, cond_stride, w_packed, x_stride, y_stride, channels, slope, res_stride, res_scale, arith, stream);
 }
 
 extern "C" int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
@@ -1277,5 +1478,5 @@ extern "C" int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* 
                            int64_t n_pix, float slope, const float* res, int32_t res_stride, float res_scale, void* stream) {
     k4_sft_job j{};
     j.cond = cond; j.x = x; j.y = y; j.res = res; j.n_pix = n_pix;
-    return sft_multi(&j, 1, cond_stride, w_packed, x_stride, y_stride, channels, slope, res ? res_stride : 0, res_scale, stream);
+    return sft_multi(&j, 1, cond_stride, w_packed, x_stride, y_stride, channels, slope, res ? res_stride : 0, res_scale, K4_SFT_ARITH_FP32, stream);
 }

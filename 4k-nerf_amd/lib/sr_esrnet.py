@@ -186,8 +186,37 @@ def pack_sft(layer):
     parts = [block(wa, ba, 2, lambda st, h: 2 * st + h),
              block(ws, layer.SFT_scale_conv1.bias.detach().float(), C // 32, lambda st, h: row(st) + 4 * h),
              block(wh, layer.SFT_shift_conv1.bias.detach().float(), C // 32, lambda st, h: row(st) + 4 * h)]
+    # split-bf16 section (csrc/k4_sr.hip, k4_sft_b6_kernel): v_mfma_f32_32x32x16_bf16 A operands [blk][kb][term][lane][8 bf16],
+    # k walked in cond-channel order for GEMM 1 and in accumulator-register order n(kb, half, e) for GEMM 2; biases per
+    # accumulator register [blk][half][16]
+    e = torch.arange(8, device=dev)
+    kb = torch.arange(2, device=dev)
+    r16 = torch.arange(16, device=dev)
+    hh = torch.arange(2, device=dev)
+
+    def split_block(w2d, nblk, k_idx):
+        blkv = torch.arange(nblk, device=dev)
+        j = (blkv[:, None, None, None] * 32 + l31[None, None, :, None]).expand(nblk, 2, 64, 8)
+        k = k_idx[None].expand(nblk, 2, 64, 8)
+        hi = w2d.to(torch.bfloat16)
+        r1 = w2d - hi.float()
+        mid = r1.to(torch.bfloat16)
+        lo = (r1 - mid.float()).to(torch.bfloat16)
+        g = torch.stack([t[j, k] for t in (hi, mid, lo)], dim=2)              # [blk][kb][term][lane][8]
+        return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+    def bias_block(bias, nblk):
+        blkv = torch.arange(nblk, device=dev)
+        idx = blkv[:, None, None] * 32 + (r16 & 3)[None, None, :] + 8 * (r16 >> 2)[None, None, :] + 4 * hh[None, :, None]
+        return bias[idx].reshape(-1)
+
+    k1 = kb[:, None, None] * 16 + 8 * half[None, :, None] + e[None, None, :]
+    k2 = (e & 3)[None, None, :] + 8 * (2 * kb[:, None, None] + (e >> 2)[None, None, :]) + 4 * half[None, :, None]
+    bs_, bh_ = layer.SFT_scale_conv1.bias.detach().float(), layer.SFT_shift_conv1.bias.detach().float()
+    parts += [split_block(wa, 2, k1), split_block(ws, C // 32, k2), split_block(wh, C // 32, k2),
+              bias_block(ba, 2), bias_block(bs_, C // 32), bias_block(bh_, C // 32)]
     out = torch.cat(parts).contiguous()
-    assert out.numel() == N.lib().k4_sft_weight_floats(C)
+    assert out.numel() == N.lib().k4_sft_weight_floats(C), (out.numel(), N.lib().k4_sft_weight_floats(C))
     out.channels = C
     return out
 
@@ -355,7 +384,8 @@ class SFTNet(nn.Module):
             jobs[j].n_pix = h * w
         rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
         fn = N.lib().k4_sft_nhwc_multi
-        args = (jobs, len(Bs), self.num_grow_ch, N.f32(wp), x_stride, y_stride, cfeat, 0.2, rs, rscale)
+        arith = 0 if (self.k4_mode == 'fp32' or os.environ.get('K4_SFT_FP32', '0') == '1') else 1     # K4_SFT_ARITH_*
+        args = (jobs, len(Bs), self.num_grow_ch, N.f32(wp), x_stride, y_stride, cfeat, 0.2, rs, rscale, arith)
         if plan is not None:
             plan.append((fn, args, 'k4_sft_nhwc_multi'))
         N.check(fn(*args, N.stream()), 'k4_sft_nhwc_multi')

@@ -296,14 +296,17 @@ int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t
  * tiles than the chip holds at once then run as persistent workgroups pulling tiles from this counter (no partly filled last round).
  * Launches that may run concurrently must not share a queue. */
 typedef struct k4_sft_job { const float* cond; const float* x; float* y; const float* res; int64_t n_pix; } k4_sft_job;
+#define K4_SFT_ARITH_FP32   0      /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (what k4_sft_nhwc computes)                    */
+#define K4_SFT_ARITH_BF16X6 1      /* exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16 (fp32-equivalent)    */
 int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
-                      int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, void* stream);
+                      int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith, void* stream);
 
 /* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then
  * *res_scale + res if res != NULL), scale/shift = conv1x1(lrelu(conv1x1(cond))) evaluated in one launch, the hidden
  * activations stay in registers.  cond: [n_pix][cond_stride] (32 channels, 16-B aligned rows); channels = 32 or 64;
  * w_packed: k4_sft_weight_floats(channels) floats = WA [2][17][64] | WS [C/32][17][64] | WH [C/32][17][64] in
- * v_mfma_f32_32x32x2_f32 operand order (k-step 16 carries the bias); y may alias x. */
+ * v_mfma_f32_32x32x2_f32 operand order (k-step 16 carries the bias), followed by the split-bf16 section of the same weights that
+ * K4_SFT_ARITH_BF16X6 reads (layout: csrc/k4_sr.hip, k4_sft_b6_kernel; host packer sr_esrnet.pack_sft); y may alias x. */
 int64_t k4_sft_weight_floats(int32_t channels);
 int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
                 const float* x, int32_t x_stride, float* y, int32_t y_stride, int32_t channels,

@@ -180,10 +180,12 @@ def test_split_bf16_conv_and_network(mode, conv_tol, mod_tol, min_psnr):
     assert p32 >= 100.0 and p16 >= min_psnr, (p32, p16)
 
 
+@pytest.mark.parametrize('arith', [0, 1])
 @pytest.mark.parametrize('C', [64, 32])
-def test_fused_sft_layer(C):
-    """k4_sft_nhwc (both 1x1 convs + LeakyReLU + modulation [+ residual] in one launch) against the module graph,
-    on a pixel count that is not a multiple of the 64-pixel wave tile, with channel-sliced in-place x/y."""
+def test_fused_sft_layer(C, arith):
+    """k4_sft_nhwc / k4_sft_nhwc_multi (both 1x1 convs + LeakyReLU + modulation [+ residual] in one launch) against the module
+    graph, on a pixel count that is not a multiple of the 64-pixel wave tile, with channel-sliced in-place x/y; arith 0 = fp32 MFMA
+    (K4_SFT_ARITH_FP32), 1 = exact 3-term bf16 splits on the bf16 MFMA (K4_SFT_ARITH_BF16X6, the decoder's default)."""
     from nerf4k_amd import _native as N
     torch.manual_seed(C)
     layer = sr_esrnet.SFTLayer(C, 32).cuda()
@@ -198,8 +200,13 @@ def test_fused_sft_layer(C):
         want = layer(x.permute(2, 0, 1).unsqueeze(0), cond.permute(2, 0, 1).unsqueeze(0))[0].permute(1, 2, 0) * 0.2 + res
     wp = sr_esrnet.pack_sft(layer)
     keep = buf.clone()
-    N.check(N.lib().k4_sft_nhwc(N.f32(cond), 32, N.f32(wp), N.C.c_void_p(buf.data_ptr() + 64), 96,
-                                N.C.c_void_p(buf.data_ptr() + 64), 96, C, H * W, 0.2, N.f32(res), C, 0.2, N.stream()), 'sft')
+    if arith == 0:
+        N.check(N.lib().k4_sft_nhwc(N.f32(cond), 32, N.f32(wp), N.C.c_void_p(buf.data_ptr() + 64), 96,
+                                    N.C.c_void_p(buf.data_ptr() + 64), 96, C, H * W, 0.2, N.f32(res), C, 0.2, N.stream()), 'sft')
+    else:
+        job = (N.SftJob * 1)()
+        job[0].cond, job[0].x, job[0].y, job[0].res, job[0].n_pix = cond.data_ptr(), buf.data_ptr() + 64, buf.data_ptr() + 64, res.data_ptr(), H * W
+        N.check(N.lib().k4_sft_nhwc_multi(job, 1, 32, N.f32(wp), 96, 96, C, 0.2, C, 0.2, arith, N.stream()), 'sft_multi')
     assert torch.allclose(buf[:, :, 16:16 + C], want, atol=3e-5, rtol=1e-5), float((buf[:, :, 16:16 + C] - want).abs().max())
     assert torch.equal(buf[:, :, :16], keep[:, :, :16]) and torch.equal(buf[:, :, 16 + C:], keep[:, :, 16 + C:])
 
