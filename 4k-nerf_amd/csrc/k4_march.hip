@@ -58,6 +58,7 @@ struct MarchParams {
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
+    int* order;                                    // workspace: [n_bundles] bundle ids, most records first (k4_order_kernel)
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     int serp;               // 1: serpentine ray order inside a tile (default)
@@ -154,6 +155,9 @@ __device__ __forceinline__ void ray_setup(const MarchParams& P, float ox, float 
 #endif
 #ifndef K4_SHADE_WG_PER_CU
 #define K4_SHADE_WG_PER_CU 2      // 256 VGPRs per wave: at 3 (168 VGPRs) the batch loop spilled ~90 dwords and its scratch reloads cost 0.4 ms/frame
+#endif
+#ifndef K4_SHADE_SCAN
+#define K4_SHADE_SCAN 0           // 1: per-ray sums by a segmented wave scan + one LDS atomic per run (the earlier form)
 #endif
 #define K4_RING 512
 #define K4_TKTAB 256              // MPI: k/(Ns-1) for k < K4_TKTAB is tabulated once per workgroup (an IEEE division costs ~10 VALU per sample)
@@ -659,12 +663,15 @@ __device__ __forceinline__ void k4_split3(const float (&v)[8], uint4& t0, uint4&
     unsigned p0[4], p1[4], p2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        p0[i] = k4_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(p0[i] << 16), rb = b - __uint_as_float(p0[i] & 0xffff0000u);
-        p1[i] = k4_pk_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(p1[i] << 16), sb = rb - __uint_as_float(p1[i] & 0xffff0000u);
-        p2[i] = k4_pk_bf16(sa, sb);
+        // 2-wide fp32 vectors: the two subtractions of a pair are one v_pk_add_f32 (same IEEE results as the scalar form)
+        const k4_f32x2 x = {v[2 * i], v[2 * i + 1]};
+        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, k4_bf16x2));
+        const k4_f32x2 h0 = {__uint_as_float(p0[i] << 16), __uint_as_float(p0[i] & 0xffff0000u)};
+        const k4_f32x2 r = x - h0;
+        p1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, k4_bf16x2));
+        const k4_f32x2 h1 = {__uint_as_float(p1[i] << 16), __uint_as_float(p1[i] & 0xffff0000u)};
+        const k4_f32x2 q = r - h1;
+        p2[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, k4_bf16x2));
     }
     t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
 }
@@ -726,7 +733,8 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                 K4_MFMA_B3(h1[mb], a0, a1, a2, x0, x1, x2);
             }
         }
-        float pt[3] = {0.f, 0.f, 0.f};
+        k4_f32x2 pt01 = {0.f, 0.f};
+        float pt2 = 0.f;
         if (NHID == 1 && !(debug & 2)) {
             // relu + split of this tile's hidden activations once; the NB output blocks accumulate side by side
             uint4 hs[KB2][3];
@@ -759,7 +767,9 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                 for (int r = 0; r < 16; ++r) {
                     const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
                     const float a0 = fmaxf(c[mb2][r], 0.f);
-                    pt[0] = fmaf(wo.x, a0, pt[0]); pt[1] = fmaf(wo.y, a0, pt[1]); pt[2] = fmaf(wo.z, a0, pt[2]);
+                    const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
+                    pt01 = __builtin_elementwise_fma(w01, aa, pt01);                  // v_pk_fma_f32: channels 0 and 1 in one instruction
+                    pt2 = fmaf(wo.z, a0, pt2);
                 }
         } else {
 #pragma unroll
@@ -768,15 +778,61 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                 for (int r = 0; r < 16; ++r) {
                     const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
                     const float a0 = fmaxf(h1[mb][r], 0.f);
-                    pt[0] = fmaf(wo.x, a0, pt[0]); pt[1] = fmaf(wo.y, a0, pt[1]); pt[2] = fmaf(wo.z, a0, pt[2]);
+                    const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
+                    pt01 = __builtin_elementwise_fma(w01, aa, pt01);
+                    pt2 = fmaf(wo.z, a0, pt2);
                 }
         }
         // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of this tile; sample 32*t + (l&31) belongs to
         // lane 32*t + (l&31)
-        const float q0 = pt[0] + __shfl_xor(pt[0], 32) + bo[0];
-        const float q1 = pt[1] + __shfl_xor(pt[1], 32) + bo[1];
-        const float q2 = pt[2] + __shfl_xor(pt[2], 32) + bo[2];
+        const float q0 = pt01.x + __shfl_xor(pt01.x, 32) + bo[0];
+        const float q1 = pt01.y + __shfl_xor(pt01.y, 32) + bo[1];
+        const float q2 = pt2 + __shfl_xor(pt2, 32) + bo[2];
         if (half == t) { out0 = q0; out1 = q1; out2 = q2; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Between K1 and K2: the order in which the shading kernel's persistent waves take the bundles.  A bundle is shaded by ONE
+// wave, 64 records at a time, and bundles carry 0 .. thousands of records: taken in image order, a heavy bundle pulled near
+// the end of the queue finished hundreds of microseconds after every other wave had run dry (SQ_WAVE_CYCLES: the average
+// wave was alive for 67 % of the kernel).  Longest-processing-time-first: a counting sort of the bundle ids by their number
+// of 64-record batches, descending -- the tail of the queue is then made of the lightest bundles.  One workgroup; the
+// shading results do not depend on the order (exact per-ray sums, independent bundles).
+// ------------------------------------------------------------------------------------------------------------------
+#define K4_ORDER_CLASSES 1024
+__global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int* __restrict__ order, int n_bundles, int* qhead) {
+    __shared__ int hist[K4_ORDER_CLASSES];
+    __shared__ int wsum[16];
+    const int tid = (int)threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) *qhead = 0;
+    __syncthreads();
+    // class 0 = the most batches
+    for (int b = tid; b < n_bundles; b += 1024) {
+        const int nb = min((counts[b] + 63) >> 6, K4_ORDER_CLASSES - 1);
+        atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the 1024 classes: wave scans + scan of the 16 wave totals
+    const int lane = tid & 63, wv = tid >> 6;
+    const int mine = hist[tid];
+    int inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wv; ++w) wbase += wsum[w];
+    __syncthreads();
+    hist[tid] = wbase + inc - mine;
+    __syncthreads();
+    for (int b = tid; b < n_bundles; b += 1024) {
+        const int nb = min((counts[b] + 63) >> 6, K4_ORDER_CLASSES - 1);
+        order[atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1)] = b;
     }
 }
 
@@ -810,7 +866,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     if (lane == 0) bid = atomicAdd(P.qhead, 1);
     bid = __builtin_amdgcn_readfirstlane(bid);
     if (bid >= P.n_bundles) break;
-    const Bundle B = bundle_from_id(P, bid);
+    const Bundle B = bundle_from_id(P, P.order[bid]);
     acc[lane * 4 + 0] = 0.; acc[lane * 4 + 1] = 0.; acc[lane * 4 + 2] = 0.; acc[lane * 4 + 3] = 0.;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
@@ -843,15 +899,27 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
         const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
         const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
         const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
-        const K4Tri t = k4_tri_setup(k4_unnorm(nx, P.X), k4_unnorm(ny, P.Y), k4_unnorm(nz, P.Z));
+        // Corner indices and weights.  The geometry kernel only records samples inside the bounding box (mask_outbbox, lib/dvgo.py:
+        // 306-316), so the lower corner is a voxel and an upper corner leaves the grid only at the far faces: its axis factor is
+        // zeroed there (grid_sample's zero padding; the same weights as testing the 8 corners one by one: zl*yl*0 == 0) and its
+        // address offset dropped.  ~15 VALU instead of ~100 for the eight bounds tests.
         unsigned cidx[8];                                        // voxel index (< 2^31 voxels)
         float cw[8];
+        {
+            const float ux = k4_unnorm(nx, P.X), uy = k4_unnorm(ny, P.Y), uz = k4_unnorm(nz, P.Z);
+            const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+            const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+            const bool hx = x0 + 1 < P.X, hy = y0 + 1 < P.Y, hz = z0 + 1 < P.Z;
+            const float xl = (fx + 1.f) - ux, xh = hx ? ux - fx : 0.f;
+            const float yl = (fy + 1.f) - uy, yh = hy ? uy - fy : 0.f;
+            const float zl = (fz + 1.f) - uz, zh = hz ? uz - fz : 0.f;
+            cw[0] = zl * yl * xl; cw[1] = zh * yl * xl; cw[2] = zl * yh * xl; cw[3] = zh * yh * xl;
+            cw[4] = zl * yl * xh; cw[5] = zh * yl * xh; cw[6] = zl * yh * xh; cw[7] = zh * yh * xh;
+            const int xc = min(max(x0, 0), P.X - 1), yc = min(max(y0, 0), P.Y - 1), zc = min(max(z0, 0), P.Z - 1);   // never an out-of-range address
+            const unsigned base = (unsigned)(xc * P.Y + yc) * (unsigned)P.Z + (unsigned)zc;
+            const unsigned ox = hx ? (unsigned)(P.Y * P.Z) : 0u, oy = hy ? (unsigned)P.Z : 0u, oz = hz ? 1u : 0u;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
-            const bool ok = (unsigned)x < (unsigned)P.X && (unsigned)y < (unsigned)P.Y && (unsigned)z < (unsigned)P.Z;
-            cidx[c] = ok ? (unsigned)(x * P.Y + y) * (unsigned)P.Z + (unsigned)z : 0u;
-            cw[c] = ok ? t.w[c] : 0.f;
+            for (int c = 0; c < 8; ++c) cidx[c] = base + (K4_CX(c) ? ox : 0u) + (K4_CY(c) ? oy : 0u) + (K4_CZ(c) ? oz : 0u);
         }
         float o0, o1, o2;
         if (WIDTH == 0) {
@@ -881,12 +949,15 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < 3; ++g4) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    k4_f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};                 // v_pk_fma_f32: two channels per instruction, corner order kept
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        v.x += q[g4][c].x * cw[c]; v.y += q[g4][c].y * cw[c]; v.z += q[g4][c].z * cw[c]; v.w += q[g4][c].w * cw[c];
+                        const k4_f32x2 ww = {cw[c], cw[c]};
+                        const k4_f32x2 qa = {q[g4][c].x, q[g4][c].y}, qb = {q[g4][c].z, q[g4][c].w};
+                        va = __builtin_elementwise_fma(qa, ww, va);
+                        vb = __builtin_elementwise_fma(qb, ww, vb);
                     }
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    const float vv[4] = {va.x, va.y, vb.x, vb.y};
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         const int ch = g4 * 4 + cc;
@@ -973,6 +1044,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
         double v1 = ((double)(w * (1.f / (1.f + expf(-o1)))) + QC) - QC;
         double v2 = ((double)(w * (1.f / (1.f + expf(-o2)))) + QC) - QC;
         double v3 = ((double)(w * (((float)k + 0.5f) / (float)P.depth_n)) + QC) - QC;       // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
+#if K4_SHADE_SCAN
         // segmented inclusive scan over RUNS of equal ray (a ray's records are contiguous within a depth quarter, so
         // one batch can hold two runs of the same ray: key = index of the run, not the ray)
         const int keyr = k4_run_id(lact ? rl : (256 + lane), lane);
@@ -987,6 +1059,14 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             // ds_add_f64: two runs of one ray can end in the same batch (sparse bundles), a plain read-modify-write would lose one
             k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
         }
+#else
+        // every record adds its four terms to its ray's fp64 sums with ds_add_f64: exact additions commute, so the LDS unit's own
+        // serialisation of same-address lanes replaces the ~180 VALU + 54 ds_bpermute of a segmented wave scan (the LDS pipe is
+        // otherwise nearly idle in this kernel, the VALU is what bounds it)
+        if (lact) {
+            k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
+        }
+#endif
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -1043,6 +1123,9 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     }
     int rc = k4_check_launch();
     if (rc) return rc;
+    hipLaunchKernelGGL(k4_order_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.order, P.n_bundles, P.qhead);
+    rc = k4_check_launch();
+    if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
     // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; k4_mlp_desc.arith =
     // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
@@ -1078,7 +1161,7 @@ static inline int64_t ent_stride_of(int32_t max_steps) { return 64 * (((int64_t)
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
     if (n_rays < 0 || img_w < 0 || max_steps <= 0 || (img_w > 0 && n_rays % img_w != 0)) return -1;
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
-    return nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2) + (((nb + 9) * (int64_t)sizeof(int) + 255) / 256) * 256;
+    return nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2) + (((2 * nb + 9) * (int64_t)sizeof(int) + 255) / 256) * 256;
 }
 
 static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -1119,6 +1202,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + nb * ent_stride_of(max_steps) * (int64_t)sizeof(uint2));
     P.qhead = P.counts + nb;
+    P.order = P.qhead + 8;
     P.n_bundles = (int)nb;
     P.debug = k4_env().debug; P.serp = k4_env().serp;
     // XCD bands of the geometry kernel: K4_GEOM_BAND rows of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to
