@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0, n_shade = 0;
 
     // static, XCD-banded bundle map, one bundle per workgroup: per-XCD or global work queues measured 6-25 % slower -- the
-    // hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2
+    // hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2.  (Heaviest-first by the previous frame's record
+    // counts, as the shading kernel orders its queue, measured 4 % slower: 1.263 vs 1.216 ms per call -- neighbouring bundles no
+    // longer share cache lines.  One ray table per workgroup instead of one per wave, 15.4 KB of LDS -> 10 resident workgroups
+    // instead of 7: no gain, 1.23 vs 1.19-1.22 ms -- the 5 waves per SIMD of the register allocation are the cap.)
     for (bool once = true; once; once = false) {
     const int bid = k4_xcd_remap_banded((int)blockIdx.x, (int)gridDim.x, P.band_blocks);
     if (bid >= P.n_bundles) break;
@@ -683,6 +686,25 @@ __device__ __forceinline__ void k4_split3(const float (&v)[8], uint4& t0, uint4&
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B1), ACC, 0, 0, 0); \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); } while (0)
 
+#ifndef K4_MLP_X2
+#define K4_MLP_X2 1
+#endif
+// two accumulators side by side (same B operand): consecutive MFMAs never depend on each other; each accumulator still receives its
+// six products in the order of K4_MFMA_B3 (bit-identical results)
+#define K4_MFMA_B3_X2(ACCA, ACCB, A0, A1, A2, C0, C1, C2, B0, B1, B2) do { \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A2), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C2), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B2), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B2), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B1), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C1), __builtin_bit_cast(k4_bf16x8, B1), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C1), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B1), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B1), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); } while (0)
+
 template <int W, int NHID>
 struct MlpLayoutB3 {                      // offsets in floats from the start of the split section
     static constexpr int NB = W / 32;
@@ -726,11 +748,18 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
             }
             uint4 x0, x1, x2;
             k4_split3(v, x0, x1, x2);
+            if constexpr (NB == 2 && K4_MLP_X2) {
+                const uint4* const wp = w1s + (kb * 3) * 64 + lane;
+                const uint4* const wq = w1s + ((ML::kb1(k1p) + kb) * 3) * 64 + lane;
+                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
+                K4_MFMA_B3_X2(h1[0], h1[1], a0, a1, a2, c0, c1, c2, x0, x1, x2);
+            } else {
 #pragma unroll
-            for (int mb = 0; mb < NB; ++mb) {
-                const uint4* const wp = w1s + ((mb * ML::kb1(k1p) + kb) * 3) * 64 + lane;
-                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
-                K4_MFMA_B3(h1[mb], a0, a1, a2, x0, x1, x2);
+                for (int mb = 0; mb < NB; ++mb) {
+                    const uint4* const wp = w1s + ((mb * ML::kb1(k1p) + kb) * 3) * 64 + lane;
+                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                    K4_MFMA_B3(h1[mb], a0, a1, a2, x0, x1, x2);
+                }
             }
         }
         k4_f32x2 pt01 = {0.f, 0.f};
@@ -754,13 +783,21 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                     c[mb2][r4 * 4 + 0] = bv.x; c[mb2][r4 * 4 + 1] = bv.y; c[mb2][r4 * 4 + 2] = bv.z; c[mb2][r4 * 4 + 3] = bv.w;
                 }
 #pragma unroll
-            for (int kb = 0; kb < KB2; ++kb)
+            for (int kb = 0; kb < KB2; ++kb) {
+                if constexpr (NB == 2 && K4_MLP_X2) {
+                    const uint4* const wp = w2s + (kb * 3) * 64 + lane;
+                    const uint4* const wq = w2s + ((KB2 + kb) * 3) * 64 + lane;
+                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
+                    K4_MFMA_B3_X2(c[0], c[1], a0, a1, a2, c0, c1, c2, hs[kb][0], hs[kb][1], hs[kb][2]);
+                } else {
 #pragma unroll
-                for (int mb2 = 0; mb2 < NB; ++mb2) {
-                    const uint4* const wp = w2s + ((mb2 * KB2 + kb) * 3) * 64 + lane;
-                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
-                    K4_MFMA_B3(c[mb2], a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][2]);
+                    for (int mb2 = 0; mb2 < NB; ++mb2) {
+                        const uint4* const wp = w2s + ((mb2 * KB2 + kb) * 3) * 64 + lane;
+                        const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                        K4_MFMA_B3(c[mb2], a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][2]);
+                    }
                 }
+            }
 #pragma unroll
             for (int mb2 = 0; mb2 < NB; ++mb2)
 #pragma unroll
@@ -810,7 +847,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
     __syncthreads();
     // class 0 = the most batches
     for (int b = tid; b < n_bundles; b += 1024) {
-        const int nb = min((counts[b] + 63) >> 6, K4_ORDER_CLASSES - 1);
+        const int nb = (int)min(((unsigned)counts[b] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));     // any int is a valid key
         atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1);
     }
     __syncthreads();
@@ -831,7 +868,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
     hist[tid] = wbase + inc - mine;
     __syncthreads();
     for (int b = tid; b < n_bundles; b += 1024) {
-        const int nb = min((counts[b] + 63) >> 6, K4_ORDER_CLASSES - 1);
+        const int nb = (int)min(((unsigned)counts[b] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));
         order[atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1)] = b;
     }
 }
