@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      2       /* 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith */
+#define K4_ABI_VERSION      3       /* 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -295,6 +295,20 @@ int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t
 /* tile_queue: NULL, or 2 device ints that are ZERO when the launch starts (the kernel leaves them zero again): 3x3 layers with more
  * tiles than the chip holds at once then run as persistent workgroups pulling tiles from this counter (no partly filled last round).
  * Launches that may run concurrently must not share a queue. */
+/* 3x3 convolution + the SFTLayer that follows it in the network, in ONE launch (lib/sr_esrnet.py:149-158: conv4 -> sft1, conv5 of one
+ * dense block -> sft0 of the next): with v = the convolution's result after bias / K4_EPI_LRELU / K4_EPI_RES and
+ * m = v*(scale(cond)+1) + shift(cond) (the arithmetic of k4_sft_nhwc_multi with K4_SFT_ARITH_BF16X6, bit-identical to running it
+ * as a separate launch on v):   y_sft[g] == NULL:  y <- m;     otherwise:  y <- v  and  y_sft[g] <- m.
+ * cout = the SFT layer's channels (32 | 64); w_packed = that layer's k4_sft_weight_floats(cout) buffer; cond[g]: [H*W][cond_stride]
+ * condition map of window g (32 channels, 16-byte aligned). */
+typedef struct k4_sft_epilogue {
+    const float* w_packed; int32_t cond_stride; int32_t y_sft_stride;
+    const float* cond[K4_MAX_JOBS]; float* y_sft[K4_MAX_JOBS];
+} k4_sft_epilogue;
+int k4_conv2d_sft_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                                    const void* w_split, const float* bias, int32_t cout, int32_t cout_stride,
+                                    uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                                    const k4_sft_epilogue* sft, void* stream);
 typedef struct k4_sft_job { const float* cond; const float* x; float* y; const float* res; int64_t n_pix; } k4_sft_job;
 #define K4_SFT_ARITH_FP32   0      /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (what k4_sft_nhwc computes)                    */
 #define K4_SFT_ARITH_BF16X6 1      /* exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16 (fp32-equivalent)    */
