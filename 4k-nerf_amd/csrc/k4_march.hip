@@ -837,23 +837,36 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
 // of 64-record batches, descending -- the tail of the queue is then made of the lightest bundles.  One workgroup; the
 // shading results do not depend on the order (exact per-ray sums, independent bundles).
 // ------------------------------------------------------------------------------------------------------------------
-#define K4_ORDER_CLASSES 1024
+#define K4_ORDER_CLASSES 256     // bundles of >= 255 batches share the first class
+#define K4_ORDER_SUB 16          // sub-bins per class (bundle id & 15): 16x fewer same-address LDS atomics -- most bundles fall in a few classes
 __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int* __restrict__ order, int n_bundles, int* qhead) {
-    __shared__ int hist[K4_ORDER_CLASSES];
+    constexpr int NBIN = K4_ORDER_CLASSES * K4_ORDER_SUB;            // 4096 = 4 per thread
+    __shared__ int hist[NBIN];
     __shared__ int wsum[16];
     const int tid = (int)threadIdx.x;
-    hist[tid] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist[tid * 4 + i] = 0;
     if (tid == 0) *qhead = 0;
     __syncthreads();
-    // class 0 = the most batches
-    for (int b = tid; b < n_bundles; b += 1024) {
-        const int nb = (int)min(((unsigned)counts[b] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));     // any int is a valid key
-        atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1);
+    // class 0 = the most batches; any int is a valid key (the workspace may hold anything before its first use)
+    // (16 counts per thread are fetched together: one memory round trip per 16384 bundles instead of one per 1024)
+    for (int base = 0; base < n_bundles; base += 1024 * 16) {
+        int v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int b = base + i * 1024 + tid; v[i] = counts[b < n_bundles ? b : 0]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = base + i * 1024 + tid;
+            const int nb = (int)min(((unsigned)v[i] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));
+            if (b < n_bundles) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - nb) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
+        }
     }
     __syncthreads();
-    // exclusive prefix over the 1024 classes: wave scans + scan of the 16 wave totals
+    // exclusive prefix over the bins: 4 per thread, wave scans, scan of the 16 wave totals
     const int lane = tid & 63, wv = tid >> 6;
-    const int mine = hist[tid];
+    int c[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = hist[tid * 4 + i]; mine += c[i]; }
     int inc = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -862,14 +875,21 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
     }
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wv; ++w) wbase += wsum[w];
+    int run = inc - mine;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hist[tid * 4 + i] = run; run += c[i]; }
     __syncthreads();
-    hist[tid] = wbase + inc - mine;
-    __syncthreads();
-    for (int b = tid; b < n_bundles; b += 1024) {
-        const int nb = (int)min(((unsigned)counts[b] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));
-        order[atomicAdd(&hist[K4_ORDER_CLASSES - 1 - nb], 1)] = b;
+    for (int base = 0; base < n_bundles; base += 1024 * 16) {
+        int v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int b = base + i * 1024 + tid; v[i] = counts[b < n_bundles ? b : 0]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = base + i * 1024 + tid;
+            const int nb = (int)min(((unsigned)v[i] + 63u) >> 6, (unsigned)(K4_ORDER_CLASSES - 1));
+            if (b < n_bundles) order[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - nb) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = b;
+        }
     }
 }
 

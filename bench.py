@@ -246,7 +246,7 @@ def main():
             'mrays_isolated': round(n_band / (iso_ms * 1e-3) / 1e6, 3),
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'marcher call = k4_geom2_kernel<MPI> + k4_shade_kernel<MPI,64,1>, isolated (1 stream, HIP events)',
+                         'kernel': 'marcher call = k4_geom3_kernel<MPI> + k4_order_kernel + k4_shade_kernel<MPI,64,1,b3>, isolated (1 stream, HIP events)',
                          'kernel_ms': round(iso_ms, 4), 'overlapped_launch_ms': round(overlapped_ms, 4),
                          'algorithmic_bytes_per_launch': int(b_alg),
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
