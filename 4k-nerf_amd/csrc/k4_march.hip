@@ -718,7 +718,7 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
 };
 
 template <int W, int NHID>
-__device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, int k1p, int lane, int half, int debug,
+__device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, int k1p, int lane, int half, int debug, int nproc,
                                             float& out0, float& out1, float& out2) {
     constexpr int NB = W / 32;
     constexpr int KB2 = W / 16;
@@ -735,6 +735,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
     // the second tile reuses the code and the registers
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
+        if (t * 32 >= nproc) break;                  // a bundle's last batch: no record in the second tile (wave-uniform)
         // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s] ----------------
         f32x16 h1[NB];
 #pragma unroll
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             __builtin_amdgcn_wave_barrier();
 
             float l0, l1, l2;
-            if (B3) mlp_mfma_b3<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
+            if (B3) mlp_mfma_b3<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, nproc, l0, l1, l2);
             else mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
