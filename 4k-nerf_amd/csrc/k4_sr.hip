@@ -948,6 +948,12 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                 }
             }
         } else
+#ifdef K4_V2_NOEPI        /* timing experiment only (WRONG results): one store per lane instead of the epilogue */
+        { float sum_ = 0.f;
+          _Pragma("unroll") for (int r = 0; r < RPW; ++r) _Pragma("unroll") for (int e = 0; e < 16; ++e) sum_ += acc[r][e];
+          if (sum_ == 123.456f) T.y[lane] = sum_; }
+        if (false)
+#endif
         {
             const int co = T.nb * 32 + l31;
             if (co < P.cout) {

@@ -350,6 +350,21 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         shape = density.shape
         return Raw2Alpha.apply(density.flatten(), self.act_shift, interval).reshape(shape)
 
+    @torch.no_grad()
+    def hit_coarse_geo(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
+        '''Which rays meet an occupied cell of the mask cache (lib/dvgo.py:281-293)?  Rays of any leading shape -> bool of that shape.'''
+        shape = rays_o.shape[:-1]
+        ro = rays_o.reshape(-1, 3).contiguous()
+        rd = rays_d.reshape(-1, 3).contiguous()
+        # far = 1e9: the caller's far can be too small, rays end at the scene box anyway
+        ray_pts, mask_outbbox, ray_id = render_utils_cuda.sample_pts_on_rays(
+            ro, rd, self.xyz_min, self.xyz_max, near, 1e9, stepsize * self.voxel_size)[:3]
+        inside = ~mask_outbbox
+        occupied = self.mask_cache(ray_pts[inside])
+        hit = torch.zeros([ro.shape[0]], dtype=torch.bool, device=ro.device)
+        hit[ray_id[inside][occupied]] = True
+        return hit.reshape(shape)
+
     def sample_ray(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
         '''Sample query points on rays (lib/dvgo.py:295-325): points sorted near to far.'''
         far = 1e9  # the given far can be too small while rays stop when hitting scene bbox
@@ -722,3 +737,79 @@ def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='cente
     if ndc:
         rays_o, rays_d = ndc_rays(H, W, float(K[0][0]), 1., rays_o, rays_d)
     return rays_o, rays_d, viewdirs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training-ray tables and batch generators (lib/dvgo.py:584-680,761-768): what run.py / run_sr.py call before the optimisation
+# loop.  Rays come from get_rays_of_a_view (one HIP launch per view on a GPU pose); same return tuples as the reference.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rays_of(view_hw, K, c2w, ndc, inverse_y, flip_x, flip_y, device):
+    H, W = int(view_hw[0]), int(view_hw[1])
+    ro, rd, vd = get_rays_of_a_view(H=H, W=W, K=K, c2w=c2w, ndc=ndc, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+    return ro.to(device), rd.to(device), vd.to(device)
+
+
+@torch.no_grad()
+def get_training_rays(rgb_tr, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """All views share one size and one intrinsic matrix: per-view [H,W,3] tables (lib/dvgo.py:584-607)."""
+    n = len(rgb_tr)
+    assert n == len(train_poses) == len(Ks) == len(HW)
+    assert len(np.unique(np.asarray(HW), axis=0)) == 1, 'get_training_rays: views of one size only'
+    assert len(np.unique(np.asarray(Ks).reshape(n, -1), axis=0)) == 1, 'get_training_rays: one intrinsic matrix only'
+    H, W = (int(v) for v in HW[0])
+    dev = rgb_tr.device
+    rays_o_tr, rays_d_tr, viewdirs_tr = (torch.zeros([n, H, W, 3], device=dev) for _ in range(3))
+    for i, c2w in enumerate(train_poses):
+        rays_o_tr[i], rays_d_tr[i], viewdirs_tr[i] = _rays_of((H, W), Ks[0], c2w, ndc, inverse_y, flip_x, flip_y, dev)
+    return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, [1] * n
+
+
+@torch.no_grad()
+def get_training_rays_flatten(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """Views of different sizes: one flat [N,3] table, imsz = pixels per view (lib/dvgo.py:610-640)."""
+    assert len(rgb_tr_ori) == len(train_poses) == len(Ks) == len(HW)
+    dev = rgb_tr_ori[0].device
+    cols = ([], [], [], [])
+    imsz = []
+    for c2w, img, hw, K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        assert tuple(img.shape[:2]) == (int(hw[0]), int(hw[1]))
+        ro, rd, vd = _rays_of(hw, K, c2w, ndc, inverse_y, flip_x, flip_y, dev)
+        for lst, t in zip(cols, (img, ro, rd, vd)):
+            lst.append(t.reshape(-1, 3).float())
+        imsz.append(int(hw[0]) * int(hw[1]))
+    rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr = (torch.cat(c, 0) for c in cols)
+    return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, imsz
+
+
+@torch.no_grad()
+def get_training_rays_in_maskcache_sampling(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model, render_kwargs):
+    """Only the rays that meet the coarse geometry (model.hit_coarse_geo), flat tables, imsz = kept rays per view
+    (lib/dvgo.py:643-680; 64 image rows per hit test as there)."""
+    assert len(rgb_tr_ori) == len(train_poses) == len(Ks) == len(HW)
+    dev = rgb_tr_ori[0].device
+    rows = 64
+    cols = ([], [], [], [])
+    imsz = []
+    total = 0
+    for c2w, img, hw, K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        assert tuple(img.shape[:2]) == (int(hw[0]), int(hw[1]))
+        ro, rd, vd = _rays_of(hw, K, c2w, ndc, inverse_y, flip_x, flip_y, dev)
+        keep = torch.cat([model.hit_coarse_geo(rays_o=ro[i:i + rows], rays_d=rd[i:i + rows], **render_kwargs).to(dev)
+                          for i in range(0, img.shape[0], rows)], 0)
+        for lst, t in zip(cols, (img, ro, rd, vd)):
+            lst.append(t[keep].float())
+        imsz.append(keep.sum())
+        total += img.shape[0] * img.shape[1]
+    rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr = (torch.cat(c, 0) for c in cols)
+    print('get_training_rays_in_maskcache_sampling: ratio', rgb_tr.shape[0] / max(total, 1))
+    return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, imsz
+
+
+def batch_indices_generator(N, BS):
+    """Endless batches of BS indices out of N, a fresh host-side permutation whenever fewer than BS are left (lib/dvgo.py:761-768)."""
+    perm, pos = torch.from_numpy(np.random.permutation(N)).long(), 0
+    while True:
+        if pos + BS > N:
+            perm, pos = torch.from_numpy(np.random.permutation(N)).long(), 0
+        yield perm[pos:pos + BS]
+        pos += BS

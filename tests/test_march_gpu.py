@@ -341,3 +341,59 @@ def test_fused_and_staged_vs_reference_native_end_to_end(name):
             want = torch.from_numpy(z[k])
             assert float((staged[k].cpu() - want).abs().max()) <= 3e-6, k
             _cmp(fused[k], want, name + '/' + k)
+
+
+def test_training_ray_tables_and_coarse_geometry_hits():
+    """dvgo.get_training_rays / get_training_rays_flatten / get_training_rays_in_maskcache_sampling and DirectVoxGO.hit_coarse_geo
+    (lib/dvgo.py:281-293,584-680): tables equal the per-view rays of the oracle; kept rays = rays whose in-box samples meet an
+    occupied mask cell, recomputed with the oracle's sampler + mask lookup."""
+    from nerf4k_amd.lib import dvgo as D
+    from oracle import native_cpu as nat
+    ck = scene.make_lego_checkpoint(seed=47, num_voxels=36 ** 3)
+    model = _model(ck)
+    # carve the mask so that only part of the rays hit
+    m = model.mask_cache.mask
+    m[: m.shape[0] // 2] = False
+    from torch.autograd.graph import increment_version
+    increment_version(m)
+    H, W = 40, 56
+    K = scene.lego_K(H, W)
+    poses = [scene.lego_pose(theta_deg=t) for t in (10., 130., 250.)]
+    imgs = torch.rand([3, H, W, 3], device='cuda')
+    HW = np.array([[H, W]] * 3)
+    Ks = np.stack([K] * 3)
+    poses_t = torch.stack([torch.as_tensor(p[:3, :4], dtype=torch.float32) for p in poses]).cuda()
+    rgb, ro, rd, vd, imsz = D.get_training_rays(imgs, poses_t, HW, Ks, ndc=False, inverse_y=False, flip_x=False, flip_y=False)
+    assert rgb is imgs and ro.shape == (3, H, W, 3) and imsz == [1, 1, 1]
+    for i, p in enumerate(poses):
+        wo, wd, wv = marcher.get_rays_of_a_view(H, W, K, p, ndc=False)
+        for got, want in ((ro[i], wo), (rd[i], wd), (vd[i], wv)):
+            assert float((got.cpu() - want).abs().max()) <= 2e-6
+    rgb_f, ro_f, rd_f, vd_f, imsz_f = D.get_training_rays_flatten(list(imgs), poses_t, HW, Ks, False, False, False, False)
+    assert imsz_f == [H * W] * 3 and torch.equal(ro_f, ro.reshape(-1, 3)) and torch.equal(rgb_f, imgs.reshape(-1, 3))
+    rk = dict(ck['render_kwargs'])
+    rgb_m, ro_m, rd_m, vd_m, imsz_m = D.get_training_rays_in_maskcache_sampling(list(imgs), poses_t, HW, Ks, False, False, False, False, model, rk)
+    # oracle: sampler + mask lookup on the CPU
+    kw = ck['model_kwargs']
+    mask = m.cpu()
+    xmin, xmax = torch.as_tensor(kw['xyz_min']), torch.as_tensor(kw['xyz_max'])
+    scale, shift = marcher.mask_scale_shift(mask.shape, xmin, xmax)
+    want_keep = []
+    vox = float(model.voxel_size)
+    for i in range(3):
+        o = ro[i].reshape(-1, 3).cpu(); d = rd[i].reshape(-1, 3).cpu()
+        pts, outb, rid = nat.sample_pts_on_rays(o, d, xmin, xmax, rk['near'], 1e9, rk['stepsize'] * vox)[:3]
+        ins = ~outb
+        occ = marcher.mask_grid(mask, pts[ins], scale, shift)
+        hit = torch.zeros([o.shape[0]], dtype=torch.bool)
+        hit[rid[ins][occ]] = True
+        want_keep.append(hit)
+    want_keep = torch.cat(want_keep).numpy()
+    assert 0.05 < want_keep.mean() < 0.95, want_keep.mean()
+    got_n = [int(v) for v in imsz_m]
+    # a sample within float rounding of a mask cell boundary may flip: allow a handful of rays
+    assert abs(sum(got_n) - int(want_keep.sum())) <= 4, (got_n, int(want_keep.sum()))
+    assert ro_m.shape[0] == sum(got_n) == rgb_m.shape[0] == vd_m.shape[0]
+    hit_all = torch.cat([model.hit_coarse_geo(rays_o=ro[i], rays_d=rd[i], **rk).reshape(-1) for i in range(3)]).cpu().numpy()
+    assert (hit_all != want_keep).sum() <= 4
+    assert torch.equal(ro_m, ro.reshape(-1, 3)[torch.from_numpy(hit_all).cuda()])
