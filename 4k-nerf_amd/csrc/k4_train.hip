@@ -1,0 +1,444 @@
+// Training-step kernels of the marcher that the reference leaves to PyTorch library ops (SURVEY.md 8f rank 1 "MLP bwd", 3.4):
+//   * the colour MLP `rgbnet` forward WITH saved activations and its backward (lib/dmpigo.py:112-120,375-379,
+//     lib/dvgo.py:116-124,407-412: nn.Sequential of nn.Linear / ReLU + torch.sigmoid, differentiated by autograd over
+//     cuBLAS GEMMs): two launches instead of ~20, exact fp32 FMA chains, deterministic (no atomics);
+//   * the distortion loss of the joint training step (run_sr.py:976-988 calls torch_efficient_distloss.flatten_eff_distloss,
+//     a third-party CUDA extension that is not vendored: the published prefix-sum form is restated here), forward value and
+//     gradient in one launch;
+//   * compaction / expansion of the sparsely touched voxel-grid gradients for the data-parallel exchange (SURVEY.md 8e
+//     "Training (config 5)": dense k0 grad 1.36 GB, a 64x64 patch touches < 1 % of it).
+// gfx950 only (wave64).  A training batch is ~10^5 points x (15..39 -> 64..128 -> 64..128 -> 3): ~1 GFLOP, far below the
+// matrix cores' interest; what matters is launch count and that nothing but x / h / grad streams through HBM once.
+#include "k4_common.h"
+
+#define TR_LS 68            // LDS row stride in floats: rows 16-byte aligned (ds_read_b128 along the sample axis), lane = sample reads conflict-free
+#define TR_MAX_DIM0 64
+
+// --------------------------------------------------------------------------------------------------------------------
+// rgbnet forward: tile = 64 samples, lane = sample, wave w owns a quarter of a layer's neurons (4 per pass: one LDS read
+// of the input feeds 4 FMAs whose weights are wave-uniform -> scalar loads, SGPR operands)
+// --------------------------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void tr_dense_relu(const float* in, int K, k4_cptr w, k4_cptr b, float* out, int wv, int lane) {
+    constexpr int PER = W / 4;
+    for (int j0 = wv * PER; j0 < (wv + 1) * PER; j0 += 4) {
+        float a0 = b[j0], a1 = b[j0 + 1], a2 = b[j0 + 2], a3 = b[j0 + 3];
+        for (int k = 0; k < K; ++k) {
+            const float v = in[k * TR_LS + lane];
+            a0 = fmaf(v, w[(j0 + 0) * K + k], a0);
+            a1 = fmaf(v, w[(j0 + 1) * K + k], a1);
+            a2 = fmaf(v, w[(j0 + 2) * K + k], a2);
+            a3 = fmaf(v, w[(j0 + 3) * K + k], a3);
+        }
+        out[(j0 + 0) * TR_LS + lane] = fmaxf(a0, 0.f);
+        out[(j0 + 1) * TR_LS + lane] = fmaxf(a1, 0.f);
+        out[(j0 + 2) * TR_LS + lane] = fmaxf(a2, 0.f);
+        out[(j0 + 3) * TR_LS + lane] = fmaxf(a3, 0.f);
+    }
+}
+
+// [n][K] row-major global tile (64 samples from `base`) -> LDS [K][TR_LS] (sample fastest); samples >= nv read as 0
+__device__ __forceinline__ void tr_load_tile(const float* __restrict__ g, int64_t base, int K, int nv, float* lds, int t) {
+    const float* const src = g + base * K;
+    for (int i = t; i < 64 * K; i += 256) {
+        const int s = i / K, k = i - s * K;
+        lds[k * TR_LS + s] = s < nv ? src[i] : 0.f;
+    }
+}
+__device__ __forceinline__ void tr_store_tile(const float* lds, float* __restrict__ g, int64_t base, int K, int nv, int t) {
+    float* const dst = g + base * K;
+    for (int i = t; i < 64 * K; i += 256) {
+        const int s = i / K, k = i - s * K;
+        if (s < nv) dst[i] = lds[k * TR_LS + s];
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_rgbnet_fwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
+                                                    const float* __restrict__ w1, const float* __restrict__ b1,
+                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    const float* __restrict__ w3, const float* __restrict__ b3,
+                                                    const float* __restrict__ add, float* __restrict__ h1g, float* __restrict__ h2g,
+                                                    float* __restrict__ rgb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xs = smem;                              // [dim0][LS]
+    float* const h1s = xs + TR_MAX_DIM0 * TR_LS;         // [W][LS]
+    float* const h2s = h1s + W * TR_LS;                  // [W][LS]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+    tr_load_tile(x, base, dim0, nv, xs, t);
+    __syncthreads();
+    tr_dense_relu<W>(xs, dim0, k4_const(w1), k4_const(b1), h1s, wv, lane);
+    __syncthreads();
+    if (h1g) tr_store_tile(h1s, h1g, base, W, nv, t);
+    if (n_hidden) {
+        tr_dense_relu<W>(h1s, W, k4_const(w2), k4_const(b2), h2s, wv, lane);
+        __syncthreads();
+        if (h2g) tr_store_tile(h2s, h2g, base, W, nv, t);
+    }
+    const float* const hl = n_hidden ? h2s : h1s;
+    if (wv < 3 && lane < nv) {
+        const k4_cptr w3c = k4_const(w3) + wv * W;
+        float acc = k4_const(b3)[wv];
+        for (int j = 0; j < W; ++j) acc = fmaf(hl[j * TR_LS + lane], w3c[j], acc);
+        if (add) acc += add[(base + lane) * 3 + wv];              // rgb_logit + k0_diffuse (lib/dvgo.py:412)
+        rgb[(base + lane) * 3 + wv] = 1.f / (1.f + expf(-acc));   // torch.sigmoid
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// rgbnet backward.  Persistent workgroups walk the 64-sample tiles; per tile
+//   g3  = grad_rgb * (1 - y) * y                                   (sigmoid)
+//   gh_L = (h_L > 0) * g3 W3 ;  gh_1 = (h_1 > 0) * gh_2 W2 ;  gx = gh_1 W1          (lane = sample, scalar weights)
+//   dW3 += g3^T [h_L | 1] ;  dW2 += gh_2^T [h_1 | 1] ;  dW1 += gh_1^T [x | 1]        (the appended ones row carries the bias gradient)
+// The weight-gradient products are sums over the SAMPLE axis: every thread owns 4x4 blocks of (row of A, row of B) pairs and
+// walks the 64 samples with ds_read_b128 (8 reads per 64 FMAs), accumulating in registers across all tiles of the workgroup;
+// the per-workgroup partial sums go to `part` and k_rgbnet_reduce adds them in workgroup order: no atomics, the result
+// depends on the grid size only.
+// --------------------------------------------------------------------------------------------------------------------
+struct TrBlock { int aoff, boff, ooff, ostride; };
+
+template <int W>
+struct TrBwdLayout {
+    static constexpr int WB = W + 4;                                  // W rows + ones row + 3 zero rows
+    static constexpr int GH2_ROWS = W > TR_MAX_DIM0 ? W : TR_MAX_DIM0; // also the staging area of gx
+    static __host__ __device__ int d1b(int dim0) { return (dim0 + 4) & ~3; }     // dim0 rows + ones row, padded to 4
+    static __host__ __device__ int lds_floats(int dim0) { return (d1b(dim0) + 2 * WB + 4 + W + GH2_ROWS) * TR_LS; }
+    static __host__ __device__ int n_part(int dim0) { return 4 * WB + W * WB + W * d1b(dim0); }   // P3 [4][WB] | P2 [W][WB] | P1 [W][D1B]
+};
+
+template <int W, int MAXB>
+__global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
+                                                    const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                                    const float* __restrict__ h1g, const float* __restrict__ h2g,
+                                                    const float* __restrict__ rgb, const float* __restrict__ grgb,
+                                                    float* __restrict__ gx, float* __restrict__ glogit, float* __restrict__ part) {
+    typedef TrBwdLayout<W> L;
+    constexpr int WB = L::WB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D1B = L::d1b(dim0);
+    float* const xs = smem;                      // [D1B][LS]   x^T | ones | 0
+    float* const h1s = xs + D1B * TR_LS;         // [WB][LS]    h1^T | ones | 0
+    float* const h2s = h1s + WB * TR_LS;         // [WB][LS]
+    float* const g3s = h2s + WB * TR_LS;         // [4][LS]     row 3 = 0
+    float* const gh1 = g3s + 4 * TR_LS;          // [W][LS]
+    float* const gh2 = gh1 + W * TR_LS;          // [GH2_ROWS][LS]; reused as the gx staging tile
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int i = t; i < L::lds_floats(dim0); i += 256) smem[i] = 0.f;       // the zero padding rows stay zero for the whole kernel
+
+    float* const hls = n_hidden ? h2s : h1s;     // last hidden activation, its gradient:
+    float* const ghl = n_hidden ? gh2 : gh1;
+
+    // this thread's 4x4 blocks of the three weight-gradient products
+    const int nb3 = WB / 4, nb2 = n_hidden ? (W / 4) * (WB / 4) : 0, nb1 = (W / 4) * (D1B / 4);
+    TrBlock blk[MAXB];
+    float acc[MAXB][16];
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+        int b = t + 256 * q;
+        blk[q].aoff = -1;
+        if (b < nb3) {
+            blk[q] = {(int)(g3s - smem), (int)(hls - smem) + 4 * b * TR_LS, 4 * b, WB};
+        } else if (b < nb3 + nb2) {
+            b -= nb3;
+            const int ar = b / (WB / 4), bc = b - ar * (WB / 4);
+            blk[q] = {(int)(gh2 - smem) + 4 * ar * TR_LS, (int)(h1s - smem) + 4 * bc * TR_LS, 4 * WB + 4 * ar * WB + 4 * bc, WB};
+        } else if (b < nb3 + nb2 + nb1) {
+            b -= nb3 + nb2;
+            const int ar = b / (D1B / 4), bc = b - ar * (D1B / 4);
+            blk[q] = {(int)(gh1 - smem) + 4 * ar * TR_LS, (int)(xs - smem) + 4 * bc * TR_LS, 4 * WB + W * WB + 4 * ar * D1B + 4 * bc, D1B};
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    }
+    __syncthreads();
+
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * 64;
+        const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+        // ---- loads ----
+        tr_load_tile(x, base, dim0, nv, xs, t);
+        tr_load_tile(h1g, base, W, nv, h1s, t);
+        if (n_hidden) tr_load_tile(h2g, base, W, nv, h2s, t);
+        if (t < 64) {
+            const float one = t < nv ? 1.f : 0.f;
+            xs[dim0 * TR_LS + t] = one;
+            h1s[W * TR_LS + t] = one;
+            h2s[W * TR_LS + t] = one;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float g3 = 0.f;
+                if (t < nv) {
+                    const float y = rgb[(base + t) * 3 + c];
+                    g3 = (grgb[(base + t) * 3 + c] * (1.f - y)) * y;            // sigmoid_backward: grad * (1 - y) * y
+                    if (glogit) glogit[(base + t) * 3 + c] = g3;
+                }
+                g3s[c * TR_LS + t] = g3;
+            }
+        }
+        __syncthreads();
+        // ---- gh_L = relu'(h_L) * (g3 W3) ----
+        {
+            const k4_cptr w3c = k4_const(w3);
+            const float g0 = g3s[lane], g1 = g3s[TR_LS + lane], g2 = g3s[2 * TR_LS + lane];
+            constexpr int PER = W / 4;
+            for (int j = wv * PER; j < (wv + 1) * PER; ++j) {
+                float a = g0 * w3c[j];
+                a = fmaf(g1, w3c[W + j], a);
+                a = fmaf(g2, w3c[2 * W + j], a);
+                ghl[j * TR_LS + lane] = hls[j * TR_LS + lane] > 0.f ? a : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- gh_1 = relu'(h_1) * (gh_2 W2) ----
+        if (n_hidden) {
+            const k4_cptr w2c = k4_const(w2);
+            constexpr int PER = W / 4;
+            for (int k0 = wv * PER; k0 < (wv + 1) * PER; k0 += 4) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int j = 0; j < W; ++j) {
+                    const float v = gh2[j * TR_LS + lane];
+                    a0 = fmaf(v, w2c[j * W + k0 + 0], a0);
+                    a1 = fmaf(v, w2c[j * W + k0 + 1], a1);
+                    a2 = fmaf(v, w2c[j * W + k0 + 2], a2);
+                    a3 = fmaf(v, w2c[j * W + k0 + 3], a3);
+                }
+                gh1[(k0 + 0) * TR_LS + lane] = h1s[(k0 + 0) * TR_LS + lane] > 0.f ? a0 : 0.f;
+                gh1[(k0 + 1) * TR_LS + lane] = h1s[(k0 + 1) * TR_LS + lane] > 0.f ? a1 : 0.f;
+                gh1[(k0 + 2) * TR_LS + lane] = h1s[(k0 + 2) * TR_LS + lane] > 0.f ? a2 : 0.f;
+                gh1[(k0 + 3) * TR_LS + lane] = h1s[(k0 + 3) * TR_LS + lane] > 0.f ? a3 : 0.f;
+            }
+            __syncthreads();
+        }
+        // ---- weight-gradient blocks: acc[a][b] += sum_s A[a][s] * B[b][s] ----
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) {
+            if (blk[q].aoff < 0) continue;
+            const float4* const A = reinterpret_cast<const float4*>(smem + blk[q].aoff);
+            const float4* const B = reinterpret_cast<const float4*>(smem + blk[q].boff);
+            for (int s4 = 0; s4 < 16; ++s4) {
+                float4 av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = A[r * (TR_LS / 4) + s4]; bv[r] = B[r * (TR_LS / 4) + s4]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        float v = acc[q][a * 4 + b];
+                        v = fmaf(av[a].x, bv[b].x, v);
+                        v = fmaf(av[a].y, bv[b].y, v);
+                        v = fmaf(av[a].z, bv[b].z, v);
+                        v = fmaf(av[a].w, bv[b].w, v);
+                        acc[q][a * 4 + b] = v;
+                    }
+            }
+        }
+        __syncthreads();                                   // gh2 is free from here on: gx is staged in it
+        // ---- gx = gh_1 W1 ----
+        if (gx) {
+            const k4_cptr w1c = k4_const(w1);
+            const int nbx = (dim0 + 3) / 4;
+            for (int bi = wv; bi < nbx; bi += 4) {
+                const int i0 = bi * 4;
+                const int i1 = min(i0 + 1, dim0 - 1), i2 = min(i0 + 2, dim0 - 1), i3 = min(i0 + 3, dim0 - 1);    // clamped: never out of W1
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int k = 0; k < W; ++k) {
+                    const float v = gh1[k * TR_LS + lane];
+                    a0 = fmaf(v, w1c[k * dim0 + i0], a0);
+                    a1 = fmaf(v, w1c[k * dim0 + i1], a1);
+                    a2 = fmaf(v, w1c[k * dim0 + i2], a2);
+                    a3 = fmaf(v, w1c[k * dim0 + i3], a3);
+                }
+                gh2[i0 * TR_LS + lane] = a0;
+                if (i0 + 1 < dim0) gh2[(i0 + 1) * TR_LS + lane] = a1;
+                if (i0 + 2 < dim0) gh2[(i0 + 2) * TR_LS + lane] = a2;
+                if (i0 + 3 < dim0) gh2[(i0 + 3) * TR_LS + lane] = a3;
+            }
+            __syncthreads();
+            tr_store_tile(gh2, gx, base, dim0, nv, t);
+        }
+        __syncthreads();
+    }
+
+    float* const mine = part + (size_t)blockIdx.x * L::n_part(dim0);
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+        if (blk[q].aoff < 0) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mine[blk[q].ooff + a * blk[q].ostride + b] = acc[q][a * 4 + b];
+    }
+}
+
+// partial sums [n_wg][P3 | P2 | P1] -> gW3 [3][W], gb3 [3], gW2 [W][W], gb2 [W], gW1 [W][dim0], gb1 [W]; workgroup order
+__global__ void k_rgbnet_reduce(const float* __restrict__ part, int n_wg, int n_part, int W, int WB, int dim0, int D1B, int n_hidden,
+                                float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2,
+                                float* __restrict__ gw3, float* __restrict__ gb3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n3 = 3 * (W + 1), n2 = n_hidden ? W * (W + 1) : 0, n1 = W * (dim0 + 1);
+    if (i >= n3 + n2 + n1) return;
+    int off;
+    float* dst;
+    if (i < n3) {
+        const int c = i / (W + 1), j = i - c * (W + 1);
+        off = c * WB + j;
+        dst = j < W ? gw3 + c * W + j : gb3 + c;
+    } else if (i < n3 + n2) {
+        const int r = i - n3, a = r / (W + 1), j = r - a * (W + 1);
+        off = 4 * WB + a * WB + j;
+        dst = j < W ? gw2 + a * W + j : gb2 + a;
+    } else {
+        const int r = i - n3 - n2, a = r / (dim0 + 1), j = r - a * (dim0 + 1);
+        off = 4 * WB + W * WB + a * D1B + j;
+        dst = j < dim0 ? gw1 + a * dim0 + j : gb1 + a;
+    }
+    float s = 0.f;
+    for (int g = 0; g < n_wg; ++g) s += part[(size_t)g * n_part + off];
+    *dst = s;
+}
+
+static int tr_bwd_grid(int64_t n) {
+    const int64_t tiles = (n + 63) / 64;
+    const int64_t cap = 2 * (int64_t)k4_num_cus();
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
+template <int W>
+static int tr_launch_fwd(const float* x, int64_t n, int dim0, int n_hidden, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* w3, const float* b3, const float* add, float* h1, float* h2, float* rgb, hipStream_t st) {
+    const size_t lds = (size_t)(TR_MAX_DIM0 + 2 * W) * TR_LS * sizeof(float);
+    K4_ENSURE_DYN_LDS(k_rgbnet_fwd<W>, lds);
+    hipLaunchKernelGGL(k_rgbnet_fwd<W>, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, x, n, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb);
+    return k4_check_launch();
+}
+
+template <int W, int MAXB>
+static int tr_launch_bwd(const float* x, int64_t n, int dim0, int n_hidden, const float* w1, const float* w2, const float* w3,
+                         const float* h1, const float* h2, const float* rgb, const float* grgb, float* gx, float* glogit,
+                         float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3, float* ws, hipStream_t st) {
+    typedef TrBwdLayout<W> L;
+    const size_t lds = (size_t)L::lds_floats(dim0) * sizeof(float);
+    K4_ENSURE_DYN_LDS((k_rgbnet_bwd<W, MAXB>), lds);
+    const int grid = tr_bwd_grid(n);
+    hipLaunchKernelGGL((k_rgbnet_bwd<W, MAXB>), dim3(grid), dim3(256), lds, st, x, n, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grgb, gx, glogit, ws);
+    int rc = k4_check_launch();
+    if (rc) return rc;
+    const int total = 3 * (W + 1) + (n_hidden ? W * (W + 1) : 0) + W * (dim0 + 1);
+    hipLaunchKernelGGL(k_rgbnet_reduce, dim3((total + 255) / 256), dim3(256), 0, st, ws, grid, L::n_part(dim0), W, L::WB, dim0, L::d1b(dim0), n_hidden,
+                       gw1, gb1, gw2, gb2, gw3, gb3);
+    return k4_check_launch();
+}
+
+static bool tr_shape_ok(int dim0, int width, int n_hidden) {
+    return (width == 32 || width == 64 || width == 128) && (n_hidden == 0 || n_hidden == 1) && dim0 >= 1 && dim0 <= TR_MAX_DIM0;
+}
+
+extern "C" int64_t k4_rgbnet_bwd_workspace_bytes(int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden) {
+    if (!tr_shape_ok(dim0, width, n_hidden) || n_pts < 0) return -1;
+    const int np = width == 32 ? TrBwdLayout<32>::n_part(dim0) : width == 64 ? TrBwdLayout<64>::n_part(dim0) : TrBwdLayout<128>::n_part(dim0);
+    return (int64_t)tr_bwd_grid(n_pts) * np * (int64_t)sizeof(float);
+}
+
+extern "C" int k4_rgbnet_fwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden,
+                             const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                             const float* add, float* h1, float* h2, float* rgb, void* stream) {
+    if (!tr_shape_ok(dim0, width, n_hidden)) return K4_ERR_UNSUPPORTED;
+    if (n_pts < 0 || !w1 || !b1 || !w3 || !b3 || (n_hidden && (!w2 || !b2))) return K4_ERR_BAD_ARG;
+    if (n_pts == 0) return K4_OK;
+    if (!x || !rgb) return K4_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (width) {
+        case 32: return tr_launch_fwd<32>(x, n_pts, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb, st);
+        case 64: return tr_launch_fwd<64>(x, n_pts, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb, st);
+        default: return tr_launch_fwd<128>(x, n_pts, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb, st);
+    }
+}
+
+extern "C" int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden,
+                             const float* w1, const float* w2, const float* w3, const float* h1, const float* h2,
+                             const float* rgb, const float* grad_rgb, float* grad_x, float* grad_logit,
+                             float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
+                             float* workspace, int64_t workspace_bytes, void* stream) {
+    if (!tr_shape_ok(dim0, width, n_hidden)) return K4_ERR_UNSUPPORTED;
+    if (n_pts < 0 || !w1 || !w3 || !gw1 || !gb1 || !gw3 || !gb3 || (n_hidden && (!w2 || !gw2 || !gb2 || !h2))) return K4_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < k4_rgbnet_bwd_workspace_bytes(n_pts, dim0, width, n_hidden)) return K4_ERR_BAD_ARG;
+    if (n_pts > 0 && (!x || !h1 || !rgb || !grad_rgb)) return K4_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (width) {          // MAXB = ceil(blocks / 256) at dim0 = TR_MAX_DIM0: 32 -> 226, 64 -> 561, 128 -> 1633 blocks
+        case 32: return tr_launch_bwd<32, 1>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
+        case 64: return tr_launch_bwd<64, 3>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
+        default: return tr_launch_bwd<128, 7>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// Distortion loss of flattened samples (run_sr.py:976-988 -> torch_efficient_distloss.flatten_eff_distloss(w, s, 1/n_max, ray_id)).
+// Per ray, samples in ascending s:   L = sum_i [ interval/3 * w_i^2 + 2 w_i (s_i P_i - Q_i) ],  P/Q = EXCLUSIVE prefix sums of w / w s
+// (= sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval);   dL/dw_i = 2 (s_i (P_i - S_i) + (R_i - Q_i)) + 2/3 interval w_i with
+// S/R the exclusive SUFFIX sums.  One wave per ray (its samples are contiguous: ray_id is ascending), segment bounds by binary
+// search, 64 samples per scan step; value and gradient in one launch.  The caller divides by ray_id.max()+1 like the extension.
+// --------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int64_t tr_lower_bound(const int64_t* __restrict__ a, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_distloss(const float* __restrict__ w, const float* __restrict__ m, const int64_t* __restrict__ ray_id,
+                                                  int64_t n_pts, int64_t n_rays, float interval, float* __restrict__ ray_loss,
+                                                  float* __restrict__ grad) {
+    const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = k4_lane();
+    if (ray >= n_rays) return;
+    const int64_t i0 = tr_lower_bound(ray_id, 0, n_pts, ray);
+    const int64_t i1 = tr_lower_bound(ray_id, i0, n_pts, ray + 1);
+    float tw = 0.f, twm = 0.f;
+    for (int64_t i = i0 + lane; i < i1; i += 64) { const float wi = w[i]; tw += wi; twm = fmaf(wi, m[i], twm); }
+    tw = tr_wave_sum(tw); twm = tr_wave_sum(twm);
+    const float third = interval * (1.f / 3.f);
+    float cw = 0.f, cwm = 0.f, lsum = 0.f;
+    for (int64_t base = i0; base < i1; base += 64) {
+        const int64_t i = base + lane;
+        const bool act = i < i1;
+        const float wi = act ? w[i] : 0.f, mi = act ? m[i] : 0.f, wm = wi * mi;
+        float sw = wi, swm = wm;                                   // inclusive scans
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float u = __shfl_up(sw, off), v = __shfl_up(swm, off);
+            if (lane >= off) { sw += u; swm += v; }
+        }
+        const float ew = __shfl_up(sw, 1), ewm = __shfl_up(swm, 1);
+        const float wp = cw + (lane ? ew : 0.f), wmp = cwm + (lane ? ewm : 0.f);       // exclusive prefixes
+        const float wsuf = tw - (wp + wi), wmsuf = twm - (wmp + wm);                    // exclusive suffixes
+        if (act) {
+            lsum += third * wi * wi + 2.f * wi * (mi * wp - wmp);
+            grad[i] = 2.f * (mi * (wp - wsuf) + (wmsuf - wmp)) + 2.f * third * wi;
+        }
+        cw += __shfl(sw, 63); cwm += __shfl(swm, 63);
+    }
+    lsum = tr_wave_sum(lsum);
+    if (lane == 0) ray_loss[ray] = lsum;
+}
+
+extern "C" int k4_distortion_loss(const float* w, const float* s, const int64_t* ray_id, int64_t n_pts, int64_t n_rays, float interval,
+                                  float* ray_loss, float* grad_w, void* stream) {
+    if (n_pts < 0 || n_rays < 0) return K4_ERR_BAD_ARG;
+    if (n_rays == 0) return K4_OK;
+    if (!ray_loss || (n_pts > 0 && (!w || !s || !ray_id || !grad_w))) return K4_ERR_BAD_ARG;
+    const int64_t threads = n_rays * 64;
+    hipLaunchKernelGGL(k_distloss, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, s, ray_id, n_pts, n_rays, interval,
+                       ray_loss, grad_w);
+    return k4_check_launch();
+}

@@ -1,0 +1,167 @@
+"""Joint training step of the marcher and the VC-Decoder (BASELINE configs[4]; SURVEY.md 3.4, 8e "Training", 8f ranks 1-3).
+
+Restates ONE iteration of the reference's joint loop (/root/reference/run_sr.py:801-1061, configuration
+configs/llff/fern_lg_joint_l1.py) on this package's HIP training graph:
+
+    patch of rays -> DirectMPIGO / DirectVoxGO forward (staged HIP ops under autograd, colour MLP on k4_rgbnet_*)
+                  -> SFTNet(rgb_feature, depth)   (lib/sr_train.py: every convolution forward / dgrad / wgrad on MFMA kernels)
+                  -> L1(LR) + L1(HR) + background entropy + distortion (k4_distortion_loss) + per-point rgb
+                  -> backward -> [data parallel: gradient exchange] -> total-variation add-grad -> MaskedAdam x 2 -> lr decay
+
+The perceptual / GAN terms (weight_pcp, weight_gan; VGG and discriminator networks) are outside SURVEY.md 8 and raise.
+
+Data parallelism (one 64x64 patch per rank, run_sr.py:829-835): the decoder's 15.8 MB of gradients, the rgbnet and every other
+small tensor travel in ONE flat all-reduce (lib/sr_train.allreduce_gradients); the voxel grids do not -- `k0.grid` is 1.36 GB
+dense while a patch touches well under 1 % of it -- they use ``sparse_grad_allreduce``: every rank compacts the voxels its
+backward touched to (int32 index, values) lists, ONE all-gather of the padded lists moves them, and every rank adds all
+lists into its dense gradient in RANK order, so the replicas hold bit-identical gradients (and MaskedAdam's "skip voxels
+with zero gradient" sees the union of the touched voxels).  Pure torch.distributed plumbing: RCCL on the GPUs, gloo in the
+CPU tests.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .lib import sr_train, train_ops, utils
+from .lib.masked_adam import MaskedAdam
+
+SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
+
+
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def sparse_grad_allreduce(params, group=None, average=True):
+    """Sum (average) the gradients of voxel-grid parameters [1, C, X, Y, Z] over the ranks by exchanging only touched voxels.
+    A voxel is touched when any of its C channels has a non-zero gradient.  Returns a dict of exchange statistics."""
+    world = _world(group)
+    stats = {'world': world, 'bytes_gathered': 0, 'touched': []}
+    params = [p for p in params if p.requires_grad]
+    if world == 1:
+        return stats
+    for p in params:
+        C = p.shape[1] if p.dim() == 5 else 1
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        g = p.grad.view(C, -1)
+        V = g.shape[1]
+        assert V < 2 ** 31
+        idx = (g != 0).any(0).nonzero().flatten().to(torch.int32)
+        n = torch.tensor([idx.numel()], dtype=torch.int64, device=g.device)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n, group=group)
+        counts = [int(c) for c in counts]
+        cap = max(max(counts), 1)
+        # one message per rank: [cap] int32 indices followed by the bits of the [C][cap] fp32 values (integer buffers: plain byte moves)
+        send = torch.zeros([(C + 1) * cap], dtype=torch.int32, device=g.device)
+        send[:idx.numel()] = idx
+        send[cap:].view(torch.float32).view(C, cap)[:, :idx.numel()] = g[:, idx.long()]
+        recv = torch.empty([world * (C + 1) * cap], dtype=torch.int32, device=g.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        g[:, idx.long()] = 0                                     # own contribution comes back with the others, in rank order
+        scale = 1.0 / world if average else 1.0
+        for r in range(world):
+            msg = recv[r * (C + 1) * cap:(r + 1) * (C + 1) * cap]
+            ri = msg[:counts[r]].long()
+            g.index_add_(1, ri, msg[cap:].view(torch.float32).view(C, cap)[:, :counts[r]] * scale)
+        stats['bytes_gathered'] += recv.numel() * 4
+        stats['touched'].append((counts, V))
+    return stats
+
+
+def exchange_gradients(model, net_sr, group=None):
+    """Data-parallel gradient exchange of the joint step: big grids sparse, everything else in one dense bucket."""
+    if _world(group) == 1:
+        return {'world': 1}
+    everything = [p for p in list(model.parameters()) + list(net_sr.parameters()) if p.requires_grad]
+    big = [p for p in everything if p.numel() >= SPARSE_MIN_NUMEL and p.dim() == 5]
+    big_ids = {id(p) for p in big}
+    small = [p for p in everything if id(p) not in big_ids]
+    stats = sparse_grad_allreduce(big, group=group)
+    stats['bytes_dense'] = sr_train.allreduce_gradients(small, group=group)
+    return stats
+
+
+class JointCfg(dict):
+    """Attribute-style view of the `fine_train` section (mmcv ConfigDict upstream)."""
+    __getattr__ = dict.__getitem__
+
+    @classmethod
+    def fern_lg_joint_l1(cls, **over):
+        """configs/llff/fern_lg_joint_l1.py on top of llff_default_lg.py and default.py (the values the joint loop reads)."""
+        cfg = dict(N_iters=300000, N_rand=4096, N_patch=64, ray_sampler='patch_mimg',
+                   lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_srnet=2e-4, lrate_decay=300,
+                   skip_zero_grad_fields=['density', 'k0'],
+                   weight_main=1.0, weight_entropy_last=0.001, weight_nearclip=0, weight_distortion=0.01, weight_rgbper=0.01,
+                   weight_pcp=0, weight_gan=0, weight_style=0,
+                   tv_every=1, tv_after=0, tv_before=10000, tv_dense_before=10000, weight_tv_density=1e-5, weight_tv_k0=1e-6)
+        cfg.update(over)
+        return cls(cfg)
+
+
+class JointTrainer:
+    """Optimizers + one-iteration method of the joint loop.  ``render_kwargs`` as run_sr.py:690-702 builds them
+    (``render_depth=True``; ``rand_bkgd`` for LLFF); ``n_train_images`` = len(rays_o_tr), the TV weights' divisor (:1008-1011)."""
+
+    def __init__(self, model, net_sr, cfg_train, render_kwargs, n_train_images, sr_ratio=4, num_cond=1, dim_rend=3, group=None):
+        if cfg_train.weight_pcp > 0 or cfg_train.weight_gan > 0:
+            raise NotImplementedError('perceptual / GAN losses (run_sr.py:934-957) are outside the hot-path scope (SURVEY.md 8)')
+        if num_cond != 1 or dim_rend != 3:
+            raise NotImplementedError('joint step: num_cond=1 (depth condition), dim_rend=3 as configs/llff/fern_lg_joint_l1.py')
+        self.model, self.net_sr, self.cfg, self.group = model, net_sr, cfg_train, group
+        self.render_kwargs = dict(render_kwargs)
+        self.n_train_images, self.sr_ratio = n_train_images, sr_ratio
+        self.optimizer = utils.create_optimizer_or_freeze_model(model, cfg_train, global_step=0)                  # run_sr.py:640
+        self.optimizer_sr = MaskedAdam([{'params': net_sr.parameters(), 'lr': cfg_train.lrate_srnet, 'kname': 'srnet',
+                                         'skip_zero_grad': False}])                                               # run_sr.py:665-667
+        self.last_exchange = None
+
+    def losses(self, rr, rgb_sr, target, target_4x, pr, pc, n_rays):
+        """run_sr.py:877-995: the scalar terms of one iteration (dict of tensors; 'total' is what is back-propagated)."""
+        cfg, s = self.cfg, self.sr_ratio
+        out = {'photo': cfg.weight_main * F.l1_loss(rr['rgb_feature'], target)}
+        rgb_hr = target_4x.detach().reshape(s * pr, s * pc, 3).movedim(-1, 0).unsqueeze(0)
+        out['l1'] = F.l1_loss(rgb_sr, rgb_hr)
+        out['psnr_sr'] = -10.0 * torch.log10((rgb_sr.detach().clamp(0, 1) - rgb_hr).pow(2).mean())
+        if cfg.weight_entropy_last > 0:
+            p = rr['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+            out['entropy_last'] = -(p * torch.log(p) + (1 - p) * torch.log(1 - p)).mean() * cfg.weight_entropy_last
+        if cfg.weight_nearclip > 0:
+            raise NotImplementedError("weight_nearclip needs the 't' / 'raw_density' keys no BASELINE configuration produces")
+        if cfg.weight_distortion > 0:
+            out['distortion'] = cfg.weight_distortion * train_ops.flatten_eff_distloss(rr['weights'], rr['s'], 1 / rr['n_max'], rr['ray_id'])
+        if cfg.weight_rgbper > 0:
+            per = (rr['raw_rgb'] - target[rr['ray_id']]).pow(2).sum(-1)
+            out['rgbper'] = cfg.weight_rgbper * (per * rr['weights'].detach()).sum() / n_rays
+        out['total'] = sum(v for k, v in out.items() if k != 'psnr_sr')
+        return out
+
+    def forward(self, rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step):
+        rr = self.model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **self.render_kwargs)
+        rgb_cache = rr['rgb_feature'].reshape(1, pr, pc, -1).movedim(-1, 1)
+        cond = rr['depth'].reshape(1, pr, pc, 1).movedim(-1, 1)                          # num_cond == 1 (run_sr.py:894-897)
+        rgb_sr = self.net_sr(rgb_cache, cond)                                            # run_sr.py:918
+        return rr, rgb_sr, self.losses(rr, rgb_sr, target, target_4x, pr, pc, len(rays_o))
+
+    def step(self, rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step):
+        """One iteration (run_sr.py:869-1014,1052-1061).  Returns the dict of loss tensors (detached)."""
+        cfg = self.cfg
+        with torch.enable_grad():
+            rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
+            self.optimizer.zero_grad(set_to_none=True)
+            self.optimizer_sr.zero_grad(set_to_none=True)
+            ls['total'].backward()
+        self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
+        if cfg.tv_after < global_step < cfg.tv_before and global_step % cfg.tv_every == 0:                       # run_sr.py:1005-1011
+            if cfg.weight_tv_density > 0:
+                self.model.density_total_variation_add_grad(cfg.weight_tv_density / self.n_train_images, global_step < cfg.tv_dense_before)
+            if cfg.weight_tv_k0 > 0:
+                self.model.k0_total_variation_add_grad(cfg.weight_tv_k0 / self.n_train_images, global_step < cfg.tv_dense_before)
+        self.optimizer.step()
+        self.optimizer_sr.step()
+        factor = 0.1 ** (1 / (cfg.lrate_decay * 1000))                                                           # run_sr.py:1052-1061
+        for opt in (self.optimizer, self.optimizer_sr):
+            for pg in opt.param_groups:
+                pg['lr'] = pg['lr'] * factor
+        return {k: v.detach() for k, v in ls.items()}

@@ -279,7 +279,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             viewdirs_emb = viewdirs_emb[ray_id]
             pe_emb = (pe_spa.unsqueeze(-1) * self.posfreq).flatten(-2)
             pe_emb = torch.cat([pe_spa, pe_emb.sin(), pe_emb.cos()], -1)
-            rgb_raw = torch.sigmoid(self.rgbnet(torch.cat([vox_emb, pe_emb, viewdirs_emb], -1)))
+            rgb_raw = self._k4_rgbnet_sigmoid(torch.cat([vox_emb, pe_emb, viewdirs_emb], -1))
         rgb_feature = segment_sum(weights.unsqueeze(-1) * rgb_raw, ray_id, Nr)
         rgb_marched = rgb_feature
         if rand_bkgd and global_step is not None:

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from .. import _native as N
 from . import grid
 from . import render_utils_cuda
+from . import train_ops
 
 _FUSED_WIDTHS = (32, 64, 128)
 
@@ -95,6 +96,17 @@ class _FusedMarcher:
         md.width = lins[0].out_features
         md.n_hidden = len(lins) - 2
         return md, c['mlp_packed']
+
+    def _k4_rgbnet_sigmoid(self, feat, add=None):
+        """``torch.sigmoid(self.rgbnet(feat) [+ add])`` of the staged / training forward (lib/dmpigo.py:375-379, lib/dvgo.py:407-412)
+        on k4_rgbnet_fwd / k4_rgbnet_bwd (lib/train_ops.py).  MLP shapes outside the kernels' range stay on the nn.Sequential."""
+        c = self._k4_cache()
+        if 'rgbnet_native' not in c:
+            c['rgbnet_native'] = train_ops.rgbnet_supported(self.rgbnet) and os.environ.get('K4_RGBNET') != 'torch'
+        if c['rgbnet_native']:
+            return train_ops.rgbnet_sigmoid(self.rgbnet, feat, add)
+        logit = self.rgbnet(feat)
+        return torch.sigmoid(logit if add is None else logit + add)
 
     def _k4_workspace(self, n_rays, img_w, max_steps, device, slot=0):
         """Scratch between the geometry and the shading kernel: worst-case sized (every sample of every ray
@@ -462,8 +474,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
             viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
             viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
-            rgb_logit = self.rgbnet(torch.cat([k0_view, viewdirs_emb], -1))
-            rgb_raw = torch.sigmoid(rgb_logit if self.rgbnet_direct else rgb_logit + k0_diffuse)
+            rgb_raw = self._k4_rgbnet_sigmoid(torch.cat([k0_view, viewdirs_emb], -1), None if self.rgbnet_direct else k0_diffuse)
         rgb_feature = segment_sum(weights.unsqueeze(-1) * rgb_raw, ray_id, Nr)
         rgb_marched = rgb_feature
         rgb_marched += (alphainv_last.unsqueeze(-1) * bg)                 # aliases rgb_feature (lib/dvgo.py:425-427)
@@ -813,3 +824,42 @@ def batch_indices_generator(N, BS):
             perm, pos = torch.from_numpy(np.random.permutation(N)).long(), 0
         yield perm[pos:pos + BS]
         pos += BS
+
+
+def patch_gen(imsz, num_im, BS, sz_patch):
+    """The patch table of the 'patch_mimg' ray sampler (lib/dvgo.py:822-850): the image is cut in bs x bs tiles, bs = BS // sz_patch
+    (4096 // 64 = 64 for configs/llff/fern_lg_joint_l1.py).  Returns a list of [rows, cols, 2] int64 arrays of (row, col) pixel indices
+    in the reference's order: the full tiles column band by column band, then the right-edge remainders (one per row band), then the
+    bottom-edge remainders (one per column band, then the corner).  As upstream, an exactly divisible side yields EMPTY remainder
+    entries (the list length, which seeds the permutation, is kept)."""
+    bs = BS // sz_patch
+    H, W = int(imsz[0]), int(imsz[1])
+    nr, nc = H // bs, W // bs
+
+    def patch(r0, r1, c0, c1):
+        rr, cc = np.meshgrid(np.arange(r0, r1, dtype=np.int64), np.arange(c0, c1, dtype=np.int64), indexing='ij')
+        return np.stack((rr, cc), axis=-1)
+
+    full = [patch(rb * bs, (rb + 1) * bs, cb * bs, (cb + 1) * bs) for cb in range(nc) for rb in range(nr)]
+    right = [patch(rb * bs, (rb + 1) * bs, nc * bs, W) for rb in range(nr)]
+    bottom = [patch(nr * bs, H, cb * bs, (cb + 1) * bs) for cb in range(nc)] + [patch(nr * bs, H, nc * bs, W)]
+    return full + right + bottom
+
+
+def mimg_patch_indices_generator(imsz, num_im, BS, sz_patch, sr_ratio):
+    """Endless (image, LR patch, matching HR patch) choices for the joint training loop (lib/dvgo.py:852-880, used at
+    run_sr.py:753-754,828-835): every (image, patch) pair once per epoch in a host-side random order.
+    Yields ``image, rows, cols, rows_4x, cols_4x, [pr, pc]`` (flattened pixel index lists, patch height / width)."""
+    imsz = np.asarray(imsz)
+    lr, hr = patch_gen(imsz, num_im, BS, sz_patch), patch_gen(imsz * sr_ratio, num_im, BS * sr_ratio, sz_patch)
+    num_p = len(lr)
+    pairs = np.stack((np.repeat(np.arange(num_im, dtype=np.float64), num_p), np.tile(np.arange(num_p, dtype=np.float64), num_im)), axis=1)
+    order, pos = torch.LongTensor(np.random.permutation(pairs)), 0
+    while True:
+        if pos >= len(pairs):
+            order, pos = torch.LongTensor(np.random.permutation(pairs)), 0
+        image, p = order[pos][0], int(order[pos][1])
+        pos += 1
+        pr, pc = lr[p].shape[0], lr[p].shape[1]
+        a, b = lr[p].reshape(-1, 2), hr[p].reshape(-1, 2)
+        yield image, list(a[:, 0]), list(a[:, 1]), list(b[:, 0]), list(b[:, 1]), [pr, pc]

@@ -1,0 +1,134 @@
+"""Training-graph operators of the marcher on HIP kernels (csrc/k4_train.hip; SURVEY.md 8f rank 1 "MLP bwd", 3.4).
+
+``rgbnet_sigmoid``      the colour MLP + sigmoid of ``DirectMPIGO.forward`` / ``DirectVoxGO.forward`` under autograd
+                        (/root/reference/lib/dmpigo.py:375-379, lib/dvgo.py:407-412: ``torch.sigmoid(self.rgbnet(feat))``,
+                        differentiated by PyTorch autograd over library GEMMs): ONE launch forward (activations saved),
+                        two launches backward (everything + the ordered sum of the per-workgroup weight-gradient partials).
+``flatten_eff_distloss`` the distortion loss of the joint training step (run_sr.py:976-988; third-party
+                        ``torch_efficient_distloss``, not vendored upstream): value and gradient in one launch.
+
+There is no CPU path: CPU tensors raise ``K4Error``.  MLP shapes the kernels do not cover (width not in {32, 64, 128}, more than
+one hidden->hidden layer, dim0 > 64) stay on the ``nn.Sequential`` (rocBLAS) -- ``rgbnet_supported`` tells which.
+"""
+import torch
+from torch import nn
+
+from .. import _native as N
+
+
+def _linears(rgbnet):
+    return [m for m in rgbnet.modules() if isinstance(m, nn.Linear)]
+
+
+def rgbnet_supported(rgbnet):
+    """True when `rgbnet` is Linear-ReLU-[Linear-ReLU]-Linear(->3) with a shape k4_rgbnet_* covers."""
+    lins = _linears(rgbnet)
+    if len(lins) not in (2, 3) or lins[-1].out_features != 3:
+        return False
+    acts = [m for m in rgbnet.modules() if not isinstance(m, (nn.Linear, nn.Sequential))]
+    if not all(isinstance(a, nn.ReLU) for a in acts):
+        return False
+    width = lins[0].out_features
+    if any(l.bias is None for l in lins) or any(l.in_features != width for l in lins[1:]) or any(l.out_features != width for l in lins[1:-1]):
+        return False
+    return N.lib().k4_rgbnet_bwd_workspace_bytes(1, lins[0].in_features, width, len(lins) - 2) >= 0
+
+
+class RgbNetSigmoid(torch.autograd.Function):
+    """rgb = sigmoid(W3 relu(W2 relu(W1 x + b1) + b2) + b3 (+ add)); w2/b2 None for a 2-layer rgbnet."""
+
+    @staticmethod
+    def forward(ctx, x, add, w1, b1, w2, b2, w3, b3):
+        x = x.detach().float().contiguous()
+        n, dim0 = x.shape
+        width = w1.shape[0]
+        nh = 0 if w2 is None else 1
+        dev = x.device
+        ws = [t.detach().contiguous() if t is not None else None for t in (w1, b1, w2, b2, w3, b3)]
+        addc = None if add is None else add.detach().float().contiguous()
+        need = any(ctx.needs_input_grad)
+        h1 = torch.empty([n, width], dtype=torch.float32, device=dev) if need else None
+        h2 = torch.empty([n, width], dtype=torch.float32, device=dev) if need and nh else None
+        rgb = torch.empty([n, 3], dtype=torch.float32, device=dev)
+        N.check(N.lib().k4_rgbnet_fwd(N.f32(x), n, dim0, width, nh, N.f32(ws[0]), N.f32(ws[1]),
+                                      None if ws[2] is None else N.f32(ws[2]), None if ws[3] is None else N.f32(ws[3]),
+                                      N.f32(ws[4]), N.f32(ws[5]), None if addc is None else N.f32(addc),
+                                      None if h1 is None else N.f32(h1), None if h2 is None else N.f32(h2), N.f32(rgb), N.stream()),
+                'k4_rgbnet_fwd')
+        if need:
+            ctx.save_for_backward(x, h1, h2, rgb, ws[0], ws[2], ws[4])
+            ctx.has_add = add is not None
+        return rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_rgb):
+        x, h1, h2, rgb, w1, w2, w3 = ctx.saved_tensors
+        n, dim0 = x.shape
+        width = w1.shape[0]
+        nh = 0 if w2 is None else 1
+        dev = x.device
+        g = grad_rgb.float().contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gl = torch.empty([n, 3], dtype=torch.float32, device=dev) if ctx.has_add and ctx.needs_input_grad[1] else None
+        gw1, gb1 = torch.empty_like(w1), torch.empty([width], dtype=torch.float32, device=dev)
+        gw2, gb2 = (torch.empty_like(w2), torch.empty([width], dtype=torch.float32, device=dev)) if nh else (None, None)
+        gw3, gb3 = torch.empty_like(w3), torch.empty([3], dtype=torch.float32, device=dev)
+        L = N.lib()
+        wsb = int(L.k4_rgbnet_bwd_workspace_bytes(n, dim0, width, nh))
+        work = torch.empty([max(wsb, 4) // 4], dtype=torch.float32, device=dev)
+        N.check(L.k4_rgbnet_bwd(N.f32(x), n, dim0, width, nh, N.f32(w1), None if w2 is None else N.f32(w2), N.f32(w3),
+                                N.f32(h1), None if h2 is None else N.f32(h2), N.f32(rgb), N.f32(g),
+                                None if gx is None else N.f32(gx), None if gl is None else N.f32(gl),
+                                N.f32(gw1), N.f32(gb1), None if gw2 is None else N.f32(gw2), None if gb2 is None else N.f32(gb2),
+                                N.f32(gw3), N.f32(gb3), N.f32(work), wsb, N.stream()), 'k4_rgbnet_bwd')
+        return gx, gl, gw1, gb1, gw2, gb2, gw3, gb3
+
+
+def rgbnet_sigmoid(rgbnet, x, add=None):
+    """``torch.sigmoid(rgbnet(x) [+ add])`` on the HIP kernels (x [n, dim0]; add [n, 3] = k0_diffuse or None)."""
+    if not x.is_cuda:
+        raise N.K4Error('rgbnet_sigmoid: tensor must be on the GPU (no CPU path exists for this op)')
+    lins = _linears(rgbnet)
+    w2, b2 = (lins[1].weight, lins[1].bias) if len(lins) == 3 else (None, None)
+    return RgbNetSigmoid.apply(x, add, lins[0].weight, lins[0].bias, w2, b2, lins[-1].weight, lins[-1].bias)
+
+
+class FlattenEffDistLoss(torch.autograd.Function):
+    """sum_rays [ sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval ] / (ray_id.max() + 1), gradient w.r.t. w only."""
+
+    @staticmethod
+    def forward(ctx, w, s, interval, ray_id):
+        if not w.is_cuda:
+            raise N.K4Error('flatten_eff_distloss: tensor must be on the GPU (no CPU path exists for this op)')
+        if torch.is_tensor(interval):
+            raise NotImplementedError('per-sample interval tensors: run_sr.py:985 passes the scalar 1/n_max')
+        wc, sc, idx = w.detach().float().contiguous(), s.detach().float().contiguous(), ray_id.contiguous()
+        n = wc.shape[0]
+        if n == 0:
+            ctx.empty = True
+            return wc.new_zeros([])
+        ctx.empty = False
+        n_rays_t = idx.max() + 1                                  # the package's normaliser; stays on the device
+        # ray_id < n_rays of the batch; bounding the launch needs a host integer: the segment search makes any upper bound correct
+        n_rays = int(n_rays_t)
+        ray_loss = torch.empty([n_rays], dtype=torch.float32, device=wc.device)
+        grad = torch.empty_like(wc)
+        N.check(N.lib().k4_distortion_loss(N.f32(wc), N.f32(sc), N.ptr(idx), n, n_rays, float(interval), N.f32(ray_loss), N.f32(grad),
+                                           N.stream()), 'k4_distortion_loss')
+        ctx.save_for_backward(grad)
+        ctx.n_rays = n_rays
+        return ray_loss.sum() / n_rays
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        if ctx.empty:
+            return None, None, None, None
+        grad, = ctx.saved_tensors
+        return grad * (grad_back / ctx.n_rays), None, None, None
+
+
+def flatten_eff_distloss(w, s, interval, ray_id):
+    """Drop-in for ``torch_efficient_distloss.flatten_eff_distloss`` as run_sr.py:985 calls it."""
+    return FlattenEffDistLoss.apply(w, s, interval, ray_id)

@@ -31,6 +31,7 @@ Objects on the JSON line (rank 0):
                       as ``cpu_baseline``; ``four_k_fp32mfma`` / ``four_k_bf16x3`` = the other decoder arithmetics.
   own_staged_pipeline   -- the reference's op-per-launch sequence on THIS package's staged kernels (8192-ray chunks).
   training_step_kernels -- Adam / masked Adam / TV / grid-sample backward streaming kernels vs the HBM roof.
+  joint_train_step      -- BASELINE configs[4] on one GPU: ms per iteration of the joint marcher + decoder training loop.
 """
 import argparse
 import glob
@@ -269,6 +270,7 @@ def main():
         if world == 1 and not args.small and not args.no_extras:
             res['own_staged_pipeline'] = own_staged_pipeline(model, run.rays[0], rk)
             res['training_step_kernels'] = training_step_kernels(dev, run.rays[0], model)
+            res['joint_train_step'] = joint_train_step(ck, run.rays[0], H, W, dev)
         if not args.no_cpu_baseline:
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
@@ -482,6 +484,63 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
         ms = scatter(pts, model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous())
         out['grid_sample_bwd_8192_rays_x_256'] = {'ms': round(ms, 3), 'B_per_point': bpp, 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
     return out
+
+
+def joint_train_step(ck, frame_rays, H, W, dev, iters=4):
+    """BASELINE configs[4] on ONE GPU: iterations of the joint loop (run_sr.py:801-1061 -> 4k-nerf_amd/joint_train.JointTrainer.step) at
+    the sizes of configs/llff/fern_lg_joint_l1.py -- a 64x64 ray patch of the 1008x756 view marched through the full 417x353x256
+    scene under autograd, SFTNet(5 blocks) x4 to 256x256, L1 + L1 + entropy + distortion + per-point rgb, backward, dense
+    total-variation add-grad on both grids, MaskedAdam on the marcher and on the decoder.  Synthetic targets."""
+    from nerf4k_amd import joint_train
+    from nerf4k_amd.lib import sr_esrnet, utils
+    model = utils.model_from_checkpoint_dict(ck).to(dev).train()
+    torch.manual_seed(778)
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).train()
+    cfg = joint_train.JointCfg.fern_lg_joint_l1()
+    rk = dict(ck['render_kwargs'], render_depth=True, rand_bkgd=True)
+    tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+    pr = pc = cfg.N_rand // cfg.N_patch
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ro, rd, vd = (x.reshape(H, W, 3) for x in frame_rays)
+
+    def batch(i):
+        r0, c0 = (37 * i) % (H - pr), (101 * i) % (W - pc)
+        rays = [x[r0:r0 + pr, c0:c0 + pc].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
+        return rays + [torch.rand([pr * pc, 3], device=dev, generator=gen), torch.rand([16 * pr * pc, 3], device=dev, generator=gen), pr, pc]
+    first = float(tr.step(*batch(0), global_step=1)['total'])            # warm-up: packing, optimizer state, allocator
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n_samples = 0
+    for i in range(iters):
+        tr.step(*batch(1 + i), global_step=2 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / iters
+    # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
+    b = batch(9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.enable_grad():
+        rr, _, ls = tr.forward(*b, global_step=9)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    tr.optimizer.zero_grad(set_to_none=True)
+    tr.optimizer_sr.zero_grad(set_to_none=True)
+    ls['total'].backward()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    model.density_total_variation_add_grad(cfg.weight_tv_density / 17, True)
+    model.k0_total_variation_add_grad(cfg.weight_tv_k0 / 17, True)
+    tr.optimizer.step()
+    tr.optimizer_sr.step()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    n_samples = int(rr['weights'].numel())
+    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'rays_per_iteration': pr * pc,
+            'shaded_samples': n_samples, 'first_loss': round(first, 5),
+            'breakdown_ms': {'forward (march train + SFTNet + losses)': round((t1 - t0) * 1e3, 2), 'backward': round((t2 - t1) * 1e3, 2),
+                             'TV add-grad (dense, both grids) + MaskedAdam x 2': round((t3 - t2) * 1e3, 2)},
+            'workload': 'configs[4] fern_lg_joint_l1 on 1 GPU: 64x64 patch, 417x353x256 grids (k0 9 ch), rgbnet 15->64->64->3 on k4_rgbnet_*, '
+                        'SFTNet 5 blocks on the MFMA conv kernels (fwd / dgrad / wgrad), synthetic targets'}
 
 
 def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):

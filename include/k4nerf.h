@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      3       /* 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      4       /* 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -358,6 +358,35 @@ int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, floa
  * naming; dense_mode == 0 restricts the update to elements whose grad is non-zero. */
 int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
                                 int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream);
+
+/* ---- marcher training step: colour MLP with its backward, distortion loss (SURVEY.md 8f rank 1 "MLP bwd", 3.4) --------------
+ * k4_rgbnet_fwd / k4_rgbnet_bwd replace, in the training graph, the `rgbnet` nn.Sequential + torch.sigmoid that the reference
+ * evaluates and differentiates with PyTorch autograd over library GEMMs (lib/dmpigo.py:112-120,375-379; lib/dvgo.py:116-124,
+ * 407-412).  Weights are the nn.Linear tensors AS STORED (w1 [width][dim0], w2 [width][width], w3 [3][width], row-major; b*),
+ * nothing is repacked.  width in {32, 64, 128}, n_hidden in {0, 1} (rgbnet_depth 2 | 3), 1 <= dim0 <= 64; other shapes
+ * return K4_ERR_UNSUPPORTED (the host keeps them on the nn.Module).
+ *   fwd: rgb[n][3] = sigmoid(W3 relu(W2 relu(W1 x + b1) + b2) + b3 (+ add[n][3]));  h1 / h2 [n][width] (post-ReLU, NULL = not
+ *        saved) are what the backward needs.  `add` = k0_diffuse of rgbnet_direct=False (lib/dvgo.py:412), NULL otherwise.
+ *   bwd: grad_x [n][dim0] (NULL = not wanted), grad_logit [n][3] (= gradient of `add`; NULL = not wanted), gw* / gb* are
+ *        OVERWRITTEN with the sums over the n samples.  Exact fp32 FMA chains, no atomics: per-workgroup partial sums land in
+ *        `workspace` (k4_rgbnet_bwd_workspace_bytes) and are added in workgroup order. */
+int k4_rgbnet_fwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden,
+                  const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                  const float* add, float* h1, float* h2, float* rgb, void* stream);
+int64_t k4_rgbnet_bwd_workspace_bytes(int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden);      /* <0: unsupported shape */
+int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, int32_t n_hidden,
+                  const float* w1, const float* w2, const float* w3, const float* h1, const float* h2,
+                  const float* rgb, const float* grad_rgb, float* grad_x, float* grad_logit,
+                  float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
+                  float* workspace, int64_t workspace_bytes, void* stream);
+/* Distortion loss of the joint training step: run_sr.py:976-988 calls `flatten_eff_distloss(w, s, 1/n_max, ray_id)` of the
+ * third-party package torch_efficient_distloss (not vendored in the reference tree).  Its published form is evaluated per
+ * ray over samples sorted by s (ray_id ascending, as the marcher emits them):
+ *   ray_loss[r] = sum_i [ interval/3 * w_i^2 + 2 w_i (s_i P_i - Q_i) ],   P / Q = exclusive prefix sums of w / w*s along the ray
+ *   grad_w[i]   = d(sum_r ray_loss[r]) / d w_i
+ * The package's value is sum(ray_loss) / (ray_id.max() + 1): that division stays on the host. */
+int k4_distortion_loss(const float* w, const float* s, const int64_t* ray_id, int64_t n_pts, int64_t n_rays, float interval,
+                       float* ray_loss, float* grad_w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -281,6 +281,87 @@ def gen_occ(ref):
               f'mask {float(arrs["scale/mask"].mean()):.3f}')
 
 
+def gen_patch(ref):
+    """The 'patch_mimg' ray sampler of the joint loop (lib/dvgo.py:822-880) under a fixed numpy seed: the first draws of the
+    reference's own generator, for a non-divisible image (LLFF-like remainders) and an exactly divisible one (empty remainder
+    entries upstream)."""
+    arrs = {}
+    for tag, imsz, num_im, BS, szp, sr, draws in (('a', (20, 27), 3, 32, 8, 4, 60), ('b', (16, 16), 2, 64, 16, 2, 24), ('c', (756, 1008), 2, 4096, 64, 4, 6)):
+        np.random.seed(1234)
+        gen = ref.dvgo.mimg_patch_indices_generator(np.array(imsz), num_im, BS, szp, sr)
+        rows = []
+        for _ in range(draws):
+            im, r, c, r4, c4, ps = next(gen)
+            r, c, r4, c4 = (np.asarray(v, dtype=np.int64) for v in (r, c, r4, c4))
+            # a draw is summarised by sizes + position-weighted checksums (the index lists of a 64x64 / 256x256 patch pair are 70k numbers)
+            chk = [int((v * (np.arange(v.size) % 97 + 1)).sum()) for v in (r, c, r4, c4)]
+            rows.append([int(im), ps[0], ps[1], r.size, r4.size] + chk + [int(r.min()) if r.size else -1, int(c.min()) if c.size else -1])
+        arrs[tag + '/args'] = np.array([imsz[0], imsz[1], num_im, BS, szp, sr])
+        arrs[tag + '/draws'] = np.array(rows, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, 'patch_sampler.npz'), **arrs)
+    print('patch_sampler:', {k: v.shape for k, v in arrs.items()})
+
+
+def gen_grad_joint(ref):
+    """ONE iteration of the joint loop (run_sr.py:869-1000) on the reference's own modules: DirectMPIGO.forward (train) ->
+    SFTNet(rgb_feature, depth) -> L1(LR) + L1(HR) + entropy + distortion + per-point rgb (oracle/train_ops.joint_losses restates the
+    loss lines; the distortion term is the literal O(n^2) definition, torch_efficient_distloss is not installed) -> backward.
+    Stores every loss term, the marcher's parameter gradients in full and (sum, L2 norm) of every decoder gradient."""
+    from oracle import train_ops as oto
+    poses = scene.llff_spiral_poses()
+    ck = scene.make_llff_checkpoint(seed=17, num_voxels=14 * 14 * 12, mpi_depth=12)
+    model = _ref_model(ref, ck).train()
+    H, W, pr, pc, r0, c0 = 24, 32, 8, 10, 9, 13
+    K = scene.LLFF_K.copy()
+    K[:2] *= (W / scene.LLFF_HW[1])
+    ro, rd, vd = ref.dvgo.get_rays_of_a_view(H, W, K, torch.Tensor(poses[7]), True, inverse_y=False, flip_x=False, flip_y=False)
+    rays = [x[r0:r0 + pr, c0:c0 + pc].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
+    nb = 1
+    sd = osr.make_state_dict(seed=400, num_block=nb)
+    net = ref.sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=nb, num_grow_ch=32, num_cond=1)
+    net.load_state_dict(sd)
+    net.train()
+    g = torch.Generator().manual_seed(31)
+    target = torch.rand([pr * pc, 3], generator=g)
+    target_4x = torch.rand([16 * pr * pc, 3], generator=g)
+    cfg = dict(weight_main=1.0, weight_entropy_last=0.001, weight_distortion=0.01, weight_rgbper=0.01)
+    rk = dict(ck['render_kwargs'], render_depth=True, rand_bkgd=True)
+    torch.manual_seed(3)
+    rr = model(*rays, global_step=5, is_train=True, **rk)
+    rgb_cache = rr['rgb_feature'].reshape(1, pr, pc, -1).movedim(-1, 1)
+    cond = rr['depth'].reshape(1, pr, pc, 1).movedim(-1, 1)
+    rgb_sr = net(rgb_cache, cond)
+    total, terms = oto.joint_losses(rr, rgb_sr, target, target_4x, pr, pc, cfg)
+    total.backward()
+    arrs = {'model_class': np.array(ck['model_class']), 'model_kwargs_json': np.array(_kwargs_json(ck['model_kwargs'])),
+            'render_kwargs_json': np.array(json.dumps(rk)), 'cfg_json': np.array(json.dumps(cfg)),
+            'sr_seed': np.array(400), 'num_block': np.array(nb), 'patch': np.array([pr, pc]), 'global_step': np.array(5),
+            'target': _np(target), 'target_4x': _np(target_4x), 'loss/total': _np(total.detach()),
+            'out/rgb_sr': _np(rgb_sr.detach()), 'out/rgb_feature': _np(rr['rgb_feature'].detach()), 'out/depth': _np(rr['depth'])}
+    for k, v in terms.items():
+        arrs['loss/' + k] = _np(v.detach())
+    for k, v in ck['model_state_dict'].items():
+        arrs['sd/' + k] = _np(v)
+    for k, v in zip(('rays_o', 'rays_d', 'viewdirs'), rays):
+        arrs['in/' + k] = _np(v)
+    ng = 0
+    for k, prm in model.named_parameters():
+        if prm.grad is not None:
+            arrs['grad/' + k] = _np(prm.grad)
+            ng += 1
+    names, stats = [], []
+    for k, prm in net.named_parameters():
+        names.append(k)
+        stats.append([float(prm.grad.double().sum()), float(prm.grad.double().norm())])
+    arrs['sr_names'], arrs['sr_stats'] = np.array(names), np.array(stats, dtype=np.float64)
+    for k in ('conv_first.weight', 'CondNet.0.weight', 'conv_last.bias'):
+        arrs['sr_grad/' + k] = _np(dict(net.named_parameters())[k].grad)
+    path = os.path.join(GOLDEN, 'grad_joint.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'grad_joint: {os.path.getsize(path) / 1024:.1f} KiB, total {float(total):.6f}', {k: float(v) for k, v in terms.items()},
+          f'{ng} marcher gradients, {len(names)} decoder gradients, samples {rr["weights"].numel()}')
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ref = ref_import.load_reference()
@@ -293,12 +374,18 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'grad_sr':
         gen_grad_sr(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'joint':
+        gen_patch(ref)
+        gen_grad_joint(ref)
+        return
     gen_rays(ref)
     gen_march(ref)
     gen_sr(ref)
     gen_grad(ref)
     gen_occ(ref)
     gen_grad_sr(ref)
+    gen_patch(ref)
+    gen_grad_joint(ref)
 
 
 if __name__ == '__main__':

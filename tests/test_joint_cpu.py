@@ -1,0 +1,161 @@
+"""CPU-side checks of the joint training step's host logic (4k-nerf_amd/joint_train.py, lib/dvgo.py patch sampler):
+  * the 'patch_mimg' ray sampler against draws of the REFERENCE's own generator (tests/golden/patch_sampler.npz,
+    oracle/gen_golden.py::gen_patch) under the same numpy seed;
+  * the sparse voxel-grid gradient exchange on world_size 2 and 3 (gloo): every rank ends with the mean of the ranks' dense
+    gradients, bit-identical across ranks, and only touched voxels travel;
+  * the oracle's literal O(n^2) distortion loss against the prefix-sum form the HIP kernel evaluates (both restated from the
+    published definition: torch_efficient_distloss itself is not available, see oracle/train_ops.py).
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd.lib import dvgo
+from helpers import GOLDEN
+
+
+def test_patch_sampler_matches_reference_draws():
+    z = np.load(os.path.join(GOLDEN, 'patch_sampler.npz'))
+    for tag in ('a', 'b', 'c'):
+        h, w, num_im, BS, szp, sr = (int(v) for v in z[tag + '/args'])
+        np.random.seed(1234)
+        gen = dvgo.mimg_patch_indices_generator(np.array([h, w]), num_im, BS, szp, sr)
+        for want in z[tag + '/draws']:
+            im, r, c, r4, c4, ps = next(gen)
+            r, c, r4, c4 = (np.asarray(v, dtype=np.int64) for v in (r, c, r4, c4))
+            chk = [int((v * (np.arange(v.size) % 97 + 1)).sum()) for v in (r, c, r4, c4)]
+            got = [int(im), ps[0], ps[1], r.size, r4.size] + chk + [int(r.min()) if r.size else -1, int(c.min()) if c.size else -1]
+            assert got == want.tolist(), (tag, got, want.tolist())
+            assert r.size == ps[0] * ps[1] and r4.size == sr * sr * r.size
+            if r.size:                                            # the HR patch is the LR patch scaled by sr
+                assert r4.min() == sr * r.min() and c4.min() == sr * c.min() and r4.max() == sr * r.max() + sr - 1
+
+
+def test_patch_table_covers_the_image_once():
+    tab = dvgo.patch_gen((756, 1008), 1, 4096, 64)
+    assert len(tab) == 11 * 15 + 11 + 16
+    seen = np.zeros([756, 1008], dtype=np.int32)
+    for p in tab:
+        seen[p[..., 0], p[..., 1]] += 1
+    assert (seen == 1).all()
+    assert tab[0].shape == (64, 64, 2) and tab[11 * 15].shape == (64, 48, 2) and tab[-1].shape == (52, 48, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+SHAPES = [(1, 9, 12, 11, 10), (1, 1, 12, 11, 10)]
+
+
+def _rank_grads(rank):
+    """Sparse gradients as a ray batch leaves them: a few touched voxels (all channels), overlapping between ranks."""
+    g = torch.Generator().manual_seed(7 + rank)
+    out = []
+    for shp in SHAPES:
+        C, V = shp[1], shp[2] * shp[3] * shp[4]
+        dense = torch.zeros([C, V])
+        idx = torch.randperm(V, generator=g)[:40 + 15 * rank]
+        idx = torch.cat([idx, torch.tensor([3, 4, 5])])              # voxels every rank touches
+        dense[:, idx] = torch.randn([C, idx.numel()], generator=g)
+        out.append(dense.reshape(shp))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from nerf4k_amd import joint_train
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in SHAPES]
+        grads = _rank_grads(rank)
+        params[0].grad = grads[0].clone()
+        if rank != 1:
+            params[1].grad = grads[1].clone()                        # rank 1 has no gradient for the second grid
+        stats = joint_train.sparse_grad_allreduce(params)
+        q.put((rank, [p.grad.numpy().copy() for p in params], stats['bytes_gathered'], stats['touched']))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, grads, nbytes, touched = q.get(timeout=240)
+        got[r] = (grads, nbytes, touched)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_sparse_grid_gradient_exchange_gloo():
+    for world in (2, 3):
+        got = _run(world)
+        want = [sum(_rank_grads(r)[0] for r in range(world)) / world,
+                sum(_rank_grads(r)[1] for r in range(world) if r != 1) / world]
+        dense_bytes = sum(int(np.prod(s)) for s in SHAPES) * 4 * world
+        for r in range(world):
+            for i in range(2):
+                assert np.array_equal(got[r][0][i], got[0][0][i]), (world, r, i)             # replicas identical
+                np.testing.assert_allclose(got[r][0][i], want[i].numpy(), rtol=0, atol=1e-6)        # (a/3 + b/3 + c/3) vs (a + b + c)/3 in fp32
+                # a voxel no rank touched stays exactly zero (MaskedAdam's skip test)
+                assert np.array_equal(got[r][0][i] != 0, want[i].numpy() != 0)
+            assert got[r][1] < 0.25 * dense_bytes                                            # only touched voxels travelled
+            counts = got[r][2][1][0]
+            assert counts[1] == 0                                                            # the rank without a gradient sent nothing
+
+
+def test_sparse_exchange_single_process_is_identity():
+    from nerf4k_amd import joint_train
+    p = torch.nn.Parameter(torch.zeros(SHAPES[0]))
+    p.grad = _rank_grads(0)[0].clone()
+    joint_train.sparse_grad_allreduce([p])
+    assert torch.equal(p.grad, _rank_grads(0)[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_distortion_loss_equals_prefix_sum_form():
+    from oracle import train_ops as oto
+    g = torch.Generator().manual_seed(2)
+    n_rays, per = 7, [0, 1, 5, 70, 3, 0, 130]
+    ray_id = torch.cat([torch.full([c], r, dtype=torch.long) for r, c in enumerate(per)])
+    w = torch.rand([ray_id.numel()], generator=g, dtype=torch.float64).requires_grad_(True)
+    s = torch.cat([torch.sort(torch.rand([c], generator=g, dtype=torch.float64)).values for c in per])
+    interval = 1 / 256
+    loss = oto.distortion_loss(w, s, interval, ray_id)
+    loss.backward()
+    # prefix-sum form (what csrc/k4_train.hip::k_distloss evaluates), numpy fp64
+    wn, sn = w.detach().numpy(), s.numpy()
+    tot, grad = 0.0, np.zeros_like(wn)
+    off = 0
+    for c in per:
+        wr, sr = wn[off:off + c], sn[off:off + c]
+        P, Q = np.cumsum(wr) - wr, np.cumsum(wr * sr) - wr * sr
+        S, R = wr.sum() - P - wr, (wr * sr).sum() - Q - wr * sr
+        tot += (interval / 3 * wr * wr + 2 * wr * (sr * P - Q)).sum()
+        grad[off:off + c] = 2 * (sr * (P - S) + (R - Q)) + 2 / 3 * interval * wr
+        off += c
+    n_norm = int(ray_id.max()) + 1
+    assert n_norm == 7
+    assert abs(float(loss) - tot / n_norm) < 1e-12
+    np.testing.assert_allclose(w.grad.numpy(), grad / n_norm, rtol=0, atol=1e-12)

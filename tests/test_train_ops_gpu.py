@@ -1,0 +1,187 @@
+"""GPU parity of the marcher's training-graph kernels (csrc/k4_train.hip, lib/train_ops.py) and of the joint training step
+(4k-nerf_amd/joint_train.py; SURVEY.md 3.4, 8f rank 1 "MLP bwd"):
+  * k4_rgbnet_fwd / k4_rgbnet_bwd against the oracle's fp64 autograd of the same nn.Sequential + sigmoid
+    (tolerance: fp32 FMA chains of <= 129 terms forward, sums over n samples in the weight gradients:
+     |err| <= 1e-5 * max|want| + 1e-7 per tensor), deterministic (two runs bit-equal), shapes incl. ragged tiles, n = 0 and 1;
+  * k4_distortion_loss against the oracle's literal O(n^2) definition incl. empty rays, single-sample rays and rays longer
+    than one 64-sample scan step (1e-5 relative);
+  * one joint iteration (DirectMPIGO train forward -> SFTNet -> 5 loss terms -> backward) against tests/golden/grad_joint.npz
+    = the same iteration on the REFERENCE's own modules (oracle/gen_golden.py::gen_grad_joint), then JointTrainer.step
+    (TV add-grad + MaskedAdam x 2 + lr decay) lowering the loss over a few iterations.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd import _native as N, joint_train
+from nerf4k_amd.lib import dmpigo, sr_esrnet, train_ops, utils
+from oracle import sr as osr, train_ops as oto
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, name, rel=1e-5, abs_=1e-7):
+    got, want = got.detach().cpu().double(), want.detach().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = float(want.abs().max()) if want.numel() else 0.0
+    err = float((got - want).abs().max()) if want.numel() else 0.0
+    assert err <= rel * scale + abs_, (name, err, scale)
+
+
+@pytest.mark.parametrize('dim0,width,depth,n,with_add', [(15, 64, 3, 1000, False), (39, 128, 3, 333, False), (39, 128, 2, 200, True),
+                                                         (7, 32, 3, 64, True), (64, 32, 2, 1, False), (27, 64, 2, 129, False),
+                                                         (15, 64, 3, 0, False), (33, 128, 3, 70000, True)])
+def test_rgbnet_kernels_match_fp64_autograd(dim0, width, depth, n, with_add):
+    g = torch.Generator().manual_seed(dim0 * 1000 + width + depth)
+    net = dmpigo._mlp(dim0, width, depth, 3)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(p.shape[-1], 1) ** 0.5 if p.dim() == 2 else 0.1))
+    assert train_ops.rgbnet_supported(net)
+    x = torch.randn([n, dim0], generator=g)
+    add = torch.randn([n, 3], generator=g) * 0.3 if with_add else None
+    gy = torch.randn([n, 3], generator=g)
+    # oracle, fp64
+    lins = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+    wr = [(l.weight.detach().double().requires_grad_(True), l.bias.detach().double().requires_grad_(True)) for l in lins]
+    xr = x.double().requires_grad_(True)
+    ar = None if add is None else add.double().requires_grad_(True)
+    yr = oto.rgbnet_sigmoid(xr, wr, ar)
+    yr.backward(gy.double())
+    # HIP
+    net = net.cuda()
+    xd = x.cuda().requires_grad_(True)
+    ad = None if add is None else add.cuda().requires_grad_(True)
+    y = train_ops.rgbnet_sigmoid(net, xd, ad)
+    _close(y, yr, 'rgb', rel=2e-6, abs_=2e-7)
+    y.backward(gy.cuda())
+    _close(xd.grad, xr.grad, 'grad_x')
+    if ad is not None:
+        _close(ad.grad, ar.grad, 'grad_add')
+    lins_d = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+    for i, (l, (w, b)) in enumerate(zip(lins_d, wr)):
+        _close(l.weight.grad, w.grad, f'grad_w{i}')
+        _close(l.bias.grad, b.grad, f'grad_b{i}')
+    if n > 0:                                                        # no atomics: a second evaluation is bit-identical
+        first = [p.grad.clone() for p in net.parameters()] + [xd.grad.clone()]
+        net.zero_grad(set_to_none=True)
+        xd.grad = None
+        train_ops.rgbnet_sigmoid(net, xd, ad).backward(gy.cuda())
+        for a, b in zip(first, [p.grad for p in net.parameters()] + [xd.grad]):
+            assert torch.equal(a, b)
+    # inference form (no activations saved) gives the same values
+    with torch.no_grad():
+        assert torch.equal(train_ops.rgbnet_sigmoid(net, xd.detach(), None if ad is None else ad.detach()), y.detach())
+
+
+def test_rgbnet_unsupported_shapes_are_reported():
+    assert not train_ops.rgbnet_supported(dmpigo._mlp(15, 64, 4, 3))          # two hidden->hidden layers
+    assert not train_ops.rgbnet_supported(dmpigo._mlp(70, 64, 3, 3))          # dim0 > 64
+    assert not train_ops.rgbnet_supported(dmpigo._mlp(15, 48, 3, 3))          # width
+    L = N.lib()
+    assert L.k4_rgbnet_bwd_workspace_bytes(100, 15, 48, 1) < 0
+    x = torch.zeros([4, 15], device='cuda')
+    assert L.k4_rgbnet_fwd(N.f32(x), 4, 15, 48, 1, N.f32(x), N.f32(x), N.f32(x), N.f32(x), N.f32(x), N.f32(x), None, None, None, N.f32(x),
+                           N.stream()) == N.K4_ERR_UNSUPPORTED
+    with pytest.raises(N.K4Error):
+        train_ops.rgbnet_sigmoid(dmpigo._mlp(15, 64, 3, 3), torch.zeros([4, 15]))
+
+
+def test_distortion_loss_matches_the_definition():
+    g = torch.Generator().manual_seed(4)
+    per = [0, 1, 5, 70, 3, 0, 130, 64, 65, 0]                         # empty rays, one sample, > one scan step, exact multiples
+    ray_id = torch.cat([torch.full([c], r, dtype=torch.long) for r, c in enumerate(per)])
+    w = torch.rand([ray_id.numel()], generator=g) * 0.2
+    s = torch.cat([torch.sort(torch.rand([c], generator=g)).values for c in per])
+    interval = 1 / 256
+    wr = w.double().requires_grad_(True)
+    want = oto.distortion_loss(wr, s.double(), interval, ray_id)
+    want.backward()
+    wd = w.cuda().requires_grad_(True)
+    got = train_ops.flatten_eff_distloss(wd, s.cuda(), interval, ray_id.cuda())
+    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want)), (float(got), float(want))
+    (got * 3.0).backward()
+    _close(wd.grad, wr.grad * 3.0, 'grad_w', rel=1e-5, abs_=1e-7)
+    # the last ray being empty does not change the normaliser (ray_id.max() + 1 = 9 here, as the package computes it)
+    assert int(ray_id.max()) + 1 == 9
+    # no samples at all
+    e = train_ops.flatten_eff_distloss(torch.zeros([0], device='cuda', requires_grad=True), torch.zeros([0], device='cuda'), interval,
+                                       torch.zeros([0], dtype=torch.long, device='cuda'))
+    assert float(e) == 0.0
+
+
+def _load_joint():
+    z = np.load(os.path.join(GOLDEN, 'grad_joint.npz'), allow_pickle=False)
+    kw = json.loads(str(z['model_kwargs_json']))
+    for k in ('xyz_min', 'xyz_max'):
+        kw[k] = np.asarray(kw[k], dtype=np.float32)
+    ck = {'model_class': str(z['model_class']), 'model_kwargs': kw,
+          'model_state_dict': {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}}
+    model = utils.model_from_checkpoint_dict(ck).cuda().train()
+    nb = int(z['num_block'])
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=nb, num_grow_ch=32, num_cond=1)
+    net.load_state_dict(osr.make_state_dict(seed=int(z['sr_seed']), num_block=nb))
+    net = net.cuda().train()
+    rk = json.loads(str(z['render_kwargs_json']))
+    cfg = joint_train.JointCfg.fern_lg_joint_l1(**json.loads(str(z['cfg_json'])))
+    batch = [torch.from_numpy(z['in/' + k]).cuda() for k in ('rays_o', 'rays_d', 'viewdirs')] + \
+            [torch.from_numpy(z['target']).cuda(), torch.from_numpy(z['target_4x']).cuda(), int(z['patch'][0]), int(z['patch'][1])]
+    return z, model, net, rk, cfg, batch
+
+
+def test_joint_iteration_matches_the_reference_modules():
+    z, model, net, rk, cfg, batch = _load_joint()
+    tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+    with torch.enable_grad():
+        rr, rgb_sr, ls = tr.forward(*batch, global_step=int(z['global_step']))
+        ls['total'].backward()
+    _close(rr['rgb_feature'], torch.from_numpy(z['out/rgb_feature']), 'rgb_feature', rel=2e-6, abs_=2e-7)
+    _close(rr['depth'], torch.from_numpy(z['out/depth']), 'depth', rel=2e-6, abs_=2e-7)
+    _close(rgb_sr, torch.from_numpy(z['out/rgb_sr']), 'rgb_sr', rel=2e-5)
+    for k in ('photo', 'l1', 'entropy_last', 'distortion', 'rgbper', 'total'):
+        want = float(z['loss/' + k])
+        assert abs(float(ls[k]) - want) <= 1e-5 * max(abs(want), 1e-4), (k, float(ls[k]), want)
+    named = dict(model.named_parameters())
+    n_checked = 0
+    for k in z.files:
+        if k.startswith('grad/'):
+            assert named[k[5:]].grad is not None, k
+            _close(named[k[5:]].grad, torch.from_numpy(z[k]), k, rel=5e-5, abs_=1e-9)
+            n_checked += 1
+    assert n_checked >= 6
+    sr_named = dict(net.named_parameters())
+    for k in z.files:
+        if k.startswith('sr_grad/'):
+            _close(sr_named[k[8:]].grad, torch.from_numpy(z[k]), k, rel=5e-5, abs_=1e-9)
+    stats = z['sr_stats']
+    gsum = np.array([float(sr_named[str(nm)].grad.double().sum()) for nm in z['sr_names']])
+    gnorm = np.array([float(sr_named[str(nm)].grad.double().norm()) for nm in z['sr_names']])
+    assert np.abs(gnorm - stats[:, 1]).max() <= 1e-4 * stats[:, 1].max()
+    assert np.abs(gsum - stats[:, 0]).max() <= 1e-4 * np.abs(stats[:, 0]).max() + 1e-7
+
+
+def test_joint_trainer_steps_lower_the_loss():
+    z, model, net, rk, cfg, batch = _load_joint()
+    cfg = joint_train.JointCfg(dict(cfg, tv_before=100, tv_dense_before=2))
+    tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+    lr0 = [pg['lr'] for pg in tr.optimizer.param_groups]
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    hist = [float(tr.step(*batch, global_step=1 + i)['total']) for i in range(8)]
+    assert hist[-1] < hist[0], hist
+    assert all(np.isfinite(hist))
+    changed = [k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert 'density.grid' in changed and 'k0.grid' in changed and any(k.startswith('rgbnet') for k in changed)
+    factor = 0.1 ** (1 / (cfg.lrate_decay * 1000))
+    for a, pg in zip(lr0, tr.optimizer.param_groups):
+        assert abs(pg['lr'] - a * factor ** 8) <= 1e-12 * a
+    assert tr.last_exchange == {'world': 1}
+    # the render path after training steps sees the updated parameters (repack caches re-key on the bumped versions)
+    with torch.no_grad():
+        a = model(*batch[:3], **{k: v for k, v in rk.items() if k != 'rand_bkgd'})
+        b = model(*batch[:3], k4_staged=True, **{k: v for k, v in rk.items() if k != 'rand_bkgd'})
+    assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)
