@@ -637,8 +637,12 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 // leaves the registers -- y = v*(scale(cond)+1) + shift(cond), the two 1x1-conv pairs of the condition map evaluated per output row
 // on the matrix cores exactly as k4_sft_b6_kernel does (same operands, same product order: bit-identical to the separate launch).
 // The decoder's 36 SFT launches per frame were 12 % of its time for 6 % of its FLOPs: each re-read and re-wrote a whole feature map.
-template <bool PERSIST, int RPW, bool SFT = false>
+// NTERM = 2 (flag K4_ARITH_2TERM, the decoder's opt-in 'bf16x3' arithmetic): only the two leading split terms of both operands are
+// staged / loaded and 3 of the 6 products are formed (a1 b0 + a0 b1 + a0 b0, ~2^-16 relative per product) -- half the matrix
+// instructions, a third less LDS and register traffic, same packed weights (their third term is simply not read).
+template <bool PERSIST, int RPW, bool SFT = false, int NTERM = 3>
 __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M) {
+    static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;
     constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     constexpr int NPIX = ROWS * COLS;                         // haloed input tile
     constexpr int IN_PER = (NPIX * 4 + THREADS - 1) / THREADS;   // staged items per thread: (pixel, QUARTER of the 16-channel chunk)
     constexpr int IN_PLANE = 2 * NPIX;                        // uint4 per term
-    __shared__ uint4 in_s[3 * IN_PLANE];                      // [term][channel group][row][col] x 8 bf16
+    __shared__ uint4 in_s[NTERM * IN_PLANE];                  // [term][channel group][row][col] x 8 bf16
     __shared__ int ticket_sh;
     const ConvParams& P = M.base;                             // shared by every window: cin, strides, weights, bias, cout, flags ...
     const int nb_count = (P.cout + 31) >> 5;
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     const uint4* wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 + l31;
 #define K4_V2_LOADB(DST, CH, TAP) do { \
         const uint4* wp_ = wlane + (size_t)(CH) * W_ITEMS; \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) DST[q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT]; } while (0)
+        _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT]; } while (0)
     K4_V2_LOADB(bbuf[0], 0, 0);
     if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
 
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
     const uint4* const arow = in_s + (half * ROWS + wv * RPW) * COLS + l31;   // A fragment of (term q, input row i, dx): arow[q*IN_PLANE + i*COLS + dx]
 #define K4_V2_READA(DST, U) do { \
         const int t_ = (U) / RPW, r_ = (U) % RPW; \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
+        _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
 
     bool first = true;
     for (;;) {                                                               // tiles
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
 #endif
             {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bbuf[0][q] = bbuf[1][q];
+                for (int q = 0; q < NTERM; ++q) bbuf[0][q] = bbuf[1][q];
             }
             first = false;
             // ---- split + store this chunk's haloed input tile ----
@@ -769,7 +773,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                 k4s_split3x4(rv[i], t0, t1, t2);
                 if (sp0 + 64 * i < NPIX) {           // 8-byte unit of (term, channel group kg = q>>1, pixel, q&1); i*128 is a constant offset
                     uint2* const d = in2 + sdst + i * 128;
-                    d[0] = t0; d[2 * IN_PLANE] = t1; d[4 * IN_PLANE] = t2;
+                    d[0] = t0; d[2 * IN_PLANE] = t1;
+                    if (NTERM == 3) d[4 * IN_PLANE] = t2;
                 }
             }
             __syncthreads();
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                     else {
                         const uint4* wp_ = wnext + (size_t)chn * W_ITEMS;
 #pragma unroll
-                        for (int q_ = 0; q_ < 3; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
+                        for (int q_ = 0; q_ < NTERM; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
                     }
                 }
 #ifdef K4_V2_LATEPF       /* timing experiment only: the activation prefetch issued after the chunk's last weight load */
@@ -820,23 +825,25 @@ __global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M)
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
-                                 a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][2]);
+                                 a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][NTERM - 1]);
 #ifdef K4_V2_WONCE
 #define K4_BSLOT 0
 #else
 #define K4_BSLOT (t % K4_V2_BRING)
 #endif
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][1]),
-                                 b2 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][2]);
+                                 b2 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][NTERM - 1]);
 #undef K4_BSLOT
 #ifdef K4_V2_DEPTEST      /* timing experiment only (WRONG results): consecutive MFMAs on different accumulators */
 #define K4_ACC(k) acc[(r + (k)) % RPW]
 #else
 #define K4_ACC(k) acc[r]
 #endif
-                    K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, K4_ACC(0), 0, 0, 0);
-                    K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, K4_ACC(1), 0, 0, 0);
-                    K4_ACC(2) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, K4_ACC(2), 0, 0, 0);
+                    if (NTERM == 3) {
+                        K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, K4_ACC(0), 0, 0, 0);
+                        K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, K4_ACC(1), 0, 0, 0);
+                        K4_ACC(2) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, K4_ACC(2), 0, 0, 0);
+                    }
                     K4_ACC(3) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, K4_ACC(3), 0, 0, 0);
                     K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, K4_ACC(0), 0, 0, 0);
                     K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, K4_ACC(1), 0, 0, 0);
@@ -1023,6 +1030,12 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2, true>), dim3((unsigned)total), dim3(256), 0, st, M);
         else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3, true>), dim3((unsigned)total), dim3(256), 0, st, M);
         else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4, true>), dim3((unsigned)total), dim3(256), 0, st, M);
+        return k4_check_launch();
+    }
+    if (M.base.flags & K4_ARITH_2TERM) {
+        if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
+        else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
+        else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
         return k4_check_launch();
     }
     if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
@@ -1236,8 +1249,11 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
         if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
         return launch_conv_taps_b6(M, st);
     }
-    if (sft) return launch_conv_b6v2(M, st);
-    if (ksize == 3 && !modulate && (nt > 2 || k4_env().sr_variant == 0)) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel (<= 64 channels)
+    if (sft) {
+        if (flags & K4_ARITH_2TERM) return K4_ERR_BAD_ARG;
+        return launch_conv_b6v2(M, st);
+    }
+    if (ksize == 3 && !modulate && (nt > 2 || k4_env().sr_variant == 0 || (flags & K4_ARITH_2TERM))) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel (<= 64 channels)
     const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
     if (ksize == 3) {
         if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(M, st) : launch_conv_b6<3, 1, 8>(M, st);

@@ -365,9 +365,9 @@ extern "C" int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_
                              float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
                              float* workspace, int64_t workspace_bytes, void* stream) {
     if (!tr_shape_ok(dim0, width, n_hidden)) return K4_ERR_UNSUPPORTED;
-    if (n_pts < 0 || !w1 || !w3 || !gw1 || !gb1 || !gw3 || !gb3 || (n_hidden && (!w2 || !gw2 || !gb2 || !h2))) return K4_ERR_BAD_ARG;
+    if (n_pts < 0 || !w1 || !w3 || !gw1 || !gb1 || !gw3 || !gb3 || (n_hidden && (!w2 || !gw2 || !gb2))) return K4_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < k4_rgbnet_bwd_workspace_bytes(n_pts, dim0, width, n_hidden)) return K4_ERR_BAD_ARG;
-    if (n_pts > 0 && (!x || !h1 || !rgb || !grad_rgb)) return K4_ERR_BAD_ARG;
+    if (n_pts > 0 && (!x || !h1 || !rgb || !grad_rgb || (n_hidden && !h2))) return K4_ERR_BAD_ARG;      // n_pts == 0: the gradients are zeros
     hipStream_t st = (hipStream_t)stream;
     switch (width) {          // MAXB = ceil(blocks / 256) at dim0 = TR_MAX_DIM0: 32 -> 226, 64 -> 561, 128 -> 1633 blocks
         case 32: return tr_launch_bwd<32, 1>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);

@@ -28,7 +28,7 @@ from torch.nn import init as init
 
 from .. import _native as N
 
-EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT = 2, 4, 8, 16, 32
+EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM = 2, 4, 8, 16, 32, 64
 
 
 @torch.no_grad()
@@ -117,8 +117,14 @@ class _Packed:
         nt = (cout + 31) // 32
         dev = weight.device
         wf = weight.detach().float()
-        self.mode = 'bf16x6' if mode == 'bf16x6_plain' else mode
         self.flags_extra = 0
+        if mode == 'bf16x3':
+            # the opt-in 2-term arithmetic runs on the DEFAULT kernels: same packed weights as 'bf16x6', plain 3x3 layers form only the
+            # three leading products (K4_ARITH_2TERM); 1x1 layers and conv_last keep all six.  'bf16x3_v1' = the round-1 kernel + packing.
+            mode = 'bf16x6'
+            if k == 3 and cout > 3:
+                self.flags_extra = ARITH_2TERM
+        self.mode = {'bf16x6_plain': 'bf16x6', 'bf16x3_v1': 'bf16x3'}.get(mode, mode)
         if mode == 'fp32':
             kc = 8
             nch = (cin + kc - 1) // kc
@@ -132,7 +138,7 @@ class _Packed:
             w1 = wf.permute(2, 3, 0, 1).reshape(9 * cout, cin, 1, 1)             # [(dy,dx,co)][cin]
             inner = _Packed(w1, torch.zeros([9 * cout], dtype=torch.float32, device=dev), 'bf16x6_plain')
             self.w = inner.w
-            self.flags_extra = W_TAPS_AS_COUT
+            self.flags_extra |= W_TAPS_AS_COUT
         elif mode in ('bf16x6', 'bf16x6_plain'):
             nch = (cin + 15) // 16
             w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)

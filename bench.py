@@ -493,12 +493,14 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4):
     total-variation add-grad on both grids, MaskedAdam on the marcher and on the decoder.  Synthetic targets."""
     from nerf4k_amd import joint_train
     from nerf4k_amd.lib import sr_esrnet, utils
+    import contextlib
     model = utils.model_from_checkpoint_dict(ck).to(dev).train()
     torch.manual_seed(778)
     net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).train()
     cfg = joint_train.JointCfg.fern_lg_joint_l1()
     rk = dict(ck['render_kwargs'], render_depth=True, rand_bkgd=True)
-    tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+    with contextlib.redirect_stdout(sys.stderr):              # create_optimizer_or_freeze_model prints like upstream; stdout carries the JSON line only
+        tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
     pr = pc = cfg.N_rand // cfg.N_patch
     gen = torch.Generator(device=dev).manual_seed(5)
     ro, rd, vd = (x.reshape(H, W, 3) for x in frame_rays)

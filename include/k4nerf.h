@@ -238,6 +238,9 @@ int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, fl
 #define K4_W_TAPS_AS_COUT 32u    /* k4_conv2d_nhwc_bf16x6 only, 3x3 with cout <= 3: w_split holds the 1x1 layer [9*cout -> 32][cin]
                                     (n = tap*cout + co) in the bf16x6 layout; the kernel sums the 9 taps from LDS        */
 #define K4_PRE_UPSAMPLE2X 16u    /* the input is read through a nearest x2 upsample (lib/sr_esrnet.py:461-463)  */
+#define K4_ARITH_2TERM    64u    /* k4_conv2d_nhwc_bf16x6(_multi), plain 3x3 layers: use the two leading split terms of both operands only -- 3 of the
+                                    6 products (a1 b0 + a0 b1 + a0 b0), ~2^-16 relative per product: the decoder's opt-in 'bf16x3' arithmetic on the
+                                    default kernel (1x1 layers, K4_W_TAPS_AS_COUT and the fused-SFT entry ignore / reject it) */
 
 /* stride-1 "same" (zero padded) 3x3 or 1x1 convolution, NHWC:
  *   x        : [H_in][W_in][cin_stride], channels [0,cin) are read (pre-offset the pointer for a slice);

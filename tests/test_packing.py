@@ -95,7 +95,7 @@ def test_pack_mlp_sections_reproduce_the_weights(dim0, W, depth):
 
 
 @pytest.mark.parametrize('cout,cin,k', [(32, 160, 3), (64, 192, 3), (64, 3, 3), (3, 64, 3), (128, 64, 1), (64, 1, 3)])
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3_v1', 'bf16x6', 'bf16x3'])
 def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
     g = torch.Generator().manual_seed(cout * 7 + cin)
     w = torch.randn([cout, cin, k, k], generator=g)
@@ -103,6 +103,13 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
     pk = _Packed(w, b, mode)
     nt = (cout + 31) // 32
     assert torch.equal(pk.b[:cout], b) and float(pk.b[cout:].abs().sum()) == 0
+    if mode == 'bf16x3':
+        # the opt-in 2-term arithmetic = the default packing + K4_ARITH_2TERM on plain 3x3 layers (the kernel skips the third term)
+        from nerf4k_amd.lib.sr_esrnet import ARITH_2TERM
+        ref = _Packed(w, b, 'bf16x6')
+        assert pk.mode == 'bf16x6' and torch.equal(pk.w, ref.w)
+        assert pk.flags_extra == (ref.flags_extra | (ARITH_2TERM if (k == 3 and cout > 3) else 0))
+        return
     if mode == 'bf16x6' and k == 3 and cout <= 3:
         # few output channels: taps become the N dimension of a 1x1 layer, n = tap*cout + co (K4_W_TAPS_AS_COUT)
         from nerf4k_amd.lib.sr_esrnet import W_TAPS_AS_COUT
@@ -120,12 +127,13 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
         got = pk.w.reshape(nch, k * k, 8, nt * 32).permute(1, 0, 2, 3).reshape(k * k, nch * 8, nt * 32)
     else:
         nterm = 3 if mode == 'bf16x6' else 2
+        assert pk.mode == ('bf16x6' if mode == 'bf16x6' else 'bf16x3')
         nch = (cin + 15) // 16
         terms = pk.w.view(torch.bfloat16).reshape(nch, nterm, k * k, 2, nt * 32, 8).float()
         got = terms.sum(1).permute(1, 0, 2, 4, 3).reshape(k * k, nch * 16, nt * 32)         # [tap][channel][cout]
     want = torch.zeros_like(got)
     want[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
-    if mode == 'bf16x3':                                  # 2-term split: 16 significant bits
+    if mode == 'bf16x3_v1':                               # 2-term split: 16 significant bits
         assert float((got - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
     else:
         assert torch.equal(got, want)

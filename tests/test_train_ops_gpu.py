@@ -48,6 +48,16 @@ def test_rgbnet_kernels_match_fp64_autograd(dim0, width, depth, n, with_add):
     gy = torch.randn([n, 3], generator=g)
     # oracle, fp64
     lins = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+    # A hidden unit whose pre-activation is within rounding of 0 gets its ReLU gate from the ROUNDING (fp32 chain vs fp64): such samples
+    # (a few per 10^5 x 256 units) are given a zero output gradient on both sides -- the comparison is about arithmetic, not about ties.
+    with torch.no_grad():
+        h, amb = x.double(), torch.zeros([n], dtype=torch.bool)
+        for l in lins[:-1]:
+            z = torch.nn.functional.linear(h, l.weight.double(), l.bias.double())
+            amb |= (z.abs() < 1e-5).any(1)
+            h = torch.relu(z)
+        gy[amb] = 0
+        assert int(amb.sum()) <= max(2, n // 20)
     wr = [(l.weight.detach().double().requires_grad_(True), l.bias.detach().double().requires_grad_(True)) for l in lins]
     xr = x.double().requires_grad_(True)
     ar = None if add is None else add.double().requires_grad_(True)
