@@ -11,7 +11,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'lib4k_hip.so')
+LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
 K4_ABI_VERSION = 4
 K4_ERR_UNSUPPORTED = 10002
 

@@ -640,8 +640,11 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 // NTERM = 2 (flag K4_ARITH_2TERM, the decoder's opt-in 'bf16x3' arithmetic): only the two leading split terms of both operands are
 // staged / loaded and 3 of the 6 products are formed (a1 b0 + a0 b1 + a0 b0, ~2^-16 relative per product) -- half the matrix
 // instructions, a third less LDS and register traffic, same packed weights (their third term is simply not read).
+#ifndef K4_V2_MINWG_2T
+#define K4_V2_MINWG_2T 2   // workgroups per CU the 2-term instantiation's register allocation is bounded for (39 KB of LDS would allow 3-4)
+#endif
 template <bool PERSIST, int RPW, bool SFT = false, int NTERM = 3>
-__global__ __launch_bounds__(256, 2) void k4_conv_b6v2_kernel(const ConvMulti M) {
+__global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
     static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;

@@ -257,11 +257,13 @@ def main():
             res['frames_sharded' if by_rows else 'rows_sharded'] = secondary
     four_k = four_k_fp32 = four_k_fast = None
     if args.sr_frames > 0 and not args.small:
+        keep = {}
         four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x6',
-                               check=not args.no_cpu_baseline)
+                               check=not args.no_cpu_baseline, keep=keep)
         if not args.no_extras:
             four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32')
-            four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3')
+            four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3', keep=keep)
+        keep.clear()
     if rank == 0:
         if four_k is not None:
             res['four_k'] = four_k
@@ -288,7 +290,7 @@ def _cpu_threads():
     return cores, used
 
 
-def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mode='bf16x6', check=False):
+def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mode='bf16x6', check=False, keep=None):
     """BASELINE configs[2] (N=1) / configs[3] (N>1): LLFF 4K render_test = march 1008x756 + SFTNet x4 to 4032x3024,
     reference tile geometry (test_tile=510, tile_pad=10; 252 / 189 when 4 / 8 ranks need tiles), tiles sharded over
     the ranks, ONE all-gather of the final HR pixels per frame.  SFTNet weights: seeded default init."""
@@ -324,8 +326,17 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
     tflops = flop_per_px * px / dt / 1e12
     base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'n_gpus': world, 'test_tile': tile,
             'effective_tflops': round(tflops, 2)}
+    if keep is not None and mode == 'bf16x6':
+        keep['hr'] = hr.clone()                    # the default arithmetic's frame: the 2-term mode is compared with it below
     if mode == 'bf16x3':
-        base['arithmetic'] = 'SR convs: 2-term bf16 splits, 3 MFMA products (opt-in K4_SR_MODE=bf16x3, >= 75 dB vs the fp32 oracle)'
+        base['arithmetic'] = ('SR 3x3 convs: the two leading bf16 split terms, 3 of the 6 MFMA products on the default kernel (opt-in '
+                              'K4_SR_MODE=bf16x3, K4_ARITH_2TERM; >= 75 dB vs the fp32 oracle in tests/test_sr_gpu.py)')
+        base['frac_of_bf16x3_floor'] = round(tflops / (2500.0 / 3 * world), 4)
+        if keep is not None and 'hr' in keep:      # same pose, same weights: the whole 4032x3024 frame against the default arithmetic's
+            d = (hr.double() - keep['hr'].double())
+            mse = float((d ** 2).mean())
+            base['psnr_vs_bf16x6_frame_db'] = round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1)
+            base['max_abs_vs_bf16x6_frame'] = float(d.abs().max())
         return base
     if mode == 'fp32':
         base['arithmetic'] = 'SR convs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains; K4_SR_MODE=fp32)'
