@@ -33,3 +33,15 @@ done
 python $R/tools/pmc_summary.py $R/gpurun_out/pmc_srf_* > $O/sr_pmc.md
 rm -rf $R/gpurun_out/pmc_srf_[0-9] $R/gpurun_out/pmc_srf_*.log
 ls -la $O
+# the opt-in 2-term arithmetic on the default kernel, and the marcher training iteration
+cd /tmp
+rm -rf $R/gpurun_out/prof_tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_tmp -o run -- python $R/tools/sr_frame_time.py bf16x3 > $O/sr2_stats.log 2>&1
+f=$(find $R/gpurun_out/prof_tmp -name "*kernel_stats.csv" | head -1); head -12 "$f" > $O/sr_bf16x3_kernel_stats.csv
+grep "ms/frame" $O/sr2_stats.log > $O/sr_bf16x3_line.txt
+rm -rf $R/gpurun_out/prof_tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_tmp -o run -- python $R/tools/train_step_time.py > $O/train_stats.log 2>&1
+f=$(find $R/gpurun_out/prof_tmp -name "*kernel_stats.csv" | head -1); head -30 "$f" > $O/train_kernel_stats.csv
+tail -1 $O/train_stats.log > $O/train_line.txt
+rm -rf $R/gpurun_out/prof_tmp
+ls -la $O
