@@ -103,6 +103,75 @@ extern "C" int k4_adam_upd_with_perlr(float* param, const float* grad, float* ex
                                          (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------------------------------------ many small tensors, one launch
+// The decoder has 458 parameter tensors (3.96 M floats, 15.8 MB): one k4_adam_upd per tensor is 458 launches of a few microseconds each
+// per optimizer step -- launch-bound on the host.  k4_adam_upd_multi walks up to K4_ADAM_MULTI_MAX tensors per launch: the job table
+// travels as a kernel argument, a workgroup owns K4_ADAM_MULTI_CHUNK consecutive elements of one tensor (found by a scan of the block
+// prefix table), same arithmetic per element as the single-tensor kernels.
+struct K4AdamMultiArgs {
+    float* param[K4_ADAM_MULTI_MAX];
+    const float* grad[K4_ADAM_MULTI_MAX];
+    float* exp_avg[K4_ADAM_MULTI_MAX];
+    float* exp_avg_sq[K4_ADAM_MULTI_MAX];
+    int64_t n[K4_ADAM_MULTI_MAX];
+    int32_t blk_end[K4_ADAM_MULTI_MAX];       // exclusive prefix end of each job's workgroups
+    int32_t n_jobs;
+};
+#define K4_ADAM_MULTI_CHUNK 1024
+
+template <int MODE>
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_multi_kernel(const K4AdamMultiArgs A, float step_size, float beta1, float beta2, float eps) {
+    int j = 0;
+    const int b = (int)blockIdx.x;
+    while (j + 1 < A.n_jobs && b >= A.blk_end[j]) ++j;
+    const int64_t base = (int64_t)(b - (j ? A.blk_end[j - 1] : 0)) * K4_ADAM_MULTI_CHUNK;
+    float* const param = A.param[j];
+    const float* const grad = A.grad[j];
+    float* const em = A.exp_avg[j];
+    float* const ev = A.exp_avg_sq[j];
+    const int64_t n = A.n[j];
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+#pragma unroll
+    for (int u = 0; u < K4_ADAM_MULTI_CHUNK / K4_OPT_THREADS; ++u) {
+        const int64_t i = base + u * K4_OPT_THREADS + threadIdx.x;
+        if (i >= n) break;
+        const float g = grad[i];
+        if (MODE == K4_ADAM_MASKED && g == 0.f) continue;
+        float p = param[i], m = em[i], v = ev[i];
+        k4_adam_one(p, g, m, v, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        param[i] = p; em[i] = m; ev[i] = v;
+    }
+}
+
+extern "C" int k4_adam_upd_multi(const k4_adam_job* jobs, int32_t n_jobs, int32_t masked, int32_t step, float beta1, float beta2, float lr,
+                                 float eps, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs) || step < 1) return K4_ERR_BAD_ARG;
+    const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));      // adam_upd_kernel.cu:71
+    for (int first = 0; first < n_jobs;) {
+        K4AdamMultiArgs A{};
+        int k = 0, blocks = 0;
+        for (; first < n_jobs && k < K4_ADAM_MULTI_MAX; ++first) {
+            const k4_adam_job& J = jobs[first];
+            if (J.n < 0) return K4_ERR_BAD_ARG;
+            if (J.n == 0) continue;
+            if (!J.param || !J.grad || !J.exp_avg || !J.exp_avg_sq) return K4_ERR_BAD_ARG;
+            const int64_t nb = (J.n + K4_ADAM_MULTI_CHUNK - 1) / K4_ADAM_MULTI_CHUNK;
+            if (nb + blocks > 0x3fffffffLL) return K4_ERR_BAD_ARG;
+            A.param[k] = J.param; A.grad[k] = J.grad; A.exp_avg[k] = J.exp_avg; A.exp_avg_sq[k] = J.exp_avg_sq; A.n[k] = J.n;
+            blocks += (int)nb;
+            A.blk_end[k] = blocks;
+            ++k;
+        }
+        if (k == 0) continue;
+        A.n_jobs = k;
+        if (masked) hipLaunchKernelGGL(k4_adam_multi_kernel<K4_ADAM_MASKED>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, (hipStream_t)stream, A, step_size, beta1, beta2, eps);
+        else hipLaunchKernelGGL(k4_adam_multi_kernel<K4_ADAM_PLAIN>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, (hipStream_t)stream, A, step_size, beta1, beta2, eps);
+        const int rc = k4_check_launch();
+        if (rc) return rc;
+    }
+    return K4_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ total variation
 __device__ __forceinline__ float k4_clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 

@@ -10,7 +10,7 @@
 //          pixels of a row for one input channel (lanes = channels: 128-byte coalesced reads per pixel), B fragment = the same 8
 //          pixels of dY for one output channel.  The image is cut in bands of K4_WG_BAND rows (split-K): one workgroup per
 //          (tap, ci block, co block, band), its 4 waves take rows round-robin, are reduced through LDS and added to dW with fp32
-//          atomics (dW must be zero-initialised by the caller; <= H/K4_WG_BAND addends per element).
+//          atomics (the entry point zeroes dW first; <= H/K4_WG_BAND addends per element).
 //   dbias  = sum_p dY[p][co]: k4_conv2d_bias_grad (one workgroup per 32 channels, wave shuffles + LDS).
 #include "k4_common.h"
 
@@ -102,21 +102,32 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
     }
 }
 
-// dbias[co] = sum over pixels of gy[p][co]: one workgroup per 32 channels, lanes = channel x 8 pixel phases
+// dbias[co] = sum over pixels of gy[p][co].  Workgroup = 32 channels x a slab of K4_BG_SLAB pixels; lanes = channel x 8 pixel phases, 8
+// independent loads in flight per thread; the slab sums are added to the zeroed dbias with one fp32 atomic per channel and workgroup
+// (like wgrad's split-K).  The first form -- ONE workgroup per 32 channels walking the whole image with a dependent add per load -- took
+// 120 us per layer on the 64x64 training patch and was HALF of the joint iteration's GPU time (229 layers, profiles/r02_final_tree.md).
+#define K4_BG_SLAB 512
 __global__ __launch_bounds__(256) void k4_bias_grad_kernel(const float* __restrict__ gy, int cout, int gy_stride, int64_t n_pix, float* __restrict__ db) {
     __shared__ float part[8][32];
-    const int c = (int)blockIdx.x * 32 + (int)(threadIdx.x & 31);
+    const int cb = (int)blockIdx.x, c = cb * 32 + (int)(threadIdx.x & 31);
     const int ph = (int)(threadIdx.x >> 5);                              // 0..7
-    float s = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.y * K4_BG_SLAB, p1 = (p0 + K4_BG_SLAB < n_pix) ? p0 + K4_BG_SLAB : n_pix;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (c < cout)
-        for (int64_t p = ph; p < n_pix; p += 8) s += gy[p * gy_stride + c];
-    part[ph][threadIdx.x & 31] = s;
+        for (int64_t p = p0 + ph; p < p1; p += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t q = p + 8 * u;
+                if (q < p1) s[u] += gy[q * gy_stride + c];
+            }
+        }
+    part[ph][threadIdx.x & 31] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (ph == 0 && c < cout) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += part[q][threadIdx.x & 31];
-        db[c] = t;
+        unsafeAtomicAdd(db + c, t);
     }
 }
 
@@ -129,12 +140,74 @@ extern "C" int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_str
     P.ks = ksize; P.H = H; P.W = W; P.dw = dw;
     P.ci_blocks = (cin + 31) / 32; P.co_blocks = (cout + 31) / 32; P.bands = (H + K4_WG_BAND - 1) / K4_WG_BAND;
     const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)cout * cin * ksize * ksize * sizeof(float), (hipStream_t)stream);     // split-K partial sums are ADDED
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k4_conv_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
     return k4_check_launch();
 }
 
 extern "C" int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream) {
     if (!gy || !dbias || cout <= 0 || gy_stride < cout || n_pix <= 0) return K4_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k4_bias_grad_kernel, dim3((unsigned)((cout + 31) / 32)), dim3(256), 0, (hipStream_t)stream, gy, cout, gy_stride, n_pix, dbias);
+    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const int64_t slabs = (n_pix + K4_BG_SLAB - 1) / K4_BG_SLAB;
+    if (slabs > 65535) return K4_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k4_bias_grad_kernel, dim3((unsigned)((cout + 31) / 32), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, gy, cout, gy_stride, n_pix, dbias);
+    return k4_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight packing on the device.  Under training every optimizer step changes every weight, so each iteration re-packs all 260
+// convolutions of SFTNet twice (forward operand and the flipped-transposed dgrad operand): as PyTorch ops (zeros / permute / three
+// bf16 casts and subtractions / stack / contiguous ...) that was ~6000 tiny launches per iteration, most of the joint step's wall
+// time.  One launch per (layer, operand) here, bit-identical to the host packer (lib/sr_esrnet.py::_Packed):
+//   out[ch][term][tap][g2][n][e] (8 x bf16 = one 16-byte unit per (ch, term, tap, g2, n)),  channel c = 16 ch + 8 g2 + e,
+//   form 0: v = W[n][c][tap]                       the layer as stored, [cout][cin][k][k]
+//   form 1: v = W[c][n][taps-1-tap]                dgrad operand: the layer (cin -> cout) seen as (cout -> cin), taps flipped
+//   form 2: v = W[n % cout][c][n / cout]           3x3 layer with cout <= 3 as a 1x1 layer whose outputs are (tap, co)  (K4_W_TAPS_AS_COUT)
+//   form 3: v = W[c][n % cin][taps-1 - n / cin]    form 2 of the dgrad operand (layers with cin <= 3: conv_first, CondNet.0)
+//   term q of v: t0 = bf16(v), t1 = bf16(v - t0), t2 = bf16(v - t0 - t1)   (round to nearest even, exact residuals)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k4_pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin, int taps, int form,
+                                    int nch, int taps_l, int NOUT, uint4* __restrict__ out, float* __restrict__ bias_out, int n_bias) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_bias) bias_out[idx] = (bias && (form == 0 || form == 2) && idx < cout) ? bias[idx] : 0.f;
+    if (idx >= nch * taps_l * 2 * NOUT) return;
+    const int n = idx % NOUT;
+    int r = idx / NOUT;
+    const int g2 = r & 1; r >>= 1;
+    const int tap = r % taps_l, ch = r / taps_l;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = ch * 16 + g2 * 8 + e;
+        float q = 0.f;
+        if (form == 0) { if (n < cout && c < cin) q = w[((size_t)n * cin + c) * taps + tap]; }
+        else if (form == 1) { if (n < cin && c < cout) q = w[((size_t)c * cin + n) * taps + (taps - 1 - tap)]; }
+        else if (form == 2) { if (n < taps * cout && c < cin) q = w[((size_t)(n % cout) * cin + c) * taps + n / cout]; }
+        else { if (n < taps * cin && c < cout) q = w[((size_t)c * cin + n % cin) * taps + (taps - 1 - n / cin)]; }
+        v[e] = q;
+    }
+    uint4 t0, t1, t2;
+    wg_split3(v, t0, t1, t2);
+    const size_t plane = (size_t)taps_l * 2 * NOUT;                   // 16-byte units per (ch, term)
+    uint4* const o = out + ((size_t)ch * 3) * plane + ((size_t)tap * 2 + g2) * NOUT + n;
+    o[0] = t0; o[plane] = t1; o[2 * plane] = t2;
+}
+
+extern "C" int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int32_t cout, int32_t cin, int32_t ksize, int32_t form,
+                                          void* w_split, float* bias_out, void* stream) {
+    if (!w || !w_split || !bias_out || cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3) || form < 0 || form > 3) return K4_ERR_BAD_ARG;
+    if ((form == 2 && (ksize != 3 || cout > 3)) || (form == 3 && (ksize != 3 || cin > 3))) return K4_ERR_BAD_ARG;
+    const int taps = ksize * ksize;
+    const int cout_l = form == 0 ? cout : form == 1 ? cin : form == 2 ? taps * cout : taps * cin;     // the logical layer the kernels see
+    const int cin_l = (form == 1 || form == 3) ? cout : cin;
+    const int taps_l = form >= 2 ? 1 : taps;
+    const int NOUT = (cout_l + 31) / 32 * 32, nch = (cin_l + 15) / 16;
+    const int n_bias = form >= 2 ? 32 : NOUT;                                   // taps forms: the bias of the 3x3 layer itself (<= 3 channels)
+    const int total = nch * taps_l * 2 * NOUT;
+    const int threads = total > n_bias ? total : n_bias;
+    hipLaunchKernelGGL(k4_pack_conv_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, cout, cin, taps, form, nch, taps_l, NOUT,
+                       reinterpret_cast<uint4*>(w_split), bias_out, n_bias);
     return k4_check_launch();
 }

@@ -42,6 +42,27 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
     _launch('k4_adam_upd_with_perlr', param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps)
 
 
+_MULTI_BELOW = 1 << 20          # tensors smaller than this are updated through k4_adam_upd_multi (same arithmetic per element)
+
+
+def adam_upd_multi(items, masked, step, beta1, beta2, lr, eps):
+    """adam_upd / masked_adam_upd of many (param, grad, exp_avg, exp_avg_sq) tuples in ceil(len / 64) launches (k4_adam_upd_multi)."""
+    if not items:
+        return
+    jobs = (N.AdamJob * len(items))()
+    for j, ts in enumerate(items):
+        for t in ts:
+            if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != ts[0].numel():
+                raise ValueError('adam_upd_multi: tensors must be contiguous fp32 device tensors of one size')     # adam_upd.cpp CHECK_INPUT
+        jobs[j].param, jobs[j].grad, jobs[j].exp_avg, jobs[j].exp_avg_sq = (t.data_ptr() for t in ts)
+        jobs[j].n = ts[0].numel()
+    N.check(N.lib().k4_adam_upd_multi(jobs, len(items), int(bool(masked)), int(step), float(beta1), float(beta2), float(lr), float(eps),
+                                      N.stream()), 'k4_adam_upd_multi')
+    for param, _, m, v in items:
+        for t in (param, m, v):
+            torch.autograd.graph.increment_version(t)
+
+
 class MaskedAdam(torch.optim.Optimizer):
     """Adam with (1) per-voxel learning rate and (2) masked update that skips zero-gradient voxels."""
 
@@ -65,6 +86,7 @@ class MaskedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             (beta1, beta2), lr, eps = group['betas'], group['lr'], group['eps']
             masked = group['skip_zero_grad']                   # KeyError without it, as upstream (masked_adam.py:45)
+            small = {}
             for param in (p for p in group['params'] if p.grad is not None):
                 state = self.state[param]
                 if not state:                                   # lazy state, zeros in the parameter's memory format
@@ -77,7 +99,13 @@ class MaskedAdam(torch.optim.Optimizer):
                 # kernel selection order of lib/masked_adam.py:58-71: per-voxel lr first, then the masked update
                 if self.per_lr is not None and param.shape == self.per_lr.shape:
                     adam_upd_with_perlr(param, grad, *moments, self.per_lr, *hyper)
+                elif param.numel() < _MULTI_BELOW:
+                    small.setdefault((bool(masked), state['step']), []).append((param, grad) + moments)
                 elif masked:
                     masked_adam_upd(param, grad, *moments, *hyper)
                 else:
                     adam_upd(param, grad, *moments, *hyper)
+            # the group's small tensors (the decoder: 458 of them) share hyper-parameters: a handful of launches instead of one each
+            for (msk, step), items in small.items():
+                adam_upd_multi(items, msk, step, beta1, beta2, lr, eps)
+            small.clear()

@@ -165,6 +165,39 @@ class _Packed:
         self.b[:cout] = bias.detach().float()
         self.cin, self.k = cin, k
 
+    @classmethod
+    def native(cls, weight, bias, dgrad=False):
+        """The 'bf16x6' packing of an nn.Conv2d weight by ONE kernel launch (k4_pack_conv_weight_bf16x6), bit-identical to
+        ``_Packed(weight, bias, 'bf16x6')`` -- or, with ``dgrad``, to the packing of the flipped-transposed filter the dgrad
+        convolution uses.  The training loop re-packs every layer twice per iteration; as PyTorch ops that was ~6000 tiny launches."""
+        cout, cin, k, _ = weight.shape
+        L = N.lib()
+        self = cls.__new__(cls)
+        self.mode, self.flags_extra = 'bf16x6', 0
+        taps_ok = k == 3 and os.environ.get('K4_CONV_TAPS', '1') != '0'
+        if dgrad and taps_ok and cin <= 3:                  # the dgrad layer has <= 3 outputs (conv_first, CondNet.0): taps form of it
+            form, lc_out, lc_in, lk = 3, 9 * cin, cout, 1
+            self.flags_extra = W_TAPS_AS_COUT
+        elif dgrad:
+            form, lc_out, lc_in, lk = 1, cin, cout, k
+        elif taps_ok and cout <= 3:
+            form, lc_out, lc_in, lk = 2, 9 * cout, cin, 1
+            self.flags_extra = W_TAPS_AS_COUT
+        else:
+            form, lc_out, lc_in, lk = 0, cout, cin, k
+        nbytes = int(L.k4_conv_weight_bf16x6_bytes(lc_out, lc_in, lk))
+        if nbytes <= 0:
+            raise N.K4Error(f'unsupported convolution shape {tuple(weight.shape)}')
+        wc = weight.detach().float().contiguous()
+        self.w = torch.empty([nbytes // 2], dtype=torch.int16, device=wc.device)
+        nb = 32 if form >= 2 else ((cin if dgrad else cout) + 31) // 32 * 32
+        self.b = torch.empty([nb], dtype=torch.float32, device=wc.device)
+        bc = None if (bias is None or dgrad) else bias.detach().float().contiguous()
+        N.check(L.k4_pack_conv_weight_bf16x6(N.f32(wc), None if bc is None else N.f32(bc), cout, cin, k, form, N.ptr(self.w), N.f32(self.b),
+                                             N.stream()), 'k4_pack_conv_weight_bf16x6')
+        self.cin, self.k = (cout if dgrad else cin), k
+        return self
+
 
 def pack_sft(layer):
     """SFTLayer weights in the operand order of the fused kernel (include/k4nerf.h, k4_sft_nhwc)."""

@@ -39,13 +39,11 @@ class _WeightCache:
         return hit[1]
 
     def fwd(self, weight, bias):
-        return self._get('f', weight, bias, lambda: _Packed(weight, bias if bias is not None else weight.new_zeros([weight.shape[0]]), 'bf16x6'))
+        return self._get('f', weight, bias, lambda: _Packed.native(weight, bias))
 
     def bwd(self, weight):
-        def make():
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # [cin, cout, k, k], taps flipped
-            return _Packed(wt, wt.new_zeros([wt.shape[0]]), 'bf16x6')
-        return self._get('b', weight, None, make)
+        # dgrad operand: the filter flipped in both taps axes and transposed to [cin, cout, k, k], packed by the same kernel
+        return self._get('b', weight, None, lambda: _Packed.native(weight, None, dgrad=True))
 
 
 class K4Conv2d(torch.autograd.Function):
@@ -78,7 +76,7 @@ class K4Conv2d(torch.autograd.Function):
             gx = torch.empty([H, W, cin], dtype=torch.float32, device=x.device)
             SFTNet._conv(ctx.cache.bwd(weight), gy, 0, cout, gx, 0, cin, cin, H, W)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)          # zeroed by the entry point
             N.check(L.k4_conv2d_wgrad_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.f32(gw), N.stream()),
                     'k4_conv2d_wgrad_bf16x6')
         if ctx.has_bias and ctx.needs_input_grad[2]:

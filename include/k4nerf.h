@@ -332,13 +332,24 @@ int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
 /* ---- decoder backward (run_sr.py:869-1014 back-propagates through SFTNet) ----------------------------------
  * dgrad needs no entry point of its own: dX = conv(dY, W') with W'[ci][co][2-dy][2-dx] = W[co][ci][dy][dx] runs on
  * k4_conv2d_nhwc_bf16x6 with the host-packed W' (3x3: any number of 32-channel output blocks).
- *   k4_conv2d_wgrad_bf16x6 : dW[co][ci][dy][dx] += sum_p dY[p][co] * X[p + (dy-pad, dx-pad)][ci]  (zero padded), MFMA GEMM over the
- *                            pixels with exact 3-term bf16 splits of both operands; `dw` ([cout][cin][k][k], PyTorch layout) must
- *                            be zero-initialised (split-K partial sums are added with fp32 atomics)
- *   k4_conv2d_bias_grad    : dbias[co] = sum_p dY[p][co] */
+ *   k4_conv2d_wgrad_bf16x6 : dW[co][ci][dy][dx] = sum_p dY[p][co] * X[p + (dy-pad, dx-pad)][ci]  (zero padded), MFMA GEMM over the
+ *                            pixels with exact 3-term bf16 splits of both operands; `dw` ([cout][cin][k][k], PyTorch layout) is
+ *                            OVERWRITTEN: zeroed on the stream, then the split-K partial sums are added with fp32 atomics
+ *   k4_conv2d_bias_grad    : dbias[co] = sum_p dY[p][co]   (dbias is overwritten; pixel slabs are summed with fp32 atomics) */
 int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                            int32_t ksize, int32_t H, int32_t W, float* dw, void* stream);
 int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream);
+/* Device-side weight packing for the training loop (every optimizer step changes every weight: 2 x 260 packings per iteration).
+ * Writes the `w_split` operand of k4_conv2d_nhwc_bf16x6 for the nn.Conv2d weight w [cout][cin][k][k], bit-identical to the host packer:
+ *   form 0: the layer as stored (k4_conv_weight_bf16x6_bytes(cout, cin, k) bytes; bias_out [ceil(cout/32)*32] = bias, zero padded)
+ *   form 1: the dgrad operand W'[ci][co][2-dy][2-dx] = W[co][ci][dy][dx], a layer cout -> cin (k4_conv_weight_bf16x6_bytes(cin, cout, k)
+ *           bytes; bias_out [ceil(cin/32)*32] = 0)
+ *   form 2: K4_W_TAPS_AS_COUT (3x3, cout <= 3): the 1x1 layer [9*cout -> 32][cin] (k4_conv_weight_bf16x6_bytes(9*cout, cin, 1) bytes;
+ *           bias_out [32] = bias)
+ *   form 3: form 2 of the dgrad operand (3x3, cin <= 3: a layer cout -> cin with <= 3 outputs; k4_conv_weight_bf16x6_bytes(9*cin, cout, 1)
+ *           bytes; bias_out [32] = 0).   bias == NULL reads as zeros. */
+int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int32_t cout, int32_t cin, int32_t ksize, int32_t form,
+                               void* w_split, float* bias_out, void* stream);
 
 /* ---- training-step streaming kernels --------------------------------------------------------
  * Replace the reference extension `adam_upd_cuda` (lib/cuda/adam_upd.cpp:10-67 -> adam_upd_kernel.cu:60-133) that
@@ -353,6 +364,15 @@ int k4_masked_adam_upd(float* param, const float* grad, float* exp_avg, float* e
                        float beta1, float beta2, float lr, float eps, void* stream);
 int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* perlr,
                            int64_t n, int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
+
+/* The same update for MANY tensors in as few launches as possible (the decoder's optimizer step, run_sr.py:665-667,1014: 458 parameter
+ * tensors = 458 launches of k4_adam_upd otherwise).  `jobs` is a HOST array; hyper-parameters and the step count are shared (one
+ * param group whose tensors have been stepped together); masked != 0 selects the masked_adam_upd arithmetic.  Per element identical to
+ * k4_adam_upd / k4_masked_adam_upd. */
+#define K4_ADAM_MULTI_MAX 64       /* tensors per launch */
+typedef struct k4_adam_job { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; } k4_adam_job;
+int k4_adam_upd_multi(const k4_adam_job* jobs, int32_t n_jobs, int32_t masked, int32_t step, float beta1, float beta2, float lr, float eps,
+                      void* stream);
 
 /* total_variation_cuda.total_variation_add_grad (lib/cuda/total_variation.cpp:16-20 ->
  * total_variation_kernel.cu:13-66), called by DenseGrid.total_variation_add_grad (lib/grid.py:137-140).

@@ -193,3 +193,27 @@ def test_optimizer_kernels_vs_reference_compiled_kernels():
         p, g = T('in/param'), T('in/grad')
         G.total_variation_add_grad(p, g, 0.3, 0.2, 0.7, dense)
         np.testing.assert_allclose(g.cpu().numpy(), z[f'tv/{"dense" if dense else "sparse"}/grad'], rtol=0, atol=5e-7)
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_multi_tensor_adam_is_bit_identical_to_the_single_tensor_kernels(masked):
+    """k4_adam_upd_multi (the decoder's optimizer step: 458 tensors in 8 launches) against k4_adam_upd / k4_masked_adam_upd per tensor:
+    ragged sizes incl. empty, one element, chunk boundaries (1023 / 1024 / 1025) and more tensors than one launch holds."""
+    from nerf4k_amd.lib import masked_adam as MA
+    g = torch.Generator().manual_seed(3)
+    sizes = [0, 1, 3, 1023, 1024, 1025, 5000, 64, 2048, 7] * 15
+    items_a, items_b = [], []
+    for n in sizes:
+        p, gr = torch.randn([n], generator=g), torch.randn([n], generator=g)
+        if masked and n:
+            gr[torch.rand([n], generator=g) < 0.5] = 0
+        m, v = torch.randn([n], generator=g) * 0.1, torch.rand([n], generator=g) * 0.1
+        items_a.append(tuple(t.clone().cuda() for t in (p, gr, m, v)))
+        items_b.append(tuple(t.clone().cuda() for t in (p, gr, m, v)))
+    MA.adam_upd_multi(items_a, masked, 7, 0.9, 0.99, 2e-4, 1e-8)
+    for p, gr, m, v in items_b:
+        (MA.masked_adam_upd if masked else MA.adam_upd)(p, gr, m, v, 7, 0.9, 0.99, 2e-4, 1e-8)
+    for a, b in zip(items_a, items_b):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert items_a[3][0]._version > 0                                   # versions bumped like the single-tensor wrappers do

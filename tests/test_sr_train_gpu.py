@@ -100,3 +100,28 @@ def test_training_step_updates_inference_path():
         want = osr.sftnet_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), c.cpu())
     assert float((after - before).abs().max()) > 1e-4
     assert _rel(after, want) <= 2e-5
+
+
+@pytest.mark.parametrize('cout,cin,k', [(32, 64, 3), (32, 160, 3), (64, 192, 3), (64, 3, 3), (3, 64, 3), (64, 1, 3), (64, 32, 1), (32, 32, 1),
+                                        (64, 64, 1), (2, 5, 3), (40, 24, 3)])
+def test_device_weight_packer_is_bit_identical_to_the_host_packer(cout, cin, k):
+    """k4_pack_conv_weight_bf16x6 (one launch per layer and operand, what the training loop uses every iteration) against the PyTorch-op
+    packer of the inference path, for the forward operand and for the flipped-transposed dgrad operand, incl. the taps-as-outputs forms."""
+    from nerf4k_amd.lib.sr_esrnet import _Packed
+    g = torch.Generator().manual_seed(cout * 31 + cin + k)
+    w = (torch.randn([cout, cin, k, k], generator=g) * torch.rand([cout, 1, 1, 1], generator=g) * 3).cuda()
+    w[0, 0, 0, 0] = 0.0
+    if w.numel() > 6:
+        w.view(-1)[5] = 1.0 + 2.0 ** -9 + 2.0 ** -18                  # a value that needs all three terms
+    b = torch.randn([cout], generator=g).cuda()
+    for dgrad in (False, True):
+        if dgrad:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()
+            want = _Packed(wt, wt.new_zeros([wt.shape[0]]), 'bf16x6')
+            got = _Packed.native(w, None, dgrad=True)
+        else:
+            want = _Packed(w, b, 'bf16x6')
+            got = _Packed.native(w, b)
+        assert got.mode == want.mode and got.flags_extra == want.flags_extra and got.cin == want.cin and got.k == want.k
+        assert got.w.numel() == want.w.numel() and torch.equal(got.w.reshape(-1), want.w.reshape(-1)), (cout, cin, k, dgrad)
+        assert got.b.shape == want.b.shape and torch.equal(got.b, want.b)
