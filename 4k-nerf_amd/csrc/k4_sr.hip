@@ -1028,6 +1028,10 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         }
         total = count(4 * rpw);
     }
+    if ((M.base.flags & K4_ARITH_2TERM) && rpw == 4 && (k4_env().sr_2t_rpw == 2 || k4_env().sr_2t_rpw == 3)) {     // A/B knob
+        rpw = k4_env().sr_2t_rpw;
+        total = count(4 * rpw);
+    }
     M.total = total;
     if (M.base.sft_w) {
         if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2, true>), dim3((unsigned)total), dim3(256), 0, st, M);
