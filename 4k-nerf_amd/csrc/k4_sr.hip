@@ -1028,8 +1028,9 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         }
         total = count(4 * rpw);
     }
-    if ((M.base.flags & K4_ARITH_2TERM) && rpw == 4 && (k4_env().sr_2t_rpw == 2 || k4_env().sr_2t_rpw == 3)) {     // A/B knob
-        rpw = k4_env().sr_2t_rpw;
+    const int rpw_big = (M.base.flags & K4_ARITH_2TERM) ? k4_env().sr_2t_rpw : k4_env().sr_3t_rpw;      // tile height of launches beyond the small-launch rule
+    if (rpw == 4 && (rpw_big == 2 || rpw_big == 3) && !(M.queue && !k4_env().sr_static)) {
+        rpw = rpw_big;
         total = count(4 * rpw);
     }
     M.total = total;
