@@ -39,6 +39,16 @@ __device__ __forceinline__ void wg_split3(const float (&v)[8], uint4& t0, uint4&
     t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
 }
 
+// zero-fill as a KERNEL (not hipMemsetAsync): inside a hipGraph capture (lib/sr_train.GraphedDecoder) the memset of this ROCm build ran
+// once at capture time instead of becoming a node -- replays then added their split-K partial sums to stale contents
+__global__ void wg_zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+static inline void wg_zero(float* p, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(wg_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
+
 struct WgradParams {
     const float* x; int cin; int x_stride;
     const float* gy; int cout; int gy_stride;
@@ -140,16 +150,14 @@ extern "C" int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_str
     P.ks = ksize; P.H = H; P.W = W; P.dw = dw;
     P.ci_blocks = (cin + 31) / 32; P.co_blocks = (cout + 31) / 32; P.bands = (H + K4_WG_BAND - 1) / K4_WG_BAND;
     const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)cout * cin * ksize * ksize * sizeof(float), (hipStream_t)stream);     // split-K partial sums are ADDED
-    if (e != hipSuccess) return (int)e;
+    wg_zero(dw, (int64_t)cout * cin * ksize * ksize, (hipStream_t)stream);                                            // split-K partial sums are ADDED
     hipLaunchKernelGGL(k4_conv_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
     return k4_check_launch();
 }
 
 extern "C" int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream) {
     if (!gy || !dbias || cout <= 0 || gy_stride < cout || n_pix <= 0) return K4_ERR_BAD_ARG;
-    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    wg_zero(dbias, cout, (hipStream_t)stream);
     const int64_t slabs = (n_pix + K4_BG_SLAB - 1) / K4_BG_SLAB;
     if (slabs > 65535) return K4_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k4_bias_grad_kernel, dim3((unsigned)((cout + 31) / 32), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, gy, cout, gy_stride, n_pix, dbias);

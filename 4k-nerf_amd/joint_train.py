@@ -18,6 +18,8 @@ lists into its dense gradient in RANK order, so the replicas hold bit-identical 
 with zero gradient" sees the union of the touched voxels).  Pure torch.distributed plumbing: RCCL on the GPUs, gloo in the
 CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -104,7 +106,7 @@ class JointTrainer:
     """Optimizers + one-iteration method of the joint loop.  ``render_kwargs`` as run_sr.py:690-702 builds them
     (``render_depth=True``; ``rand_bkgd`` for LLFF); ``n_train_images`` = len(rays_o_tr), the TV weights' divisor (:1008-1011)."""
 
-    def __init__(self, model, net_sr, cfg_train, render_kwargs, n_train_images, sr_ratio=4, num_cond=1, dim_rend=3, group=None):
+    def __init__(self, model, net_sr, cfg_train, render_kwargs, n_train_images, sr_ratio=4, num_cond=1, dim_rend=3, group=None, use_graph=None):
         if cfg_train.weight_pcp > 0 or cfg_train.weight_gan > 0:
             raise NotImplementedError('perceptual / GAN losses (run_sr.py:934-957) are outside the hot-path scope (SURVEY.md 8)')
         if num_cond != 1 or dim_rend != 3:
@@ -116,6 +118,9 @@ class JointTrainer:
         self.optimizer_sr = MaskedAdam([{'params': net_sr.parameters(), 'lr': cfg_train.lrate_srnet, 'kname': 'srnet',
                                          'skip_zero_grad': False}])                                               # run_sr.py:665-667
         self.last_exchange = None
+        # K4_TRAIN_GRAPH=1 / use_graph: the decoder's forward + backward of the full-size patch replayed as hipGraphs (lib/sr_train.GraphedDecoder)
+        self.use_graph = (os.environ.get('K4_TRAIN_GRAPH', '0') == '1') if use_graph is None else bool(use_graph)
+        self._graphed = None
 
     def losses(self, rr, rgb_sr, target, target_4x, pr, pc, n_rays):
         """run_sr.py:877-995: the scalar terms of one iteration (dict of tensors; 'total' is what is back-propagated)."""
@@ -141,8 +146,18 @@ class JointTrainer:
         rr = self.model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **self.render_kwargs)
         rgb_cache = rr['rgb_feature'].reshape(1, pr, pc, -1).movedim(-1, 1)
         cond = rr['depth'].reshape(1, pr, pc, 1).movedim(-1, 1)                          # num_cond == 1 (run_sr.py:894-897)
-        rgb_sr = self.net_sr(rgb_cache, cond)                                            # run_sr.py:918
+        rgb_sr = self._decoder(rgb_cache, cond)                                          # run_sr.py:918
         return rr, rgb_sr, self.losses(rr, rgb_sr, target, target_4x, pr, pc, len(rays_o))
+
+    def _decoder(self, x, cond):
+        if self.use_graph and torch.is_grad_enabled() and x.requires_grad:
+            if self._graphed is None:
+                N_patch = self.cfg.N_rand // self.cfg.N_patch
+                if tuple(x.shape[2:]) == (N_patch, N_patch):                 # capture once, for the full-size patch (edge patches stay eager)
+                    self._graphed = sr_train.GraphedDecoder(self.net_sr, x.shape, cond.shape)
+            if self._graphed is not None and self._graphed.matches(x, cond):
+                return self._graphed(x, cond)
+        return self.net_sr(x, cond)
 
     def step(self, rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step):
         """One iteration (run_sr.py:869-1014,1052-1061).  Returns the dict of loss tensors (detached)."""

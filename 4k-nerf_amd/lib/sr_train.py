@@ -29,8 +29,11 @@ class _WeightCache:
 
     def __init__(self):
         self._c = {}
+        self.always = False        # True: pack on every call (hipGraph capture: the packing kernels must be part of the graph, see GraphedDecoder)
 
     def _get(self, kind, weight, bias, make):
+        if self.always:
+            return make()
         key = (kind, weight.data_ptr(), weight._version, None if bias is None else bias._version, str(weight.device))
         hit = self._c.get((kind, weight.data_ptr()))
         if hit is None or hit[0] != key:
@@ -134,6 +137,41 @@ def forward_train(net, x, cond):
             body = lrelu(conv(net.conv_up2, _up2(body)))
     out = conv(net.conv_last, lrelu(conv(net.conv_hr, body)))
     return out.permute(2, 0, 1).unsqueeze(0)
+
+
+class GraphedDecoder:
+    """``forward_train`` + its backward for ONE input shape as two hipGraphs (``torch.cuda.make_graphed_callables``).
+
+    The decoder's training graph on a 64x64 patch is ~2500 launches of 4-30 us (229 convolutions x (pack, forward | pack, dgrad,
+    wgrad, dbias) + the elementwise glue): 25 of the joint iteration's 42 ms were host time spent issuing them.  Every launch goes
+    to torch's current stream and every buffer comes from torch's allocator, so the whole thing is capturable; the weight packers
+    are kernels (k4_pack_conv_weight_bf16x6) and run INSIDE the graphs (``_WeightCache.always``): a replay after an optimizer step
+    re-packs the updated weights.  Shapes other than the captured one fall back to the eager path (the caller keeps both)."""
+
+    def __init__(self, net, x_shape, cond_shape):
+        dev = next(net.parameters()).device
+        cache = net._k4.setdefault('train_cache', _WeightCache())
+
+        class _Fwd(torch.nn.Module):
+            def __init__(self, net):
+                super().__init__()
+                self.net = net
+
+            def forward(self, x, cond):
+                return forward_train(self.net, x, cond)
+        self.x_shape, self.cond_shape = tuple(x_shape), tuple(cond_shape)
+        sample = (torch.rand(self.x_shape, device=dev, requires_grad=True), torch.rand(self.cond_shape, device=dev))
+        cache.always = True
+        try:
+            self.fn = torch.cuda.make_graphed_callables(_Fwd(net), sample)
+        finally:
+            cache.always = False
+
+    def matches(self, x, cond):
+        return tuple(x.shape) == self.x_shape and tuple(cond.shape) == self.cond_shape and x.requires_grad and not cond.requires_grad
+
+    def __call__(self, x, cond):
+        return self.fn(x.contiguous(), cond.contiguous())
 
 
 # ---------------------------------------------------------------------------------------------------------------------

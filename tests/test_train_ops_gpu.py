@@ -195,3 +195,35 @@ def test_joint_trainer_steps_lower_the_loss():
         a = model(*batch[:3], **{k: v for k, v in rk.items() if k != 'rand_bkgd'})
         b = model(*batch[:3], k4_staged=True, **{k: v for k, v in rk.items() if k != 'rand_bkgd'})
     assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)
+
+
+def test_graphed_decoder_matches_eager_and_sees_weight_updates():
+    """lib/sr_train.GraphedDecoder: SFTNet's training forward + backward captured as hipGraphs (the weight packers run inside them).
+    Replays must equal the eager path (same kernels; wgrad / dbias sum with atomics: 2e-5 relative) -- also after the weights changed."""
+    from nerf4k_amd.lib import sr_train
+    torch.manual_seed(11)
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=1, num_grow_ch=32, num_cond=1).cuda().train()
+    g = torch.Generator().manual_seed(12)
+    shape_x, shape_c = (1, 3, 16, 20), (1, 1, 16, 20)
+    graphed = sr_train.GraphedDecoder(net, shape_x, shape_c)
+    for it in range(3):
+        x0 = torch.rand(shape_x, generator=g).cuda()
+        cond = torch.rand(shape_c, generator=g).cuda()
+        tgt = torch.rand([1, 3, 64, 80], generator=g).cuda()
+        res = []
+        for fn in (lambda a, b: net(a, b), graphed):
+            net.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            assert graphed.matches(x, cond)
+            with torch.enable_grad():
+                out = fn(x, cond)
+                torch.nn.functional.l1_loss(out, tgt).backward()
+            res.append((out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+        (oe, xe, pe), (og, xg, pg) = res
+        assert torch.equal(oe, og), it
+        _close(xg, xe.cpu(), 'grad_x', rel=2e-5, abs_=1e-9)
+        for a, b in zip(pg, pe):
+            _close(a, b.cpu(), 'grad_param', rel=2e-5, abs_=1e-9)
+        with torch.no_grad():                                       # an "optimizer step": the next replay must pack the new weights
+            for p in net.parameters():
+                p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02 * p.abs().mean())
