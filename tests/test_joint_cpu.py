@@ -159,3 +159,71 @@ def test_oracle_distortion_loss_equals_prefix_sum_form():
     assert n_norm == 7
     assert abs(float(loss) - tot / n_norm) < 1e-12
     np.testing.assert_allclose(w.grad.numpy(), grad / n_norm, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class _ToyScene(torch.nn.Module):
+    """Parameter shapes of the joint step: one voxel grid large enough for the sparse path, small tensors for the dense bucket."""
+
+    def __init__(self):
+        super().__init__()
+        self.grid = torch.nn.Parameter(torch.zeros([1, 4, 64, 64, 64]))          # 1,048,576 elements = joint_train.SPARSE_MIN_NUMEL
+        self.small_grid = torch.nn.Parameter(torch.zeros([1, 1, 1, 1, 16]))       # 5-D but small: dense bucket (act_shift.grid)
+        self.lin = torch.nn.Linear(5, 3)
+
+
+def _toy_grads(rank, m):
+    g = torch.Generator().manual_seed(50 + rank)
+    grid = torch.zeros(m.grid.shape).view(4, -1)
+    idx = torch.randperm(grid.shape[1], generator=g)[:300 + 40 * rank]
+    grid[:, idx] = torch.randn([4, idx.numel()], generator=g)
+    return {'grid': grid.view(m.grid.shape), 'small_grid': torch.randn(m.small_grid.shape, generator=g),
+            'lin.weight': torch.randn(m.lin.weight.shape, generator=g), 'lin.bias': torch.randn(m.lin.bias.shape, generator=g)}
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from nerf4k_amd import joint_train
+        model, head = _ToyScene(), torch.nn.Linear(4, 2)
+        for k, v in _toy_grads(rank, model).items():
+            dict(model.named_parameters())[k].grad = v.clone()
+        head.weight.grad = torch.full(head.weight.shape, float(rank + 1))
+        stats = joint_train.exchange_gradients(model, head)           # head.bias has no gradient anywhere: zeros
+        out = {k: p.grad.numpy().copy() for k, p in list(model.named_parameters()) + [('head.' + k, p) for k, p in head.named_parameters()]}
+        q.put((rank, out, stats['bytes_gathered'], stats['bytes_dense']))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_joint_gradient_exchange_routes_grids_sparse_and_the_rest_dense():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, out, b_sparse, b_dense = q.get(timeout=240)
+        got[r] = (out, b_sparse, b_dense)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = _ToyScene()
+    want = {k: sum(_toy_grads(r, m)[k] for r in range(world)) / world for k in ('grid', 'small_grid', 'lin.weight', 'lin.bias')}
+    for r in range(world):
+        out, b_sparse, b_dense = got[r]
+        for k, v in want.items():
+            np.testing.assert_allclose(out[k], v.numpy(), rtol=0, atol=1e-6)
+            assert np.array_equal(out[k], got[0][0][k])                                       # replicas identical
+        np.testing.assert_allclose(out['head.weight'], np.full([2, 4], 1.5), rtol=0, atol=0)
+        assert float(np.abs(out['head.bias']).sum()) == 0.0
+        # only the 1 M-element grid went through the sparse exchange: (4 + 1) words x max touched voxels x world ranks
+        assert b_sparse == world * 5 * (300 + 40 * (world - 1)) * 4
+        assert b_dense == 4 * (16 + 15 + 3 + 8 + 2)                                           # small_grid + lin + head in ONE bucket
