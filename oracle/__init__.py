@@ -20,4 +20,11 @@ Parity pin status (see DESIGN.md "Oracle"):
     git-ignored) and run on an MI355X (``oracle/gen_native_golden.py``); vectors in
     ``tests/golden/native_*.npz`` / ``optim_ref.npz``.  ``native_march_*.npz`` re-evaluate the
     march fixtures with those compiled kernels serving every native step.
+  * Training graph and joint step (``oracle/train_ops.py``): the colour MLP and the loss lines of
+    ``run_sr.py:877-995`` are pinned through ``tests/golden/grad_joint.npz`` = one joint iteration
+    on the reference's own ``DirectMPIGO`` + ``SFTNet`` modules; the 'patch_mimg' sampler through
+    draws of the reference's own generator (``patch_sampler.npz``).  PARITY UNPINNED for one term:
+    the distortion loss comes from the third-party package ``torch_efficient_distloss`` (PyPI 0.1.3,
+    not vendored in /root/reference, not installed here) -- it is restated from its published
+    definition (literal O(n^2) form) and the HIP kernel's prefix-sum form is checked against that.
 """
