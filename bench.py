@@ -270,9 +270,10 @@ def main():
         if four_k_fp32 is not None:
             res['four_k_fp32mfma'], res['four_k_bf16x3'] = four_k_fp32, four_k_fast
         if world == 1 and not args.small and not args.no_extras:
-            res['own_staged_pipeline'] = own_staged_pipeline(model, run.rays[0], rk)
-            res['training_step_kernels'] = training_step_kernels(dev, run.rays[0], model)
-            res['joint_train_step'] = joint_train_step(ck, run.rays[0], H, W, dev)
+            # side measurements (single process, no collectives): a failure in one of them must not take the headline line with it
+            res['own_staged_pipeline'] = _side(own_staged_pipeline, model, run.rays[0], rk)
+            res['training_step_kernels'] = _side(training_step_kernels, dev, run.rays[0], model)
+            res['joint_train_step'] = _side(joint_train_step, ck, run.rays[0], H, W, dev)
         if not args.no_cpu_baseline:
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
@@ -281,6 +282,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _side(fn, *a):
+    try:
+        return fn(*a)
+    except Exception as e:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {'error': f'{type(e).__name__}: {str(e)[:200]}'}
 
 
 def _cpu_threads():
