@@ -1189,8 +1189,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
     const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 8 + (width ? (size_t)P.k1p * 64 : 0)));
-    const int shade_wg = k4_env().shade_grid_wg;
-    const dim3 sgrid((unsigned)min(nwg, n_cu * shade_wg));
+    const int shade_wg = k4_env().shade_grid_wg, tenths = k4_env().shade_grid_tenths;
+    const dim3 sgrid((unsigned)min(nwg, tenths > 0 ? max(1, n_cu * tenths / 10) : n_cu * shade_wg));
     const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
@@ -1278,7 +1278,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
     env_int("K4_GEOM_OCC", 5), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
-    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_B6_NW1", 8), env_int("K4_SR_VARIANT", 0), env_int("K4_SR_SMALL", 1), env_int("K4_SR_STATIC", 0), env_int("K4_GEOM_BAND", 1), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2)};
+    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_B6_NW1", 8), env_int("K4_SR_VARIANT", 0), env_int("K4_SR_SMALL", 1), env_int("K4_SR_STATIC", 0), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];
