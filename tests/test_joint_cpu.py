@@ -227,3 +227,34 @@ def test_joint_gradient_exchange_routes_grids_sparse_and_the_rest_dense():
         # only the 1 M-element grid went through the sparse exchange: (4 + 1) words x max touched voxels x world ranks
         assert b_sparse == world * 5 * (300 + 40 * (world - 1)) * 4
         assert b_dense == 4 * (16 + 15 + 3 + 8 + 2)                                           # small_grid + lin + head in ONE bucket
+
+
+def test_joint_loss_terms_equal_the_oracle_restatement():
+    """JointTrainer.losses (host logic: the loss lines of run_sr.py:877-995) on CPU tensors against oracle/train_ops.joint_losses -- without
+    the distortion term, whose product implementation is a HIP kernel (checked on the GPU against tests/golden/grad_joint.npz)."""
+    from nerf4k_amd import joint_train
+    from oracle import train_ops as oto
+    g = torch.Generator().manual_seed(8)
+    pr, pc, n_pts = 5, 6, 70
+    n = pr * pc
+    rr = {'rgb_feature': torch.rand([n, 3], generator=g), 'alphainv_last': torch.rand([n], generator=g),
+          'weights': torch.rand([n_pts], generator=g), 'raw_rgb': torch.rand([n_pts, 3], generator=g),
+          'ray_id': torch.sort(torch.randint(0, n, [n_pts], generator=g)).values, 's': torch.rand([n_pts], generator=g), 'n_max': 12}
+    rr['alphainv_last'][:3] = torch.tensor([0.0, 1.0, 1e-9])                      # the entropy term clamps to [1e-6, 1 - 1e-6]
+    rgb_sr = torch.rand([1, 3, 4 * pr, 4 * pc], generator=g)
+    target, target_4x = torch.rand([n, 3], generator=g), torch.rand([16 * n, 3], generator=g)
+    cfg = joint_train.JointCfg.fern_lg_joint_l1(weight_distortion=0)
+    tr = joint_train.JointTrainer.__new__(joint_train.JointTrainer)               # losses() needs cfg and sr_ratio only
+    tr.cfg, tr.sr_ratio = cfg, 4
+    got = tr.losses(rr, rgb_sr, target, target_4x, pr, pc, n)
+    total, terms = oto.joint_losses(rr, rgb_sr, target, target_4x, pr, pc, dict(cfg))
+    assert set(terms) == {'photo', 'l1', 'entropy_last', 'rgbper'} and 'distortion' not in got
+    for k, v in terms.items():
+        assert torch.equal(got[k], v), k
+    assert torch.equal(got['total'], total)
+    want_psnr = -10.0 * torch.log10((rgb_sr.clamp(0, 1) - target_4x.reshape(4 * pr, 4 * pc, 3).movedim(-1, 0).unsqueeze(0)).pow(2).mean())
+    assert torch.equal(got['psnr_sr'], want_psnr)
+    # perceptual / GAN terms are out of scope and say so
+    import pytest
+    with pytest.raises(NotImplementedError):
+        joint_train.JointTrainer(None, None, joint_train.JointCfg.fern_lg_joint_l1(weight_gan=0.1), {}, 1)
