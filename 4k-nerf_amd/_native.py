@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 4
+K4_ABI_VERSION = 5
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
@@ -135,6 +135,8 @@ _EXTRA_SIGS = {
     'k4_alpha_maxpool3_gt': ([_P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'k4_occupancy_summary_bytes': ([_I32, _I32, _I32], C.c_int64),
     'k4_build_occupancy_summary': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_live_mask_workspace_bytes': ([_I32, _I32, _I32], C.c_int64),
+    'k4_build_live_mask': ([C.POINTER(GridDesc), _F, _F, _F, _P, _P, _P], C.c_int),
     'k4_rgbnet_fwd': ([_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'k4_rgbnet_bwd_workspace_bytes': ([_I64, _I32, _I32, _I32], C.c_int64),
     'k4_rgbnet_bwd': ([_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),

@@ -437,6 +437,101 @@ __global__ void k_occ_summary(const uint8_t* __restrict__ mask, int MX, int MY, 
     out[t] = bits;
 }
 
+// ---------------------------------------------------------------- "live" occupancy mask of the fused marcher (k4nerf.h)
+// The reference drops a sample when MaskGrid.forward says "free" (lib/dmpigo.py:308-313) OR when its activated density fails
+// alpha > fast_color_thres (lib/dmpigo.py:316-323, lib/dvgo.py:353-360).  mask_cache is a 3^3-dilated bound frozen at some earlier
+// time; on the LLFF scene 52 M samples pass it and only 12.6 M pass the alpha test that follows.  The second test can be bounded
+// from the density grid itself: trilinear interpolation never exceeds the largest of its 8 corner values, so a cell whose corner
+// maximum (+ the largest act_shift plane value it can see) cannot reach the threshold holds no surviving sample.
+//   k_cell_live : one thread per density cell (i,j,k) = [i,i+1]x[j,j+1]x[k,k+1]: live iff the bound passes (or any input is NaN)
+//   k_live_mask : one thread per MASK voxel: out = mask && OR(live cells a sample that rounds to this voxel can lie in)
+// `out` replaces `mask` in the geometry kernel's per-sample lookup: a sample is dropped there iff mask == 0 (the reference drops
+// it) or every cell it can lie in is dead (its alpha <= thres: the reference drops it one step later).  Rounding: the fp32
+// interpolation is sum_c w_c d_c with w_c >= 0 and sum w_c within 6 ulp of 1, each term rounded at most 8 times, so the computed
+// value is <= dmax + |dmax| 2^-20; the bound is evaluated in fp64 with 2^-17-relative and 1e-6-absolute head room (device expf /
+// powf / the 1 - 1/(1+e) form are within 2.4e-7 of the true alpha, tests/helpers.py NATIVE_TOL), index boxes carry a slack of
+// >= 16 ulp of the coordinate.  Conservative by construction; tests hold the fused kernels bit-identical with and without it.
+struct LiveParams {
+    const float* density; const float* act_shift; const uint8_t* mask;
+    int X, Y, Z, D, MX, MY, MZ;
+    double mn[3], len[3];          // xyz_min, xyz_max - xyz_min (fp32 values, widened)
+    double ms[3], mt[3];           // xyz2ijk_scale / shift of the MaskGrid
+    double shift, interval, thres;
+    int mpi;
+};
+
+__device__ __forceinline__ bool k4_not_finite_or_nan(float v) { return !(fabsf(v) <= 3.4028234e38f); }
+
+__global__ void k_cell_live(const LiveParams P, uint8_t* __restrict__ cell) {
+    const int CX = max(P.X - 1, 1), CY = max(P.Y - 1, 1), CZ = max(P.Z - 1, 1);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)CX * CY * CZ) return;
+    const int k = (int)(t % CZ), j = (int)((t / CZ) % CY), i = (int)(t / ((int64_t)CZ * CY));
+    const int i1 = min(i + 1, P.X - 1), j1 = min(j + 1, P.Y - 1), k1 = min(k + 1, P.Z - 1);
+    float dmax = -INFINITY;
+    bool odd = false;                                   // NaN / +inf anywhere: keep the cell
+    const int xs[2] = {i, i1}, ys[2] = {j, j1}, zs[2] = {k, k1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float d = P.density[((size_t)xs[a] * P.Y + ys[b]) * P.Z + zs[c]];
+                odd |= (d != d) | (d == INFINITY);
+                dmax = fmaxf(dmax, d);
+            }
+    double sb = dmax == -INFINITY ? -INFINITY : (double)dmax + fabs((double)dmax) * 7.62939453125e-6;          // 2^-17
+    if (P.mpi) {
+        // act_shift planes a sample of this z cell can interpolate between: ua = u_z (D-1)/(Z-1) with u_z in [k, k+1]
+        double lo = 0.0, hi = (double)(P.D - 1);
+        if (P.Z > 1) { const double r = (double)(P.D - 1) / (double)(P.Z - 1); lo = (double)k * r; hi = (double)(k + 1) * r; }
+        const int a0 = max((int)floor(lo) - 1, 0), a1 = min((int)floor(hi) + 2, P.D - 1);
+        float amax = -INFINITY;
+        for (int a = a0; a <= a1; ++a) { const float v = P.act_shift[a]; odd |= (v != v) | (v == INFINITY); amax = fmaxf(amax, v); }
+        sb += amax == -INFINITY ? -INFINITY : (double)amax + fabs((double)amax) * 7.62939453125e-6;
+    }
+    if (sb != -INFINITY) sb += fabs(sb) * 7.62939453125e-6 + 1e-6;
+    // alpha = 1 - (1 + exp(sigma + shift))^(-interval)   (render_utils_kernel.cu:439-441), monotone in sigma
+    const double ab = -expm1(-P.interval * log1p(exp(sb + P.shift)));
+    const bool live = odd || !(ab * (1.0 + 1e-5) + 1e-6 <= P.thres);
+    cell[t] = live ? 1 : 0;
+}
+
+__global__ void k_live_mask(const LiveParams P, const uint8_t* __restrict__ cell, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)P.MX * P.MY * P.MZ) return;
+    if (!P.mask[t]) { out[t] = 0; return; }
+    const int idx[3] = {(int)(t / ((int64_t)P.MZ * P.MY)), (int)((t / P.MZ) % P.MY), (int)(t % P.MZ)};
+    const int dims[3] = {P.X, P.Y, P.Z};
+    int c0[3], c1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // world-coordinate interval of the in-bbox points whose MaskGrid index (C round() of p*ms + mt, render_utils_kernel.cu:385-387)
+        // is idx[a]; ms == 0 (a 1-voxel axis) maps every point to index round(mt)
+        double plo = P.mn[a], phi = P.mn[a] + P.len[a];
+        if (P.ms[a] > 0.0) {
+            const double e = 0.5 + 16.0 * 5.9604644775390625e-8 * (fabs((double)idx[a]) + 1.0);          // half a voxel + 16 ulp of the index
+            plo = ((double)idx[a] - e - P.mt[a]) / P.ms[a];
+            phi = ((double)idx[a] + e - P.mt[a]) / P.ms[a];
+        }
+        // grid_sample coordinate u = (p - min)/(max - min) * (dim - 1)   (lib/grid.py:123, align_corners=True); samples outside the
+        // bbox never reach the lookup, so the cell range is clamped to the grid
+        const double s = (double)(dims[a] - 1) / P.len[a];
+        const double slack = 1e-3 + 16.0 * 5.9604644775390625e-8 * (double)dims[a];
+        const int nc = max(dims[a] - 1, 1);
+        c0[a] = (int)fmin(fmax(floor((plo - P.mn[a]) * s - slack), 0.0), (double)(nc - 1));
+        c1[a] = (int)fmin(fmax(floor((phi - P.mn[a]) * s + slack), 0.0), (double)(nc - 1));
+    }
+    const int CY = max(P.Y - 1, 1), CZ = max(P.Z - 1, 1);
+    bool live = false;
+    for (int i = c0[0]; i <= c1[0] && !live; ++i)
+        for (int j = c0[1]; j <= c1[1] && !live; ++j)
+            for (int k = c0[2]; k <= c1[2]; ++k)
+                if (cell[((size_t)i * CY + j) * CZ + k]) { live = true; break; }
+    out[t] = live ? 1 : 0;
+}
+
 // ================================================================ C ABI
 #define ST ((hipStream_t)stream)
 #define REQ(c) do { if (!(c)) return K4_ERR_BAD_ARG; } while (0)
@@ -608,6 +703,33 @@ extern "C" int k4_build_occupancy_summary(const uint8_t* mask, int32_t mx, int32
     REQ(mask && out && mx > 0 && my > 0 && mz > 0);
     const int ncx = (mx + K4_OCC_CELL - 1) / K4_OCC_CELL, ncy = (my + K4_OCC_CELL - 1) / K4_OCC_CELL, zw = (mz + 31) / 32;
     hipLaunchKernelGGL(k_occ_summary, dim3(k4_blocks((int64_t)ncx * ncy * zw)), dim3(K4_THREADS), 0, ST, mask, mx, my, mz, ncx, ncy, zw, out);
+    return k4_check_launch();
+}
+extern "C" int64_t k4_live_mask_workspace_bytes(int32_t x, int32_t y, int32_t z) {
+    if (x <= 0 || y <= 0 || z <= 0) return -1;
+    return (int64_t)(x > 1 ? x - 1 : 1) * (y > 1 ? y - 1 : 1) * (z > 1 ? z - 1 : 1);
+}
+extern "C" int k4_build_live_mask(const k4_grid_desc* g, float act_shift_scalar, float interval, float fast_color_thres,
+                                  uint8_t* workspace, uint8_t* out_mask, void* stream) {
+    REQ(g && g->density && g->mask && workspace && out_mask);
+    REQ(g->dims[0] > 0 && g->dims[1] > 0 && g->dims[2] > 0 && g->mask_dims[0] > 0 && g->mask_dims[1] > 0 && g->mask_dims[2] > 0);
+    REQ(fast_color_thres > 0.f && interval > 0.f);
+    REQ(!g->act_shift || g->act_depth > 0);
+    LiveParams P{};
+    P.density = g->density; P.act_shift = g->act_shift; P.mask = g->mask;
+    P.X = g->dims[0]; P.Y = g->dims[1]; P.Z = g->dims[2]; P.D = g->act_depth;
+    P.MX = g->mask_dims[0]; P.MY = g->mask_dims[1]; P.MZ = g->mask_dims[2];
+    for (int a = 0; a < 3; ++a) {
+        P.mn[a] = (double)g->xyz_min[a];
+        P.len[a] = (double)(g->xyz_max[a] - g->xyz_min[a]);                  // the fp32 difference the kernels divide by (lib/grid.py:123)
+        REQ(P.len[a] > 0.0);
+        P.ms[a] = (double)g->xyz2ijk_scale[a]; P.mt[a] = (double)g->xyz2ijk_shift[a];
+    }
+    P.shift = (double)act_shift_scalar; P.interval = (double)interval; P.thres = (double)fast_color_thres;
+    P.mpi = g->act_shift != nullptr;
+    const int64_t ncell = k4_live_mask_workspace_bytes(P.X, P.Y, P.Z);
+    hipLaunchKernelGGL(k_cell_live, dim3(k4_blocks(ncell)), dim3(K4_THREADS), 0, ST, P, workspace);
+    hipLaunchKernelGGL(k_live_mask, dim3(k4_blocks((int64_t)P.MX * P.MY * P.MZ)), dim3(K4_THREADS), 0, ST, P, workspace, out_mask);
     return k4_check_launch();
 }
 extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {

@@ -219,7 +219,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, **_ignored):
+                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, k4_live_mask=True, **_ignored):
         assert near == 0 and far == 1                                     # lib/dmpigo.py:275
         Nr = rays_o.shape[0]
         dev = rays_o.device
@@ -230,10 +230,12 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
             depth = torch.empty([Nr], dtype=torch.float32, device=dev)
             ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
-        gd = self._k4_grid(act_shift_grid=self.act_shift.grid)
         md, _keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
         N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278
         interval = float(stepsize * self.voxel_size_ratio)                # lib/dmpigo.py:306
+        # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
+        gd = self._k4_grid(act_shift_grid=self.act_shift.grid,
+                           live=(0.0, interval) if (k4_live_mask and k4_counters is None) else None)
         if Nr > 0:
             ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot)
             N.check(N.lib().k4_march_mpi_fwd(

@@ -28,6 +28,7 @@ from . import render_utils_cuda
 from . import train_ops
 
 _FUSED_WIDTHS = (32, 64, 128)
+_LIVE_MASK = os.environ.get('K4_LIVE_MASK', '1') != '0'      # A/B switch of the density-derived live mask (identical results)
 
 
 class _FusedMarcher:
@@ -63,19 +64,44 @@ class _FusedMarcher:
             c['k0_key'], c['k0_cl'], c['k0_cpad'] = key, out, CP
         return c['k0_cl'], c['k0_cpad']
 
-    def _k4_occ_summary(self):
-        """Load-time coarse occupancy summary of mask_cache.mask (k4_build_occupancy_summary), cached per mask version: lets the
+    def _k4_occ_summary(self, m=None, slot='occ'):
+        """Load-time coarse occupancy summary of a mask (k4_build_occupancy_summary), cached per mask version: lets the
         geometry kernel skip 16-sample groups of a ray that cannot touch an occupied voxel (identical results)."""
-        m = self.mask_cache.mask
-        key = ('occ', m.data_ptr(), m._version, str(m.device))
+        m = self.mask_cache.mask if m is None else m
+        key = (slot, m.data_ptr(), m._version, str(m.device))
         c = self._k4_cache()
-        if c.get('occ_key') != key:
+        if c.get(slot + '_key') != key:
             mx, my, mz = (int(v) for v in m.shape)
             nbytes = int(N.lib().k4_occupancy_summary_bytes(mx, my, mz))
             out = torch.empty([nbytes // 4], dtype=torch.int32, device=m.device)
             N.check(N.lib().k4_build_occupancy_summary(N.ptr(m), mx, my, mz, N.ptr(out), N.stream()), 'k4_build_occupancy_summary')
-            c['occ_key'], c['occ'] = key, out
-        return c['occ']
+            c[slot + '_key'], c[slot] = key, out
+        return c[slot]
+
+    def _k4_live_mask(self, gd, act_shift_grid, shift, interval):
+        """mask_cache.mask AND "some density cell a sample of this voxel can lie in reaches alpha > fast_color_thres"
+        (k4_build_live_mask): the geometry kernel looks samples up in THIS mask, so the density stage no longer runs on samples that
+        the reference drops one step later at lib/dmpigo.py:319-323 / lib/dvgo.py:356-360.  Bit-identical outputs; cached per
+        density / act_shift / mask version and per (shift, interval, threshold).  Returns (live mask, its coarse summary)."""
+        dens, m = self.density.grid, self.mask_cache.mask
+        key = ('live', dens.data_ptr(), dens._version, m.data_ptr(), m._version, str(m.device), float(shift), float(interval),
+               float(self.fast_color_thres)) + ((act_shift_grid.data_ptr(), act_shift_grid._version) if act_shift_grid is not None else ())
+        c = self._k4_cache()
+        if c.get('live_key') != key:
+            X, Y, Z = (int(v) for v in dens.shape[2:])
+            ws = torch.empty([int(N.lib().k4_live_mask_workspace_bytes(X, Y, Z))], dtype=torch.uint8, device=m.device)
+            out = torch.empty(list(m.shape), dtype=torch.uint8, device=m.device)
+            N.check(N.lib().k4_build_live_mask(N.C.byref(gd), float(shift), float(interval), float(self.fast_color_thres),
+                                               N.ptr(ws), N.ptr(out), N.stream()), 'k4_build_live_mask')
+            occ = self._k4_occ_summary(out, slot='occ_live')
+            ev = torch.cuda.Event()
+            ev.record()
+            c['live_key'], c['live'], c['live_ev'], c['live_seen'] = key, (out, occ), ev, {N.stream().value}
+        elif N.stream().value not in c['live_seen']:
+            # first use on another HIP stream: order it behind the build (streams forked before the build would race with it)
+            torch.cuda.current_stream().wait_event(c['live_ev'])
+            c['live_seen'].add(N.stream().value)
+        return c['live']
 
     def _k4_mlp(self, k0_skip, spatial_pe):
         md = N.MlpDesc()
@@ -122,7 +148,9 @@ class _FusedMarcher:
             c[('workspace', slot)] = ws
         return ws, need
 
-    def _k4_grid(self, act_shift_grid=None):
+    def _k4_grid(self, act_shift_grid=None, live=None):
+        """k4_grid_desc of this model.  live = (act_shift scalar, interval): look samples up in the live mask (_k4_live_mask)
+        instead of mask_cache.mask -- the render path; None: the MaskGrid itself (sample counters, fast_color_thres == 0)."""
         gd = N.GridDesc()
         dens = self.density.grid
         k0cl, cpad = self._k4_k0_channel_last()
@@ -138,7 +166,6 @@ class _FusedMarcher:
         mc = self.mask_cache
         gd.mask = mc.mask.data_ptr()
         gd.mask_dims = (N.C.c_int32 * 3)(*[int(v) for v in mc.mask.shape])
-        gd.occ_summary = self._k4_occ_summary().data_ptr()
         c = self._k4_cache()
         hkey = ('host3', str(dens.device)) + tuple((t.data_ptr(), t._version) for t in
                                                    (self.xyz_min, self.xyz_max, mc.xyz2ijk_scale, mc.xyz2ijk_shift))
@@ -146,14 +173,25 @@ class _FusedMarcher:
             c['host_key'] = hkey
             c['host'] = (N.vec3(self.xyz_min), N.vec3(self.xyz_max), N.vec3(mc.xyz2ijk_scale), N.vec3(mc.xyz2ijk_shift))
         gd.xyz_min, gd.xyz_max, gd.xyz2ijk_scale, gd.xyz2ijk_shift = c['host']
+        if live is not None and self.fast_color_thres > 0 and _LIVE_MASK:
+            lm, occ = self._k4_live_mask(gd, act_shift_grid, live[0], live[1])
+            gd.mask = lm.data_ptr()
+            gd.occ_summary = occ.data_ptr()
+        else:
+            gd.occ_summary = self._k4_occ_summary().data_ptr()
         return gd
 
-    def k4_warm(self):
-        """Build every load-time cache of the fused path (k0 channel-last repack, packed rgbnet, host copies of the bbox) on the
-        current stream.  Callers that fan work out over several HIP streams call this before forking them."""
+    def k4_warm(self, stepsize=None):
+        """Build every load-time cache of the fused path (k0 channel-last repack, packed rgbnet, host copies of the bbox and, when the
+        caller names the render stepsize, the live mask) on the current stream.  Callers that fan work out over several HIP streams
+        call this before forking them."""
         if self._k4_fusable():
             act = getattr(self, 'act_shift', None)
-            self._k4_grid(act_shift_grid=act.grid if isinstance(act, nn.Module) else None)
+            mpi = isinstance(act, nn.Module)
+            live = None
+            if stepsize is not None:
+                live = (0.0 if mpi else self._k4_host_scalar('act_shift', act), float(stepsize * self.voxel_size_ratio))
+            self._k4_grid(act_shift_grid=act.grid if mpi else None, live=live)
             if self.rgbnet is not None:
                 self._k4_mlp(k0_skip=0, spatial_pe=0)
 
@@ -406,7 +444,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, **_ignored):
+                       k4_img_w=0, k4_counters=None, k4_out=None, k4_ws_slot=0, k4_live_mask=True, **_ignored):
         Nr = rays_o.shape[0]
         dev = rays_o.device
         if k4_out is not None:                  # caller-provided outputs (e.g. slices of an all-gather send buffer)
@@ -416,10 +454,12 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
             depth = torch.empty([Nr], dtype=torch.float32, device=dev)
             ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
-        gd = self._k4_grid()
         md, _keep = self._k4_mlp(k0_skip=0 if (self.rgbnet is None or self.rgbnet_direct) else 3, spatial_pe=0)
         stepdist = float(stepsize * self.voxel_size)                       # lib/dvgo.py:310
         interval = float(stepsize * self.voxel_size_ratio)                # lib/dvgo.py:341
+        act_shift = self._k4_host_scalar('act_shift', self.act_shift)
+        # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
+        gd = self._k4_grid(live=(act_shift, interval) if (k4_live_mask and k4_counters is None) else None)
         depth_n = int((self.max_world_size - 1) / stepsize) + 1           # lib/dvgo.py:311
         diag = self._k4_host_scalar('diag', (self.xyz_max - self.xyz_min).norm())
         max_steps = int(np.ceil(diag / stepdist)) + 2
@@ -431,7 +471,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot)
         N.check(N.lib().k4_march_dvgo_fwd(
             N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
-            float(near), 1e9, stepdist, max_steps, depth_n, self._k4_host_scalar('act_shift', self.act_shift), interval,
+            float(near), 1e9, stepdist, max_steps, depth_n, act_shift, interval,
             float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes, N.f32(rgb), N.f32(depth), N.f32(ainv),
             None if k4_counters is None else N.ptr(k4_counters), N.stream()), 'k4_march_dvgo_fwd')
         ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb}

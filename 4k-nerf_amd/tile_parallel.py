@@ -156,7 +156,7 @@ def hip_march_fn(model, render_kwargs):
         o = model(ro, rd, vd, k4_img_w=window_w, k4_ws_slot=8 + slot, **kw)
         return o['rgb_feature'], o['depth']
     fn.k4_slots = True
-    fn.k4_warm = model.k4_warm
+    fn.k4_warm = lambda: model.k4_warm(stepsize=kw.get('stepsize'))
     return fn
 
 

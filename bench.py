@@ -95,7 +95,7 @@ class MarcherRun:
         self.outs = [(b[:3 * n_band].view(n_band, 3), b[3 * slot:3 * slot + n_band], b[4 * slot:4 * slot + n_band]) for b in self.send]
         self.works = [None, None]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_streams))]
-        model.k4_warm()                        # load-time caches on the current stream, before the side streams fork
+        model.k4_warm(stepsize=rk.get('stepsize'))      # load-time caches on the current stream, before the side streams fork
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream())
 
@@ -140,6 +140,9 @@ class MarcherRun:
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # per-frame completion intervals inside the overlapped region (end event of frame i - end event of frame i-1): a single slow
+        # frame shows in the spread, the median is what a long run converges to
+        self.frame_intervals_ms = [ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, steps)]
         return float(t.item()), float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     def isolated(self, n):
@@ -159,16 +162,33 @@ class MarcherRun:
                     iso.append((e0, e1))
                     self.model(ro, rd, vd, k4_img_w=self.W, k4_counters=cnt, k4_out=self.outs[0], k4_ws_slot=0, **self.rk)
             self.sync()
-        return float(np.mean([a.elapsed_time(b) for a, b in iso])), [c / n for c in cnt.cpu().tolist()]
+        self.iso_ms_all = [a.elapsed_time(b) for a, b in iso]
+        return float(np.mean(self.iso_ms_all)), [c / n for c in cnt.cpu().tolist()]
+
+
+def marcher_source_sha1():
+    """Fingerprint of the marcher's kernel source: profiles/*_marcher_traffic.json records the one it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ('k4_march.hip', 'k4_common.h'):
+        h.update(open(os.path.join(ROOT, '4k-nerf_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:12]
 
 
 def newest_traffic_profile():
-    """HBM-side bytes per launch: PMC passes of this command, committed under profiles/ (the newest round's file)."""
+    """HBM-side bytes per launch: PMC passes of this command, committed under profiles/ (the newest round's file).  The file names
+    the kernel source it was measured on; a mismatch with the tree being benchmarked is stamped, not hidden."""
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_marcher_traffic.json')))
     if not files:
         return None, None
     tj = json.load(open(files[-1]))
-    return int(tj['fabric_bytes_per_launch']), os.path.relpath(files[-1], ROOT) + (' @ ' + tj['commit'] if 'commit' in tj else '')
+    src = os.path.relpath(files[-1], ROOT) + (' @ ' + tj['commit'] if 'commit' in tj else '')
+    have = marcher_source_sha1()
+    if tj.get('kernel_source_sha1') == have:
+        src += ' (kernel source matches this tree)'
+    else:
+        src += f' (STALE: measured on kernel source {tj.get("kernel_source_sha1", "unrecorded")}, this tree is {have})'
+    return int(tj['fabric_bytes_per_launch']), src
 
 
 def main():
@@ -234,7 +254,9 @@ def main():
         res = {
             'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
             'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(eff_ms, 4), 'higher_is_better': True,
+            'ms_per_step': round(eff_ms, 4), 'ms_per_step_median': round(float(np.median(run.frame_intervals_ms)), 4) if run.frame_intervals_ms else None,
+            'ms_per_step_p90': round(float(np.percentile(run.frame_intervals_ms, 90)), 4) if run.frame_intervals_ms else None,
+            'higher_is_better': True,
             'scaling': 'strong' if by_rows or world == 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: LLFF fern_lg_pretrain render_test 1008x756, DirectMPIGO '
                                    '417x353x256 grid, 256 samples/ray, rgbnet 15->64->64->3, marcher only (no SR)'
@@ -248,7 +270,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'marcher call = k4_geom3_kernel<MPI> + k4_order_kernel + k4_shade_kernel<MPI,64,1,b3>, isolated (1 stream, HIP events)',
-                         'kernel_ms': round(iso_ms, 4), 'overlapped_launch_ms': round(overlapped_ms, 4),
+                         'kernel_ms': round(iso_ms, 4), 'kernel_ms_median': round(float(np.median(run.iso_ms_all)), 4),
+                         'overlapped_launch_ms': round(overlapped_ms, 4),
                          'algorithmic_bytes_per_launch': int(b_alg),
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
                                                 'shaded': int(n_shade)}},
@@ -264,7 +287,18 @@ def main():
             four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32')
             four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3', keep=keep)
         keep.clear()
+    joint_dp = None
+    if world > 1 and not args.small and not args.no_extras:
+        # BASELINE configs[4]: one 64x64 patch per rank, gradients exchanged over RCCL (every rank runs it; rank 0 reports)
+        full_rays = None
+        with torch.no_grad():
+            from nerf4k_amd.lib import dvgo as _dv
+            full_rays = [x.reshape(-1, 3).contiguous() for x in
+                         _dv.get_rays_of_a_view(H, W, K, torch.from_numpy(poses[0]).to(dev), True, False, False, False)]
+        joint_dp = _side(joint_train_step, ck, full_rays, H, W, dev, 4, world, rank)
     if rank == 0:
+        if joint_dp is not None:
+            res['joint_train_step'] = joint_dp
         if four_k is not None:
             res['four_k'] = four_k
         if four_k_fp32 is not None:
@@ -274,6 +308,8 @@ def main():
             res['own_staged_pipeline'] = _side(own_staged_pipeline, model, run.rays[0], rk)
             res['training_step_kernels'] = _side(training_step_kernels, dev, run.rays[0], model)
             res['joint_train_step'] = _side(joint_train_step, ck, run.rays[0], H, W, dev)
+            res['reference_pipeline_rocm'] = _side(reference_pipeline_rocm, ck, run.rays[0], dev)
+            res['dvgo_config0'] = _side(dvgo_config0, dev, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
@@ -507,7 +543,7 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
     return out
 
 
-def joint_train_step(ck, frame_rays, H, W, dev, iters=4):
+def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
     """BASELINE configs[4] on ONE GPU: iterations of the joint loop (run_sr.py:801-1061 -> 4k-nerf_amd/joint_train.JointTrainer.step) at
     the sizes of configs/llff/fern_lg_joint_l1.py -- a 64x64 ray patch of the 1008x756 view marched through the full 417x353x256
     scene under autograd, SFTNet(5 blocks) x4 to 256x256, L1 + L1 + entropy + distortion + per-point rgb, backward, dense
@@ -527,6 +563,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4):
     ro, rd, vd = (x.reshape(H, W, 3) for x in frame_rays)
 
     def batch(i):
+        i = i * world + rank                 # data parallel: every rank its own patch (run_sr.py:829-835 is the per-rank unit)
         r0, c0 = (37 * i) % (H - pr), (101 * i) % (W - pc)
         rays = [x[r0:r0 + pr, c0:c0 + pc].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
         return rays + [torch.rand([pr * pc, 3], device=dev, generator=gen), torch.rand([16 * pr * pc, 3], device=dev, generator=gen), pr, pc]
@@ -538,6 +575,18 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4):
         tr.step(*batch(1 + i), global_step=2 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / iters
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ex = tr.last_exchange or {}
+        return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'n_gpus': world,
+                'rays_per_iteration': pr * pc * world, 'patches_per_iteration': world, 'first_loss': round(first, 5),
+                'gradient_exchange': {'sparse_bytes_gathered_per_rank': int(ex.get('bytes_gathered', 0)),
+                                      'dense_bucket_bytes': int(ex.get('bytes_dense', 0)),
+                                      'touched_voxels_per_rank': [{'counts': c, 'of': v} for c, v in ex.get('touched', [])]},
+                'workload': f'configs[4] fern_lg_joint_l1, patch-parallel over {world} GPUs: one 64x64 patch per rank, decoder + small tensors in ONE '
+                            'all-reduce bucket, voxel-grid gradients as (index, value) lists in ONE all-gather per grid (RCCL)'}
     # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
     b = batch(9)
     torch.cuda.synchronize()
@@ -605,6 +654,80 @@ def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):
         dt = (time.perf_counter() - t) / frames
     return {'value': round(ro.shape[0] / dt / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(dt * 1e3, 2),
             'what': 'reference op sequence, per-op launches of our own staged kernels, 8192-ray chunks, same GPU'}
+
+
+def reference_pipeline_rocm(ck, frame_rays, dev, frames=2, chunk=8192):
+    """Denominator of north_star's ">= 30x the reference single-GPU Mrays/s" (BASELINE.md B1): the REFERENCE's pipeline on
+    this MI355X -- its own lib/cuda/render_utils_kernel.cu compiled for gfx950 (oracle/_ref, MEASUREMENT ONLY: never loaded by the
+    product) serving every native step, F.grid_sample / nn.Linear-shaped torch ops for the rest, boolean-mask compactions with
+    their host syncs, in the 8192-ray chunk loop of run_sr.py:121-124 -- as oracle/marcher.py restates DirectMPIGO.forward."""
+    from oracle import build_ref, marcher
+    if not os.path.exists(build_ref.so_path('render_utils_cuda_ref')):
+        return {'error': 'oracle/_ref/render_utils_cuda_ref.so not built (needs /root/reference in the build container)'}
+    ref = build_ref.load('render_utils_cuda_ref')
+    sd = {k: v.to(dev) for k, v in ck['model_state_dict'].items()}
+    ro, rd, vd = frame_rays
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    saved = marcher.nat
+    marcher.nat = ref
+    try:
+        with torch.no_grad():
+            marcher.forward('DirectMPIGO', ck['model_kwargs'], sd, ro[:2 * chunk], rd[:2 * chunk], vd[:2 * chunk], chunk=chunk, **rk)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(frames):
+                out = marcher.forward('DirectMPIGO', ck['model_kwargs'], sd, ro, rd, vd, chunk=chunk, **rk)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / frames
+    finally:
+        marcher.nat = saved
+    return {'value': round(ro.shape[0] / dt / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(dt * 1e3, 2), 'rays': int(ro.shape[0]),
+            'mean_rgb': round(float(out['rgb_marched'].mean()), 5),
+            'what': 'reference pipeline on 1x MI355X: the reference\'s own render_utils_cuda kernels (hipified by its own build call, '
+                    'oracle/build_ref.py) + torch-ROCm eager ops, 8192-ray chunks; measurement only'}
+
+
+def dvgo_config0(dev, with_oracle=True):
+    """BASELINE configs[0] at its own size on the GPU: DirectVoxGO 160^3, rgbnet_dim 12, viewbase_pe 4, rgbnet 39->128->128->3,
+    stepsize 0.5, 64x64 rays (configs/default.py:107-119) -- HIP event time of the fused call, parity against the CPU oracle, and
+    an 800x800 frame of the same scene for a throughput figure of k4_geom3_kernel<DVGO> / k4_shade_kernel<DVGO,128,1>."""
+    from nerf4k_amd import scene
+    from nerf4k_amd.lib import utils, dvgo
+    from oracle import marcher
+    ck = scene.make_lego_checkpoint()
+    model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
+    rk = ck['render_kwargs']
+    out = {'workload': 'configs[0]: nerf_synthetic-lego-like DirectVoxGO ' + 'x'.join(str(int(v)) for v in model.world_size.tolist())
+                       + ', rgbnet 39->128->128->3 (fp32-input MFMA), stepsize 0.5'}
+    pose = scene.lego_pose()
+    with torch.no_grad():
+        for H in (64, 800):
+            K = scene.lego_K(H, H)
+            ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in
+                          dvgo.get_rays_of_a_view(H, H, K, torch.from_numpy(pose[:3, :4].astype(np.float32)).to(dev), False, False, False, False)]
+            cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+            model(ro, rd, vd, k4_img_w=H, k4_counters=cnt, **rk)
+            got = model(ro, rd, vd, k4_img_w=H, **rk)
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); model(ro, rd, vd, k4_img_w=H, **rk); b.record()
+                ev.append((a, b))
+            torch.cuda.synchronize()
+            ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+            inb, msk, alp, shd = cnt.cpu().tolist()
+            b_alg = H * H * 56 + inb + msk * 32 + shd * 8 * model.k0_dim * 4
+            out[f'{H}x{H}'] = {'ms': round(ms, 4), 'mrays_per_s': round(H * H / (ms * 1e-3) / 1e6, 2),
+                               'samples': {'in_bbox': inb, 'mask': msk, 'alpha': alp, 'shaded': shd},
+                               'algorithmic_GBs': round(b_alg / (ms * 1e-3) / 1e9, 1)}
+            if H == 64 and with_oracle:
+                want = marcher.forward('DirectVoxGO', ck['model_kwargs'], ck['model_state_dict'], ro.cpu(), rd.cpu(), vd.cpu(), **rk)
+                d = got['rgb_marched'].cpu().double() - want['rgb_marched'].double()
+                mse = float((d ** 2).mean())
+                out['64x64']['psnr_vs_oracle_db'] = round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1)
+                out['64x64']['max_abs_vs_oracle'] = float(d.abs().max())
+    return out
 
 
 def cpu_baseline(ck, pose, stride, model=None):

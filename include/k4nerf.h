@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      4       /* 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -71,6 +71,21 @@ typedef struct k4_grid_desc {
 #define K4_OCC_SHIFT 3
 int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz);
 int k4_build_occupancy_summary(const uint8_t* mask, int32_t mx, int32_t my, int32_t mz, uint32_t* out, void* stream);
+
+/* "Live" mask of the fused marchers (load-time, cached by the host per density / act_shift / mask version and per
+ * (interval, threshold)): out_mask[v] = mask[v] && (some density cell that a sample rounding to mask voxel v can lie in has
+ * raw2alpha(max of its 8 corner densities + the largest act_shift plane value it can see + act_shift_scalar) > fast_color_thres,
+ * evaluated with head room for every fp32 rounding of the kernels).  Trilinear interpolation never exceeds its corner maximum, so a
+ * sample that out_mask drops is one the reference drops either at MaskGrid.forward (lib/dmpigo.py:308-313, lib/dvgo.py:345-350)
+ * or at the alpha > fast_color_thres test that follows it (lib/dmpigo.py:316-323, lib/dvgo.py:353-360): passing out_mask (and its
+ * k4_build_occupancy_summary) as k4_grid_desc.mask / .occ_summary leaves every output of k4_march_*_fwd bit-identical, while the
+ * density stage stops running on samples that cannot survive it.  (The `mask-pass` counter of out_counters then counts out_mask.)
+ *   grid      : density, dims, act_shift / act_depth (MPI; NULL for DVGO), mask, mask_dims, xyz_min/max, xyz2ijk_* are read
+ *   workspace : k4_live_mask_workspace_bytes(X, Y, Z) bytes of device scratch (one byte per density cell)
+ *   out_mask  : [MX][MY][MZ] bytes.   fast_color_thres must be > 0 (with 0 the reference keeps every sample). */
+int64_t k4_live_mask_workspace_bytes(int32_t x, int32_t y, int32_t z);
+int k4_build_live_mask(const k4_grid_desc* grid, float act_shift_scalar, float interval, float fast_color_thres,
+                       uint8_t* workspace, uint8_t* out_mask, void* stream);
 
 /* Colour MLP `Sequential(Linear, ReLU, [Sequential(Linear, ReLU)] x n_hidden, Linear)`
  * (lib/dmpigo.py:112-120, lib/dvgo.py:116-124), repacked by the host into ONE contiguous fp32 buffer in

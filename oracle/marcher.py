@@ -139,7 +139,7 @@ def _pe(v, freq):
 
 def _segment_sum(src, index, n):
     """torch_scatter.segment_coo(src, index, out=zeros, reduce='sum') for sorted index."""
-    out = torch.zeros([n] + list(src.shape[1:]), dtype=src.dtype)
+    out = torch.zeros([n] + list(src.shape[1:]), dtype=src.dtype, device=src.device)
     if src.numel():
         out.index_add_(0, index, src)
     return out
@@ -167,8 +167,9 @@ def mpi_forward(model_kwargs, sd, rays_o, rays_d, viewdirs, near=0, far=1, steps
     pts, mask_outbbox = nat.sample_ndc_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, N_samples)
     mask_inbbox = ~mask_outbbox
     ray_pts = pts.view(-1, 3)[mask_inbbox.view(-1)]
-    ray_id = torch.arange(N).view(-1, 1).expand_as(mask_inbbox)[mask_inbbox]
-    step_id = torch.arange(N_samples).view(1, -1).expand_as(mask_inbbox)[mask_inbbox]
+    dev = rays_o.device          # CPU everywhere except bench.py's `reference_pipeline_rocm` leg (reference-compiled kernels on the GPU)
+    ray_id = torch.arange(N, device=dev).view(-1, 1).expand_as(mask_inbbox)[mask_inbbox]
+    step_id = torch.arange(N_samples, device=dev).view(1, -1).expand_as(mask_inbbox)[mask_inbbox]
     n_inbbox = ray_pts.shape[0]
 
     # skip known free space (lib/dmpigo.py:309-313)

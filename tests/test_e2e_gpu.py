@@ -137,6 +137,24 @@ def test_full_frame_tile_parallel_equals_tile_process_device(full_scene):
     _assert_same_frame(single, got)
 
 
+def test_full_4k_frame_vs_oracle(full_scene):
+    """The WHOLE 4032x3024 frame of BASELINE configs[2] (/root/reference/run_sr.py:1361-1390: render_viewpoints -> tile_process at
+    test_tile=510): HIP march of all 762,048 rays + SFTNet x4 over the 4 reference windows against the CPU oracle's march + the
+    reference module's tile_process on the same rays.  Tolerance as stated at the top of this file (>= 90 dB, 99.9 % within 1e-4)."""
+    ck, model, net, sd = full_scene
+    H, W = scene.LLFF_HW
+    pose = scene.llff_spiral_poses()[2]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    want, o = _oracle_frame(ck, H, W, scene.LLFF_K, pose, sd, 510)
+    rays = dvgo.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(pose).cuda(), True, False, False, False)
+    res = render.render_frame(model, H, W, scene.LLFF_K, pose, True, ck['render_kwargs'], rays=rays)
+    _close(res['rgb_feature'].reshape(-1, 3), o['rgb_feature'], min_psnr=80.0, tol=2e-5)
+    got = net.tile_process_device(res['rgb_feature'].permute(2, 0, 1).unsqueeze(0).contiguous(), res['depth'].unsqueeze(0), 510)
+    assert got.shape == want.shape == (1, 3, 4 * H, 4 * W)
+    p = _close(got, want)
+    print(f'whole 4K frame: HR PSNR vs oracle {p:.1f} dB, max abs {float((got.cpu() - want).abs().max()):.2e}')
+
+
 def test_render_viewpoints_contract():
     """run_sr.py:75-182: return tuple (rgbs, depths, bgmaps, psnrs, viewdirs_all, rgb_features), shapes, clamped rgb vs UNclamped
     feature (:130-131), psnr against gt, render_factor, flipy / rot90, values against the oracle."""

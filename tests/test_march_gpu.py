@@ -397,3 +397,153 @@ def test_training_ray_tables_and_coarse_geometry_hits():
     hit_all = torch.cat([model.hit_coarse_geo(rays_o=ro[i], rays_d=rd[i], **rk).reshape(-1) for i in range(3)]).cpu().numpy()
     assert (hit_all != want_keep).sum() <= 4
     assert torch.equal(ro_m, ro.reshape(-1, 3)[torch.from_numpy(hit_all).cuda()])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Live mask (k4_build_live_mask): mask_cache AND a per-cell upper bound of alpha.  Contract: every output of the fused
+# marcher is BIT-IDENTICAL with and without it -- it only removes samples the reference drops at `alpha > fast_color_thres`.
+# ---------------------------------------------------------------------------------------------------------------------
+def _llff_rays(H, W, frame=7):
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    return [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[frame], ndc=True)]
+
+
+def _lego_rays(H, W, theta=40.):
+    return [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, scene.lego_K(H, W), scene.lego_pose(theta_deg=theta), ndc=False)]
+
+
+def _live_state(model, rk):
+    """(live mask, mask) of a model for the render kwargs `rk`."""
+    mpi = isinstance(model.act_shift, torch.nn.Module)
+    interval = float(rk['stepsize'] * model.voxel_size_ratio)
+    shift = 0.0 if mpi else float(model.act_shift)
+    model._k4_grid(act_shift_grid=model.act_shift.grid if mpi else None, live=(shift, interval))
+    return model._k4_cache()['live'][0], model.mask_cache.mask
+
+
+LIVE = [
+    ('mpi', dict(seed=31, num_voxels=64 * 64 * 48, mpi_depth=48)),
+    ('mpi', dict(seed=34, num_voxels=56 * 56 * 64, mpi_depth=64, stepsize=0.5)),                       # interval != 1: the powf form
+    ('mpi', dict(seed=36, num_voxels=60 * 60 * 40, mpi_depth=40, mask_cache_world_size=[33, 29, 23])),  # mask coarser than the density grid
+    ('mpi', dict(seed=37, num_voxels=40 * 40 * 32, mpi_depth=32, mask_cache_world_size=[77, 71, 90])),  # mask finer than the density grid
+    ('dvgo', dict(seed=41, num_voxels=48 ** 3)),
+    ('dvgo', dict(seed=42, num_voxels=40 ** 3, rgbnet_direct=False, rgbnet_dim=9, rgbnet_width=64, viewbase_pe=2)),
+]
+
+
+@pytest.mark.parametrize('kind,cfg', LIVE)
+def test_live_mask_outputs_bit_identical(kind, cfg):
+    ck = scene.make_llff_checkpoint(**cfg) if kind == 'mpi' else scene.make_lego_checkpoint(**cfg)
+    model = _model(ck)
+    rk = ck['render_kwargs']
+    H, W = (90, 120) if kind == 'mpi' else (64, 64)
+    rays = _llff_rays(H, W) if kind == 'mpi' else _lego_rays(H, W)
+    a = model(*rays, k4_img_w=W, **rk)
+    b = model(*rays, k4_img_w=W, k4_live_mask=False, **rk)
+    for k in ('rgb_marched', 'depth', 'alphainv_last'):
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    live, mask = _live_state(model, rk)
+    assert live.shape == mask.shape and bool((live.bool() <= mask).all())          # a subset of the MaskGrid
+    assert 0 < int(live.sum()) < int(mask.sum())                                  # and a strict one on these scenes
+    # every sample the reference keeps after `mask_cache` AND `alpha > thres` (lib/dmpigo.py:308-323, lib/dvgo.py:345-360) passes
+    # the lookup in the live mask
+    pts = model.sample_ray(rays_o=rays[0], rays_d=rays[1], **rk)[0]             # in-bbox points (both classes compact them)
+    m1 = model.mask_cache(pts)
+    pts = pts[m1]
+    interval = rk['stepsize'] * model.voxel_size_ratio
+    dens = model.density(pts) + (model.act_shift(pts) if kind == 'mpi' else 0)
+    alpha = model.activate_density(dens, interval)
+    keep = pts[alpha > model.fast_color_thres]
+    assert keep.shape[0] > 1000
+    mc = model.mask_cache
+    hit = ruc.maskcache_lookup(live.bool(), keep.contiguous(), mc.xyz2ijk_scale, mc.xyz2ijk_shift)
+    assert bool(hit.all()), int((~hit).sum())
+    # and it is worth having: fewer samples reach the density stage
+    n_mask = int(m1.sum())
+    n_live = int(ruc.maskcache_lookup(live.bool(), pts.contiguous(), mc.xyz2ijk_scale, mc.xyz2ijk_shift).sum())
+    assert keep.shape[0] <= n_live < n_mask, (keep.shape[0], n_live, n_mask)
+
+
+@pytest.mark.parametrize('kind', ['mpi', 'dvgo'])
+def test_live_mask_adversarial_density_at_the_threshold(kind):
+    """Every voxel within a few 1e-6 .. 1e-2 of the density at which alpha == fast_color_thres, all-ones MaskGrid: cells sit on both
+    sides of the bound and rounding decides -- the outputs must still be bit-identical (the bound keeps head room, it never guesses)."""
+    if kind == 'mpi':
+        ck = scene.make_llff_checkpoint(seed=61, num_voxels=48 * 48 * 40, mpi_depth=40)
+    else:
+        ck = scene.make_lego_checkpoint(seed=62, num_voxels=40 ** 3)
+    model = _model(ck)
+    rk = ck['render_kwargs']
+    thres = float(model.fast_color_thres)
+    interval = float(rk['stepsize'] * model.voxel_size_ratio)
+    # sigma* with 1 - (1 + exp(sigma*))^(-interval) == thres
+    sig = float(np.log(np.power(1.0 - thres, -1.0 / interval) - 1.0))
+    g = torch.Generator().manual_seed(9)
+    d = model.density.grid
+    noise = torch.randn(d.shape, generator=g) * torch.pow(10.0, torch.randint(-6, -1, d.shape, generator=g).float())
+    with torch.no_grad():
+        if kind == 'mpi':
+            zi = torch.linspace(0, model.act_shift.grid.numel() - 1, d.shape[-1]).round().long()
+            base = sig - model.act_shift.grid.reshape(-1)[zi].cpu()                      # per-plane bias removed: density + act_shift ~ sigma*
+            d.copy_((base.view(1, 1, 1, 1, -1) + noise).to(d.device))
+        else:
+            d.copy_((sig - float(model.act_shift) + noise).to(d.device))
+        model.mask_cache.mask.fill_(True)
+    from torch.autograd.graph import increment_version
+    increment_version(model.mask_cache.mask)
+    H, W = (60, 80) if kind == 'mpi' else (48, 48)
+    rays = _llff_rays(H, W, frame=3) if kind == 'mpi' else _lego_rays(H, W, theta=100.)
+    a = model(*rays, k4_img_w=W, **rk)
+    b = model(*rays, k4_img_w=W, k4_live_mask=False, **rk)
+    for k in ('rgb_marched', 'depth', 'alphainv_last'):
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    live, mask = _live_state(model, rk)
+    frac = float(live.float().mean())
+    assert 0.02 < frac < 0.98, frac                       # the scene really straddles the bound
+    assert float(a['alphainv_last'].min()) < 0.999        # and something was composited
+
+
+def test_live_mask_tracks_parameter_versions():
+    """The cache re-keys on density / mask versions and on (stepsize -> interval): an edit after a render is seen by the next one."""
+    ck = scene.make_llff_checkpoint(seed=63, num_voxels=40 * 40 * 32, mpi_depth=32)
+    model = _model(ck)
+    rk = ck['render_kwargs']
+    rays = _llff_rays(48, 64)
+    a = model(*rays, k4_img_w=64, **rk)
+    with torch.no_grad():
+        model.density.grid.add_(3.0)                      # in-place: bumps ._version
+    b = model(*rays, k4_img_w=64, **rk)
+    b0 = model(*rays, k4_img_w=64, k4_live_mask=False, **rk)
+    assert torch.equal(b['rgb_marched'], b0['rgb_marched']) and not torch.equal(a['rgb_marched'], b['rgb_marched'])
+    c = model(*rays, k4_img_w=64, **dict(rk, stepsize=0.5))
+    c0 = model(*rays, k4_img_w=64, k4_live_mask=False, **dict(rk, stepsize=0.5))
+    assert torch.equal(c['rgb_marched'], c0['rgb_marched']) and torch.equal(c['depth'], c0['depth'])
+
+
+def test_dvgo_config0_at_baseline_size():
+    """BASELINE configs[0] at ITS size (configs/default.py:107-119, configs/syn/syn_default.py): DirectVoxGO
+    160^3, rgbnet_dim 12, viewbase_pe 4 -> rgbnet 39->128->128->3, stepsize 0.5, near/far 2/6, white background, 64x64 rays from
+    pose_spherical(30, -30, 4) -- fused kernels (k4_geom3_kernel<DVGO>, k4_shade_kernel<DVGO,128,1>) against the CPU oracle."""
+    ck = scene.make_lego_checkpoint()
+    kw = ck['model_kwargs']
+    assert kw['num_voxels'] == 160 ** 3 and kw['rgbnet_dim'] == 12 and kw['rgbnet_width'] == 128 and kw['viewbase_pe'] == 4
+    model = _model(ck)
+    assert model.world_size.tolist() == [160, 160, 160]
+    H = W = 64
+    K = scene.lego_K(H, W)
+    pose = scene.lego_pose()
+    cnt = torch.zeros(4, dtype=torch.int64, device='cuda')
+    rays = marcher.get_rays_of_a_view(H, W, K, pose, ndc=False)
+    res = render.render_frame(model, H, W, K, pose[:3, :4], False, dict(ck['render_kwargs'], k4_counters=cnt),
+                              rays=[x.cuda() for x in rays])
+    ro, rd, vd = [x.reshape(-1, 3) for x in rays]
+    want = marcher.forward('DirectVoxGO', kw, ck['model_state_dict'], ro, rd, vd, **ck['render_kwargs'])
+    _cmp(res['rgb_marched'].reshape(-1, 3), want['rgb_marched'], 'rgb')
+    _cmp(res['depth'].reshape(-1), want['depth'], 'depth')
+    _cmp(res['alphainv_last'].reshape(-1), want['alphainv_last'], 'alphainv')
+    _check_counters(cnt, want['counters'], kw['fast_color_thres'])
+    assert want['counters']['n_shade'] > 20000                              # the frame really sees the object
+    # the render path (live mask) gives the counting path's pixels
+    live = render.render_frame(model, H, W, K, pose[:3, :4], False, ck['render_kwargs'], rays=[x.cuda() for x in rays])
+    assert torch.equal(live['rgb_marched'], res['rgb_marched']) and torch.equal(live['depth'], res['depth'])
