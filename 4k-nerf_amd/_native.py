@@ -111,21 +111,19 @@ _EXTRA_SIGS = {
     'k4_conv_weight_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_sft_weight_floats': ([_I32], C.c_int64),
     'k4_sft_nhwc': ([_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I64, _F, _P, _I32, _F, _P], C.c_int),
-    'k4_conv_weight_bf16x3_bytes': ([_I32, _I32, _I32], C.c_int64),
-    'k4_conv2d_nhwc_bf16x3': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
-                               _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_masked_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_adam_upd_with_perlr': ([_P, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_total_variation_add_grad': ([_P, _P, _F, _F, _F, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     'k4_conv_weight_bf16x6_bytes': ([_I32, _I32, _I32], C.c_int64),
+    'k4_conv_weight_f16x3_bytes': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_nhwc_bf16x6': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                                _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_sft_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F,
                                          C.POINTER(SftEpilogue), _P], C.c_int),
-    'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P, _P], C.c_int),
+    'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_bias_grad': ([_P, _I32, _I32, _I64, _P, _P], C.c_int),

@@ -126,14 +126,11 @@ struct K4Env {
     int shade_grid_wg;   // K4_SHADE_GRID_WG    persistent shading workgroups per CU
     int debug;           // K4_DEBUG        (0) ablation bits, profiling only
     int serp;            // K4_SERP         (1) serpentine ray order inside an 8x8 tile
-    int b6_nw1;          // K4_B6_NW1       (8) waves per workgroup of the 32-output-channel bf16x6 convolution
-    int sr_variant;      // K4_SR_VARIANT   (0) experiment selector of the decoder kernels
     int sr_small;        // K4_SR_SMALL     (1) 0: never use the 8-row tile form of the 3x3 convolution for small launches
-    int sr_static;       // K4_SR_STATIC    (0) 1: never use the persistent tile loop of the 3x3 convolution
     int geom_band;       // K4_GEOM_BAND    (1) rows of workgroup tiles per XCD band of the geometry kernel (0: one contiguous band per XCD)
     int shade_grid_tenths; // K4_SHADE_GRID_TENTHS (0) > 0: persistent shading workgroups = CUs x tenths / 10 (overrides K4_SHADE_GRID_WG; pipelined-rate A/B)
     int sr_3t_rpw;       // K4_SR_3T_RPW    (4) the same knob for the default 3-term kernel
-    int sr_2t_rpw;       // K4_SR_2T_RPW    (2) output rows per wave of the 2-term 3x3 convolution for launches beyond the small-launch rule (2 | 3 | 4):
+    int sr_2t_rpw;       // K4_SR_2T_RPW    (2) output rows per wave of the 2-term (bf16x3 / f16x3) 3x3 convolution for launches beyond the small-launch rule (2 | 3 | 4):
                          //                     8-row tiles measured 37.1 ms per 4K frame, 12-row 39.3, 16-row 38.5-38.8; 3 workgroups per CU: no gain / spills
 };
 const K4Env& k4_env();

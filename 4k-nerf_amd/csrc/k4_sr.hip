@@ -49,7 +49,6 @@ struct ConvMulti {
     const float* x[K4_MAX_JOBS]; float* y[K4_MAX_JOBS]; const float* res[K4_MAX_JOBS]; const float* modx[K4_MAX_JOBS];
     const float* sft_cond[K4_MAX_JOBS]; float* sft_y[K4_MAX_JOBS];     // fused SFT epilogue: condition map, optional second output
     int H[K4_MAX_JOBS], W[K4_MAX_JOBS], tiles_x[K4_MAX_JOBS];
-    int* queue;                            // persistent form: {next ticket, workgroups done}, zero at launch, reset by the last workgroup; NULL: one workgroup per tile
     int total;                             // workgroup-tiles of the launch
 };
 // -> this workgroup's window parameters and its tile index inside that window (workgroup-uniform)
@@ -184,124 +183,11 @@ __global__ __launch_bounds__(256) void k4_conv_kernel(const ConvParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Split-bf16 variant (opt-in, "bf16x3"): every fp32 operand is split into two bf16 numbers x = x_hi + x_lo
-// (x_hi = RNE_bf16(x), x_lo = RNE_bf16(x - x_hi): 16 significant bits) and a product is evaluated as
-// x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error ~2^-16 per
-// product instead of bf16's 2^-8, at 3 matrix instructions of 32 cycles per 32x32x16 block = 5.3x the rate of the
-// fp32-input MFMA.  Activations stay fp32 in HBM; the split happens while the input chunk is staged into LDS.
-// Same tiling as k4_conv_kernel; K is walked in chunks of 16 input channels (one MFMA K-step per tap).
+// Split-bf16 arithmetic on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): K is walked in chunks of KC2 = 16 input channels
+// (one MFMA K-step per tap); activations stay fp32 in HBM, the split happens while a chunk is staged into LDS.
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define KC2 16
-
-__device__ __forceinline__ unsigned k4_bf16_rne_bits(float x) {          // fp32 -> bf16 (round to nearest even), in the top 16 bits
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-}
-__device__ __forceinline__ void k4_split8(const float (&v)[8], uint4& hi, uint4& lo) {
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = k4_bf16_rne_bits(v[i]);
-        l[i] = k4_bf16_rne_bits(v[i] - __uint_as_float(h[i]));
-    }
-    hi = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
-    lo = make_uint4((l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]);
-}
-
-template <int KS, int NT>
-__global__ __launch_bounds__(256) void k4_conv_bf16x3_kernel(const ConvParams P) {
-    constexpr int TAPS = KS * KS;
-    constexpr int PADW = KS / 2;
-    constexpr int ROWS = TILE_H + 2 * PADW;
-    constexpr int COLS = TILE_W + 2 * PADW;
-    constexpr int NOUT = NT * 32;
-    __shared__ uint4 in_s[2][2][ROWS][COLS];          // [hi|lo][channel group of 8][row][col] x 8 bf16
-    __shared__ uint4 w_s[2][TAPS][2][NOUT];            // [hi|lo][tap][channel group][cout] x 8 bf16
-
-    const int lane = k4_lane();
-    const int wv = (int)(threadIdx.x >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int tile = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
-
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x16)(0.f);
-
-    const int nchunks = (P.cin + KC2 - 1) / KC2;
-    const uint4* wsrc_all = reinterpret_cast<const uint4*>(P.w);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * KC2;
-        // ---- stage + split the haloed input tile: items = (pixel, channel group of 8) ----
-        for (int it = (int)threadIdx.x; it < ROWS * COLS * 2; it += 256) {
-            const int kg = it & 1, p = it >> 1;
-            const int py = p / COLS, px = p - py * COLS;
-            const int gy = y0 - PADW + py, gx = x0 - PADW + px;
-            float v[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = 0.f;
-            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) {
-                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
-                const int cb = c0 + kg * 8;
-                const float* src = P.x + ((size_t)sy * P.srcW + sx) * P.cin_stride + cb;
-                if (cb + 8 <= P.cin && ((((size_t)src) & 15) == 0)) {
-                    const float4 a = *reinterpret_cast<const float4*>(src);
-                    const float4 b = *reinterpret_cast<const float4*>(src + 4);
-                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) if (cb + c < P.cin) v[c] = src[c];
-                }
-            }
-            uint4 hi, lo;
-            k4_split8(v, hi, lo);
-            in_s[0][kg][py][px] = hi;
-            in_s[1][kg][py][px] = lo;
-        }
-        // ---- stage this chunk's pre-split weights ([chunk][hi|lo][tap][group][cout] x 16 B, LDS order) ----
-        {
-            const uint4* src = wsrc_all + (size_t)ch * 2 * TAPS * 2 * NOUT;
-            uint4* dst = &w_s[0][0][0][0];
-            for (int i = (int)threadIdx.x; i < 2 * TAPS * 2 * NOUT; i += 256) dst[i] = src[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int dy = t / KS, dx = t - dy * KS;
-            bf16x8 ah[2], al[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ah[m] = __builtin_bit_cast(bf16x8, in_s[0][half][wv * 2 + m + dy][l31 + dx]);
-                al[m] = __builtin_bit_cast(bf16x8, in_s[1][half][wv * 2 + m + dy][l31 + dx]);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, w_s[0][t][half][n * 32 + l31]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, w_s[1][t][half][n * 32 + l31]);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    k4_conv_epilogue<NT>(P, acc, x0, y0, wv, half, l31);
-}
-
-template <int KS, int NT>
-static int launch_conv_bf16x3(const ConvParams& P, hipStream_t st) {
-    const dim3 grid((unsigned)(P.tiles_x * P.tiles_y)), block(256);
-    hipLaunchKernelGGL((k4_conv_bf16x3_kernel<KS, NT>), grid, block, 0, st, P);
-    return k4_check_launch();
-}
 
 template <int KS, int NT>
 static int launch_conv(const ConvParams& P, hipStream_t st) {
@@ -352,47 +238,6 @@ extern "C" int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
     return K4_ERR_UNSUPPORTED;
 }
 
-extern "C" int64_t k4_conv_weight_bf16x3_bytes(int32_t cout, int32_t cin, int32_t ksize) {
-    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
-    const int64_t nt = (cout + 31) / 32;
-    if (nt != 1 && nt != 2 && nt != 4) return -1;
-    return (int64_t)((cin + KC2 - 1) / KC2) * 2 * ksize * ksize * 2 * nt * 32 * 16;
-}
-
-extern "C" int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
-                                     const void* w_split, const float* bias, int32_t ksize,
-                                     float* y, int32_t cout, int32_t cout_stride,
-                                     int32_t H, int32_t W, uint32_t flags, float slope,
-                                     const float* res, int32_t res_stride, float res_scale,
-                                     const float* mod_x, int32_t mod_stride, void* stream) {
-    if (!x || !w_split || !bias || !y || cin <= 0 || cout <= 0 || H <= 0 || W <= 0) return K4_ERR_BAD_ARG;
-    if (cin_stride < cin || (ksize != 1 && ksize != 3)) return K4_ERR_BAD_ARG;
-    if ((flags & K4_EPI_RES) && (!res || res_stride <= 0)) return K4_ERR_BAD_ARG;
-    const bool modulate = (flags & K4_EPI_MODULATE) != 0;
-    if (modulate && (!mod_x || mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
-    if ((flags & K4_PRE_UPSAMPLE2X) && ((H & 1) || (W & 1))) return K4_ERR_BAD_ARG;
-    const int gemm_n = modulate ? 2 * cout : cout;
-    const int nt = (gemm_n + 31) / 32;
-    if (cout_stride < cout) return K4_ERR_BAD_ARG;
-    ConvParams P{};
-    P.x = x; P.cin = cin; P.cin_stride = cin_stride; P.w = (const float*)w_split; P.bias = bias;
-    P.y = y; P.cout = cout; P.cout_stride = cout_stride; P.H = H; P.W = W;
-    P.srcH = (flags & K4_PRE_UPSAMPLE2X) ? H / 2 : H; P.srcW = (flags & K4_PRE_UPSAMPLE2X) ? W / 2 : W;
-    P.flags = flags; P.slope = slope; P.res = res; P.res_stride = res_stride; P.res_scale = res_scale;
-    P.modx = mod_x; P.mod_stride = mod_stride;
-    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
-    hipStream_t st = (hipStream_t)stream;
-    if (ksize == 3) {
-        if (nt == 1) return launch_conv_bf16x3<3, 1>(P, st);
-        if (nt == 2) return launch_conv_bf16x3<3, 2>(P, st);
-    } else {
-        if (nt == 1) return launch_conv_bf16x3<1, 1>(P, st);
-        if (nt == 2) return launch_conv_bf16x3<1, 2>(P, st);
-        if (nt == 4) return launch_conv_bf16x3<1, 4>(P, st);
-    }
-    return K4_ERR_UNSUPPORTED;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // 3-term split ("bf16x6", the default decoder arithmetic): fp32-EQUIVALENT convolutions on the bf16 matrix pipe.
 // Every fp32 operand is split exactly into three bf16 terms v = v0 + v1 + v2 (8+8+8 significant bits, RNE of the running
@@ -424,6 +269,23 @@ __device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4
         p2[i] = k4s_pk_bf16(sa, sb);
     }
     t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]); t2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 k4s_f16x2 __attribute__((ext_vector_type(2)));
+// 4 channels, scaled by the power of two `sc` -> fp16 hi (RNE) and fp16 lo = RNE(x*sc - hi): x*sc == hi + lo up to 2^-22 relative
+__device__ __forceinline__ void k4s_split2h_x4(const float4& v, float sc, uint2& hi, uint2& lo) {
+    const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    unsigned ph[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const k4s_f32x2 x = {f[2 * i], f[2 * i + 1]};
+        const k4s_f16x2 h = __builtin_convertvector(x, k4s_f16x2);
+        const k4s_f32x2 r = x - __builtin_convertvector(h, k4s_f32x2);        // exact: hi is x rounded to 11 bits
+        const k4s_f16x2 l = __builtin_convertvector(r, k4s_f16x2);
+        ph[i] = __builtin_bit_cast(unsigned, h); pl[i] = __builtin_bit_cast(unsigned, l);
+    }
+    hi = make_uint2(ph[0], ph[1]); lo = make_uint2(pl[0], pl[1]);
 }
 
 __device__ __forceinline__ void k4s_split3x4(const float4& v, uint2& t0, uint2& t1, uint2& t2) {   // 4 channels -> 3 terms x 4 bf16
@@ -626,11 +488,6 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
     return T;
 }
 
-// PERSIST: 2 workgroups per CU pull tiles from a ticket counter until it runs out, and the chunk pipeline runs ACROSS tiles: the
-// raw activations of the next tile's first chunk are fetched under the MFMAs of the current tile's last chunk, the epilogue's
-// stores drain under the next tile's staging.  (Ablation on the 2080x2080 64->64 layer: of 1.9 ms, 0.58 ms were per-workgroup
-// prologue / epilogue latency that nothing overlapped -- the two workgroups of a CU run in phase -- and a static grid of 1649
-// tiles runs in 3.2 "rounds" of 512 and pays for 4.)
 // RPW = output rows per wave: 4 (16-row tiles) by default; 2 (8-row tiles, half the serial work per workgroup) for launches too
 // small to fill the chip with 16-row tiles -- the 209x209 windows of the 8-GPU job are 98 tiles per layer each.
 // SFT: the layer's output goes through the SFTLayer that follows it in the network (lib/sr_esrnet.py:120-123, 149-158) before it
@@ -640,12 +497,26 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 // NTERM = 2 (flag K4_ARITH_2TERM, the decoder's opt-in 'bf16x3' arithmetic): only the two leading split terms of both operands are
 // staged / loaded and 3 of the 6 products are formed (a1 b0 + a0 b1 + a0 b0, ~2^-16 relative per product) -- half the matrix
 // instructions, a third less LDS and register traffic, same packed weights (their third term is simply not read).
+// F16 (flag K4_ARITH_F16X3, the decoder's 'f16x3' arithmetic): 2-term splits in fp16 instead of bf16 -- 11 + 11 = 22 significant bits per
+// operand, 3 products (a_lo b_hi + a_hi b_lo + a_hi b_hi) on v_mfma_f32_32x32x16_f16, ~2^-21 relative per product against 2^-23 of the
+// 6-product bf16 form and 2^-16 of the 3-product bf16 form, at half the matrix instructions of the former.  fp16 has 5 exponent bits, so
+// both operands are scaled by powers of two (exact): the weights at packing time by 2^a[co] 2^b[chunk] (largest |w| of an output channel
+// -> [2^13, 2^14), then the largest scaled |w| of a 16-input-channel chunk -> [2^13, 2^14); the tables ride behind the packed
+// terms), the activations per 16-channel chunk of the tile being staged (largest magnitude
+// of the chunk's haloed tile -> [2^13, 2^14), found with one wave reduction + 4 LDS words under the previous chunk's MFMAs).  When the
+// scale changes between two chunks of a tile the accumulators are re-based by the exact power-of-two ratio.  Elements 2^-16 below the
+// largest one of their chunk start to lose bits of the low term (fp16 subnormals): an absolute error 2^-38 of the chunk's scale.
+// Same LDS footprint and loop structure as NTERM = 2.
 #ifndef K4_V2_MINWG_2T
 #define K4_V2_MINWG_2T 2   // workgroups per CU the 2-term instantiation's register allocation is bounded for (39 KB of LDS would allow 3-4)
 #endif
-template <bool PERSIST, int RPW, bool SFT = false, int NTERM = 3>
-__global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
+#ifndef K4_V2_MINWG_F16
+#define K4_V2_MINWG_F16 2
+#endif
+template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false>
+__global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
     static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
+    static_assert(!F16 || NTERM == 2, "the fp16 arithmetic is a 2-term split");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;
     constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
@@ -653,8 +524,8 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
     constexpr int NPIX = ROWS * COLS;                         // haloed input tile
     constexpr int IN_PER = (NPIX * 4 + THREADS - 1) / THREADS;   // staged items per thread: (pixel, QUARTER of the 16-channel chunk)
     constexpr int IN_PLANE = 2 * NPIX;                        // uint4 per term
-    __shared__ uint4 in_s[NTERM * IN_PLANE];                  // [term][channel group][row][col] x 8 bf16
-    __shared__ int ticket_sh;
+    __shared__ uint4 in_s[NTERM * IN_PLANE];                  // [term][channel group][row][col] x 8 bf16 (F16: 8 fp16)
+    __shared__ float smax[2][4];                              // F16: largest |activation| of the chunk being staged, per wave (double buffered)
     const ConvParams& P = M.base;                             // shared by every window: cin, strides, weights, bias, cout, flags ...
     const int nb_count = (P.cout + 31) >> 5;
     const int NOUT = nb_count * 32;
@@ -664,18 +535,12 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
     const int half = lane >> 5, l31 = lane & 31;
     const bool ups = (P.flags & K4_PRE_UPSAMPLE2X) != 0;
     const int nchunks = (P.cin + KC2 - 1) / KC2;
-    const int W_ITEMS = 3 * 9 * 2 * NOUT;                                    // 16-byte units of one chunk's split weights
+    const int W_ITEMS = (F16 ? 2 : 3) * 9 * 2 * NOUT;                       // 16-byte units of one chunk's split weights
     const bool vec_base = (P.cin_stride & 3) == 0;
 
-    int bcur;
-    if (PERSIST) {
-        if (tid == 0) ticket_sh = atomicAdd(&M.queue[0], 1);
-        __syncthreads();
-        bcur = ticket_sh;
-        __syncthreads();
-    } else bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (bcur < M.total) {
-    V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count, ups);
+    const V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count, ups);
 
     // Staging map: thread -> quarter q = tid&3 (4 channels = 16 bytes) of pixels pp = (tid>>2) + 64*i.  Four adjacent lanes read the
     // 64 contiguous bytes of one pixel's chunk, so a wave's load instruction touches 16 cache lines with 64 bytes each (the
@@ -747,116 +612,123 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
         const int t_ = (U) / RPW, r_ = (U) % RPW; \
         _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
 
-    bool first = true;
-    for (;;) {                                                               // tiles
-        int bnext = M.total;
-        V2Tile Tn = T;
-        if (PERSIST && tid == 0) ticket_sh = atomicAdd(&M.queue[0], 1);      // read by everyone after the first barrier below
-        f32x16 acc[RPW];
+    f32x16 acc[RPW];
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) acc[r] = (f32x16)(0.f);
+    for (int r = 0; r < RPW; ++r) acc[r] = (f32x16)(0.f);
+    // F16: power-of-two scale of the staged activations, one per 16-channel chunk of this tile (see the header comment): 2^sexp maps the
+    // chunk's largest magnitude into [2^13, 2^14) -- but the accumulators' base never rises more than 2^60 above the smallest base a
+    // chunk of this tile has had, so that re-basing them (an exact multiplication by 2^(new - old), either direction) cannot overflow
+    // fp32: a chunk adds at most 144 x 2^14 x 2^14 < 2^36 in its own units
+    // The weights carry their own power-of-two factors (packing time): 2^a[co] per output channel (undone per lane in the epilogue) and
+    // 2^b[chunk] per 16-input-channel chunk, which simply adds to the chunk's activation exponent: t = sexp + b is what the
+    // accumulators are based on.
+    int sexp = 0, tcur = 0, tmin = 1000;
+    const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(P.w) + (size_t)nchunks * W_ITEMS);     // [NOUT] 2^-a | [nchunks] b
+    if constexpr (F16) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(rv[i].x)), fabsf(rv[i].y)), fmaxf(fabsf(rv[i].z), fabsf(rv[i].w)));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) smax[0][wv] = m;
+        __syncthreads();
+    }
+    {
         for (int ch = 0; ch < nchunks; ++ch) {
-#ifndef K4_V2_WONCE
-            if (K4_V2_BRING == 2 && !first)
-#else
-            if (false)
-#endif
-            {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
+            if (K4_V2_BRING == 2 && ch > 0) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
                 for (int q = 0; q < NTERM; ++q) bbuf[0][q] = bbuf[1][q];
             }
-            first = false;
             // ---- split + store this chunk's haloed input tile ----
-#ifdef K4_V2_NOSTAGE      /* timing experiment only (WRONG results): stage the first chunk only */
-            if (ch == 0)
-#endif
+            if constexpr (F16) {
+                const float m = fmaxf(fmaxf(smax[ch & 1][0], smax[ch & 1][1]), fmaxf(smax[ch & 1][2], smax[ch & 1][3]));
+                const int eb = (int)((__float_as_uint(m) >> 23) & 0xffu);                 // biased exponent of the chunk's largest magnitude
+                const int enat = m > 0.f ? min(max(13 - (eb - 127), -100), 100) : 100;
+                const int bch = F16 ? reinterpret_cast<const int*>(wtail + NOUT)[ch] : 0;
+                tmin = min(tmin, enat + bch);
+                const int tnew = min(enat + bch, tmin + 60);
+                if (tnew != tcur && ch > 0) {                                              // workgroup-uniform
+                    const int d = tnew - tcur;
 #pragma unroll
-            for (int i = 0; i < IN_PER; ++i) {
-                uint2 t0, t1, t2;
-                k4s_split3x4(rv[i], t0, t1, t2);
-                if (sp0 + 64 * i < NPIX) {           // 8-byte unit of (term, channel group kg = q>>1, pixel, q&1); i*128 is a constant offset
-                    uint2* const d = in2 + sdst + i * 128;
-                    d[0] = t0; d[2 * IN_PLANE] = t1;
-                    if (NTERM == 3) d[4 * IN_PLANE] = t2;
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[r][e] = ldexpf(acc[r][e], d);
+                }
+                tcur = tnew;
+                sexp = tnew - bch;                                                         // <= enat: the chunk fits fp16
+                const float sc = ldexpf(1.f, sexp);
+#pragma unroll
+                for (int i = 0; i < IN_PER; ++i) {
+                    uint2 t0, t1;
+                    k4s_split2h_x4(rv[i], sc, t0, t1);
+                    if (sp0 + 64 * i < NPIX) {
+                        uint2* const d = in2 + sdst + i * 128;
+                        d[0] = t0; d[2 * IN_PLANE] = t1;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < IN_PER; ++i) {
+                    uint2 t0, t1, t2;
+                    k4s_split3x4(rv[i], t0, t1, t2);
+                    if (sp0 + 64 * i < NPIX) {           // 8-byte unit of (term, channel group kg = q>>1, pixel, q&1); i*128 is a constant offset
+                        uint2* const d = in2 + sdst + i * 128;
+                        d[0] = t0; d[2 * IN_PLANE] = t1;
+                        if (NTERM == 3) d[4 * IN_PLANE] = t2;
+                    }
                 }
             }
             __syncthreads();
-            if (PERSIST && ch == 0) bnext = ticket_sh;
-            // next staging unit: the next chunk of this tile, or the first chunk of the next tile (its loads fly during the MFMAs below)
-#if !defined(K4_V2_LATEPF) && !defined(K4_V2_NOLOAD)       /* NOLOAD: timing experiment only (WRONG results) */
+            // next staging unit: the next chunk of this tile (its loads fly during the MFMAs below)
             if (ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
-            else
-#endif
-            if (PERSIST && bnext < M.total) {
-                Tn = k4_v2_tile<TROWS>(M, bnext, nb_count, ups);
-                K4_V2_SETUP(Tn);
-                K4_V2_LOADRAW(0);
-            }
-            // ---- 9*RPW sub-stages u = tap*RPW + r: 6 MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
+            // ---- 9*RPW sub-stages u = tap*RPW + r: 6 (3) MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
             constexpr int AD = K4_V2_ARING - 1, BD = K4_V2_BRING - 1;
-            const bool last_chunk = ch + 1 == nchunks;
-            // the tap ring runs over the chunk boundary; at a tile boundary the next tile may use another output-channel block
-            const uint4* const wnext = last_chunk ? reinterpret_cast<const uint4*>(P.w) + half * NOUT + Tn.nb * 32 + l31 : wlane;
-            const int chn = last_chunk ? 0 : ch + 1;
+            const int chn = ch + 1 == nchunks ? 0 : ch + 1;                   // the tap ring runs over the chunk boundary
             uint4 abuf[K4_V2_ARING][3];
             K4_V2_READA(abuf[0], 0);
             if (AD == 2) K4_V2_READA(abuf[1], 1);
-#ifdef K4_V2_NOMFMA       /* timing experiment only (WRONG results): staging and barriers without the MFMA phase */
-            if (ch < 0)
-#endif
 #pragma unroll
             for (int u = 0; u < NSUB; ++u) {
                 const int t = u / RPW, r = u % RPW;
-#ifdef K4_V2_WONCE        /* timing experiment only (WRONG results): no weight loads inside the MFMA phase */
-                if (false) {
-#else
                 if (r == 0) {                                                // weights of tap t+BD
-#endif
                     if (t + BD < 9) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], ch, t + BD);
-                    else {
-                        const uint4* wp_ = wnext + (size_t)chn * W_ITEMS;
-#pragma unroll
-                        for (int q_ = 0; q_ < NTERM; ++q_) bbuf[(t + BD) % K4_V2_BRING][q_] = wp_[((q_ * 9 + (t + BD - 9)) * 2) * NOUT];
-                    }
+                    else K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], chn, t + BD - 9);
                 }
-#ifdef K4_V2_LATEPF       /* timing experiment only: the activation prefetch issued after the chunk's last weight load */
-                if (u == K4_V2_LATEPF * RPW && ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
-#endif
-#ifndef K4_V2_NOAREAD     /* timing experiment only (WRONG results): no A-fragment reads inside the MFMA phase */
                 if (u + AD < NSUB) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
-                {
+                if constexpr (F16) {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(f16x8, abuf[u % K4_V2_ARING][1]);
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][1]);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[r], 0, 0, 0);
+                } else {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
                                  a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][NTERM - 1]);
-#ifdef K4_V2_WONCE
-#define K4_BSLOT 0
-#else
-#define K4_BSLOT (t % K4_V2_BRING)
-#endif
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][1]),
-                                 b2 = __builtin_bit_cast(bf16x8, bbuf[K4_BSLOT][NTERM - 1]);
-#undef K4_BSLOT
-#ifdef K4_V2_DEPTEST      /* timing experiment only (WRONG results): consecutive MFMAs on different accumulators */
-#define K4_ACC(k) acc[(r + (k)) % RPW]
-#else
-#define K4_ACC(k) acc[r]
-#endif
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][1]),
+                                 b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][NTERM - 1]);
                     if (NTERM == 3) {
-                        K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, K4_ACC(0), 0, 0, 0);
-                        K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, K4_ACC(1), 0, 0, 0);
-                        K4_ACC(2) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, K4_ACC(2), 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[r], 0, 0, 0);
                     }
-                    K4_ACC(3) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, K4_ACC(3), 0, 0, 0);
-                    K4_ACC(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, K4_ACC(0), 0, 0, 0);
-                    K4_ACC(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, K4_ACC(1), 0, 0, 0);
-#undef K4_ACC
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[r], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifndef K4_V2_NOBAR       /* timing experiment only (WRONG results) */
+            if constexpr (F16) {
+                if (ch + 1 < nchunks) {              // the next chunk's largest magnitude (its raw values have landed under the MFMAs)
+                    float m = 0.f;
+#pragma unroll
+                    for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(rv[i].x)), fabsf(rv[i].y)), fmaxf(fabsf(rv[i].z), fabsf(rv[i].w)));
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                    if (lane == 0) smax[(ch + 1) & 1][wv] = m;
+                }
+            }
             __syncthreads();
-#endif
         }
         // ---- epilogue of tile T: lane holds output channel nb*32 + l31 of pixels x0 + row(reg, half) in rows y0 + wv*4 + r ----
         if constexpr (SFT) {
@@ -957,17 +829,13 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
                     else T.y[pix * P.cout_stride + co] = m;
                 }
             }
-        } else
-#ifdef K4_V2_NOEPI        /* timing experiment only (WRONG results): one store per lane instead of the epilogue */
-        { float sum_ = 0.f;
-          _Pragma("unroll") for (int r = 0; r < RPW; ++r) _Pragma("unroll") for (int e = 0; e < 16; ++e) sum_ += acc[r][e];
-          if (sum_ == 123.456f) T.y[lane] = sum_; }
-        if (false)
-#endif
-        {
+        } else {
             const int co = T.nb * 32 + l31;
             if (co < P.cout) {
                 const float bias = P.bias[co];
+                // F16: the accumulators are in units of 2^sexp (activations) x the weights' packing scale; both are powers of two
+                float unscale = 1.f;
+                if constexpr (F16) unscale = ldexpf(wtail[co], -tcur);
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
                     const int gy = T.y0 + wv * RPW + r;
@@ -977,7 +845,7 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
                         const int gx = T.x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
                         if (gx >= T.W) continue;
                         const size_t pix = (size_t)gy * T.W + gx;
-                        float v = acc[r][e] + bias;
+                        float v = F16 ? fmaf(acc[r][e], unscale, bias) : acc[r][e] + bias;
                         if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
                         if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
                         T.y[pix * P.cout_stride + co] = v;
@@ -985,19 +853,12 @@ __global__ __launch_bounds__(256, (NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_con
                 }
             }
         }
-        if (!PERSIST || bnext >= M.total) break;
-        T = Tn;
-        wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 + l31;
-    }   // tiles
+    }
     }
 #undef K4_V2_LOADB
 #undef K4_V2_READA
 #undef K4_V2_LOADRAW
 #undef K4_V2_SETUP
-    if (PERSIST && threadIdx.x == 0) {
-        // the last workgroup to leave re-arms the counters for the next launch that is handed this queue (same stream: ordered)
-        if (atomicAdd(&M.queue[1], 1) == (int)gridDim.x - 1) { M.queue[0] = 0; M.queue[1] = 0; }
-    }
 }
 
 static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
@@ -1028,28 +889,23 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         }
         total = count(4 * rpw);
     }
-    const int rpw_big = (M.base.flags & K4_ARITH_2TERM) ? k4_env().sr_2t_rpw : k4_env().sr_3t_rpw;      // tile height of launches beyond the small-launch rule
-    if (rpw == 4 && (rpw_big == 2 || rpw_big == 3) && !(M.queue && !k4_env().sr_static)) {
+    const bool two = (M.base.flags & (K4_ARITH_2TERM | K4_ARITH_F16X3)) != 0;
+    const int rpw_big = two ? k4_env().sr_2t_rpw : k4_env().sr_3t_rpw;      // tile height of launches beyond the small-launch rule
+    if (rpw == 4 && (rpw_big == 2 || rpw_big == 3)) {
         rpw = rpw_big;
         total = count(4 * rpw);
     }
     M.total = total;
-    if (M.base.sft_w) {
-        if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2, true>), dim3((unsigned)total), dim3(256), 0, st, M);
-        else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3, true>), dim3((unsigned)total), dim3(256), 0, st, M);
-        else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4, true>), dim3((unsigned)total), dim3(256), 0, st, M);
-        return k4_check_launch();
-    }
-    if (M.base.flags & K4_ARITH_2TERM) {
-        if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
-        else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
-        else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4, false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
-        return k4_check_launch();
-    }
-    if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 2>), dim3((unsigned)total), dim3(256), 0, st, M);
-    else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 3>), dim3((unsigned)total), dim3(256), 0, st, M);
-    else if (M.queue && total > slots && !k4_env().sr_static) hipLaunchKernelGGL((k4_conv_b6v2_kernel<true, 4>), dim3((unsigned)slots), dim3(256), 0, st, M);
-    else hipLaunchKernelGGL((k4_conv_b6v2_kernel<false, 4>), dim3((unsigned)total), dim3(256), 0, st, M);
+    const dim3 grid((unsigned)total), block(256);
+#define K4_V2_LAUNCH(...) do { \
+        if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, __VA_ARGS__>), grid, block, 0, st, M); \
+        else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<3, __VA_ARGS__>), grid, block, 0, st, M); \
+        else hipLaunchKernelGGL((k4_conv_b6v2_kernel<4, __VA_ARGS__>), grid, block, 0, st, M); } while (0)
+    if (M.base.sft_w) K4_V2_LAUNCH(true, 3, false);
+    else if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(false, 2, true);
+    else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(false, 2, false);
+    else K4_V2_LAUNCH(false, 3, false);
+#undef K4_V2_LAUNCH
     return k4_check_launch();
 }
 
@@ -1217,7 +1073,7 @@ extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_
 
 static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                          const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
-                         uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride, int32_t* tile_queue,
+                         uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
                          void* stream, const k4_sft_epilogue* sft = nullptr) {
     if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_split || !bias || cin <= 0 || cout <= 0) return K4_ERR_BAD_ARG;
     if (sft) {
@@ -1237,7 +1093,6 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
     P.cout = cout; P.cout_stride = cout_stride;
     P.flags = flags; P.slope = slope; P.res_stride = res_stride; P.res_scale = res_scale; P.mod_stride = mod_stride;
     M.n = n_jobs;
-    M.queue = tile_queue;
     for (int g = 0; g < n_jobs; ++g) {
         const k4_conv_job& j = jobs[g];
         if (!j.x || !j.y || j.H <= 0 || j.W <= 0) return K4_ERR_BAD_ARG;
@@ -1258,28 +1113,33 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
         return launch_conv_taps_b6(M, st);
     }
     if (sft) {
-        if (flags & K4_ARITH_2TERM) return K4_ERR_BAD_ARG;
+        if (flags & (K4_ARITH_2TERM | K4_ARITH_F16X3)) return K4_ERR_BAD_ARG;
         return launch_conv_b6v2(M, st);
     }
-    if (ksize == 3 && !modulate && (nt > 2 || k4_env().sr_variant == 0 || (flags & K4_ARITH_2TERM))) return launch_conv_b6v2(M, st);      // K4_SR_VARIANT=1: the v1 kernel (<= 64 channels)
-    const int nw1 = k4_env().b6_nw1;   // 4 (two 60 KB workgroups per CU) measured 7 % slower
+    if ((flags & K4_ARITH_2TERM) && (flags & K4_ARITH_F16X3)) return K4_ERR_BAD_ARG;
     if (ksize == 3) {
-        if (nt == 1) return nw1 == 4 ? launch_conv_b6<3, 1, 4>(M, st) : launch_conv_b6<3, 1, 8>(M, st);
-        if (nt == 2) return launch_conv_b6<3, 2, 8>(M, st);
-    } else {
-        if (nt == 1) return launch_conv_b6<1, 1, 8>(M, st);
-        if (nt == 2) return launch_conv_b6<1, 2, 8>(M, st);
-        if (nt == 4) return launch_conv_b6<1, 4, 8>(M, st);
+        if (modulate) return K4_ERR_UNSUPPORTED;               // no 3x3 layer of the decoder modulates (SFTLayer's convolutions are 1x1)
+        return launch_conv_b6v2(M, st);
     }
+    if (flags & (K4_ARITH_2TERM | K4_ARITH_F16X3)) return K4_ERR_BAD_ARG;      // 1x1 layers keep the 6-product form
+    if (nt == 1) return launch_conv_b6<1, 1, 8>(M, st);
+    if (nt == 2) return launch_conv_b6<1, 2, 8>(M, st);
+    if (nt == 4) return launch_conv_b6<1, 4, 8>(M, st);
     return K4_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t k4_conv_weight_f16x3_bytes(int32_t cout, int32_t cin, int32_t ksize) {
+    if (cout <= 3 || cin <= 0 || ksize != 3 || (cout + 31) / 32 > 8) return -1;
+    const int64_t nch = (cin + KC2 - 1) / KC2, nout = (int64_t)((cout + 31) / 32) * 32;
+    return nch * 2 * 9 * 2 * nout * 16 + nout * 4 + (nch + 3) / 4 * 16;            // split terms | [NOUT] fp32 2^-a[co] | [nch] int32 b[chunk] (padded to 16 B)
 }
 
 extern "C" int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                                            const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
                                            uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
-                                           int32_t* tile_queue, void* stream) {
+                                           void* stream) {
     return conv_b6_multi(jobs, n_jobs, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale,
-                         mod_stride, tile_queue, stream);
+                         mod_stride, stream);
 }
 
 extern "C" int k4_conv2d_sft_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
@@ -1288,7 +1148,7 @@ extern "C" int k4_conv2d_sft_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t 
                                                const k4_sft_epilogue* sft, void* stream) {
     if (!sft) return K4_ERR_BAD_ARG;
     return conv_b6_multi(jobs, n_jobs, cin, cin_stride, w_split, bias, 3, cout, cout_stride, flags, slope, res_stride, res_scale, 0,
-                         nullptr, stream, sft);
+                         stream, sft);
 }
 
 extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
@@ -1300,7 +1160,7 @@ extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_st
     k4_conv_job j{};
     j.x = x; j.y = y; j.res = res; j.mod_x = mod_x; j.H = H; j.W = W;
     return conv_b6_multi(&j, 1, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale, mod_stride,
-                         nullptr, stream);
+                         stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

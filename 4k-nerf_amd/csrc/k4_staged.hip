@@ -484,9 +484,14 @@ __global__ void k_cell_live(const LiveParams P, uint8_t* __restrict__ cell) {
     double sb = dmax == -INFINITY ? -INFINITY : (double)dmax + fabs((double)dmax) * 7.62939453125e-6;          // 2^-17
     if (P.mpi) {
         // act_shift planes a sample of this z cell can interpolate between: ua = u_z (D-1)/(Z-1) with u_z in [k, k+1]
-        double lo = 0.0, hi = (double)(P.D - 1);
-        if (P.Z > 1) { const double r = (double)(P.D - 1) / (double)(P.Z - 1); lo = (double)k * r; hi = (double)(k + 1) * r; }
-        const int a0 = max((int)floor(lo) - 1, 0), a1 = min((int)floor(hi) + 2, P.D - 1);
+        // (D == Z, the reference's configuration: both coordinates are the same fp32 value, the planes are exactly k and k+1)
+        int a0 = k, a1 = min(k + 1, P.D - 1);
+        if (P.D != P.Z) {
+            double lo = 0.0, hi = (double)(P.D - 1);
+            if (P.Z > 1) { const double r = (double)(P.D - 1) / (double)(P.Z - 1); lo = (double)k * r; hi = (double)(k + 1) * r; }
+            const double eps = 1e-3 + 16.0 * 5.9604644775390625e-8 * (double)P.D;
+            a0 = max((int)floor(lo - eps), 0); a1 = min((int)floor(hi + eps) + 1, P.D - 1);
+        }
         float amax = -INFINITY;
         for (int a = a0; a <= a1; ++a) { const float v = P.act_shift[a]; odd |= (v != v) | (v == INFINITY); amax = fmaxf(amax, v); }
         sb += amax == -INFINITY ? -INFINITY : (double)amax + fabs((double)amax) * 7.62939453125e-6;

@@ -21,6 +21,7 @@ import os
 import time
 from copy import deepcopy
 
+import numpy as np
 import torch
 from torch import nn as nn
 from torch.nn import functional as F
@@ -28,7 +29,8 @@ from torch.nn import init as init
 
 from .. import _native as N
 
-EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM = 2, 4, 8, 16, 32, 64
+EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
+DEFAULT_MODE = 'bf16x6'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
 
 
 @torch.no_grad()
@@ -119,12 +121,14 @@ class _Packed:
         wf = weight.detach().float()
         self.flags_extra = 0
         if mode == 'bf16x3':
-            # the opt-in 2-term arithmetic runs on the DEFAULT kernels: same packed weights as 'bf16x6', plain 3x3 layers form only the
-            # three leading products (K4_ARITH_2TERM); 1x1 layers and conv_last keep all six.  'bf16x3_v1' = the round-1 kernel + packing.
+            # the opt-in 2-term bf16 arithmetic runs on the DEFAULT kernels: same packed weights as 'bf16x6', plain 3x3 layers form only
+            # the three leading products (K4_ARITH_2TERM); 1x1 layers and conv_last keep all six.
             mode = 'bf16x6'
             if k == 3 and cout > 3:
                 self.flags_extra = ARITH_2TERM
-        self.mode = {'bf16x6_plain': 'bf16x6', 'bf16x3_v1': 'bf16x3'}.get(mode, mode)
+        if mode == 'f16x3' and not (k == 3 and cout > 3):
+            mode = 'bf16x6'                       # 1x1 layers and conv_last keep the 6-product bf16 form
+        self.mode = {'bf16x6_plain': 'bf16x6', 'f16x3': 'bf16x6'}.get(mode, mode)      # the entry point family that runs it
         if mode == 'fp32':
             kc = 8
             nch = (cin + kc - 1) // kc
@@ -139,6 +143,28 @@ class _Packed:
             inner = _Packed(w1, torch.zeros([9 * cout], dtype=torch.float32, device=dev), 'bf16x6_plain')
             self.w = inner.w
             self.flags_extra |= W_TAPS_AS_COUT
+        elif mode == 'f16x3':
+            # 2-term fp16 split of w * 2^a[co] * 2^b[chunk] (include/k4nerf.h, K4_ARITH_F16X3)
+            self.flags_extra = ARITH_F16X3
+            nch = (cin + 15) // 16
+            w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)
+            w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+            def exp_to(v):          # integer e with v * 2^e in [2^13, 2^14); 0 for zero / non-finite entries
+                e = 13 - torch.floor(torch.log2(v.double().clamp_min(1e-300)))
+                return torch.where((v > 0) & torch.isfinite(v), e, torch.zeros_like(e)).clamp(-100, 100).to(torch.int32)
+            a = exp_to(w.abs().amax((0, 1)))                                              # [NOUT] per output channel
+            w1 = torch.ldexp(w, a.view(1, 1, -1))
+            bq = exp_to(w1.reshape(k * k, nch, 16, nt * 32).abs().amax((0, 2, 3)))       # [nch] per input-channel chunk, >= 0
+            ws = torch.ldexp(w1, bq.repeat_interleave(16).view(1, -1, 1))
+            hi = ws.to(torch.float16)                                 # round to nearest even, as the kernel splits activations
+            lo = (ws - hi.float()).to(torch.float16)
+            both = torch.stack([hi, lo], 0)                            # [2][taps][nch*16][NOUT]
+            both = both.reshape(2, k * k, nch, 2, 8, nt * 32).permute(2, 0, 1, 3, 5, 4).contiguous()   # [nch][2][taps][2][NOUT][8]
+            unscale = torch.ldexp(torch.ones([nt * 32], dtype=torch.float32, device=dev), -a)
+            btab = torch.zeros([(nch + 3) // 4 * 4], dtype=torch.int32, device=dev)
+            btab[:nch] = bq
+            self.w = torch.cat([both.view(torch.int16).reshape(-1), unscale.view(torch.int16), btab.view(torch.int16)])
+            assert self.w.numel() * 2 == N.lib().k4_conv_weight_f16x3_bytes(cout, cin, k)
         elif mode in ('bf16x6', 'bf16x6_plain'):
             nch = (cin + 15) // 16
             w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)
@@ -152,15 +178,7 @@ class _Packed:
             self.w = terms.view(torch.int16)
             assert self.w.numel() * 2 == N.lib().k4_conv_weight_bf16x6_bytes(cout, cin, k)
         else:
-            nch = (cin + 15) // 16
-            w = torch.zeros([k * k, nch * 16, nt * 32], dtype=torch.float32, device=dev)
-            w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
-            hi = w.to(torch.bfloat16)                                  # round to nearest even, as the kernel splits activations
-            lo = (w - hi.float()).to(torch.bfloat16)
-            both = torch.stack([hi, lo], 0)                            # [2][taps][nch*16][NOUT]
-            both = both.reshape(2, k * k, nch, 2, 8, nt * 32).permute(2, 0, 1, 3, 5, 4).contiguous()   # [nch][2][taps][2][NOUT][8]
-            self.w = both.view(torch.int16)
-            assert self.w.numel() * 2 == N.lib().k4_conv_weight_bf16x3_bytes(cout, cin, k)
+            raise ValueError(f'unknown decoder arithmetic {mode!r}')
         self.b = torch.zeros([nt * 32], dtype=torch.float32, device=dev)
         self.b[:cout] = bias.detach().float()
         self.cin, self.k = cin, k
@@ -292,8 +310,9 @@ class SFTNet(nn.Module):
         # 'bf16x6' (default): exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation --
         #            fp32-equivalent (dropped terms <= 2^-23 per product; 126 dB vs the fp32 oracle) at 2.67x less matrix time;
         # 'fp32'  : v_mfma_f32_32x32x2_f32, exact fp32 FMA chains;
-        # 'bf16x3': 2-term splits, 3 products, ~2^-16 per product (opt-in fast path, ~100 dB)
-        self.k4_mode = os.environ.get('K4_SR_MODE', 'bf16x6')
+        # 'f16x3' : 2-term fp16 splits with power-of-two scaling (22 significant bits per operand), 3 products on the 3x3 layers;
+        # 'bf16x3': 2-term bf16 splits, 3 products, ~2^-16 per product (opt-in fast path, ~100 dB)
+        self.k4_mode = os.environ.get('K4_SR_MODE', DEFAULT_MODE)
 
     # ------------------------------------------------------------------ reference graph (autograd path)
     def _forward_torch(self, x, cond, fea=None):
@@ -372,8 +391,7 @@ class SFTNet(nn.Module):
         """y[..., y_off:y_off+cout] = epilogue(conv(x[..., x_off:x_off+pk.cin]))   (one window)"""
         rp, rs, rscale = (None, 0, 0.0) if res is None else (N.C.c_void_p(res[0].data_ptr() + 4 * res[1]), res[2], res[3])
         mp, ms = (None, 0) if mod is None else (N.C.c_void_p(mod[0].data_ptr() + 4 * mod[1]), mod[2])
-        fn = {'fp32': N.lib().k4_conv2d_nhwc, 'bf16x3': N.lib().k4_conv2d_nhwc_bf16x3,
-              'bf16x6': N.lib().k4_conv2d_nhwc_bf16x6}[pk.mode]
+        fn = {'fp32': N.lib().k4_conv2d_nhwc, 'bf16x6': N.lib().k4_conv2d_nhwc_bf16x6}[pk.mode]
         args = (N.C.c_void_p(x.data_ptr() + 4 * x_off), pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.k,
                 N.C.c_void_p(y.data_ptr() + 4 * y_off), cout, y_stride, H, W, flags | pk.flags_extra, 0.2,
                 rp, rs, rscale, mp, ms)
@@ -417,15 +435,8 @@ class SFTNet(nn.Module):
             N.check(fn(*args, N.stream()), 'k4_conv2d_sft_nhwc_bf16x6_multi')
             return
         fn = N.lib().k4_conv2d_nhwc_bf16x6_multi
-        # K4_SR_PERSIST=1 (opt-in, measured 3-20 % slower than the static grid): every recorded launch owns a ticket counter (2 ints,
-        # self-resetting) for the persistent, cross-tile pipelined form of the 3x3 kernel
-        queue = None
-        if plan is not None and os.environ.get('K4_SR_PERSIST', '0') == '1':
-            q = torch.zeros([2], dtype=torch.int32, device=Bs[0][xname].device)
-            plan.append((None, (q, q), 'keepalive'))
-            queue = N.ptr(q)
         args = (jobs, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), pkc.k, cout, y_stride, flags | pkc.flags_extra, 0.2,
-                rs, rscale, 0, queue)
+                rs, rscale, 0)
         if plan is not None:
             plan.append((fn, args, 'k4_conv2d_nhwc_bf16x6_multi'))
         N.check(fn(*args, N.stream()), 'k4_conv2d_nhwc_bf16x6_multi')

@@ -278,13 +278,17 @@ def main():
         }
         if secondary is not None:
             res['frames_sharded' if by_rows else 'rows_sharded'] = secondary
-    four_k = four_k_fp32 = four_k_fast = None
+    four_k = four_k_fp32 = four_k_fast = four_k_alt = None
     if args.sr_frames > 0 and not args.small:
         keep = {}
-        four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x6',
+        from nerf4k_amd.lib import sr_esrnet as _sr
+        default_mode = _sr.DEFAULT_MODE
+        other_mode = 'bf16x6' if default_mode == 'f16x3' else 'f16x3'
+        four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=default_mode,
                                check=not args.no_cpu_baseline, keep=keep)
         if not args.no_extras:
-            four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32')
+            four_k_alt = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=other_mode, keep=keep)
+            four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32', keep=keep)
             four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3', keep=keep)
         keep.clear()
     joint_dp = None
@@ -302,7 +306,7 @@ def main():
         if four_k is not None:
             res['four_k'] = four_k
         if four_k_fp32 is not None:
-            res['four_k_fp32mfma'], res['four_k_bf16x3'] = four_k_fp32, four_k_fast
+            res['four_k_fp32mfma'], res['four_k_bf16x3'], res['four_k_' + other_mode] = four_k_fp32, four_k_fast, four_k_alt
         if world == 1 and not args.small and not args.no_extras:
             # side measurements (single process, no collectives): a failure in one of them must not take the headline line with it
             res['own_staged_pipeline'] = _side(own_staged_pipeline, model, run.rays[0], rk)
@@ -372,32 +376,40 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
     tflops = flop_per_px * px / dt / 1e12
     base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'n_gpus': world, 'test_tile': tile,
             'effective_tflops': round(tflops, 2)}
-    if keep is not None and mode == 'bf16x6':
-        keep['hr'] = hr.clone()                    # the default arithmetic's frame: the 2-term mode is compared with it below
-    if mode == 'bf16x3':
-        base['arithmetic'] = ('SR 3x3 convs: the two leading bf16 split terms, 3 of the 6 MFMA products on the default kernel (opt-in '
-                              'K4_SR_MODE=bf16x3, K4_ARITH_2TERM; >= 75 dB vs the fp32 oracle in tests/test_sr_gpu.py)')
-        base['frac_of_bf16x3_floor'] = round(tflops / (2500.0 / 3 * world), 4)
+    primary = keep is not None and 'hr' not in keep       # the first arithmetic timed is the default one: the others are compared with its frame
+    if keep is not None and primary:
+        keep['hr'], keep['mode'] = hr.clone(), mode
+    if not primary:
+        per_product = {'bf16x3': 3, 'f16x3': 3, 'bf16x6': 6}.get(mode)
+        base['arithmetic'] = {
+            'bf16x3': 'SR 3x3 convs: the two leading bf16 split terms, 3 of the 6 MFMA products (opt-in K4_SR_MODE=bf16x3; >= 75 dB vs the fp32 oracle in tests/test_sr_gpu.py)',
+            'f16x3': 'SR 3x3 convs: 2-term fp16 splits with power-of-two scaling, 3 products on v_mfma_f32_32x32x16_f16 (K4_SR_MODE=f16x3; >= 110 dB vs fp32 in tests/test_sr_gpu.py)',
+            'bf16x6': 'SR convs: exact 3-term bf16 splits, 6 products on v_mfma_f32_32x32x16_bf16 (K4_SR_MODE=bf16x6)',
+            'fp32': 'SR convs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains; K4_SR_MODE=fp32)'}[mode]
+        if per_product:
+            base[f'frac_of_{mode}_floor'] = round(tflops / (2500.0 / per_product * world), 4)
+        else:
+            base['frac_of_fp32_mfma_peak'] = round(tflops / (157.3 * world), 4)
         if keep is not None and 'hr' in keep:      # same pose, same weights: the whole 4032x3024 frame against the default arithmetic's
             d = (hr.double() - keep['hr'].double())
             mse = float((d ** 2).mean())
-            base['psnr_vs_bf16x6_frame_db'] = round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1)
-            base['max_abs_vs_bf16x6_frame'] = float(d.abs().max())
+            base[f'psnr_vs_{keep["mode"]}_frame_db'] = round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1)
+            base[f'max_abs_vs_{keep["mode"]}_frame'] = float(d.abs().max())
         return base
-    if mode == 'fp32':
-        base['arithmetic'] = 'SR convs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains; K4_SR_MODE=fp32)'
-        base['frac_of_fp32_mfma_peak'] = round(tflops / (157.3 * world), 4)
-        return base
-    peak = 2500.0 / 6 * world
+    per_product = 3 if mode == 'f16x3' else 6
+    peak = 2500.0 / per_product * world
     base.update({
         'output': list(hr.shape), 'scaling': 'strong',
         'workload': ('configs[2]' if world == 1 else 'configs[3]') + ': march 1008x756 + SFTNet x4 tile_process('
                     f'{tile}, pad 10) -> 4032x3024' + (f', tiles of ONE frame sharded over {world} GPUs + RCCL all_gather of HR pixels' if world > 1 else ''),
-        'arithmetic': 'marcher fp32; SR convs: exact 3-term bf16 splits, 6 of 9 partial products on v_mfma_f32_32x32x16_bf16, '
-                      'fp32 accumulation (fp32-equivalent, dropped terms <= 2^-23 per product)',
+        'arithmetic': ('marcher fp32; SR convs: exact 3-term bf16 splits, 6 of 9 partial products on v_mfma_f32_32x32x16_bf16, '
+                       'fp32 accumulation (fp32-equivalent, dropped terms <= 2^-23 per product)') if mode == 'bf16x6' else
+                      ('marcher fp32; SR 3x3 convs: 2-term fp16 splits with power-of-two scaling (22 significant bits per operand), 3 of 4 '
+                       'partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation (~2^-21 per product); 1x1 / SFT / conv_last layers: '
+                       'exact 3-term bf16 splits'),
         'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
                         'frac': round(tflops / peak, 4), 'flop_per_frame': flop_per_px * px,
-                        'note': 'peak = 2.5 PFLOP/s dense bf16 / 6 MFMA per fp32-equivalent product x n_gpus; time includes the '
+                        'note': f'peak = 2.5 PFLOP/s dense bf16|fp16 / {per_product} MFMA per product x n_gpus; time includes the '
                                 'marcher, layout copies and the all-gather'}})
     if world == 1:                               # rank 0's share of the 8-GPU job (3 tiles of tile_size 189), timed on this GPU
         t189 = tp.tile_geometry(H, W, 189, 10)

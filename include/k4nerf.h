@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -256,6 +256,12 @@ int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, fl
 #define K4_ARITH_2TERM    64u    /* k4_conv2d_nhwc_bf16x6(_multi), plain 3x3 layers: use the two leading split terms of both operands only -- 3 of the
                                     6 products (a1 b0 + a0 b1 + a0 b0), ~2^-16 relative per product: the decoder's opt-in 'bf16x3' arithmetic on the
                                     default kernel (1x1 layers, K4_W_TAPS_AS_COUT and the fused-SFT entry ignore / reject it) */
+#define K4_ARITH_F16X3   128u    /* k4_conv2d_nhwc_bf16x6(_multi), plain 3x3 layers with cout > 3: 2-term splits in FP16 (22 significant bits per operand), 3
+                                    products on v_mfma_f32_32x32x16_f16, ~2^-21 relative per product; w_split is then the k4_conv_weight_f16x3_bytes()
+                                    buffer: [ceil(cin/16)][hi|lo][9][2 channel groups][32*NT][8] fp16 of w[co][ci] * 2^a[co] * 2^b[ci/16] (a: largest
+                                    |w| of the output channel -> [2^13, 2^14); b >= 0: largest scaled |w| of the chunk -> [2^13, 2^14)), followed by
+                                    [32*NT] fp32 2^-a[co] and [ceil(cin/16)] int32 b (padded to 16 bytes).  Activations are scaled per staged chunk
+                                    inside the kernel. */
 
 /* stride-1 "same" (zero padded) 3x3 or 1x1 convolution, NHWC:
  *   x        : [H_in][W_in][cin_stride], channels [0,cin) are read (pre-offset the pointer for a slice);
@@ -274,25 +280,13 @@ int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
                    const float* res, int32_t res_stride, float res_scale,
                    const float* mod_x, int32_t mod_stride, void* stream);
 
-/* Split-bf16 ("bf16x3") variant of the same convolution (opt-in): x = x_hi + x_lo with x_hi = RNE_bf16(x),
- * x_lo = RNE_bf16(x - x_hi); products as x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_bf16, fp32
- * accumulation -- ~2^-16 relative error per product, 5.3x the matrix rate of the fp32-input MFMA.  Activations stay
- * fp32 in memory.  w_split : k4_conv_weight_bf16x3_bytes() bytes =
- * [ceil(cin/16)][hi|lo][ksize*ksize][2 channel groups][32*NT][8] bf16 (zero padded).  Other arguments as above. */
-int64_t k4_conv_weight_bf16x3_bytes(int32_t cout, int32_t cin, int32_t ksize);
-int k4_conv2d_nhwc_bf16x3(const float* x, int32_t cin, int32_t cin_stride,
-                          const void* w_split, const float* bias, int32_t ksize,
-                          float* y, int32_t cout, int32_t cout_stride,
-                          int32_t H, int32_t W, uint32_t flags, float slope,
-                          const float* res, int32_t res_stride, float res_scale,
-                          const float* mod_x, int32_t mod_stride, void* stream);
-
 /* 3-term split ("bf16x6", default decoder arithmetic): same contract as k4_conv2d_nhwc, fp32-equivalent results.
  * x = x0 + x1 + x2 exactly (bf16 terms), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
  * the dropped terms are <= 2^-23 |x w| per product.  w_split : k4_conv_weight_bf16x6_bytes() bytes =
  * [ceil(cin/16)][3 terms][ksize*ksize][2 channel groups][32*NT][8] bf16 (zero padded, term t = RNE_bf16 of the remainder
  * after terms < t).  Replaces the same nn.Conv2d calls of lib/sr_esrnet.py:446-465. */
 int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_t ksize);
+int64_t k4_conv_weight_f16x3_bytes(int32_t cout, int32_t cin, int32_t ksize);      /* K4_ARITH_F16X3 operand; < 0: layer shape not covered */
 int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,
                           const void* w_split, const float* bias, int32_t ksize,
                           float* y, int32_t cout, int32_t cout_stride,
@@ -309,10 +303,7 @@ typedef struct k4_conv_job { const float* x; float* y; const float* res; const f
 int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                                 const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
                                 uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
-                                int32_t* tile_queue, void* stream);
-/* tile_queue: NULL, or 2 device ints that are ZERO when the launch starts (the kernel leaves them zero again): 3x3 layers with more
- * tiles than the chip holds at once then run as persistent workgroups pulling tiles from this counter (no partly filled last round).
- * Launches that may run concurrently must not share a queue. */
+                                void* stream);
 /* 3x3 convolution + the SFTLayer that follows it in the network, in ONE launch (lib/sr_esrnet.py:149-158: conv4 -> sft1, conv5 of one
  * dense block -> sft0 of the next): with v = the convolution's result after bias / K4_EPI_LRELU / K4_EPI_RES and
  * m = v*(scale(cond)+1) + shift(cond) (the arithmetic of k4_sft_nhwc_multi with K4_SFT_ARITH_BF16X6, bit-identical to running it

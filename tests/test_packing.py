@@ -95,7 +95,7 @@ def test_pack_mlp_sections_reproduce_the_weights(dim0, W, depth):
 
 
 @pytest.mark.parametrize('cout,cin,k', [(32, 160, 3), (64, 192, 3), (64, 3, 3), (3, 64, 3), (128, 64, 1), (64, 1, 3)])
-@pytest.mark.parametrize('mode', ['fp32', 'bf16x3_v1', 'bf16x6', 'bf16x3'])
+@pytest.mark.parametrize('mode', ['fp32', 'f16x3', 'bf16x6', 'bf16x3'])
 def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
     g = torch.Generator().manual_seed(cout * 7 + cin)
     w = torch.randn([cout, cin, k, k], generator=g)
@@ -109,6 +109,32 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
         ref = _Packed(w, b, 'bf16x6')
         assert pk.mode == 'bf16x6' and torch.equal(pk.w, ref.w)
         assert pk.flags_extra == (ref.flags_extra | (ARITH_2TERM if (k == 3 and cout > 3) else 0))
+        return
+    if mode == 'f16x3':
+        # 2-term fp16 split of w * 2^kexp on plain 3x3 layers with cout > 3 (K4_ARITH_F16X3); every other layer keeps the bf16x6 packing
+        from nerf4k_amd.lib.sr_esrnet import ARITH_F16X3
+        ref = _Packed(w, b, 'bf16x6')
+        assert pk.mode == 'bf16x6'
+        if not (k == 3 and cout > 3):
+            assert torch.equal(pk.w, ref.w) and pk.flags_extra == ref.flags_extra
+            return
+        assert pk.flags_extra == ARITH_F16X3
+        nch = (cin + 15) // 16
+        nb = (nch + 3) // 4 * 4
+        tail = pk.w[-(nt * 32 * 2 + nb * 2):]
+        unscale = tail[:nt * 32 * 2].view(torch.float32).double()                           # 2^-a[co]
+        bq = tail[nt * 32 * 2:].view(torch.int32)[:nch]
+        assert bool((unscale > 0).all()) and bool((torch.log2(unscale) == torch.log2(unscale).round()).all()) and int(bq.min()) >= 0
+        terms = pk.w[:-(nt * 32 * 2 + nb * 2)].view(torch.float16).reshape(nch, 2, k * k, 2, nt * 32, 8)
+        assert torch.isfinite(terms.float()).all()
+        assert 2.0 ** 13 <= float(terms[:, 0].float().abs().max()) <= 2.0 ** 14            # operands fill fp16's range, never overflow it
+        got = terms.double().sum(1).permute(1, 0, 2, 4, 3).reshape(k * k, nch * 16, nt * 32)
+        got = got * unscale.view(1, 1, -1) * torch.ldexp(torch.ones(nch, dtype=torch.float64), -bq).repeat_interleave(16).view(1, -1, 1)
+        want = torch.zeros_like(got)
+        want[:, :cin, :cout] = w.double().permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+        # 22 significant bits of the largest weight of each (output channel, chunk) block
+        blk = want.reshape(k * k, nch, 16, nt * 32).abs().amax((0, 2), keepdim=True).expand(k * k, nch, 16, nt * 32).reshape(want.shape)
+        assert bool(((got - want).abs() <= 2.0 ** -21 * blk).all())
         return
     if mode == 'bf16x6' and k == 3 and cout <= 3:
         # few output channels: taps become the N dimension of a 1x1 layer, n = tap*cout + co (K4_W_TAPS_AS_COUT)
@@ -126,14 +152,10 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
         nch = (cin + 7) // 8
         got = pk.w.reshape(nch, k * k, 8, nt * 32).permute(1, 0, 2, 3).reshape(k * k, nch * 8, nt * 32)
     else:
-        nterm = 3 if mode == 'bf16x6' else 2
-        assert pk.mode == ('bf16x6' if mode == 'bf16x6' else 'bf16x3')
+        assert pk.mode == 'bf16x6'
         nch = (cin + 15) // 16
-        terms = pk.w.view(torch.bfloat16).reshape(nch, nterm, k * k, 2, nt * 32, 8).float()
+        terms = pk.w.view(torch.bfloat16).reshape(nch, 3, k * k, 2, nt * 32, 8).float()
         got = terms.sum(1).permute(1, 0, 2, 4, 3).reshape(k * k, nch * 16, nt * 32)         # [tap][channel][cout]
     want = torch.zeros_like(got)
     want[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
-    if mode == 'bf16x3_v1':                               # 2-term split: 16 significant bits
-        assert float((got - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
-    else:
-        assert torch.equal(got, want)
+    assert torch.equal(got, want)

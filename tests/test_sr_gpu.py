@@ -123,9 +123,11 @@ def test_load_network_semantics(tmp_path):
     assert 'params' in torch.load(tmp_path / 'sresrnet_latest.pth', weights_only=False)
 
 
-@pytest.mark.parametrize('mode,conv_tol,mod_tol,min_psnr', [('bf16x3', 3e-4, 1e-3, 75.0), ('bf16x6', 4e-6, 2e-5, 115.0)])
+@pytest.mark.parametrize('mode,conv_tol,mod_tol,min_psnr', [('bf16x3', 3e-4, 1e-3, 75.0), ('bf16x6', 4e-6, 2e-5, 115.0), ('f16x3', 8e-6, 2e-5, 110.0)])
 def test_split_bf16_conv_and_network(mode, conv_tol, mod_tol, min_psnr):
     """Split-bf16 convolutions on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    'f16x3': 2-term fp16 split with power-of-two scaling (22 significant bits per operand), 3 products on the plain 3x3 layers,
+    everything else as 'bf16x6': conv outputs within 8e-6 of torch's fp32 conv, whole network PSNR >= 110 dB.
     'bf16x3' (opt-in): 2-term split, 3 products, ~2^-16 relative per product -> conv outputs within 3e-4 of fp32, whole
     network PSNR >= 75 dB against the fp32 oracle (SURVEY 8c asked >= 60 dB for an fp32-MFMA path).
     'bf16x6' (default): exact 3-term split, 6 products, dropped terms <= 2^-23 per product -> fp32-equivalent: conv outputs
@@ -211,6 +213,86 @@ def test_fused_sft_layer(C, arith):
     assert torch.equal(buf[:, :, :16], keep[:, :, :16]) and torch.equal(buf[:, :, 16 + C:], keep[:, :, 16 + C:])
 
 
+def _conv_ref64(x, w, b):
+    import torch.nn.functional as F
+    return F.conv2d(x.double().permute(2, 0, 1).unsqueeze(0), w.double(), b.double(), padding=1)[0].permute(1, 2, 0)
+
+
+def test_f16x3_convolution_on_adversarially_scaled_operands():
+    """The fp16 split needs power-of-two scaling (5 exponent bits).  Operands built to break a careless one: input-channel chunks whose
+    magnitudes differ by 1e5 in either order with inversely scaled weights (every chunk contributes equally to the output), outlier
+    pixels 1e3 above their neighbours, a layer whose weights are 1e-6 / activations 1e+6, all-zero chunks, and a chunk of fp16-overflowing
+    values (1e6).  Bar: max error <= 4e-6 of the largest output (the 6-product bf16 form on the same data: <= 1e-6) against an fp64
+    convolution, i.e. >= 108 dB in the worst case of each operand set."""
+    from nerf4k_amd.lib.sr_esrnet import _Packed, SFTNet
+    g = torch.Generator().manual_seed(11)
+    H, W = 37, 70                                            # 3 x 3 tiles of 16 x 32 with ragged edges
+    cases = []
+    for order in (0, 1):
+        cin, cout = 96, 64
+        x = torch.randn([H, W, cin], generator=g)
+        w = torch.randn([cout, cin, 3, 3], generator=g) / (cin * 9) ** 0.5
+        mags = torch.tensor([1.0, 1e5, 1e-5, 1e3, 1e-3, 1.0])
+        if order:
+            mags = mags.flip(0)
+        cs = mags.repeat_interleave(16)
+        x = x * cs
+        w = w / cs.view(1, cin, 1, 1)
+        cases.append(('chunk magnitudes ' + ('descending' if order else 'mixed'), x, w))
+    x = torch.randn([H, W, 64], generator=g)
+    x[torch.rand([H, W], generator=g) < 0.01] *= 1e3          # outlier pixels
+    cases.append(('outlier pixels', x, torch.randn([32, 64, 3, 3], generator=g) / 24))
+    cases.append(('huge activations, tiny weights', torch.randn([H, W, 64], generator=g) * 1e6, torch.randn([64, 64, 3, 3], generator=g) * 1e-6 / 24))
+    x = torch.randn([H, W, 64], generator=g)
+    x[:, :, 16:32] = 0
+    x[:8, :, :] = 0
+    cases.append(('zero chunks and rows', x, torch.randn([64, 64, 3, 3], generator=g) / 24))
+    for name, x, w in cases:
+        cout, cin = w.shape[:2]
+        b = torch.randn([cout], generator=g)
+        want = _conv_ref64(x, w, b)
+        scale = float(want.abs().max())
+        errs = {}
+        for mode in ('f16x3', 'bf16x6'):
+            y = torch.zeros([H, W, cout]).cuda()
+            SFTNet._conv(_Packed(w.cuda(), b.cuda(), mode), x.cuda().contiguous(), 0, cin, y, 0, cout, cout, H, W, 0)
+            assert torch.isfinite(y).all(), (name, mode)
+            errs[mode] = float((y.cpu().double() - want).abs().max()) / scale
+        print(f'{name}: max err / max|y|  f16x3 {errs["f16x3"]:.2e}  bf16x6 {errs["bf16x6"]:.2e}')
+        assert errs['f16x3'] <= 4e-6 and errs['bf16x6'] <= 1e-6, (name, errs)
+
+
+def test_f16x3_network_on_swinging_layer_scales():
+    """Whole decoder with consecutive 3x3 layers scaled x30 / x(1/30) (activations swing by 30x from layer to layer, the product
+    of the scales is kept) against the exact-fp32 MFMA arithmetic of the same weights: >= 110 dB, as for the default arithmetic."""
+    torch.manual_seed(21)
+    net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=3, num_grow_ch=32, num_cond=1).cuda().eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.5)
+        for b_ in net.body:
+            for r in (b_.rdb1, b_.rdb2, b_.rdb3):
+                r.conv1.weight.mul_(30.0); r.conv1.bias.mul_(30.0)
+                r.conv2.weight[:, 64:96].mul_(1 / 30.0)          # the consumer of x1 undoes it
+                r.conv3.weight[:, 64:96].mul_(1 / 30.0)
+                r.conv4.weight[:, 64:96].mul_(1 / 30.0)
+                r.conv5.weight[:, 64:96].mul_(1 / 30.0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand([1, 3, 48, 80], generator=g).cuda()
+    c = torch.rand([1, 1, 48, 80], generator=g).cuda()
+    with torch.no_grad():
+        net.k4_mode = 'fp32'
+        ref = net(x, c).cpu()
+        out = {}
+        for mode in ('bf16x6', 'f16x3'):
+            net.k4_mode = mode
+            out[mode] = net(x, c).cpu()
+    p6, p3 = psnr(out['bf16x6'], ref), psnr(out['f16x3'], ref)
+    print(f'swinging scales: PSNR vs fp32-MFMA  bf16x6 {p6:.1f} dB  f16x3 {p3:.1f} dB  (|out| max {float(ref.abs().max()):.2f})')
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 1e-3
+    assert p6 >= 115.0 and p3 >= 110.0, (p6, p3)
+
+
 def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkeypatch):
     """BASELINE-size frame (1008x756 -> 4032x3024, test_tile=510): (1) the grouped schedule (all 4 windows per layer in one launch)
     returns bit-identical pixels to the window-by-window one (tiles are independent); (2) the default 3-term split arithmetic
@@ -231,9 +313,14 @@ def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkey
     monkeypatch.delenv('K4_SR_GROUP')
     assert a.shape == (1, 3, 3024, 4032) and torch.equal(a, b)
     net.k4_mode = 'fp32'
-    f = net.tile_process_device(x, c, 510, 10)
+    f = net.tile_process_device(x, c, 510, 10).clone()
     p = psnr(a.cpu(), f.cpu())
     assert p >= 110.0, p
+    net.k4_mode = 'f16x3'
+    h = net.tile_process_device(x, c, 510, 10)
+    ph = psnr(h.cpu(), f.cpu())
+    print(f'full frame vs fp32-MFMA: bf16x6 {p:.1f} dB, f16x3 {ph:.1f} dB')
+    assert ph >= 110.0, ph
 
 
 def test_sft_layers_fused_into_the_convolution_epilogues_are_bit_identical(monkeypatch):
