@@ -717,9 +717,21 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
     __host__ __device__ static int total(int k1p) { return bo(k1p) + 4; }
 };
 
+// K4_SHADE_TIMING (profiling builds only, tools/r03_shade_timing.sh): s_memtime stamps at the phase boundaries of a shading batch,
+// summed per wave and added to out_counters[8..15] -- where a batch's ~23k cycles go.  Not compiled into the product library.
+#ifdef K4_SHADE_TIMING
+#define K4_TSTAMP(SLOT) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                             tacc[SLOT] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define K4_TARGS , unsigned long long (&tacc)[8], unsigned long long& tlast
+#define K4_TPASS , tacc, tlast
+#else
+#define K4_TSTAMP(SLOT) do { } while (0)
+#define K4_TARGS
+#define K4_TPASS
+#endif
 template <int W, int NHID>
 __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, int k1p, int lane, int half, int debug, int nproc,
-                                            float& out0, float& out1, float& out2) {
+                                            float& out0, float& out1, float& out2 K4_TARGS) {
     constexpr int NB = W / 32;
     constexpr int KB2 = W / 16;
     typedef MlpLayoutB3<W, NHID> ML;
@@ -763,6 +775,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                 }
             }
         }
+        K4_TSTAMP(3);                                    // layer 1
         k4_f32x2 pt01 = {0.f, 0.f};
         float pt2 = 0.f;
         if (NHID == 1 && !(debug & 2)) {
@@ -799,6 +812,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
                     }
                 }
             }
+            K4_TSTAMP(4);                                // split of the hidden activations + layer 2
 #pragma unroll
             for (int mb2 = 0; mb2 < NB; ++mb2)
 #pragma unroll
@@ -827,6 +841,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
         const float q1 = pt01.y + __shfl_xor(pt01.y, 32) + bo[1];
         const float q2 = pt2 + __shfl_xor(pt2, 32) + bo[2];
         if (half == t) { out0 = q0; out1 = q1; out2 = q2; }
+        K4_TSTAMP(5);                                    // output layer
     }
 }
 
@@ -916,6 +931,9 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     }
     __syncthreads();
     const int half = lane >> 5;
+#ifdef K4_SHADE_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     // persistent waves pull bundles from a global queue (bundles carry 0..thousands of records: static
     // assignment left SIMDs idle behind the slowest tile); a bundle is still shaded by ONE wave, in order.
@@ -943,6 +961,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     uint2 en_next = ent[lane < total ? lane : 0];
 
     for (int base = 0; base < total; base += 64) {
+        K4_TSTAMP(7);                                    // between batches: queue ticket, ray setup, per-ray outputs
         const int nproc = (total - base) < 64 ? (total - base) : 64;
         const bool lact = lane < nproc;
         const uint2 en = en_next;
@@ -979,6 +998,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
 #pragma unroll
             for (int c = 0; c < 8; ++c) cidx[c] = base + (K4_CX(c) ? ox : 0u) + (K4_CY(c) ? oy : 0u) + (K4_CZ(c) ? oz : 0u);
         }
+        K4_TSTAMP(0);                                    // record unpack, sample point, corner indices / weights
         float o0, o1, o2;
         if (WIDTH == 0) {
             // rgbnet is None: rgb = sigmoid(k0)   (lib/dvgo.py:377-379)
@@ -1049,6 +1069,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
                     else feat[(ch - P.k0_skip) * 64 + lane] = v;
                 }
             }
+            K4_TSTAMP(1);                                // 24 corner fetches + interpolation
             int fi = P.C - P.k0_skip;
             if (MODE == MODE_MPI) {
                 // pe_spa = normalised position flipped to (z,y,x); [v, sin(v x freq), cos(...)]   lib/dmpigo.py:338,350-351
@@ -1086,8 +1107,9 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             for (int kx = fi + 1; kx < P.k1p; ++kx) feat[kx * 64 + lane] = 0.f;
             __builtin_amdgcn_wave_barrier();
 
+            K4_TSTAMP(2);                                // remaining features -> LDS
             float l0, l1, l2;
-            if (B3) mlp_mfma_b3<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, nproc, l0, l1, l2);
+            if (B3) mlp_mfma_b3<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
             else mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
@@ -1126,6 +1148,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
         }
 #endif
         __builtin_amdgcn_wave_barrier();
+        K4_TSTAMP(6);                                    // sigmoid, blend, per-ray sums
     }
 
     // ---- per-ray outputs: rgb_marched = sum + alphainv_last*bg (lib/dmpigo.py:397), depth ----
@@ -1139,6 +1162,12 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     }
     __builtin_amdgcn_wave_barrier();
     }   // bundle
+#ifdef K4_SHADE_TIMING
+    if (P.counters && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[8 + i], tacc[i]);
+    }
+#endif
 }
 
 
@@ -1278,7 +1307,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
     env_int("K4_GEOM_OCC", 5), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
-    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_SR_SMALL", 1), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2)};
+    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_SR_SMALL", 1), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2), env_int("K4_SR_NBK", 2)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

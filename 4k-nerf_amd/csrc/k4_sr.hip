@@ -511,12 +511,34 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 #define K4_V2_MINWG_2T 2   // workgroups per CU the 2-term instantiation's register allocation is bounded for (39 KB of LDS would allow 3-4)
 #endif
 #ifndef K4_V2_MINWG_F16
-#define K4_V2_MINWG_F16 2
-#endif
-template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false>
-__global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
+#define K4_V2_MINWG_F16 3  // 8-row tiles (RPW = 2) of the fp16 form: 167 VGPRs, 21.8 KB of LDS -> THREE workgroups per CU (4K frame 39.5 ms against 44.5 at
+#endif                     // two); the 12- / 16-row forms would spill 28 / 178 registers at that bound and keep two
+// |x|, or 0 for inf / NaN: non-finite activations must not set a chunk's scale (they stay non-finite through the fp16 conversion
+// and poison exactly the outputs they reach, as in fp32)
+__device__ __forceinline__ float k4s_finite_abs(float x) { const float a = fabsf(x); return a <= 3.4028234e38f ? a : 0.f; }
+// largest value of a wave in every lane, for v >= 0 (the bit patterns of non-negative floats order like unsigned integers): 6 DPP
+// moves + v_max_u32 instead of 6 ds_bpermute round trips
+__device__ __forceinline__ float k4s_wave_max_nonneg(float v) {
+    unsigned x = __float_as_uint(v);
+#define K4_DPP_MAX(CTRL, ROWMASK) x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROWMASK, 0xf, false))
+    K4_DPP_MAX(0x111, 0xf);      // row_shr:1
+    K4_DPP_MAX(0x112, 0xf);      // row_shr:2
+    K4_DPP_MAX(0x114, 0xf);      // row_shr:4
+    K4_DPP_MAX(0x118, 0xf);      // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+    K4_DPP_MAX(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    K4_DPP_MAX(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef K4_DPP_MAX
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)x, 63));
+}
+// NBK = 32-channel output blocks per workgroup.  2 (layers with a multiple of 64 output channels, fp16 form): the staged input tile, its
+// split and every A fragment read from LDS serve 64 output channels instead of 32 -- half the staging work, LDS reads and workgroups
+// per matrix instruction of the layers that hold 60 % of the decoder's FLOPs (conv5 192 -> 64 of every dense block, the 64 -> 64 layers
+// at 2x / 4x resolution) -- and consecutive MFMAs alternate between the two blocks' accumulators.
+template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false, int NBK = 1>
+__global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16 : 2) : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
     static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
     static_assert(!F16 || NTERM == 2, "the fp16 arithmetic is a 2-term split");
+    static_assert(NBK == 1 || (NBK == 2 && F16), "two output blocks per workgroup: fp16 form only");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;
     constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
 
     const int bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (bcur < M.total) {
-    const V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count, ups);
+    const V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count / NBK, ups);      // T.nb = index of this workgroup's group of NBK output blocks
 
     // Staging map: thread -> quarter q = tid&3 (4 channels = 16 bytes) of pixels pp = (tid>>2) + 64*i.  Four adjacent lanes read the
     // 64 contiguous bytes of one pixel's chunk, so a wave's load instruction touches 16 cache lines with 64 bytes each (the
@@ -597,11 +619,12 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
 
     // operand registers: B = the 3 split terms of ONE tap, a ring filled BRING-1 taps ahead (over chunk and tile boundaries: the
     // weights do not depend on the tile);  A = the 3 split terms of one (input row, dx), a ring filled ARING-1 sub-stages ahead
-    uint4 bbuf[K4_V2_BRING][3];
-    const uint4* wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 + l31;
+    uint4 bbuf[K4_V2_BRING][NBK][3];
+    const uint4* wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 * NBK + l31;
 #define K4_V2_LOADB(DST, CH, TAP) do { \
         const uint4* wp_ = wlane + (size_t)(CH) * W_ITEMS; \
-        _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT]; } while (0)
+        _Pragma("unroll") for (int j_ = 0; j_ < NBK; ++j_) \
+        _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[j_][q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT + j_ * 32]; } while (0)
     K4_V2_LOADB(bbuf[0], 0, 0);
     if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
 
@@ -612,9 +635,11 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
         const int t_ = (U) / RPW, r_ = (U) % RPW; \
         _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[q_] = arow[q_ * IN_PLANE + (r_ + t_ / 3) * COLS + t_ % 3]; } while (0)
 
-    f32x16 acc[RPW];
+    f32x16 acc[NBK][RPW];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) acc[r] = (f32x16)(0.f);
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[j][r] = (f32x16)(0.f);
     // F16: power-of-two scale of the staged activations, one per 16-channel chunk of this tile (see the header comment): 2^sexp maps the
     // chunk's largest magnitude into [2^13, 2^14) -- but the accumulators' base never rises more than 2^60 above the smallest base a
     // chunk of this tile has had, so that re-basing them (an exact multiplication by 2^(new - old), either direction) cannot overflow
@@ -627,9 +652,8 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
     if constexpr (F16) {
         float m = 0.f;
 #pragma unroll
-        for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(rv[i].x)), fabsf(rv[i].y)), fmaxf(fabsf(rv[i].z), fabsf(rv[i].w)));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, k4s_finite_abs(rv[i].x)), k4s_finite_abs(rv[i].y)), fmaxf(k4s_finite_abs(rv[i].z), k4s_finite_abs(rv[i].w)));
+        m = k4s_wave_max_nonneg(m);
         if (lane == 0) smax[0][wv] = m;
         __syncthreads();
     }
@@ -637,7 +661,9 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
         for (int ch = 0; ch < nchunks; ++ch) {
             if (K4_V2_BRING == 2 && ch > 0) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
-                for (int q = 0; q < NTERM; ++q) bbuf[0][q] = bbuf[1][q];
+                for (int j = 0; j < NBK; ++j)
+#pragma unroll
+                    for (int q = 0; q < NTERM; ++q) bbuf[0][j][q] = bbuf[1][j][q];
             }
             // ---- split + store this chunk's haloed input tile ----
             if constexpr (F16) {
@@ -650,9 +676,11 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                 if (tnew != tcur && ch > 0) {                                              // workgroup-uniform
                     const int d = tnew - tcur;
 #pragma unroll
-                    for (int r = 0; r < RPW; ++r)
+                    for (int j = 0; j < NBK; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[r][e] = ldexpf(acc[r][e], d);
+                        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[j][r][e] = ldexpf(acc[j][r][e], d);
                 }
                 tcur = tnew;
                 sexp = tnew - bch;                                                         // <= enat: the chunk fits fp16
@@ -698,23 +726,26 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (F16) {
                     const f16x8 a0 = __builtin_bit_cast(f16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(f16x8, abuf[u % K4_V2_ARING][1]);
-                    const f16x8 b0 = __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][1]);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[r], 0, 0, 0);
+                    // lo x hi, hi x lo, hi x hi -- per accumulator in this order, the NBK blocks' instructions interleaved
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) acc[j][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][j][0]), acc[j][r], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) acc[j][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][j][1]), acc[j][r], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) acc[j][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(f16x8, bbuf[t % K4_V2_BRING][j][0]), acc[j][r], 0, 0, 0);
                 } else {
                     const bf16x8 a0 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][0]), a1 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][1]),
                                  a2 = __builtin_bit_cast(bf16x8, abuf[u % K4_V2_ARING][NTERM - 1]);
-                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][1]),
-                                 b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][NTERM - 1]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0][0]), b1 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0][1]),
+                                 b2 = __builtin_bit_cast(bf16x8, bbuf[t % K4_V2_BRING][0][NTERM - 1]);
                     if (NTERM == 3) {
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[r], 0, 0, 0);
+                        acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[0][r], 0, 0, 0);
+                        acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[0][r], 0, 0, 0);
+                        acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][r], 0, 0, 0);
                     }
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[r], 0, 0, 0);
+                    acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[0][r], 0, 0, 0);
+                    acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][r], 0, 0, 0);
+                    acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][r], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -722,9 +753,8 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                 if (ch + 1 < nchunks) {              // the next chunk's largest magnitude (its raw values have landed under the MFMAs)
                     float m = 0.f;
 #pragma unroll
-                    for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(rv[i].x)), fabsf(rv[i].y)), fmaxf(fabsf(rv[i].z), fabsf(rv[i].w)));
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                    for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, k4s_finite_abs(rv[i].x)), k4s_finite_abs(rv[i].y)), fmaxf(k4s_finite_abs(rv[i].z), k4s_finite_abs(rv[i].w)));
+                    m = k4s_wave_max_nonneg(m);
                     if (lane == 0) smax[(ch + 1) & 1][wv] = m;
                 }
             }
@@ -821,7 +851,7 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                     const int gx = T.x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
                     if (gx >= T.W) continue;
                     const size_t pix = (size_t)gy * T.W + gx;
-                    float v = acc[r][e] + bias;
+                    float v = acc[0][r][e] + bias;
                     if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
                     if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
                     const float m = v * (cs[e] + 1.f) + ch[e];                              // x*(scale+1)+shift
@@ -830,10 +860,12 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                 }
             }
         } else {
-            const int co = T.nb * 32 + l31;
-            if (co < P.cout) {
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                const int co = (T.nb * NBK + j) * 32 + l31;
+                if (co >= P.cout) continue;
                 const float bias = P.bias[co];
-                // F16: the accumulators are in units of 2^sexp (activations) x the weights' packing scale; both are powers of two
+                // F16: the accumulators are in units of 2^tcur (activation chunk scale x the chunk's weight factor) x 2^a[co]; all powers of two
                 float unscale = 1.f;
                 if constexpr (F16) unscale = ldexpf(wtail[co], -tcur);
 #pragma unroll
@@ -845,7 +877,7 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
                         const int gx = T.x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
                         if (gx >= T.W) continue;
                         const size_t pix = (size_t)gy * T.W + gx;
-                        float v = F16 ? fmaf(acc[r][e], unscale, bias) : acc[r][e] + bias;
+                        float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
                         if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
                         if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
                         T.y[pix * P.cout_stride + co] = v;
@@ -862,7 +894,9 @@ __global__ __launch_bounds__(256, (F16 ? K4_V2_MINWG_F16 : NTERM == 2 ? K4_V2_MI
 }
 
 static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
-    const int nbc = (M.base.cout + 31) / 32;
+    // fp16 form with a multiple of 64 output channels: one workgroup computes two 32-channel blocks (k4_conv_b6v2_kernel NBK = 2)
+    const bool nb2 = (M.base.flags & K4_ARITH_F16X3) && M.base.cout % 64 == 0 && !M.base.sft_w && k4_env().sr_nbk != 1;
+    const int nbc = (M.base.cout + 31) / 32 / (nb2 ? 2 : 1);
     const int slots = 2 * k4_num_cus();
     auto count = [&](int trows) {
         int total = 0;
@@ -895,6 +929,10 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         rpw = rpw_big;
         total = count(4 * rpw);
     }
+    if (nb2 && rpw == 4) {              // the two-block form with 16-row tiles would spill 64 registers: 12 rows
+        rpw = 3;
+        total = count(12);
+    }
     M.total = total;
     const dim3 grid((unsigned)total), block(256);
 #define K4_V2_LAUNCH(...) do { \
@@ -902,6 +940,7 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<3, __VA_ARGS__>), grid, block, 0, st, M); \
         else hipLaunchKernelGGL((k4_conv_b6v2_kernel<4, __VA_ARGS__>), grid, block, 0, st, M); } while (0)
     if (M.base.sft_w) K4_V2_LAUNCH(true, 3, false);
+    else if (nb2) K4_V2_LAUNCH(false, 2, true, 2);
     else if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(false, 2, true);
     else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(false, 2, false);
     else K4_V2_LAUNCH(false, 3, false);

@@ -30,7 +30,7 @@ from torch.nn import init as init
 from .. import _native as N
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
-DEFAULT_MODE = 'bf16x6'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
+DEFAULT_MODE = 'f16x3'          # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
 
 
 @torch.no_grad()
