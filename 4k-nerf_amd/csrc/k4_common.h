@@ -132,7 +132,7 @@ struct K4Env {
     int sr_3t_rpw;       // K4_SR_3T_RPW    (4) the same knob for the default 3-term kernel
     int sr_2t_rpw;       // K4_SR_2T_RPW    (2) output rows per wave of the 2-term (bf16x3 / f16x3) 3x3 convolution for launches beyond the small-launch rule (2 | 3 | 4):
                          //                     8-row tiles measured 37.1 ms per 4K frame, 12-row 39.3, 16-row 38.5-38.8; 3 workgroups per CU: no gain / spills
-    int sr_nbk;          // K4_SR_NBK       (2) 1: never compute two 32-channel output blocks per workgroup in the fp16 3x3 convolution (A/B)
+    int sr_debug;        // K4_SR_DEBUG     (0) profiling bits of the decoder kernels (1: input channel stride 0 = no memory traffic, WRONG results)
 };
 const K4Env& k4_env();
 #define K4_MAX_DEVICES 64

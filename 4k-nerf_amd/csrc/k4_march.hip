@@ -1307,7 +1307,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
     env_int("K4_GEOM_OCC", 5), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
-    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_SR_SMALL", 1), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2), env_int("K4_SR_NBK", 2)};
+    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_SR_SMALL", 1), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2), env_int("K4_SR_DEBUG", 0)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

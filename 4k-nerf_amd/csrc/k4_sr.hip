@@ -37,6 +37,8 @@ struct ConvParams {
     int tiles_x, tiles_y;
     // fused SFTLayer epilogue of the v2 3x3 kernel (k4_conv2d_sft_nhwc_bf16x6_multi): packed SFT weights, strides of cond / second output
     const float* sft_w; int sft_cond_stride; int sft_y_stride;
+    int debug;           // K4_SR_DEBUG ablation bits of the v2 3x3 kernel (profiling only, WRONG results; 0 in production): 2 = no epilogue stores,
+                         // 4 = no MFMA phase, 8 = no split / LDS stores after the first chunk, 16 = no activation loads after the first chunk
 };
 
 // Grouped launch: one grid covers up to K4_MAX_JOBS windows (the tiles of SFTNet.tile_process are independent images that share every
@@ -530,15 +532,26 @@ __device__ __forceinline__ float k4s_wave_max_nonneg(float v) {
 #undef K4_DPP_MAX
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)x, 63));
 }
-// NBK = 32-channel output blocks per workgroup.  2 (layers with a multiple of 64 output channels, fp16 form): the staged input tile, its
-// split and every A fragment read from LDS serve 64 output channels instead of 32 -- half the staging work, LDS reads and workgroups
-// per matrix instruction of the layers that hold 60 % of the decoder's FLOPs (conv5 192 -> 64 of every dense block, the 64 -> 64 layers
-// at 2x / 4x resolution) -- and consecutive MFMAs alternate between the two blocks' accumulators.
-template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false, int NBK = 1>
-__global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16 : 2) : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
+// WL = the chunk's weight fragments go through LDS: fetched ONCE per workgroup together with the next chunk's activations (a whole MFMA phase
+// ahead), stored beside the input tile, read by every wave with ds_read_b128 one tap ahead.  Without it each wave fetches its fragments
+// from L1 / L2 one tap ahead -- 192 cycles of matrix work at 8-row tiles with 3 products, against an L2 hit of ~500+ cycles (a layer's
+// weights, 18 KB per chunk x 4..12 chunks, do not stay in the 32 KB L1 beside three workgroups' activation traffic): every layer shape
+// of the decoder sat at ~30 % of its matrix floor whatever its size (profiles/r03_sr_kernel_stats.md).
+// K4_SR_TIMING (profiling builds only, tools/r03_call8.sh): s_memtime stamps at the phase boundaries of the chunk loop, summed over all
+// waves into k4_sr_timing[] (read and reset through k4_debug_sr_timing).  Not compiled into the product library.
+#ifdef K4_SR_TIMING
+__device__ unsigned long long k4_sr_timing[16];
+#define K4_SR_TSTAMP(SLOT) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                                tacc[SLOT] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define K4_SR_TSTAMP(SLOT) do { } while (0)
+#endif
+template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false, bool WL = false>
+__global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
+    constexpr int NBK = 1;                                    // 32-channel output blocks per workgroup (two were measured neutral: profiles/r03_sr_kernel_stats.md)
+    static_assert(!WL || (F16 && !SFT), "weights through LDS: fp16 form");
     static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
     static_assert(!F16 || NTERM == 2, "the fp16 arithmetic is a 2-term split");
-    static_assert(NBK == 1 || (NBK == 2 && F16), "two output blocks per workgroup: fp16 form only");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;
     constexpr int NSUB = 9 * RPW;                             // sub-stages per chunk
@@ -548,6 +561,9 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
     constexpr int IN_PLANE = 2 * NPIX;                        // uint4 per term
     __shared__ uint4 in_s[NTERM * IN_PLANE];                  // [term][channel group][row][col] x 8 bf16 (F16: 8 fp16)
     __shared__ float smax[2][4];                              // F16: largest |activation| of the chunk being staged, per wave (double buffered)
+    constexpr int WCH = NTERM * 9 * 2 * 32 * NBK;             // WL: 16-byte units of one chunk's weight fragments for this workgroup's NBK blocks
+    constexpr int W_PER = (WCH + THREADS - 1) / THREADS;
+    __shared__ uint4 w_s[WL ? WCH : 1];                       // [term][tap][channel group][32 NBK output channels] x 8 fp16
     const ConvParams& P = M.base;                             // shared by every window: cin, strides, weights, bias, cout, flags ...
     const int nb_count = (P.cout + 31) >> 5;
     const int NOUT = nb_count * 32;
@@ -560,6 +576,9 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
     const int W_ITEMS = (F16 ? 2 : 3) * 9 * 2 * NOUT;                       // 16-byte units of one chunk's split weights
     const bool vec_base = (P.cin_stride & 3) == 0;
 
+#ifdef K4_SR_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     const int bcur = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (bcur < M.total) {
     const V2Tile T = k4_v2_tile<TROWS>(M, bcur, nb_count / NBK, ups);      // T.nb = index of this workgroup's group of NBK output blocks
@@ -621,12 +640,34 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
     // weights do not depend on the tile);  A = the 3 split terms of one (input row, dx), a ring filled ARING-1 sub-stages ahead
     uint4 bbuf[K4_V2_BRING][NBK][3];
     const uint4* wlane = reinterpret_cast<const uint4*>(P.w) + half * NOUT + T.nb * 32 * NBK + l31;
+    const uint4* const wlds = w_s + half * (32 * NBK) + l31;
 #define K4_V2_LOADB(DST, CH, TAP) do { \
-        const uint4* wp_ = wlane + (size_t)(CH) * W_ITEMS; \
-        _Pragma("unroll") for (int j_ = 0; j_ < NBK; ++j_) \
-        _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[j_][q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT + j_ * 32]; } while (0)
-    K4_V2_LOADB(bbuf[0], 0, 0);
-    if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
+        if constexpr (WL) { \
+            _Pragma("unroll") for (int j_ = 0; j_ < NBK; ++j_) \
+            _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[j_][q_] = wlds[((q_ * 9 + (TAP)) * 2) * (32 * NBK) + j_ * 32]; \
+        } else { \
+            const uint4* wp_ = wlane + (size_t)(CH) * W_ITEMS; \
+            _Pragma("unroll") for (int j_ = 0; j_ < NBK; ++j_) \
+            _Pragma("unroll") for (int q_ = 0; q_ < NTERM; ++q_) DST[j_][q_] = wp_[((q_ * 9 + (TAP)) * 2) * NOUT + j_ * 32]; \
+        } } while (0)
+    // WL: this thread's share of a chunk's fragments, global -> registers (with the activations of the same chunk) -> w_s
+    // (nine named registers, not an array: hipcc left `uint4 wr[W_PER]` in scratch memory -- every fragment went global -> VGPR -> scratch
+    // -> VGPR -> LDS with the global latency exposed at the scratch store)
+    static_assert(W_PER <= 9, "weight staging registers");
+    uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
+#define K4_V2_WR_LIST(X) X(0, wr0) X(1, wr1) X(2, wr2) X(3, wr3) X(4, wr4) X(5, wr5) X(6, wr6) X(7, wr7) X(8, wr8)
+#define K4_V2_LOADW_ONE(K, R) if constexpr (W_PER > K) { \
+            const int it_ = tid + K * THREADS, itc_ = it_ < WCH ? it_ : 0; \
+            R = wc_[(itc_ / (32 * NBK)) * NOUT + itc_ % (32 * NBK)]; }
+#define K4_V2_STOREW_ONE(K, R) if constexpr (W_PER > K) { if (tid + K * THREADS < WCH) w_s[tid + K * THREADS] = R; }
+#define K4_V2_LOADW(CH) do { \
+        const uint4* wc_ = reinterpret_cast<const uint4*>(P.w) + (size_t)(CH) * W_ITEMS + T.nb * 32 * NBK; \
+        K4_V2_WR_LIST(K4_V2_LOADW_ONE) } while (0)
+    if constexpr (WL) K4_V2_LOADW(0);
+    else {
+        K4_V2_LOADB(bbuf[0], 0, 0);
+        if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], 0, 1);
+    }
 
     uint2* const in2 = reinterpret_cast<uint2*>(in_s);
     const int sdst = ((sq >> 1) * NPIX + sp0) * 2 + (sq & 1);
@@ -657,9 +698,10 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
         if (lane == 0) smax[0][wv] = m;
         __syncthreads();
     }
+    K4_SR_TSTAMP(0);                                     // prologue: tile setup, first chunk's loads issued, (F16) its maximum + barrier
     {
         for (int ch = 0; ch < nchunks; ++ch) {
-            if (K4_V2_BRING == 2 && ch > 0) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
+            if (!WL && K4_V2_BRING == 2 && ch > 0) {  // 9 taps per chunk, ring of 2: the tap prefetched across the chunk boundary sits in the odd buffer
 #pragma unroll
                 for (int j = 0; j < NBK; ++j)
 #pragma unroll
@@ -685,6 +727,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
                 tcur = tnew;
                 sexp = tnew - bch;                                                         // <= enat: the chunk fits fp16
                 const float sc = ldexpf(1.f, sexp);
+                if (!(P.debug & 8) || ch == 0)
 #pragma unroll
                 for (int i = 0; i < IN_PER; ++i) {
                     uint2 t0, t1;
@@ -706,21 +749,33 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
                     }
                 }
             }
+            if constexpr (WL) { K4_V2_WR_LIST(K4_V2_STOREW_ONE) }
+            K4_SR_TSTAMP(1);                             // wait for the chunk's raw activations, scale, split, LDS stores
             __syncthreads();
+            K4_SR_TSTAMP(2);                             // barrier A
             // next staging unit: the next chunk of this tile (its loads fly during the MFMAs below)
-            if (ch + 1 < nchunks) K4_V2_LOADRAW(ch + 1);
+            if (ch + 1 < nchunks && !(P.debug & 16)) {
+                K4_V2_LOADRAW(ch + 1);
+                if constexpr (WL) K4_V2_LOADW(ch + 1);
+            }
+            if constexpr (WL) {
+                K4_V2_LOADB(bbuf[0], ch, 0);
+                if (K4_V2_BRING == 3) K4_V2_LOADB(bbuf[1], ch, 1);
+            }
             // ---- 9*RPW sub-stages u = tap*RPW + r: 6 (3) MFMAs each into acc[r]; A(u+AD) is fetched from LDS and B(tap+BD) from L1/L2 under them ----
             constexpr int AD = K4_V2_ARING - 1, BD = K4_V2_BRING - 1;
             const int chn = ch + 1 == nchunks ? 0 : ch + 1;                   // the tap ring runs over the chunk boundary
             uint4 abuf[K4_V2_ARING][3];
             K4_V2_READA(abuf[0], 0);
             if (AD == 2) K4_V2_READA(abuf[1], 1);
+            K4_SR_TSTAMP(3);                             // next chunk's loads issued, first fragments requested
+            if (!(P.debug & 4))
 #pragma unroll
             for (int u = 0; u < NSUB; ++u) {
                 const int t = u / RPW, r = u % RPW;
                 if (r == 0) {                                                // weights of tap t+BD
                     if (t + BD < 9) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], ch, t + BD);
-                    else K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], chn, t + BD - 9);
+                    else if constexpr (!WL) K4_V2_LOADB(bbuf[(t + BD) % K4_V2_BRING], chn, t + BD - 9);
                 }
                 if (u + AD < NSUB) K4_V2_READA(abuf[(u + AD) % K4_V2_ARING], u + AD);
                 __builtin_amdgcn_sched_barrier(0);
@@ -749,6 +804,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            K4_SR_TSTAMP(4);                             // the MFMA phase
             if constexpr (F16) {
                 if (ch + 1 < nchunks) {              // the next chunk's largest magnitude (its raw values have landed under the MFMAs)
                     float m = 0.f;
@@ -758,7 +814,9 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
                     if (lane == 0) smax[(ch + 1) & 1][wv] = m;
                 }
             }
+            K4_SR_TSTAMP(5);                             // next chunk's maximum (waits for its raw values)
             __syncthreads();
+            K4_SR_TSTAMP(6);                             // barrier B
         }
         // ---- epilogue of tile T: lane holds output channel nb*32 + l31 of pixels x0 + row(reg, half) in rows y0 + wv*4 + r ----
         if constexpr (SFT) {
@@ -859,6 +917,15 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
                     else T.y[pix * P.cout_stride + co] = m;
                 }
             }
+        } else if (P.debug & 2) {
+            float sum_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NBK; ++j)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum_ += acc[j][r][e];
+            if (sum_ == 123.456f) T.y[lane] = sum_;
         } else {
 #pragma unroll
             for (int j = 0; j < NBK; ++j) {
@@ -886,17 +953,27 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 && NBK == 1 ? K4_V2_MINWG_F16
             }
         }
     }
+    K4_SR_TSTAMP(7);                                     // epilogue
     }
+#ifdef K4_SR_TIMING
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&k4_sr_timing[i], tacc[i]);
+        atomicAdd(&k4_sr_timing[8], 1ull);
+    }
+#endif
 #undef K4_V2_LOADB
+#undef K4_V2_LOADW
+#undef K4_V2_LOADW_ONE
+#undef K4_V2_STOREW_ONE
+#undef K4_V2_WR_LIST
 #undef K4_V2_READA
 #undef K4_V2_LOADRAW
 #undef K4_V2_SETUP
 }
 
 static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
-    // fp16 form with a multiple of 64 output channels: one workgroup computes two 32-channel blocks (k4_conv_b6v2_kernel NBK = 2)
-    const bool nb2 = (M.base.flags & K4_ARITH_F16X3) && M.base.cout % 64 == 0 && !M.base.sft_w && k4_env().sr_nbk != 1;
-    const int nbc = (M.base.cout + 31) / 32 / (nb2 ? 2 : 1);
+    const int nbc = (M.base.cout + 31) / 32;
     const int slots = 2 * k4_num_cus();
     auto count = [&](int trows) {
         int total = 0;
@@ -929,19 +1006,16 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         rpw = rpw_big;
         total = count(4 * rpw);
     }
-    if (nb2 && rpw == 4) {              // the two-block form with 16-row tiles would spill 64 registers: 12 rows
-        rpw = 3;
-        total = count(12);
-    }
     M.total = total;
+    if (k4_env().sr_debug & 1) M.base.cin_stride = 0;        // profiling only (WRONG results): every pixel reads the same 64 bytes -- the kernel without memory traffic
+    M.base.debug = k4_env().sr_debug;
     const dim3 grid((unsigned)total), block(256);
 #define K4_V2_LAUNCH(...) do { \
         if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, __VA_ARGS__>), grid, block, 0, st, M); \
         else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<3, __VA_ARGS__>), grid, block, 0, st, M); \
         else hipLaunchKernelGGL((k4_conv_b6v2_kernel<4, __VA_ARGS__>), grid, block, 0, st, M); } while (0)
     if (M.base.sft_w) K4_V2_LAUNCH(true, 3, false);
-    else if (nb2) K4_V2_LAUNCH(false, 2, true, 2);
-    else if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(false, 2, true);
+    else if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(false, 2, true, true);      // fp16 form: weight fragments through LDS
     else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(false, 2, false);
     else K4_V2_LAUNCH(false, 3, false);
 #undef K4_V2_LAUNCH
@@ -1166,6 +1240,14 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
     if (nt == 4) return launch_conv_b6<1, 4, 8>(M, st);
     return K4_ERR_UNSUPPORTED;
 }
+
+#ifdef K4_SR_TIMING
+extern "C" int k4_debug_sr_timing(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(k4_sr_timing), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(k4_sr_timing), z, sizeof(z)); }
+    return (int)e;
+}
+#endif
 
 extern "C" int64_t k4_conv_weight_f16x3_bytes(int32_t cout, int32_t cin, int32_t ksize) {
     if (cout <= 3 || cin <= 0 || ksize != 3 || (cout + 31) / 32 > 8) return -1;
