@@ -126,6 +126,7 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_conv2d_wgrad_dbias_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_bias_grad': ([_P, _I32, _I32, _I64, _P, _P], C.c_int),
     'k4_adam_upd_multi': ([C.POINTER(AdamJob), _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_pack_conv_weight_bf16x6': ([_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P], C.c_int),
@@ -138,6 +139,10 @@ _EXTRA_SIGS = {
     'k4_rgbnet_fwd': ([_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'k4_rgbnet_bwd_workspace_bytes': ([_I64, _I32, _I32, _I32], C.c_int64),
     'k4_rgbnet_bwd': ([_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'k4_sft_train_fwd': ([_P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I32, _P], C.c_int),
+    'k4_sft_train_bwd_workspace_bytes': ([_I64, _I32], C.c_int64),
+    'k4_sft_train_bwd': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
+                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
 }
 

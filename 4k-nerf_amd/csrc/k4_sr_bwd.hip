@@ -54,6 +54,7 @@ struct WgradParams {
     const float* gy; int cout; int gy_stride;
     int ks, H, W;
     float* dw;                                  // [cout][cin][ks][ks]
+    float* db;                                  // NULL, or [cout]: the bias gradient, summed by the workgroups of tap 0 / input block 0
     int ci_blocks, co_blocks, bands;
 };
 
@@ -72,6 +73,8 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
     const int ci = cib * 32 + l31, co = cob * 32 + l31;
     const bool ci_ok = ci < P.cin, co_ok = co < P.cout;
     f32x16 acc = (f32x16)(0.f);
+    const bool do_bias = P.db != nullptr && tap == 0 && cib == 0;        // workgroup-uniform: these workgroups see every dY value of their band once
+    float bsum = 0.f;
     const int y_end = min((band + 1) * K4_WG_BAND, P.H);
     for (int y = band * K4_WG_BAND + wv; y < y_end; y += 4) {
         const int sy = y + dy;
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
                 a8[e] = a_ok ? P.x[((size_t)sy * P.W + sx) * P.x_stride + ci] : 0.f;
                 b8[e] = b_ok ? P.gy[((size_t)y * P.W + px) * P.gy_stride + co] : 0.f;
             }
+            if (do_bias) bsum += ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7]));
             uint4 a0, a1, a2, b0, b1, b2;
             wg_split3(a8, a0, a1, a2);
             wg_split3(b8, b0, b1, b2);
@@ -109,6 +113,13 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
             const int cii = cib * 32 + i;
             if (cii < P.cin && co_ok) atomicAdd(&P.dw[(((size_t)co * P.cin + cii) * P.ks + (dy + pad)) * P.ks + (dx + pad)], v);
         }
+    }
+    if (do_bias) {                                                      // dbias[co] += this band's sum of dY[.][co]: both pixel halves, four waves
+        bsum += __shfl_xor(bsum, 32);
+        __syncthreads();                                                // `red` is free again
+        if (half == 0) red[0][wv * 32 + l31] = bsum;
+        __syncthreads();
+        if (wv == 0 && half == 0 && co_ok) unsafeAtomicAdd(P.db + co, (red[0][l31] + red[0][32 + l31]) + (red[0][64 + l31] + red[0][96 + l31]));
     }
 }
 
@@ -141,18 +152,31 @@ __global__ __launch_bounds__(256) void k4_bias_grad_kernel(const float* __restri
     }
 }
 
-extern "C" int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
-                                      int32_t ksize, int32_t H, int32_t W, float* dw, void* stream) {
+static int wgrad_launch(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                        int32_t ksize, int32_t H, int32_t W, float* dw, float* dbias, int64_t zero_floats, void* stream) {
     if (!x || !gy || !dw || cin <= 0 || cout <= 0 || x_stride < cin || gy_stride < cout || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3))
         return K4_ERR_BAD_ARG;
     WgradParams P{};
     P.x = x; P.cin = cin; P.x_stride = x_stride; P.gy = gy; P.cout = cout; P.gy_stride = gy_stride;
-    P.ks = ksize; P.H = H; P.W = W; P.dw = dw;
+    P.ks = ksize; P.H = H; P.W = W; P.dw = dw; P.db = dbias;
     P.ci_blocks = (cin + 31) / 32; P.co_blocks = (cout + 31) / 32; P.bands = (H + K4_WG_BAND - 1) / K4_WG_BAND;
     const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
-    wg_zero(dw, (int64_t)cout * cin * ksize * ksize, (hipStream_t)stream);                                            // split-K partial sums are ADDED
+    wg_zero(dw, zero_floats, (hipStream_t)stream);                                                                      // split-K partial sums are ADDED
     hipLaunchKernelGGL(k4_conv_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
     return k4_check_launch();
+}
+
+extern "C" int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                                      int32_t ksize, int32_t H, int32_t W, float* dw, void* stream) {
+    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw, nullptr, (int64_t)cout * cin * ksize * ksize, stream);
+}
+
+extern "C" int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                                            int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream) {
+    // dw_db = [cout*cin*k*k floats of dW | cout floats of dbias], ONE buffer: one zero-fill, one launch
+    if (!dw_db) return K4_ERR_BAD_ARG;
+    const int64_t nw = (int64_t)cout * cin * ksize * ksize;
+    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, nw + cout, stream);
 }
 
 extern "C" int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream) {

@@ -460,3 +460,339 @@ extern "C" int k4_distortion_loss(const float* w, const float* s, const int64_t*
                        ray_loss, grad_w);
     return k4_check_launch();
 }
+
+// --------------------------------------------------------------------------------------------------------------------
+// SFTLayer of the VC-Decoder under autograd (lib/sr_esrnet.py:112-123): y = x * (scale(cond) + 1) + shift(cond) with
+//   scale = W1s lrelu(W0s c + b0s) + b1s,  shift = W1h lrelu(W0h c + b0h) + b1h       (1x1 convolutions 32 -> 32 -> C, slope 0.2).
+// The joint training step evaluates 36 of these per iteration on a 64x64 patch; as four convolution Functions + PyTorch elementwise
+// glue each was ~13 launches forward and ~30 backward of 4-15 us apiece -- two thirds of the decoder's ~2500 launches.  Here:
+//   k_sft_train_fwd : one launch, nothing saved but the inputs (the backward recomputes the 64 hidden activations);
+//   k_sft_train_bwd : gx, gc (gradient of the 32-channel condition map) and the per-workgroup partial sums of the eight weight /
+//                     bias gradients (4x4 register blocks over the pixel axis as in k_rgbnet_bwd: no atomics, fixed order);
+//   k_sft_train_reduce : partials -> the eight gradient tensors.
+// Tile = 64 pixels, lane = pixel, wave = a quarter of the neurons / channels; weights are the nn.Conv2d tensors as stored
+// ([out][in] row-major), read with wave-uniform indices (scalar loads).  Exact fp32 FMA chains.
+// --------------------------------------------------------------------------------------------------------------------
+#define SFT_G 32                          // condition channels = hidden width
+#define SFT_GB (SFT_G + 4)                // + ones row (bias gradient) + 3 zero rows: a multiple of 4
+
+// [n][stride] global rows (K channels from each) -> LDS [K][TR_LS]; samples >= nv read as 0
+__device__ __forceinline__ void sft_load_tile(const float* __restrict__ g, int64_t base, int stride, int K, int nv, float* lds, int t) {
+    for (int i = t; i < 64 * K; i += 256) {
+        const int s = i / K, k = i - s * K;
+        lds[k * TR_LS + s] = s < nv ? g[(base + s) * stride + k] : 0.f;
+    }
+}
+__device__ __forceinline__ void sft_store_tile(const float* lds, float* __restrict__ g, int64_t base, int stride, int K, int nv, int t) {
+    for (int i = t; i < 64 * K; i += 256) {
+        const int s = i / K, k = i - s * K;
+        if (s < nv) g[(base + s) * stride + k] = lds[k * TR_LS + s];
+    }
+}
+// hidden activations of both branches: hs[j] = lrelu(b0[j] + sum_k w0[j][k] c[k]), j < 32 scale branch, j >= 32 shift branch
+__device__ __forceinline__ void sft_hidden(const float* cs, k4_cptr w0s, k4_cptr b0s, k4_cptr w0h, k4_cptr b0h, float slope,
+                                           float* as, float* ah, int wv, int lane) {
+    for (int j0 = wv * 16; j0 < wv * 16 + 16; j0 += 4) {
+        const bool sh = j0 >= SFT_G;
+        const k4_cptr w = (sh ? w0h : w0s) + (j0 & (SFT_G - 1)) * SFT_G, b = (sh ? b0h : b0s) + (j0 & (SFT_G - 1));
+        float a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3];
+        for (int k = 0; k < SFT_G; ++k) {
+            const float v = cs[k * TR_LS + lane];
+            a0 = fmaf(v, w[k], a0); a1 = fmaf(v, w[SFT_G + k], a1); a2 = fmaf(v, w[2 * SFT_G + k], a2); a3 = fmaf(v, w[3 * SFT_G + k], a3);
+        }
+        float* const out = (sh ? ah : as) + (j0 & (SFT_G - 1)) * TR_LS + lane;
+        out[0] = a0 > 0.f ? a0 : a0 * slope; out[TR_LS] = a1 > 0.f ? a1 : a1 * slope;
+        out[2 * TR_LS] = a2 > 0.f ? a2 : a2 * slope; out[3 * TR_LS] = a3 > 0.f ? a3 : a3 * slope;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_sft_train_fwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride, int64_t n,
+                                                       const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
+                                                       const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h, const float* __restrict__ b1h,
+                                                       float slope, float* __restrict__ y, int y_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const cs = smem;                       // [32][LS]
+    float* const as = cs + SFT_G * TR_LS;         // [32][LS]
+    float* const ah = as + SFT_G * TR_LS;         // [32][LS]
+    float* const xs = ah + SFT_G * TR_LS;         // [C][LS]  x, then y in place
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+    sft_load_tile(cond, base, c_stride, SFT_G, nv, cs, t);
+    sft_load_tile(x, base, x_stride, C, nv, xs, t);
+    __syncthreads();
+    sft_hidden(cs, k4_const(w0s), k4_const(b0s), k4_const(w0h), k4_const(b0h), slope, as, ah, wv, lane);
+    __syncthreads();
+    const k4_cptr w1sc = k4_const(w1s), w1hc = k4_const(w1h), b1sc = k4_const(b1s), b1hc = k4_const(b1h);
+    for (int co = wv * (C / 4); co < (wv + 1) * (C / 4); co += 2) {
+        float s0 = b1sc[co], s1 = b1sc[co + 1], h0 = b1hc[co], h1 = b1hc[co + 1];
+        for (int k = 0; k < SFT_G; ++k) {
+            const float a = as[k * TR_LS + lane], b = ah[k * TR_LS + lane];
+            s0 = fmaf(a, w1sc[co * SFT_G + k], s0); s1 = fmaf(a, w1sc[(co + 1) * SFT_G + k], s1);
+            h0 = fmaf(b, w1hc[co * SFT_G + k], h0); h1 = fmaf(b, w1hc[(co + 1) * SFT_G + k], h1);
+        }
+        xs[co * TR_LS + lane] = fmaf(xs[co * TR_LS + lane], s0 + 1.f, h0);                  // x * (scale + 1) + shift   (lib/sr_esrnet.py:123)
+        xs[(co + 1) * TR_LS + lane] = fmaf(xs[(co + 1) * TR_LS + lane], s1 + 1.f, h1);
+    }
+    __syncthreads();
+    sft_store_tile(xs, y, base, y_stride, C, nv, t);
+}
+
+template <int C>
+struct SftBwdLayout {
+    // LDS rows: cs [GB] | as [GB] | ah [GB] | gzs [G] | gzh [G] | gs [C] | gy [C] | gx [C] | gc [G]
+    static constexpr int ROWS = 3 * SFT_GB + 2 * SFT_G + 3 * C + SFT_G;
+    // partial sums: P1s [C][GB] | P1h [C][GB] | P0s [G][GB] | P0h [G][GB]   (column G = the bias gradient)
+    static constexpr int N_PART = 2 * C * SFT_GB + 2 * SFT_G * SFT_GB;
+    static constexpr int N_BLK = N_PART / 16;
+    static constexpr int MAXB = (N_BLK + 255) / 256;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride,
+                                                       const float* __restrict__ gyg, int gy_stride, int64_t n,
+                                                       const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
+                                                       const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h,
+                                                       float slope, float* __restrict__ gxg, float* __restrict__ gcg, float* __restrict__ part) {
+    typedef SftBwdLayout<C> L;
+    constexpr int MAXB = L::MAXB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const cs = smem;
+    float* const as = cs + SFT_GB * TR_LS;
+    float* const ah = as + SFT_GB * TR_LS;
+    float* const gzs = ah + SFT_GB * TR_LS;
+    float* const gzh = gzs + SFT_G * TR_LS;
+    float* const gs = gzh + SFT_G * TR_LS;        // x on arrival, then gy * x
+    float* const gy = gs + C * TR_LS;
+    float* const gx = gy + C * TR_LS;
+    float* const gc = gx + C * TR_LS;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int i = t; i < L::ROWS * TR_LS; i += 256) smem[i] = 0.f;           // the zero padding rows stay zero for the whole kernel
+
+    TrBlock blk[MAXB];
+    float acc[MAXB][16];
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+        int b = t + 256 * q;
+        blk[q].aoff = -1;
+        constexpr int NB1 = (C / 4) * (SFT_GB / 4), NB0 = (SFT_G / 4) * (SFT_GB / 4);
+        if (b < 2 * NB1) {
+            const bool sh = b >= NB1;
+            b -= sh ? NB1 : 0;
+            const int ar = b / (SFT_GB / 4), bc = b - ar * (SFT_GB / 4);
+            blk[q] = {(int)((sh ? gy : gs) - smem) + 4 * ar * TR_LS, (int)((sh ? ah : as) - smem) + 4 * bc * TR_LS,
+                      (sh ? C * SFT_GB : 0) + 4 * ar * SFT_GB + 4 * bc, SFT_GB};
+        } else if (b < 2 * NB1 + 2 * NB0) {
+            b -= 2 * NB1;
+            const bool sh = b >= NB0;
+            b -= sh ? NB0 : 0;
+            const int ar = b / (SFT_GB / 4), bc = b - ar * (SFT_GB / 4);
+            blk[q] = {(int)((sh ? gzh : gzs) - smem) + 4 * ar * TR_LS, (int)(cs - smem) + 4 * bc * TR_LS,
+                      2 * C * SFT_GB + (sh ? SFT_G * SFT_GB : 0) + 4 * ar * SFT_GB + 4 * bc, SFT_GB};
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    }
+    __syncthreads();
+
+    const k4_cptr w0sc = k4_const(w0s), w0hc = k4_const(w0h), w1sc = k4_const(w1s), w1hc = k4_const(w1h), b1sc = k4_const(b1s);
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * 64;
+        const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+        sft_load_tile(cond, base, c_stride, SFT_G, nv, cs, t);
+        sft_load_tile(x, base, x_stride, C, nv, gs, t);
+        sft_load_tile(gyg, base, gy_stride, C, nv, gy, t);
+        if (t < 64) {
+            const float one = t < nv ? 1.f : 0.f;
+            cs[SFT_G * TR_LS + t] = one; as[SFT_G * TR_LS + t] = one; ah[SFT_G * TR_LS + t] = one;
+        }
+        __syncthreads();
+        sft_hidden(cs, w0sc, k4_const(b0s), w0hc, k4_const(b0h), slope, as, ah, wv, lane);
+        __syncthreads();
+        // gx = gy * (scale + 1);  gs = gy * x   (the shift branch's output gradient is gy itself)
+        for (int co = wv * (C / 4); co < (wv + 1) * (C / 4); co += 2) {
+            float s0 = b1sc[co], s1 = b1sc[co + 1];
+            for (int k = 0; k < SFT_G; ++k) {
+                const float a = as[k * TR_LS + lane];
+                s0 = fmaf(a, w1sc[co * SFT_G + k], s0); s1 = fmaf(a, w1sc[(co + 1) * SFT_G + k], s1);
+            }
+            const float g0 = gy[co * TR_LS + lane], g1 = gy[(co + 1) * TR_LS + lane];
+            gx[co * TR_LS + lane] = g0 * (s0 + 1.f); gx[(co + 1) * TR_LS + lane] = g1 * (s1 + 1.f);
+            gs[co * TR_LS + lane] *= g0; gs[(co + 1) * TR_LS + lane] *= g1;
+        }
+        __syncthreads();
+        // gz = lrelu'(z) * (W1^T g):  wave w -> hidden neurons 8w .. 8w+7 of both branches
+        for (int k0 = wv * 8; k0 < wv * 8 + 8; k0 += 4) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+            for (int co = 0; co < C; ++co) {
+                const float a = gs[co * TR_LS + lane], b = gy[co * TR_LS + lane];
+                s0 = fmaf(a, w1sc[co * SFT_G + k0], s0); s1 = fmaf(a, w1sc[co * SFT_G + k0 + 1], s1);
+                s2 = fmaf(a, w1sc[co * SFT_G + k0 + 2], s2); s3 = fmaf(a, w1sc[co * SFT_G + k0 + 3], s3);
+                h0 = fmaf(b, w1hc[co * SFT_G + k0], h0); h1 = fmaf(b, w1hc[co * SFT_G + k0 + 1], h1);
+                h2 = fmaf(b, w1hc[co * SFT_G + k0 + 2], h2); h3 = fmaf(b, w1hc[co * SFT_G + k0 + 3], h3);
+            }
+            const float sv[4] = {s0, s1, s2, s3}, hv[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {               // leaky_relu_backward: grad where the INPUT is > 0, slope * grad elsewhere (lrelu(z) > 0 <=> z > 0)
+                gzs[(k0 + e) * TR_LS + lane] = as[(k0 + e) * TR_LS + lane] > 0.f ? sv[e] : sv[e] * slope;
+                gzh[(k0 + e) * TR_LS + lane] = ah[(k0 + e) * TR_LS + lane] > 0.f ? hv[e] : hv[e] * slope;
+            }
+        }
+        __syncthreads();
+        // gc = W0s^T gz_s + W0h^T gz_h:  wave w -> condition channels 8w .. 8w+7
+        for (int k0 = wv * 8; k0 < wv * 8 + 8; k0 += 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int j = 0; j < SFT_G; ++j) {
+                const float u = gzs[j * TR_LS + lane], v = gzh[j * TR_LS + lane];
+                a0 = fmaf(u, w0sc[j * SFT_G + k0], a0); a1 = fmaf(u, w0sc[j * SFT_G + k0 + 1], a1);
+                a2 = fmaf(u, w0sc[j * SFT_G + k0 + 2], a2); a3 = fmaf(u, w0sc[j * SFT_G + k0 + 3], a3);
+                a0 = fmaf(v, w0hc[j * SFT_G + k0], a0); a1 = fmaf(v, w0hc[j * SFT_G + k0 + 1], a1);
+                a2 = fmaf(v, w0hc[j * SFT_G + k0 + 2], a2); a3 = fmaf(v, w0hc[j * SFT_G + k0 + 3], a3);
+            }
+            gc[k0 * TR_LS + lane] = a0; gc[(k0 + 1) * TR_LS + lane] = a1; gc[(k0 + 2) * TR_LS + lane] = a2; gc[(k0 + 3) * TR_LS + lane] = a3;
+        }
+        // weight-gradient blocks: acc[a][b] += sum_s A[a][s] * B[b][s]   (A, B rows were complete at the barrier above)
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) {
+            if (blk[q].aoff < 0) continue;
+            const float4* const A = reinterpret_cast<const float4*>(smem + blk[q].aoff);
+            const float4* const B = reinterpret_cast<const float4*>(smem + blk[q].boff);
+            for (int s4 = 0; s4 < 16; ++s4) {
+                float4 av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = A[r * (TR_LS / 4) + s4]; bv[r] = B[r * (TR_LS / 4) + s4]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        float v = acc[q][a * 4 + b];
+                        v = fmaf(av[a].x, bv[b].x, v); v = fmaf(av[a].y, bv[b].y, v); v = fmaf(av[a].z, bv[b].z, v); v = fmaf(av[a].w, bv[b].w, v);
+                        acc[q][a * 4 + b] = v;
+                    }
+            }
+        }
+        __syncthreads();
+        sft_store_tile(gx, gxg, base, C, C, nv, t);
+        sft_store_tile(gc, gcg, base, SFT_G, SFT_G, nv, t);
+        __syncthreads();
+    }
+    float* const mine = part + (size_t)blockIdx.x * L::N_PART;
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+        if (blk[q].aoff < 0) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mine[blk[q].ooff + a * blk[q].ostride + b] = acc[q][a * 4 + b];
+    }
+}
+
+// partials [n_wg][P1s | P1h | P0s | P0h] -> gw1s [C][32], gb1s [C], gw1h, gb1h, gw0s [32][32], gb0s [32], gw0h, gb0h; fixed order (see k_rgbnet_reduce)
+__global__ __launch_bounds__(256) void k_sft_train_reduce(const float* __restrict__ part, int n_wg, int C, float* __restrict__ gw1s, float* __restrict__ gb1s,
+                                                          float* __restrict__ gw1h, float* __restrict__ gb1h, float* __restrict__ gw0s, float* __restrict__ gb0s,
+                                                          float* __restrict__ gw0h, float* __restrict__ gb0h) {
+    __shared__ float red[TR_RED_SLICES][TR_RED_ELEMS + 1];
+    const int e = threadIdx.x & (TR_RED_ELEMS - 1), sl = threadIdx.x / TR_RED_ELEMS;
+    const int i = blockIdx.x * TR_RED_ELEMS + e;
+    const int per_row = SFT_G + 1;
+    const int n1 = C * per_row, n0 = SFT_G * per_row, n_part = 2 * C * SFT_GB + 2 * SFT_G * SFT_GB;
+    const bool live = i < 2 * n1 + 2 * n0;
+    int off = 0;
+    float* dst = nullptr;
+    if (live) {
+        int r = i;
+        if (r < 2 * n1) {
+            const bool sh = r >= n1;
+            r -= sh ? n1 : 0;
+            const int a = r / per_row, j = r - a * per_row;
+            off = (sh ? C * SFT_GB : 0) + a * SFT_GB + j;
+            dst = j < SFT_G ? (sh ? gw1h : gw1s) + a * SFT_G + j : (sh ? gb1h : gb1s) + a;
+        } else {
+            r -= 2 * n1;
+            const bool sh = r >= n0;
+            r -= sh ? n0 : 0;
+            const int a = r / per_row, j = r - a * per_row;
+            off = 2 * C * SFT_GB + (sh ? SFT_G * SFT_GB : 0) + a * SFT_GB + j;
+            dst = j < SFT_G ? (sh ? gw0h : gw0s) + a * SFT_G + j : (sh ? gb0h : gb0s) + a;
+        }
+    }
+    const int per = (n_wg + TR_RED_SLICES - 1) / TR_RED_SLICES;
+    const int g0 = sl * per, g1 = min(g0 + per, n_wg);
+    float s = 0.f;
+    if (live)
+        for (int g = g0; g < g1; ++g) s += part[(size_t)g * n_part + off];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+        float v = red[0][e];
+#pragma unroll
+        for (int q = 1; q < TR_RED_SLICES; ++q) v += red[q][e];
+        *dst = v;
+    }
+}
+
+static int sft_bwd_grid(int64_t n) {
+    const int64_t tiles = (n + 63) / 64;
+    const int64_t cap = (int64_t)k4_num_cus();
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
+extern "C" int64_t k4_sft_train_bwd_workspace_bytes(int64_t n_pix, int32_t channels) {
+    if ((channels != 32 && channels != 64) || n_pix < 0) return -1;
+    return (int64_t)sft_bwd_grid(n_pix) * (channels == 64 ? SftBwdLayout<64>::N_PART : SftBwdLayout<32>::N_PART) * (int64_t)sizeof(float);
+}
+
+extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
+                                const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                                const float* w0h, const float* b0h, const float* w1h, const float* b1h,
+                                float slope, float* y, int32_t y_stride, void* stream) {
+    if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
+    if (n_pix < 0 || x_stride < channels || y_stride < channels || cond_stride < SFT_G) return K4_ERR_BAD_ARG;
+    if (!w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h || !b1h) return K4_ERR_BAD_ARG;
+    if (n_pix == 0) return K4_OK;
+    if (!x || !cond || !y) return K4_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n_pix + 63) / 64)), block(256);
+    const size_t lds = (size_t)(3 * SFT_G + channels) * TR_LS * sizeof(float);
+    if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
+    else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
+    return k4_check_launch();
+}
+
+template <int C>
+static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
+                          const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                          float slope, float* gx, float* gc, float* ws, float* const* gout, hipStream_t st) {
+    typedef SftBwdLayout<C> L;
+    const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
+    K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
+    const int grid = sft_bwd_grid(n);
+    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(256), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws);
+    int rc = k4_check_launch();
+    if (rc) return rc;
+    const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
+    hipLaunchKernelGGL(k_sft_train_reduce, dim3((total + TR_RED_ELEMS - 1) / TR_RED_ELEMS), dim3(256), 0, st, ws, grid, C,
+                       gout[0], gout[1], gout[2], gout[3], gout[4], gout[5], gout[6], gout[7]);
+    return k4_check_launch();
+}
+
+extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                int64_t n_pix, int32_t channels,
+                                const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                float slope, float* grad_x, float* grad_cond,
+                                float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                                float* workspace, int64_t workspace_bytes, void* stream) {
+    if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
+    if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G) return K4_ERR_BAD_ARG;
+    if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
+    if (!gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < k4_sft_train_bwd_workspace_bytes(n_pix, channels)) return K4_ERR_BAD_ARG;
+    float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
+    hipStream_t st = (hipStream_t)stream;
+    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
+    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
+}

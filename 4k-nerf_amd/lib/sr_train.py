@@ -16,6 +16,8 @@ nearest x2 upsampling) stays on PyTorch ops and their autograd.  There is no CPU
 458 gradient tensors (15.8 MB) are flattened into one bucket and summed with ONE all-reduce (RCCL over xGMI on the GPUs:
 ring all-reduce of 15.8 MB moves 2*(N-1)/N * 15.8 MB per rank = 27.7 MB at N=8, ~0.2 ms at the per-link rate) and averaged.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -78,14 +80,59 @@ class K4Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty([H, W, cin], dtype=torch.float32, device=x.device)
             SFTNet._conv(ctx.cache.bwd(weight), gy, 0, cout, gx, 0, cin, cin, H, W)
-        if ctx.needs_input_grad[1]:
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_b:
+            # dW and dbias from one buffer: one zero-fill + one launch (the wgrad workgroups of tap 0 / input block 0 also sum dY)
+            nw = weight.numel()
+            buf = torch.empty([nw + cout], dtype=torch.float32, device=x.device)
+            N.check(L.k4_conv2d_wgrad_dbias_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.f32(buf), N.stream()),
+                    'k4_conv2d_wgrad_dbias_bf16x6')
+            gw, gb = buf[:nw].view(weight.shape), buf[nw:]
+        elif ctx.needs_input_grad[1]:
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)          # zeroed by the entry point
             N.check(L.k4_conv2d_wgrad_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.f32(gw), N.stream()),
                     'k4_conv2d_wgrad_bf16x6')
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_b:
             gb = torch.empty([cout], dtype=torch.float32, device=x.device)
             N.check(L.k4_conv2d_bias_grad(N.f32(gy), cout, cout, H * W, N.f32(gb), N.stream()), 'k4_conv2d_bias_grad')
         return gx, gw, gb, None
+
+
+class K4SFTLayer(torch.autograd.Function):
+    """SFTLayer (lib/sr_esrnet.py:112-123) of an NHWC image: ``x * (scale(cond) + 1) + shift(cond)`` with both 1x1-convolution pairs,
+    LeakyReLU and the modulation in ONE launch forward (k4_sft_train_fwd) and two backward (k4_sft_train_bwd: grad_x, grad_cond, the
+    eight weight / bias gradients).  As four K4Conv2d Functions + elementwise autograd a layer was ~45 launches per iteration."""
+
+    @staticmethod
+    def forward(ctx, x, cond, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h):
+        if not x.is_cuda:
+            raise N.K4Error('K4SFTLayer: the MI355X-native decoder has no CPU path')
+        x, cond = x.contiguous().float(), cond.contiguous().float()
+        H, W, C = x.shape
+        assert cond.shape == (H, W, 32) and w0s.shape[:2] == (32, 32) and w1s.shape[:2] == (C, 32)
+        ws = [t.detach().contiguous() for t in (w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h)]
+        y = torch.empty_like(x)
+        N.check(N.lib().k4_sft_train_fwd(N.f32(x), C, N.f32(cond), 32, H * W, C, *[N.f32(t) for t in ws], 0.2, N.f32(y), C, N.stream()),
+                'k4_sft_train_fwd')
+        ctx.save_for_backward(x, cond, *ws)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, cond, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        H, W, C = x.shape
+        n = H * W
+        L = N.lib()
+        gx, gc = torch.empty_like(x), torch.empty_like(cond)
+        g = [torch.empty_like(t) for t in (w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h)]
+        nbytes = int(L.k4_sft_train_bwd_workspace_bytes(n, C))
+        ws = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
+        N.check(L.k4_sft_train_bwd(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
+                                   N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
+                                   N.f32(ws), nbytes, N.stream()), 'k4_sft_train_bwd')
+        return (gx, gc, *g)
 
 
 def _up2(t):
@@ -111,7 +158,13 @@ def forward_train(net, x, cond):
     cn = net.CondNet
     c = conv(cn[6], lrelu(conv(cn[4], lrelu(conv(cn[2], lrelu(conv(cn[0], ci)))))))
 
+    fused_sft = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'            # 'convs': the four-convolution form (A/B, tests)
+
     def sft(layer, t):                                                        # lib/sr_esrnet.py:120-123
+        if fused_sft and t.shape[2] in (32, 64) and c.shape[2] == 32:
+            return K4SFTLayer.apply(t, c, layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight,
+                                    layer.SFT_scale_conv1.bias, layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias,
+                                    layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias)
         scale = conv(layer.SFT_scale_conv1, lrelu(conv(layer.SFT_scale_conv0, c)))
         shift = conv(layer.SFT_shift_conv1, lrelu(conv(layer.SFT_shift_conv0, c)))
         return t * (scale + 1) + shift

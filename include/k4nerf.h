@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -345,6 +345,10 @@ int k4_sft_nhwc(const float* cond, int32_t cond_stride, const float* w_packed,
 int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                            int32_t ksize, int32_t H, int32_t W, float* dw, void* stream);
 int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream);
+/* Both gradients of a biased layer in one zero-fill + ONE launch (the workgroups of tap 0 / input block 0 also sum dY): dw_db is one
+ * buffer [cout*cin*k*k floats of dW | cout floats of dbias], overwritten. */
+int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                                 int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream);
 /* Device-side weight packing for the training loop (every optimizer step changes every weight: 2 x 260 packings per iteration).
  * Writes the `w_split` operand of k4_conv2d_nhwc_bf16x6 for the nn.Conv2d weight w [cout][cin][k][k], bit-identical to the host packer:
  *   form 0: the layer as stored (k4_conv_weight_bf16x6_bytes(cout, cin, k) bytes; bias_out [ceil(cout/32)*32] = bias, zero padded)
@@ -416,6 +420,25 @@ int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, in
  * The package's value is sum(ray_loss) / (ray_id.max() + 1): that division stays on the host. */
 int k4_distortion_loss(const float* w, const float* s, const int64_t* ray_id, int64_t n_pts, int64_t n_rays, float interval,
                        float* ray_loss, float* grad_w, void* stream);
+
+/* SFTLayer of the VC-Decoder in the training graph (lib/sr_esrnet.py:112-123 under autograd, run_sr.py:869-1014):
+ *   y = x * (scale + 1) + shift,   scale = W1s lrelu(W0s c + b0s) + b1s,   shift = W1h lrelu(W0h c + b0h) + b1h
+ * x / y / grad_y / grad_x: [n_pix][stride] rows of `channels` (32 | 64) floats; cond / grad_cond: [n_pix][32]; weights are the nn.Conv2d
+ * tensors as stored (w0* [32][32], w1* [channels][32], row-major).  Forward: one launch, nothing saved (the backward recomputes the
+ * hidden activations).  Backward: grad_x, grad_cond and the eight weight / bias gradients (OVERWRITTEN) in two launches; exact fp32
+ * FMA chains, no atomics: per-workgroup partial sums go to `workspace` (k4_sft_train_bwd_workspace_bytes) and are added in
+ * workgroup order.  Replaces ~13 + ~30 launches of the convolution Functions + elementwise glue per layer. */
+int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
+                     const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                     const float* w0h, const float* b0h, const float* w1h, const float* b1h,
+                     float slope, float* y, int32_t y_stride, void* stream);
+int64_t k4_sft_train_bwd_workspace_bytes(int64_t n_pix, int32_t channels);       /* < 0: unsupported channel count */
+int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                     int64_t n_pix, int32_t channels,
+                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                     float slope, float* grad_x, float* grad_cond,
+                     float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                     float* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -125,3 +125,42 @@ def test_device_weight_packer_is_bit_identical_to_the_host_packer(cout, cin, k):
         assert got.mode == want.mode and got.flags_extra == want.flags_extra and got.cin == want.cin and got.k == want.k
         assert got.w.numel() == want.w.numel() and torch.equal(got.w.reshape(-1), want.w.reshape(-1)), (cout, cin, k, dgrad)
         assert got.b.shape == want.b.shape and torch.equal(got.b, want.b)
+
+
+@pytest.mark.parametrize('C,H,W', [(64, 19, 37), (32, 16, 32), (64, 64, 64), (32, 5, 13)])
+def test_fused_sft_layer_function_matches_torch_autograd(C, H, W):
+    """K4SFTLayer (k4_sft_train_fwd / _bwd: the whole SFTLayer forward in one launch, grad_x / grad_cond / eight parameter gradients in
+    two) against fp64 autograd of the module's formula (lib/sr_esrnet.py:112-123), ragged pixel counts included."""
+    g = torch.Generator().manual_seed(C + H)
+    layer = sr_esrnet.SFTLayer(C, 32)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.4)
+    layer = layer.cuda()
+    x = torch.randn([H, W, C], generator=g).cuda().requires_grad_(True)
+    c = torch.randn([H, W, 32], generator=g).cuda().requires_grad_(True)
+    gy = torch.randn([H, W, C], generator=g).cuda()
+    ps = [layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
+          layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias]
+    y = sr_train.K4SFTLayer.apply(x, c, *ps)
+    y.backward(gy)
+    got = [y.detach(), x.grad, c.grad] + [p.grad for p in ps]
+    xr, cr = x.detach().cpu().double().requires_grad_(True), c.detach().cpu().double().requires_grad_(True)
+    pr = [p.detach().cpu().double().requires_grad_(True) for p in ps]
+    lin = lambda t, w, b: t @ w.reshape(w.shape[0], -1).T + b
+    scale = lin(F.leaky_relu(lin(cr, pr[0], pr[1]), 0.2), pr[2], pr[3])
+    shift = lin(F.leaky_relu(lin(cr, pr[4], pr[5]), 0.2), pr[6], pr[7])
+    yr = xr * (scale + 1) + shift
+    yr.backward(gy.cpu().double())
+    want = [yr, xr.grad, cr.grad] + [p.grad for p in pr]
+    names = ['y', 'dx', 'dcond', 'dw0s', 'db0s', 'dw1s', 'db1s', 'dw0h', 'db0h', 'dw1h', 'db1h']
+    for name, a, r in zip(names, got, want):
+        assert a.shape == r.shape, name
+        assert _rel(a, r) <= 5e-6, (name, _rel(a, r))
+    # deterministic: no atomics anywhere
+    for p in ps:
+        p.grad = None
+    x.grad = c.grad = None
+    sr_train.K4SFTLayer.apply(x, c, *ps).backward(gy)
+    for a, p in zip(got[3:], ps):
+        assert torch.equal(a, p.grad)

@@ -1,0 +1,32 @@
+"""ms per joint training iteration (configs[4] on one GPU), a few iterations after warm-up.  GPU box."""
+import os, sys, time, contextlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import nerf4k_amd  # noqa: F401
+from nerf4k_amd import scene, joint_train
+from nerf4k_amd.lib import dvgo, sr_esrnet, utils
+dev = torch.device('cuda', 0)
+ck = scene.make_llff_checkpoint()
+H, W = scene.LLFF_HW
+ro, rd, vd = dvgo.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(scene.llff_spiral_poses()[0]).to(dev), True, False, False, False)
+model = utils.model_from_checkpoint_dict(ck).to(dev).train()
+torch.manual_seed(778)
+net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).train()
+cfg = joint_train.JointCfg.fern_lg_joint_l1()
+with contextlib.redirect_stdout(sys.stderr):
+    tr = joint_train.JointTrainer(model, net, cfg, dict(ck['render_kwargs'], render_depth=True, rand_bkgd=True), n_train_images=17)
+g = torch.Generator(device=dev).manual_seed(5)
+def batch(i):
+    r0, c0 = (37 * i) % (H - 64), (101 * i) % (W - 64)
+    rays = [x[r0:r0 + 64, c0:c0 + 64].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
+    return rays + [torch.rand([4096, 3], device=dev, generator=g), torch.rand([65536, 3], device=dev, generator=g), 64, 64]
+losses = []
+for i in range(3):
+    losses.append(float(tr.step(*batch(i), global_step=1 + i)['total']))
+torch.cuda.synchronize()
+n = int(os.environ.get('ITERS', '6'))
+t = time.perf_counter()
+for i in range(n):
+    tr.step(*batch(3 + i), global_step=4 + i)
+torch.cuda.synchronize()
+print('joint iteration ms', round((time.perf_counter() - t) / n * 1e3, 2), 'first losses', [round(v, 5) for v in losses])
