@@ -44,6 +44,11 @@ class AdamJob(C.Structure):          # k4_adam_job
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p), ('n', C.c_int64)]
 
 
+class PackJob(C.Structure):          # k4_pack_job
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('w_split', C.c_void_p), ('bias_out', C.c_void_p),
+                ('cout', C.c_int32), ('cin', C.c_int32), ('ksize', C.c_int32), ('form', C.c_int32)]
+
+
 class SftJob(C.Structure):           # k4_sft_job
     _fields_ = [('cond', C.c_void_p), ('x', C.c_void_p), ('y', C.c_void_p), ('res', C.c_void_p), ('n_pix', C.c_int64)]
 
@@ -127,6 +132,8 @@ _EXTRA_SIGS = {
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_wgrad_dbias_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_pack_conv_weight_bf16x6_multi': ([C.POINTER(PackJob), _I32, _P], C.c_int),
+    'k4_lrelu_bwd': ([_P, _I32, _P, _I32, _I64, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_conv2d_bias_grad': ([_P, _I32, _I32, _I64, _P, _P], C.c_int),
     'k4_adam_upd_multi': ([C.POINTER(AdamJob), _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_pack_conv_weight_bf16x6': ([_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P], C.c_int),

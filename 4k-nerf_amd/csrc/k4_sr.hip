@@ -17,6 +17,12 @@
 // fp32 MFMA issues at the fp32 vector rate (157 TFLOP/s peak), so LDS/HBM are far from limiting: the kernel is
 // matrix-pipe bound; bf16 would be 16x faster but breaks the fp32 parity contract.
 #include "k4_common.h"
+
+// a * b + c with TWO roundings, as the reference's separate PyTorch ops (`x5 * 0.2 + x`, `x * (scale + 1) + shift`, lib/sr_esrnet.py:123 /
+// :158 / :182) -- hipcc would contract the expression into one FMA.  One rounding less is not "wrong", but a LeakyReLU input within an ulp
+// of zero downstream then takes the other branch than the reference's, and the training gradients differ visibly at that pixel
+// (tests/test_sr_train_gpu.py; tools/sr_rdb_debug4.py finds such elements).
+__device__ __forceinline__ float k4s_mul_add(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -95,10 +101,10 @@ __device__ __forceinline__ void k4_conv_epilogue(const ConvParams& P, f32x16 (&a
                 if (modulate) {
                     // SFTLayer: x * (scale + 1) + shift      (lib/sr_esrnet.py:123)
                     const float sh = acc[m][(n + NT / 2) % NT][r] + bsh;
-                    v = P.modx[pix * P.mod_stride + co] * (v + 1.f) + sh;
+                    v = k4s_mul_add(P.modx[pix * P.mod_stride + co], v + 1.f, sh);
                 }
                 if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-                if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
+                if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, P.res[pix * P.res_stride + co]);
                 P.y[pix * P.cout_stride + co] = v;
             }
         }
@@ -911,8 +917,8 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                     const size_t pix = (size_t)gy * T.W + gx;
                     float v = acc[0][r][e] + bias;
                     if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-                    if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
-                    const float m = v * (cs[e] + 1.f) + ch[e];                              // x*(scale+1)+shift
+                    if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, T.res[pix * P.res_stride + co]);
+                    const float m = k4s_mul_add(v, cs[e] + 1.f, ch[e]);                             // x*(scale+1)+shift
                     if (T.y2) { T.y[pix * P.cout_stride + co] = v; T.y2[pix * P.sft_y_stride + co] = m; }
                     else T.y[pix * P.cout_stride + co] = m;
                 }
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                         const size_t pix = (size_t)gy * T.W + gx;
                         float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
                         if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-                        if (P.flags & K4_EPI_RES) v = v * P.res_scale + T.res[pix * P.res_stride + co];
+                        if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, T.res[pix * P.res_stride + co]);
                         T.y[pix * P.cout_stride + co] = v;
                     }
                 }
@@ -1161,7 +1167,7 @@ __global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvMulti M)
                 v += y_s[((oy + dy) * K4_TAPS_COLS + ox + dx) * K4_TAPS_YS + t * P.cout + co];
             }
             if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-            if (P.flags & K4_EPI_RES) v = v * P.res_scale + P.res[pix * P.res_stride + co];
+            if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, P.res[pix * P.res_stride + co]);
             P.y[pix * P.cout_stride + co] = v;
         }
     }
@@ -1411,8 +1417,8 @@ __global__ __launch_bounds__(256) void k4_sft_kernel(const SftMulti M) {
                 float ov[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = xv[e] * (cs[t][4 * q + e] + 1.f) + ch[t][4 * q + e];               // x*(scale+1)+shift
-                    if (P.res) v = v * P.res_scale + rv[e];
+                    float v = k4s_mul_add(xv[e], cs[t][4 * q + e] + 1.f, ch[t][4 * q + e]);               // x*(scale+1)+shift
+                    if (P.res) v = k4s_mul_add(v, P.res_scale, rv[e]);
                     ov[e] = v;
                 }
                 if (vec) *reinterpret_cast<float4*>(P.y + (size_t)pix * P.y_stride + co) = make_float4(ov[0], ov[1], ov[2], ov[3]);
@@ -1555,8 +1561,8 @@ __global__ __launch_bounds__(256) void k4_sft_b6_kernel(const SftMulti M) {
                 float ov[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = xv[e] * (cs[4 * q + e] + 1.f) + ch[4 * q + e];               // x*(scale+1)+shift
-                    if (P.res) v = v * P.res_scale + rv[e];
+                    float v = k4s_mul_add(xv[e], cs[4 * q + e] + 1.f, ch[4 * q + e]);               // x*(scale+1)+shift
+                    if (P.res) v = k4s_mul_add(v, P.res_scale, rv[e]);
                     ov[e] = v;
                 }
                 if (vec) *reinterpret_cast<float4*>(P.y + (size_t)pix * P.y_stride + co) = make_float4(ov[0], ov[1], ov[2], ov[3]);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
     const bool ci_ok = ci < P.cin, co_ok = co < P.cout;
     f32x16 acc = (f32x16)(0.f);
     const bool do_bias = P.db != nullptr && tap == 0 && cib == 0;        // workgroup-uniform: these workgroups see every dY value of their band once
-    float bsum = 0.f;
+    double bsum = 0.0;                                                  // the band's dY sum in fp64: one fp32 rounding per band
     const int y_end = min((band + 1) * K4_WG_BAND, P.H);
     for (int y = band * K4_WG_BAND + wv; y < y_end; y += 4) {
         const int sy = y + dy;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
                 a8[e] = a_ok ? P.x[((size_t)sy * P.W + sx) * P.x_stride + ci] : 0.f;
                 b8[e] = b_ok ? P.gy[((size_t)y * P.W + px) * P.gy_stride + co] : 0.f;
             }
-            if (do_bias) bsum += ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7]));
+            if (do_bias) bsum += (double)(((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7])));
             uint4 a0, a1, a2, b0, b1, b2;
             wg_split3(a8, a0, a1, a2);
             wg_split3(b8, b0, b1, b2);
@@ -116,10 +116,11 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
     }
     if (do_bias) {                                                      // dbias[co] += this band's sum of dY[.][co]: both pixel halves, four waves
         bsum += __shfl_xor(bsum, 32);
+        double* const redd = reinterpret_cast<double*>(&red[0][0]);
         __syncthreads();                                                // `red` is free again
-        if (half == 0) red[0][wv * 32 + l31] = bsum;
+        if (half == 0) redd[wv * 32 + l31] = bsum;
         __syncthreads();
-        if (wv == 0 && half == 0 && co_ok) unsafeAtomicAdd(P.db + co, (red[0][l31] + red[0][32 + l31]) + (red[0][64 + l31] + red[0][96 + l31]));
+        if (wv == 0 && half == 0 && co_ok) unsafeAtomicAdd(P.db + co, (float)((redd[l31] + redd[32 + l31]) + (redd[64 + l31] + redd[96 + l31])));
     }
 }
 
@@ -225,6 +226,72 @@ __global__ void k4_pack_conv_kernel(const float* __restrict__ w, const float* __
     const size_t plane = (size_t)taps_l * 2 * NOUT;                   // 16-byte units per (ch, term)
     uint4* const o = out + ((size_t)ch * 3) * plane + ((size_t)tap * 2 + g2) * NOUT + n;
     o[0] = t0; o[plane] = t1; o[2 * plane] = t2;
+}
+
+// The same packing for MANY layers in one launch: the job table travels as a kernel argument (blockIdx.y = job; workgroups past a
+// job's size leave at once).  Under training all ~170 operands of SFTNet (every convolution, forward and dgrad form) are re-packed
+// once per iteration: 170 launches of 5 us -> 3.
+struct PackJobDev { const float* w; const float* bias; uint4* out; float* bias_out; int cout, cin, taps, form, nch, taps_l, NOUT, n_bias; };
+struct PackMultiArgs { PackJobDev j[K4_PACK_MULTI_MAX]; };
+
+__global__ __launch_bounds__(256) void k4_pack_conv_multi_kernel(const PackMultiArgs A) {
+    const PackJobDev& J = A.j[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = J.nch * J.taps_l * 2 * J.NOUT;
+    if (idx >= total && idx >= J.n_bias) return;
+    if (idx < J.n_bias) J.bias_out[idx] = (J.bias && (J.form == 0 || J.form == 2) && idx < J.cout) ? J.bias[idx] : 0.f;
+    if (idx >= total) return;
+    const int cout = J.cout, cin = J.cin, taps = J.taps, form = J.form, taps_l = J.taps_l, NOUT = J.NOUT;
+    const float* __restrict__ w = J.w;
+    const int n = idx % NOUT;
+    int r = idx / NOUT;
+    const int g2 = r & 1; r >>= 1;
+    const int tap = r % taps_l, ch = r / taps_l;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = ch * 16 + g2 * 8 + e;
+        float q = 0.f;
+        if (form == 0) { if (n < cout && c < cin) q = w[((size_t)n * cin + c) * taps + tap]; }
+        else if (form == 1) { if (n < cin && c < cout) q = w[((size_t)c * cin + n) * taps + (taps - 1 - tap)]; }
+        else if (form == 2) { if (n < taps * cout && c < cin) q = w[((size_t)(n % cout) * cin + c) * taps + n / cout]; }
+        else { if (n < taps * cin && c < cout) q = w[((size_t)c * cin + n % cin) * taps + (taps - 1 - n / cin)]; }
+        v[e] = q;
+    }
+    uint4 t0, t1, t2;
+    wg_split3(v, t0, t1, t2);
+    const size_t plane = (size_t)taps_l * 2 * NOUT;
+    uint4* const o = J.out + ((size_t)ch * 3) * plane + ((size_t)tap * 2 + g2) * NOUT + n;
+    o[0] = t0; o[plane] = t1; o[2 * plane] = t2;
+}
+
+extern "C" int k4_pack_conv_weight_bf16x6_multi(const k4_pack_job* jobs, int32_t n_jobs, void* stream) {
+    if (!jobs || n_jobs < 0) return K4_ERR_BAD_ARG;
+    for (int base = 0; base < n_jobs; base += K4_PACK_MULTI_MAX) {
+        const int nj = n_jobs - base < K4_PACK_MULTI_MAX ? n_jobs - base : K4_PACK_MULTI_MAX;
+        PackMultiArgs A{};
+        int max_threads = 0;
+        for (int q = 0; q < nj; ++q) {
+            const k4_pack_job& S = jobs[base + q];
+            const int cout = S.cout, cin = S.cin, ksize = S.ksize, form = S.form;
+            if (!S.w || !S.w_split || !S.bias_out || cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3) || form < 0 || form > 3) return K4_ERR_BAD_ARG;
+            if ((form == 2 && (ksize != 3 || cout > 3)) || (form == 3 && (ksize != 3 || cin > 3))) return K4_ERR_BAD_ARG;
+            const int taps = ksize * ksize;
+            const int cout_l = form == 0 ? cout : form == 1 ? cin : form == 2 ? taps * cout : taps * cin;
+            const int cin_l = (form == 1 || form == 3) ? cout : cin;
+            PackJobDev& D = A.j[q];
+            D.w = S.w; D.bias = S.bias; D.out = reinterpret_cast<uint4*>(S.w_split); D.bias_out = S.bias_out;
+            D.cout = cout; D.cin = cin; D.taps = taps; D.form = form;
+            D.taps_l = form >= 2 ? 1 : taps;
+            D.NOUT = (cout_l + 31) / 32 * 32; D.nch = (cin_l + 15) / 16;
+            D.n_bias = form >= 2 ? 32 : D.NOUT;
+            const int total = D.nch * D.taps_l * 2 * D.NOUT;
+            const int threads = total > D.n_bias ? total : D.n_bias;
+            if (threads > max_threads) max_threads = threads;
+        }
+        hipLaunchKernelGGL(k4_pack_conv_multi_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)nj), dim3(256), 0, (hipStream_t)stream, A);
+    }
+    return k4_check_launch();
 }
 
 extern "C" int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int32_t cout, int32_t cin, int32_t ksize, int32_t form,

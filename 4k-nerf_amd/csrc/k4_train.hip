@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void k_sft_train_fwd(const float* __restrict__
             s0 = fmaf(a, w1sc[co * SFT_G + k], s0); s1 = fmaf(a, w1sc[(co + 1) * SFT_G + k], s1);
             h0 = fmaf(b, w1hc[co * SFT_G + k], h0); h1 = fmaf(b, w1hc[(co + 1) * SFT_G + k], h1);
         }
-        xs[co * TR_LS + lane] = fmaf(xs[co * TR_LS + lane], s0 + 1.f, h0);                  // x * (scale + 1) + shift   (lib/sr_esrnet.py:123)
-        xs[(co + 1) * TR_LS + lane] = fmaf(xs[(co + 1) * TR_LS + lane], s1 + 1.f, h1);
+        xs[co * TR_LS + lane] = __fadd_rn(__fmul_rn(xs[co * TR_LS + lane], s0 + 1.f), h0);                  // x * (scale + 1) + shift   (lib/sr_esrnet.py:123)
+        xs[(co + 1) * TR_LS + lane] = __fadd_rn(__fmul_rn(xs[(co + 1) * TR_LS + lane], s1 + 1.f), h1);   // two roundings, as the reference's ops
     }
     __syncthreads();
     sft_store_tile(xs, y, base, y_stride, C, nv, t);
@@ -795,4 +795,31 @@ extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* c
     hipStream_t st = (hipStream_t)stream;
     if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
     return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LeakyReLU backward on a channel slice (dense-block gradient image of the decoder's training graph, lib/sr_train.py K4RDB)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lrelu_bwd(const float* g, int g_stride, const float* __restrict__ y, int y_stride, int64_t n_pix,
+                                                   int c4, float slope, float* out, int out_stride) {          // out may alias g
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pix * c4) return;
+    const int64_t p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    const float4 yv = *reinterpret_cast<const float4*>(y + p * y_stride + c);
+    float4 gv = *reinterpret_cast<const float4*>(g + p * g_stride + c);
+    gv.x *= yv.x > 0.f ? 1.f : slope; gv.y *= yv.y > 0.f ? 1.f : slope; gv.z *= yv.z > 0.f ? 1.f : slope; gv.w *= yv.w > 0.f ? 1.f : slope;
+    *reinterpret_cast<float4*>(out + p * out_stride + c) = gv;
+}
+
+extern "C" int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y, int32_t y_stride, int64_t n_pix, int32_t channels, float slope,
+                            float* out, int32_t out_stride, void* stream) {
+    if (!grad || !y || !out || n_pix < 0 || channels <= 0 || (channels & 3) || (g_stride & 3) || (y_stride & 3) || (out_stride & 3) ||
+        g_stride < channels || y_stride < channels || out_stride < channels || ((uintptr_t)grad & 15) || ((uintptr_t)y & 15) || ((uintptr_t)out & 15))
+        return K4_ERR_BAD_ARG;
+    if (n_pix == 0) return 0;
+    const int64_t n = n_pix * (channels / 4);
+    hipLaunchKernelGGL(k_lrelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, g_stride, y, y_stride, n_pix, channels / 4, slope,
+                       out, out_stride);
+    return k4_check_launch();
 }

@@ -183,38 +183,70 @@ class _Packed:
         self.b[:cout] = bias.detach().float()
         self.cin, self.k = cin, k
 
+    @staticmethod
+    def _native_plan(weight, dgrad):
+        """(form, flags_extra, packed bytes, bias floats, logical cin) of the device packer for this layer / operand."""
+        cout, cin, k, _ = weight.shape
+        taps_ok = k == 3 and os.environ.get('K4_CONV_TAPS', '1') != '0'
+        flags_extra = 0
+        if dgrad and taps_ok and cin <= 3:                  # the dgrad layer has <= 3 outputs (conv_first, CondNet.0): taps form of it
+            form, lc_out, lc_in, lk = 3, 9 * cin, cout, 1
+            flags_extra = W_TAPS_AS_COUT
+        elif dgrad:
+            form, lc_out, lc_in, lk = 1, cin, cout, k
+        elif taps_ok and cout <= 3:
+            form, lc_out, lc_in, lk = 2, 9 * cout, cin, 1
+            flags_extra = W_TAPS_AS_COUT
+        else:
+            form, lc_out, lc_in, lk = 0, cout, cin, k
+        nbytes = int(N.lib().k4_conv_weight_bf16x6_bytes(lc_out, lc_in, lk))
+        if nbytes <= 0:
+            raise N.K4Error(f'unsupported convolution shape {tuple(weight.shape)}')
+        nb = 32 if form >= 2 else ((cin if dgrad else cout) + 31) // 32 * 32
+        return form, flags_extra, nbytes, nb, (cout if dgrad else cin)
+
     @classmethod
     def native(cls, weight, bias, dgrad=False):
         """The 'bf16x6' packing of an nn.Conv2d weight by ONE kernel launch (k4_pack_conv_weight_bf16x6), bit-identical to
         ``_Packed(weight, bias, 'bf16x6')`` -- or, with ``dgrad``, to the packing of the flipped-transposed filter the dgrad
         convolution uses.  The training loop re-packs every layer twice per iteration; as PyTorch ops that was ~6000 tiny launches."""
-        cout, cin, k, _ = weight.shape
+        return cls.native_many([(weight, bias, dgrad)])[0]
+
+    @classmethod
+    def native_many(cls, items):
+        """``native`` for a list of (weight, bias, dgrad): ONE buffer for all operands and ceil(n / 64) launches
+        (k4_pack_conv_weight_bf16x6_multi); a single item goes through k4_pack_conv_weight_bf16x6."""
+        if not items:
+            return []
         L = N.lib()
-        self = cls.__new__(cls)
-        self.mode, self.flags_extra = 'bf16x6', 0
-        taps_ok = k == 3 and os.environ.get('K4_CONV_TAPS', '1') != '0'
-        if dgrad and taps_ok and cin <= 3:                  # the dgrad layer has <= 3 outputs (conv_first, CondNet.0): taps form of it
-            form, lc_out, lc_in, lk = 3, 9 * cin, cout, 1
-            self.flags_extra = W_TAPS_AS_COUT
-        elif dgrad:
-            form, lc_out, lc_in, lk = 1, cin, cout, k
-        elif taps_ok and cout <= 3:
-            form, lc_out, lc_in, lk = 2, 9 * cout, cin, 1
-            self.flags_extra = W_TAPS_AS_COUT
+        dev = items[0][0].device
+        plans = [cls._native_plan(w, d) for w, _, d in items]
+        wbuf = torch.empty([sum(p[2] for p in plans) // 2], dtype=torch.int16, device=dev)       # operand sizes are multiples of 16 bytes
+        bbuf = torch.empty([sum(p[3] for p in plans)], dtype=torch.float32, device=dev)
+        jobs = (N.PackJob * len(items))()
+        out, keep = [], []
+        wo = bo = 0
+        for q, ((weight, bias, dgrad), (form, flags_extra, nbytes, nb, lcin)) in enumerate(zip(items, plans)):
+            cout, cin, k, _ = weight.shape
+            self = cls.__new__(cls)
+            self.mode, self.flags_extra = 'bf16x6', flags_extra
+            self.w, self.b = wbuf[wo // 2:(wo + nbytes) // 2], bbuf[bo:bo + nb]
+            self.cin, self.k = lcin, k
+            wc = weight.detach().float().contiguous()
+            bc = None if (bias is None or dgrad) else bias.detach().float().contiguous()
+            keep.append((wc, bc))
+            jobs[q].w, jobs[q].bias = wc.data_ptr(), None if bc is None else bc.data_ptr()
+            jobs[q].w_split, jobs[q].bias_out = self.w.data_ptr(), self.b.data_ptr()
+            jobs[q].cout, jobs[q].cin, jobs[q].ksize, jobs[q].form = cout, cin, k, form
+            wo, bo = wo + nbytes, bo + nb
+            out.append(self)
+        if len(items) == 1:
+            j = jobs[0]
+            N.check(L.k4_pack_conv_weight_bf16x6(j.w, j.bias, j.cout, j.cin, j.ksize, j.form, j.w_split, j.bias_out, N.stream()),
+                    'k4_pack_conv_weight_bf16x6')
         else:
-            form, lc_out, lc_in, lk = 0, cout, cin, k
-        nbytes = int(L.k4_conv_weight_bf16x6_bytes(lc_out, lc_in, lk))
-        if nbytes <= 0:
-            raise N.K4Error(f'unsupported convolution shape {tuple(weight.shape)}')
-        wc = weight.detach().float().contiguous()
-        self.w = torch.empty([nbytes // 2], dtype=torch.int16, device=wc.device)
-        nb = 32 if form >= 2 else ((cin if dgrad else cout) + 31) // 32 * 32
-        self.b = torch.empty([nb], dtype=torch.float32, device=wc.device)
-        bc = None if (bias is None or dgrad) else bias.detach().float().contiguous()
-        N.check(L.k4_pack_conv_weight_bf16x6(N.f32(wc), None if bc is None else N.f32(bc), cout, cin, k, form, N.ptr(self.w), N.f32(self.b),
-                                             N.stream()), 'k4_pack_conv_weight_bf16x6')
-        self.cin, self.k = (cout if dgrad else cin), k
-        return self
+            N.check(L.k4_pack_conv_weight_bf16x6_multi(jobs, len(items), N.stream()), 'k4_pack_conv_weight_bf16x6_multi')
+        return out
 
 
 def pack_sft(layer):

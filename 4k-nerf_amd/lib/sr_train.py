@@ -7,10 +7,13 @@ The reference back-propagates its losses through ``SFTNet`` with PyTorch autogra
     forward : k4_conv2d_nhwc_bf16x6           (csrc/k4_sr.hip: exact 3-term bf16 splits, 6 MFMA products, fp32-equivalent)
     dgrad   : the same kernel on W'[ci][co][2-dy][2-dx] = W[co][ci][dy][dx]   (a "same" convolution of dY with the flipped,
               transposed filter; packed once per weight version)
-    wgrad   : k4_conv2d_wgrad_bf16x6          (csrc/k4_sr_bwd.hip: MFMA GEMM over the pixels, split-K + fp32 atomics)
-    dbias   : k4_conv2d_bias_grad
-The elementwise glue between the convolutions (LeakyReLU, SFT modulation x*(scale+1)+shift, residual scaling, channel concat,
-nearest x2 upsampling) stays on PyTorch ops and their autograd.  There is no CPU path.
+    wgrad   : k4_conv2d_wgrad_dbias_bf16x6    (csrc/k4_sr_bwd.hip: MFMA GEMM over the pixels, split-K + fp32 atomics; the bias
+              gradient is summed by the same launch)
+A LeakyReLU that follows a convolution runs in its epilogue; an SFTLayer is one Function (``K4SFTLayer``: fused exact-fp32 kernels
+forward and backward); a ResidualDenseBlock with its two SFT layers is one Function (``K4RDB``: the dense block and its gradient live
+in one [H, W, 192] image each, no concatenations); all weight operands are re-packed by ceil(n/64) launches per iteration
+(``_WeightCache.prepack``).  What stays on PyTorch ops and their autograd: the RRDB / trunk residual adds and nearest x2 upsampling.
+There is no CPU path.
 
 ``allreduce_gradients`` is the data-parallel exchange: each rank back-propagates its own 64x64 patch (run_sr.py:829-835), the
 458 gradient tensors (15.8 MB) are flattened into one bucket and summed with ONE all-reduce (RCCL over xGMI on the GPUs:
@@ -23,7 +26,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import _native as N
-from .sr_esrnet import _Packed, SFTNet
+from .sr_esrnet import _Packed, SFTNet, EPI_LRELU, EPI_RES
 
 
 class _WeightCache:
@@ -33,11 +36,15 @@ class _WeightCache:
         self._c = {}
         self.always = False        # True: pack on every call (hipGraph capture: the packing kernels must be part of the graph, see GraphedDecoder)
 
+    @staticmethod
+    def _key(kind, weight, bias):
+        return (kind, weight.data_ptr(), weight._version, None if bias is None else bias._version, str(weight.device))
+
     def _get(self, kind, weight, bias, make):
-        if self.always:
-            return make()
-        key = (kind, weight.data_ptr(), weight._version, None if bias is None else bias._version, str(weight.device))
         hit = self._c.get((kind, weight.data_ptr()))
+        if self.always:                                   # under capture: what prepack() of THIS forward packed, else pack now
+            return hit[1] if hit is not None and hit[0] is None else make()
+        key = self._key(kind, weight, bias)
         if hit is None or hit[0] != key:
             hit = (key, make())
             self._c[(kind, weight.data_ptr())] = hit
@@ -50,12 +57,49 @@ class _WeightCache:
         # dgrad operand: the filter flipped in both taps axes and transposed to [cin, cout, k, k], packed by the same kernel
         return self._get('b', weight, None, lambda: _Packed.native(weight, None, dgrad=True))
 
+    def prepack(self, convs, dgrad=True):
+        """Pack every stale operand of `convs` (modules with .weight / .bias) now, in ceil(n / 64) launches instead of one per operand
+        (an optimizer step makes all of them stale at once).  Under ``always`` everything is packed and marked as this forward's."""
+        items, slots = [], []
+        for m in convs:
+            for kind in ('f', 'b') if dgrad else ('f',):
+                bias = m.bias if kind == 'f' else None
+                key = None if self.always else self._key(kind, m.weight, bias)
+                hit = self._c.get((kind, m.weight.data_ptr()))
+                if self.always or hit is None or hit[0] != key:
+                    items.append((m.weight, bias, kind == 'b'))
+                    slots.append(((kind, m.weight.data_ptr()), key))
+        for (slot, key), pk in zip(slots, _Packed.native_many(items)):
+            self._c[slot] = (key, pk)
+
+    def invalidate(self):
+        self._c.clear()
+
+
+def _wgrad(x, x_off, cin, x_stride, gy, gy_off, cout, gy_stride, k, H, W, weight_shape, with_bias):
+    """dW (and dbias) of a stride-1 "same" convolution from channel windows of NHWC images: one zero-fill + one launch."""
+    L = N.lib()
+    nw = cout * cin * k * k
+    buf = torch.empty([nw + (cout if with_bias else 0)], dtype=torch.float32, device=x.device)         # zeroed by the entry point
+    xp, gp = N.C.c_void_p(x.data_ptr() + 4 * x_off), N.C.c_void_p(gy.data_ptr() + 4 * gy_off)
+    if with_bias:
+        N.check(L.k4_conv2d_wgrad_dbias_bf16x6(xp, cin, x_stride, gp, cout, gy_stride, k, H, W, N.f32(buf), N.stream()), 'k4_conv2d_wgrad_dbias_bf16x6')
+        return buf[:nw].view(weight_shape), buf[nw:]
+    N.check(L.k4_conv2d_wgrad_bf16x6(xp, cin, x_stride, gp, cout, gy_stride, k, H, W, N.f32(buf), N.stream()), 'k4_conv2d_wgrad_bf16x6')
+    return buf.view(weight_shape), None
+
+
+def _lrelu_bwd(g, g_off, g_stride, y, y_off, y_stride, n_pix, channels, out, out_off, out_stride):
+    N.check(N.lib().k4_lrelu_bwd(N.C.c_void_p(g.data_ptr() + 4 * g_off), g_stride, N.C.c_void_p(y.data_ptr() + 4 * y_off), y_stride, n_pix, channels,
+                                 0.2, N.C.c_void_p(out.data_ptr() + 4 * out_off), out_stride, N.stream()), 'k4_lrelu_bwd')
+
 
 class K4Conv2d(torch.autograd.Function):
-    """stride-1 "same" convolution of an NHWC [H, W, Cin] image with an nn.Conv2d weight [Cout, Cin, k, k] (k = 1 | 3)."""
+    """stride-1 "same" convolution of an NHWC [H, W, Cin] image with an nn.Conv2d weight [Cout, Cin, k, k] (k = 1 | 3); with ``act``
+    the LeakyReLU(0.2) that follows runs in the kernel's epilogue (its backward: one k4_lrelu_bwd on the incoming gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, act=False):
         if not x.is_cuda:
             raise N.K4Error('K4Conv2d: the MI355X-native decoder has no CPU path')
         x = x.contiguous()
@@ -63,39 +107,37 @@ class K4Conv2d(torch.autograd.Function):
         cout, cin_w, k, _ = weight.shape
         assert cin == cin_w and x.dtype == torch.float32
         y = torch.empty([H, W, cout], dtype=torch.float32, device=x.device)
-        SFTNet._conv(cache.fwd(weight, bias), x, 0, cin, y, 0, cout, cout, H, W)
-        ctx.save_for_backward(x, weight)
-        ctx.cache, ctx.has_bias = cache, bias is not None
+        SFTNet._conv(cache.fwd(weight, bias), x, 0, cin, y, 0, cout, cout, H, W, flags=EPI_LRELU if act else 0)
+        if act:
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
+        ctx.cache, ctx.has_bias, ctx.act = cache, bias is not None, act
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         gy = gy.contiguous().float()
         H, W, cin = x.shape
         cout, _, k, _ = weight.shape
+        if ctx.act:
+            g2 = torch.empty_like(gy)
+            _lrelu_bwd(gy, 0, cout, ctx.saved_tensors[2], 0, cout, H * W, cout, g2, 0, cout)
+            gy = g2
         gx = gw = gb = None
         L = N.lib()
         if ctx.needs_input_grad[0]:
             gx = torch.empty([H, W, cin], dtype=torch.float32, device=x.device)
             SFTNet._conv(ctx.cache.bwd(weight), gy, 0, cout, gx, 0, cin, cin, H, W)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and want_b:
-            # dW and dbias from one buffer: one zero-fill + one launch (the wgrad workgroups of tap 0 / input block 0 also sum dY)
-            nw = weight.numel()
-            buf = torch.empty([nw + cout], dtype=torch.float32, device=x.device)
-            N.check(L.k4_conv2d_wgrad_dbias_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.f32(buf), N.stream()),
-                    'k4_conv2d_wgrad_dbias_bf16x6')
-            gw, gb = buf[:nw].view(weight.shape), buf[nw:]
-        elif ctx.needs_input_grad[1]:
-            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)          # zeroed by the entry point
-            N.check(L.k4_conv2d_wgrad_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.f32(gw), N.stream()),
-                    'k4_conv2d_wgrad_bf16x6')
+        if ctx.needs_input_grad[1]:
+            gw, gb = _wgrad(x, 0, cin, cin, gy, 0, cout, cout, k, H, W, weight.shape, want_b)
         elif want_b:
             gb = torch.empty([cout], dtype=torch.float32, device=x.device)
             N.check(L.k4_conv2d_bias_grad(N.f32(gy), cout, cout, H * W, N.f32(gb), N.stream()), 'k4_conv2d_bias_grad')
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class K4SFTLayer(torch.autograd.Function):
@@ -135,6 +177,96 @@ class K4SFTLayer(torch.autograd.Function):
         return (gx, gc, *g)
 
 
+def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
+    """k4_sft_train_bwd on channel windows: (grad_x [n_pix, C], grad_cond [n_pix, 32], the eight weight / bias gradients)."""
+    L = N.lib()
+    w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h = ws
+    gx = torch.empty([n_pix, C], dtype=torch.float32, device=x.device)
+    gc = torch.empty([n_pix, 32], dtype=torch.float32, device=x.device)
+    g = [torch.empty_like(t) for t in ws]
+    nbytes = int(L.k4_sft_train_bwd_workspace_bytes(n_pix, C))
+    wk = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
+    N.check(L.k4_sft_train_bwd(N.f32(x), x_stride, N.f32(cond), 32, N.C.c_void_p(gy.data_ptr() + 4 * gy_off), gy_stride, n_pix, C,
+                               N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s), N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc),
+                               *[N.f32(t) for t in g], N.f32(wk), nbytes, N.stream()), 'k4_sft_train_bwd')
+    return gx, gc, g
+
+
+class K4RDB(torch.autograd.Function):
+    """ResidualDenseBlock_5C with its two SFT layers (lib/sr_esrnet.py:126-158) as ONE autograd node.
+
+    Forward: the dense block lives in one [H, W, nf + 4g] image (xc0 | x1 | x2 | x3 | xc1) that every convolution reads a channel
+    prefix of and writes its slice of (as the inference path does) -- no torch.cat, LeakyReLU and ``x5 * 0.2 + x`` in the epilogues.
+    Backward: ONE gradient image of the same shape; the dgrad of conv_k ACCUMULATES into the channel prefix it read (residual epilogue
+    with the output as its own residual), so the five-way sums of the concatenations need no kernels of their own.
+    7 launches forward, 21 backward (+ the weight packers, batched by _WeightCache.prepack); as separate Functions a block was ~70.
+    params: sft0 (w0s b0s w1s b1s w0h b0h w1h b1h), conv1..conv5 (weight, bias), sft1 (8)."""
+
+    @staticmethod
+    def forward(ctx, t, c, cache, *P):
+        if not t.is_cuda:
+            raise N.K4Error('K4RDB: the MI355X-native decoder has no CPU path')
+        L = N.lib()
+        t, c = t.contiguous(), c.contiguous()
+        H, W, nf = t.shape
+        g = P[8].shape[0]
+        bw, n = nf + 4 * g, H * W
+        assert c.shape == (H, W, 32) and len(P) == 26 and g == 32 and nf in (32, 64)
+        P = [q.detach().contiguous() for q in P]
+        buf = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
+        x4 = torch.empty([H, W, g], dtype=torch.float32, device=t.device)
+        out = torch.empty([H, W, nf], dtype=torch.float32, device=t.device)
+        N.check(L.k4_sft_train_fwd(N.f32(t), nf, N.f32(c), 32, n, nf, *[N.f32(q) for q in P[0:8]], 0.2, N.f32(buf), bw, N.stream()), 'k4_sft_train_fwd')
+        for k in (1, 2, 3):
+            SFTNet._conv(cache.fwd(P[6 + 2 * k], P[7 + 2 * k]), buf, 0, bw, buf, nf + (k - 1) * g, bw, g, H, W, flags=EPI_LRELU)
+        SFTNet._conv(cache.fwd(P[14], P[15]), buf, 0, bw, x4, 0, g, g, H, W, flags=EPI_LRELU)
+        N.check(L.k4_sft_train_fwd(N.f32(x4), g, N.f32(c), 32, n, g, *[N.f32(q) for q in P[18:26]], 0.2,
+                                   N.C.c_void_p(buf.data_ptr() + 4 * (nf + 3 * g)), bw, N.stream()), 'k4_sft_train_fwd')
+        SFTNet._conv(cache.fwd(P[16], P[17]), buf, 0, bw, out, 0, nf, nf, H, W, flags=EPI_RES, res=(t, 0, nf, 0.2))
+        ctx.save_for_backward(t, c, buf, x4, *P)
+        ctx.cache = cache
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        t, c, buf, x4 = ctx.saved_tensors[:4]
+        P = ctx.saved_tensors[4:]
+        cache = ctx.cache
+        H, W, nf = t.shape
+        g = P[8].shape[0]
+        bw, n = nf + 4 * g, H * W
+        go = go.contiguous().float()
+        G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
+        grads = [None] * 26
+
+        def accum(pk, src, s_off, s_stride, cout):                      # G[..., :cout] += dgrad: the output is its own residual
+            SFTNet._conv(pk, src, s_off, s_stride, G, 0, bw, cout, H, W, flags=EPI_RES, res=(G, 0, bw, 1.0))
+
+        # conv5: out = 0.2 conv5(buf) + t
+        g5 = go * 0.2
+        SFTNet._conv(cache.bwd(P[16]), g5, 0, nf, G, 0, bw, bw, H, W)                                                 # G = dgrad (every channel)
+        grads[16], grads[17] = _wgrad(buf, 0, bw, bw, g5, 0, nf, nf, 3, H, W, P[16].shape, True)
+        # xc1 = sft1(x4), x4 = lrelu(conv4(buf[:nf+3g]))
+        gx4, gc1, grads[18:26] = _sft_bwd(x4, g, g, c, G, nf + 3 * g, bw, n, P[18:26])
+        _lrelu_bwd(gx4, 0, g, x4, 0, g, n, g, gx4, 0, g)
+        cin4 = nf + 3 * g
+        accum(cache.bwd(P[14]), gx4, 0, g, cin4)                                                                      # G[:cin4] += dgrad
+        grads[14], grads[15] = _wgrad(buf, 0, cin4, bw, gx4, 0, g, g, 3, H, W, P[14].shape, True)
+        for k in (3, 2, 1):                                                                                         # x_k = lrelu(conv_k(buf[:off]))
+            off = nf + (k - 1) * g
+            _lrelu_bwd(G, off, bw, buf, off, bw, n, g, G, off, bw)
+            accum(cache.bwd(P[6 + 2 * k]), G, off, bw, off)
+            grads[6 + 2 * k], grads[7 + 2 * k] = _wgrad(buf, 0, off, bw, G, off, g, bw, 3, H, W, P[6 + 2 * k].shape, True)
+        gx0, gc0, grads[0:8] = _sft_bwd(t, nf, nf, c, G, 0, bw, n, P[0:8])                                            # xc0 = sft0(t)
+        gt = go + gx0.view(H, W, nf)
+        gc = (gc0 + gc1).view(H, W, 32)
+        return (gt, gc, None, *grads)
+
+
+_TAP = None        # tools/sr_rdb_debug3.py: callback(block, input, cond, output) per dense block
+
+
 def _up2(t):
     """F.interpolate(scale_factor=2, mode='nearest') of an NHWC image (lib/sr_esrnet.py:461-463)."""
     return t.repeat_interleave(2, 0).repeat_interleave(2, 1)
@@ -146,30 +278,37 @@ def forward_train(net, x, cond):
     assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
     cache = net._k4.setdefault('train_cache', _WeightCache())
 
-    def conv(m, t):
-        return K4Conv2d.apply(t, m.weight, m.bias, cache)
+    def conv(m, t, act=False):
+        return K4Conv2d.apply(t, m.weight, m.bias, cache, act)
 
     def lrelu(t):
         return F.leaky_relu(t, 0.2)
+
+    fused = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'               # 'convs': one Function per convolution + elementwise autograd (A/B, tests)
+    if os.environ.get('K4_TRAIN_PREPACK', '1') != '0':                       # '0': every operand packed by its own launch on first use (A/B)
+        cache.prepack([m for name, m in net.named_modules() if isinstance(m, torch.nn.Conv2d) and not (fused and '.SFT_' in '.' + name)])
 
     xi = x[0].permute(1, 2, 0).contiguous().float()
     ci = cond[0].permute(1, 2, 0).contiguous().float()
     feat = conv(net.conv_first, xi)
     cn = net.CondNet
-    c = conv(cn[6], lrelu(conv(cn[4], lrelu(conv(cn[2], lrelu(conv(cn[0], ci)))))))
+    c = conv(cn[6], conv(cn[4], conv(cn[2], conv(cn[0], ci, True), True), True))
 
-    fused_sft = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'            # 'convs': the four-convolution form (A/B, tests)
+    def sft_params(layer):
+        return (layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
+                layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias)
 
     def sft(layer, t):                                                        # lib/sr_esrnet.py:120-123
-        if fused_sft and t.shape[2] in (32, 64) and c.shape[2] == 32:
-            return K4SFTLayer.apply(t, c, layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight,
-                                    layer.SFT_scale_conv1.bias, layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias,
-                                    layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias)
+        if fused and t.shape[2] in (32, 64) and c.shape[2] == 32:
+            return K4SFTLayer.apply(t, c, *sft_params(layer))
         scale = conv(layer.SFT_scale_conv1, lrelu(conv(layer.SFT_scale_conv0, c)))
         shift = conv(layer.SFT_shift_conv1, lrelu(conv(layer.SFT_shift_conv0, c)))
         return t * (scale + 1) + shift
 
     def rdb(blk, t):                                                          # lib/sr_esrnet.py:149-158
+        if fused and t.shape[2] in (32, 64) and c.shape[2] == 32 and blk.conv1.weight.shape[0] == 32:
+            convs = [q for m in (blk.conv1, blk.conv2, blk.conv3, blk.conv4, blk.conv5) for q in (m.weight, m.bias)]
+            return K4RDB.apply(t, c, cache, *sft_params(blk.sft0), *convs, *sft_params(blk.sft1))
         xc0 = sft(blk.sft0, t)
         x1 = lrelu(conv(blk.conv1, xc0))
         x2 = lrelu(conv(blk.conv2, torch.cat((xc0, x1), 2)))
@@ -180,15 +319,29 @@ def forward_train(net, x, cond):
         return x5 * 0.2 + t
 
     body = feat
+    if _TAP is not None:
+        _rdb = rdb
+
+        def rdb(blk, t):
+            o = _rdb(blk, t)
+            _TAP(blk, t, c, o)
+            return o
     for rr in net.body:                                                       # lib/sr_esrnet.py:176-182
         out = rdb(rr.rdb3, rdb(rr.rdb2, rdb(rr.rdb1, body)))
         body = sft(rr.sft0, out) * 0.2 + body
     body = conv(net.conv_body, sft(net.sftbody, body)) + feat
     if net.scale > 1:
-        body = lrelu(conv(net.conv_up1, _up2(body)))
+        body = conv(net.conv_up1, _up2(body), True)
+        if _TAP is not None:
+            _TAP('conv_up1', None, None, body)
         if net.scale == 4:
-            body = lrelu(conv(net.conv_up2, _up2(body)))
-    out = conv(net.conv_last, lrelu(conv(net.conv_hr, body)))
+            body = conv(net.conv_up2, _up2(body), True)
+            if _TAP is not None:
+                _TAP('conv_up2', None, None, body)
+    hr = conv(net.conv_hr, body, True)
+    if _TAP is not None:
+        _TAP('conv_hr', None, None, hr)
+    out = conv(net.conv_last, hr)
     return out.permute(2, 0, 1).unsqueeze(0)
 
 

@@ -360,6 +360,18 @@ int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t x_stride, 
  *           bytes; bias_out [32] = 0).   bias == NULL reads as zeros. */
 int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int32_t cout, int32_t cin, int32_t ksize, int32_t form,
                                void* w_split, float* bias_out, void* stream);
+/* The same for many layers: ceil(n_jobs / K4_PACK_MULTI_MAX) launches instead of n_jobs (a training iteration re-packs every layer). */
+#define K4_PACK_MULTI_MAX 64
+typedef struct k4_pack_job {
+    const float* w; const float* bias;       /* as k4_pack_conv_weight_bf16x6 */
+    void* w_split; float* bias_out;
+    int32_t cout, cin, ksize, form;
+} k4_pack_job;
+int k4_pack_conv_weight_bf16x6_multi(const k4_pack_job* jobs, int32_t n_jobs, void* stream);
+/* out[p][c] = grad[p][c] * (y[p][c] > 0 ? 1 : slope) for c < channels: LeakyReLU backward from the layer's OUTPUT y (same sign as its
+ * input); rows of `*_stride` floats (channel slices of wider images); out may be grad (in place). */
+int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y, int32_t y_stride, int64_t n_pix, int32_t channels, float slope,
+                 float* out, int32_t out_stride, void* stream);
 
 /* ---- training-step streaming kernels --------------------------------------------------------
  * Replace the reference extension `adam_upd_cuda` (lib/cuda/adam_upd.cpp:10-67 -> adam_upd_kernel.cu:60-133) that
