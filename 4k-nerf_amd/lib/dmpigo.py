@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from . import grid
-from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid
+from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid, _take
 
 
 '''Model'''
@@ -198,11 +198,11 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         ray_pts, mask_outbbox = render_utils_cuda.sample_ndc_pts_on_rays(
             rays_o, rays_d, self.xyz_min, self.xyz_max, N_samples)
         mask_inbbox = ~mask_outbbox
-        ray_pts = ray_pts.view(-1, 3)
-        ray_pts = ray_pts[mask_inbbox.view(-1)]
-        dev = rays_o.device
-        ray_id = torch.arange(mask_inbbox.shape[0], device=dev).view(-1, 1).expand_as(mask_inbbox)[mask_inbbox]
-        step_id = torch.arange(mask_inbbox.shape[1], device=dev).view(1, -1).expand_as(mask_inbbox)[mask_inbbox]
+        # ONE compaction index for the three gathers (each boolean-mask indexing is a nonzero + a host synchronisation of its own)
+        idx = mask_inbbox.view(-1).nonzero().squeeze(1)
+        ray_pts = ray_pts.view(-1, 3).index_select(0, idx)
+        ray_id = torch.div(idx, mask_inbbox.shape[1], rounding_mode='floor')        # = arange(N).expand_as(mask)[mask]
+        step_id = idx - ray_id * mask_inbbox.shape[1]                               # = arange(N_samples).expand_as(mask)[mask]
         return ray_pts, ray_id, step_id, N_samples, mask_inbbox
 
     # ------------------------------------------------------------------ forward
@@ -258,17 +258,16 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         interval = stepsize * self.voxel_size_ratio
         if self.mask_cache is not None:
             mask1 = self.mask_cache(ray_pts)
-            ray_pts, ray_id, step_id = ray_pts[mask1], ray_id[mask1], step_id[mask1]
+            ray_pts, ray_id, step_id = _take(mask1, ray_pts, ray_id, step_id)
         density = self.density(ray_pts) + self.act_shift(ray_pts)
         alpha = self.activate_density(density, interval)
         if self.fast_color_thres > 0:
             mask2 = (alpha > self.fast_color_thres)
-            ray_pts, ray_id, step_id, alpha = ray_pts[mask2], ray_id[mask2], step_id[mask2], alpha[mask2]
+            ray_pts, ray_id, step_id, alpha = _take(mask2, ray_pts, ray_id, step_id, alpha)
         weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
         if self.fast_color_thres > 0:
             mask3 = (weights > self.fast_color_thres)
-            ray_pts, ray_id, step_id = ray_pts[mask3], ray_id[mask3], step_id[mask3]
-            alpha, weights = alpha[mask3], weights[mask3]
+            ray_pts, ray_id, step_id, alpha, weights = _take(mask3, ray_pts, ray_id, step_id, alpha, weights)
         vox_emb = self.k0(ray_pts)
         if vox_emb.dim() == 1:
             vox_emb = vox_emb.unsqueeze(-1)

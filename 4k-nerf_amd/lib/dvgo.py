@@ -213,6 +213,13 @@ class _FusedMarcher:
 
 
 '''Model'''
+def _take(mask, *ts):
+    """``t[mask]`` for every t (first axis) with ONE nonzero -- one host synchronisation per mask instead of one per tensor: the staged
+    (training) forward of the reference's op sequence filters its sample list three times (lib/dvgo.py:360-378)."""
+    i = mask.nonzero().squeeze(1)
+    return [t.index_select(0, i) for t in ts]
+
+
 class DirectVoxGO(torch.nn.Module, _FusedMarcher):
     def __init__(self, xyz_min, xyz_max,
                  num_voxels=0, num_voxels_base=0,
@@ -424,10 +431,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         N_samples = int((self.max_world_size - 1) / stepsize) + 1
         ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max = render_utils_cuda.sample_pts_on_rays(
             rays_o, rays_d, self.xyz_min, self.xyz_max, near, far, stepdist)
-        mask_inbbox = ~mask_outbbox
-        ray_pts = ray_pts[mask_inbbox]
-        ray_id = ray_id[mask_inbbox]
-        step_id = step_id[mask_inbbox]
+        ray_pts, ray_id, step_id = _take(~mask_outbbox, ray_pts, ray_id, step_id)
         return ray_pts, ray_id, step_id, None, N_samples
 
     # ------------------------------------------------------------------ forward
@@ -488,18 +492,16 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         interval = stepsize * self.voxel_size_ratio
         if self.mask_cache is not None:
             mask1 = self.mask_cache(ray_pts)
-            ray_pts, ray_id, step_id = ray_pts[mask1], ray_id[mask1], step_id[mask1]
+            ray_pts, ray_id, step_id = _take(mask1, ray_pts, ray_id, step_id)
         density = self.density(ray_pts)
         alpha = self.activate_density(density, interval)
         if self.fast_color_thres > 0:
             mask2 = (alpha > self.fast_color_thres)
-            ray_pts, ray_id, step_id = ray_pts[mask2], ray_id[mask2], step_id[mask2]
-            alpha = alpha[mask2]
+            ray_pts, ray_id, step_id, alpha = _take(mask2, ray_pts, ray_id, step_id, alpha)
         weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
         if self.fast_color_thres > 0:
             mask3 = (weights > self.fast_color_thres)
-            weights, alpha = weights[mask3], alpha[mask3]
-            ray_pts, ray_id, step_id = ray_pts[mask3], ray_id[mask3], step_id[mask3]
+            ray_pts, ray_id, step_id, alpha, weights = _take(mask3, ray_pts, ray_id, step_id, alpha, weights)
         k0 = self.k0(ray_pts)
         if k0.dim() == 1:
             k0 = k0.unsqueeze(-1)

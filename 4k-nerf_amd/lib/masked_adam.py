@@ -45,22 +45,42 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
 _MULTI_BELOW = 1 << 20          # tensors smaller than this are updated through k4_adam_upd_multi (same arithmetic per element)
 
 
+_MULTI_PLANS = {}               # (ids of the parameter tensors) -> (job table with the static pointers filled in, tensors kept alive, [params, m, v])
+
+
 def adam_upd_multi(items, masked, step, beta1, beta2, lr, eps):
-    """adam_upd / masked_adam_upd of many (param, grad, exp_avg, exp_avg_sq) tuples in ceil(len / 64) launches (k4_adam_upd_multi)."""
+    """adam_upd / masked_adam_upd of many (param, grad, exp_avg, exp_avg_sq) tuples in ceil(len / 64) launches (k4_adam_upd_multi).
+    The job table of a parameter set is built (and its tensors validated) once; later steps only refresh the gradient pointers --
+    the decoder's 458 tensors cost ~3 ms of host time per step otherwise."""
     if not items:
         return
-    jobs = (N.AdamJob * len(items))()
-    for j, ts in enumerate(items):
-        for t in ts:
-            if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != ts[0].numel():
-                raise ValueError('adam_upd_multi: tensors must be contiguous fp32 device tensors of one size')     # adam_upd.cpp CHECK_INPUT
-        jobs[j].param, jobs[j].grad, jobs[j].exp_avg, jobs[j].exp_avg_sq = (t.data_ptr() for t in ts)
-        jobs[j].n = ts[0].numel()
+    key = tuple(id(ts[0]) for ts in items)
+    plan = _MULTI_PLANS.get(key)
+    if plan is not None and any(a[0].data_ptr() != q or a[2].data_ptr() != r for a, (q, r) in zip(items, plan[3])):
+        plan = None                                             # a parameter or its state was re-allocated (scale_volume_grid, load_state_dict)
+    if plan is None:
+        jobs = (N.AdamJob * len(items))()
+        for j, ts in enumerate(items):
+            for t in ts:
+                if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != ts[0].numel():
+                    raise ValueError('adam_upd_multi: tensors must be contiguous fp32 device tensors of one size')     # adam_upd.cpp CHECK_INPUT
+            jobs[j].param, jobs[j].grad, jobs[j].exp_avg, jobs[j].exp_avg_sq = (t.data_ptr() for t in ts)
+            jobs[j].n = ts[0].numel()
+        touched = [t for ts in items for t in (ts[0], ts[2], ts[3])]
+        plan = (jobs, [tuple(ts[i] for i in (0, 2, 3)) for ts in items], touched, [(ts[0].data_ptr(), ts[2].data_ptr()) for ts in items])
+        if len(_MULTI_PLANS) > 16:
+            _MULTI_PLANS.clear()
+        _MULTI_PLANS[key] = plan
+    else:
+        jobs = plan[0]
+        for j, ts in enumerate(items):
+            g = ts[1]
+            if not g.is_cuda or not g.is_contiguous() or g.dtype != torch.float32 or g.numel() != jobs[j].n:
+                raise ValueError('adam_upd_multi: tensors must be contiguous fp32 device tensors of one size')
+            jobs[j].grad = g.data_ptr()
     N.check(N.lib().k4_adam_upd_multi(jobs, len(items), int(bool(masked)), int(step), float(beta1), float(beta2), float(lr), float(eps),
                                       N.stream()), 'k4_adam_upd_multi')
-    for param, _, m, v in items:
-        for t in (param, m, v):
-            torch.autograd.graph.increment_version(t)
+    torch.autograd.graph.increment_version(plan[2])
 
 
 class MaskedAdam(torch.optim.Optimizer):

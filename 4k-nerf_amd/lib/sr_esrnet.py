@@ -216,37 +216,49 @@ class _Packed:
     def native_many(cls, items):
         """``native`` for a list of (weight, bias, dgrad): ONE buffer for all operands and ceil(n / 64) launches
         (k4_pack_conv_weight_bf16x6_multi); a single item goes through k4_pack_conv_weight_bf16x6."""
-        if not items:
-            return []
-        L = N.lib()
+        return _PackPlan(items).run().packed if items else []
+
+
+class _PackPlan:
+    """The device packing of a fixed list of (weight, bias, dgrad) operands into buffers that persist: ``run()`` re-packs all of them
+    (after an optimizer step) with ceil(n / 64) launches and no host work beyond the call -- the job table is built once."""
+
+    def __init__(self, items):
         dev = items[0][0].device
-        plans = [cls._native_plan(w, d) for w, _, d in items]
-        wbuf = torch.empty([sum(p[2] for p in plans) // 2], dtype=torch.int16, device=dev)       # operand sizes are multiples of 16 bytes
-        bbuf = torch.empty([sum(p[3] for p in plans)], dtype=torch.float32, device=dev)
-        jobs = (N.PackJob * len(items))()
-        out, keep = [], []
+        plans = [_Packed._native_plan(w, d) for w, _, d in items]
+        self.wbuf = torch.empty([sum(p[2] for p in plans) // 2], dtype=torch.int16, device=dev)       # operand sizes are multiples of 16 bytes
+        self.bbuf = torch.empty([sum(p[3] for p in plans)], dtype=torch.float32, device=dev)
+        self.jobs = (N.PackJob * len(items))()
+        self.packed, self.keep = [], []
         wo = bo = 0
         for q, ((weight, bias, dgrad), (form, flags_extra, nbytes, nb, lcin)) in enumerate(zip(items, plans)):
             cout, cin, k, _ = weight.shape
-            self = cls.__new__(cls)
-            self.mode, self.flags_extra = 'bf16x6', flags_extra
-            self.w, self.b = wbuf[wo // 2:(wo + nbytes) // 2], bbuf[bo:bo + nb]
-            self.cin, self.k = lcin, k
+            pk = _Packed.__new__(_Packed)
+            pk.mode, pk.flags_extra = 'bf16x6', flags_extra
+            pk.w, pk.b = self.wbuf[wo // 2:(wo + nbytes) // 2], self.bbuf[bo:bo + nb]
+            pk.cin, pk.k = lcin, k
             wc = weight.detach().float().contiguous()
             bc = None if (bias is None or dgrad) else bias.detach().float().contiguous()
-            keep.append((wc, bc))
-            jobs[q].w, jobs[q].bias = wc.data_ptr(), None if bc is None else bc.data_ptr()
-            jobs[q].w_split, jobs[q].bias_out = self.w.data_ptr(), self.b.data_ptr()
-            jobs[q].cout, jobs[q].cin, jobs[q].ksize, jobs[q].form = cout, cin, k, form
+            self.keep.append((wc, bc))                    # views of the parameters (fp32, contiguous: no copies), or converted copies
+            j = self.jobs[q]
+            j.w, j.bias = wc.data_ptr(), None if bc is None else bc.data_ptr()
+            j.w_split, j.bias_out = pk.w.data_ptr(), pk.b.data_ptr()
+            j.cout, j.cin, j.ksize, j.form = cout, cin, k, form
             wo, bo = wo + nbytes, bo + nb
-            out.append(self)
-        if len(items) == 1:
-            j = jobs[0]
+            self.packed.append(pk)
+        # run() reads the parameters through the pointers above: only valid while they ARE the parameters' storage
+        self.live = all(wc.data_ptr() == w.data_ptr() and (bc is None or bc.data_ptr() == b.data_ptr())
+                        for (w, b, _), (wc, bc) in zip(items, self.keep))
+
+    def run(self):
+        L = N.lib()
+        if len(self.packed) == 1:
+            j = self.jobs[0]
             N.check(L.k4_pack_conv_weight_bf16x6(j.w, j.bias, j.cout, j.cin, j.ksize, j.form, j.w_split, j.bias_out, N.stream()),
                     'k4_pack_conv_weight_bf16x6')
         else:
-            N.check(L.k4_pack_conv_weight_bf16x6_multi(jobs, len(items), N.stream()), 'k4_pack_conv_weight_bf16x6_multi')
-        return out
+            N.check(L.k4_pack_conv_weight_bf16x6_multi(self.jobs, len(self.packed), N.stream()), 'k4_pack_conv_weight_bf16x6_multi')
+        return self
 
 
 def pack_sft(layer):

@@ -26,7 +26,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import _native as N
-from .sr_esrnet import _Packed, SFTNet, EPI_LRELU, EPI_RES
+from .sr_esrnet import _Packed, _PackPlan, SFTNet, EPI_LRELU, EPI_RES
 
 
 class _WeightCache:
@@ -34,16 +34,22 @@ class _WeightCache:
 
     def __init__(self):
         self._c = {}
+        self._plan = None          # prepack(): (signature, _PackPlan, modules, [weight versions], [bias versions])
         self.always = False        # True: pack on every call (hipGraph capture: the packing kernels must be part of the graph, see GraphedDecoder)
 
     @staticmethod
     def _key(kind, weight, bias):
-        return (kind, weight.data_ptr(), weight._version, None if bias is None else bias._version, str(weight.device))
+        return (kind, weight.data_ptr(), weight._version, None if bias is None else bias._version, weight.device)
 
     def _get(self, kind, weight, bias, make):
         hit = self._c.get((kind, weight.data_ptr()))
-        if self.always:                                   # under capture: what prepack() of THIS forward packed, else pack now
-            return hit[1] if hit is not None and hit[0] is None else make()
+        if hit is not None and type(hit[0]) is int:       # an operand of the prepack plan: current iff prepack() saw these versions
+            q, plan = hit[0], self._plan
+            if self.always or (plan[3][q] == weight._version and (bias is None or plan[4][q] == bias._version)):
+                return hit[1]
+            hit = None
+        if self.always:
+            return make()
         key = self._key(kind, weight, bias)
         if hit is None or hit[0] != key:
             hit = (key, make())
@@ -58,22 +64,34 @@ class _WeightCache:
         return self._get('b', weight, None, lambda: _Packed.native(weight, None, dgrad=True))
 
     def prepack(self, convs, dgrad=True):
-        """Pack every stale operand of `convs` (modules with .weight / .bias) now, in ceil(n / 64) launches instead of one per operand
-        (an optimizer step makes all of them stale at once).  Under ``always`` everything is packed and marked as this forward's."""
-        items, slots = [], []
-        for m in convs:
-            for kind in ('f', 'b') if dgrad else ('f',):
-                bias = m.bias if kind == 'f' else None
-                key = None if self.always else self._key(kind, m.weight, bias)
-                hit = self._c.get((kind, m.weight.data_ptr()))
-                if self.always or hit is None or hit[0] != key:
-                    items.append((m.weight, bias, kind == 'b'))
-                    slots.append(((kind, m.weight.data_ptr()), key))
-        for (slot, key), pk in zip(slots, _Packed.native_many(items)):
-            self._c[slot] = (key, pk)
+        """Pack every operand of `convs` (modules with .weight / .bias) that an optimizer step made stale, now, in ceil(n / 64) launches
+        into buffers that persist (sr_esrnet._PackPlan) instead of one launch + two allocations per operand on first use.  The plan is
+        rebuilt when the module list or a parameter's storage changes; under ``always`` every call re-packs."""
+        sig = (dgrad,) + tuple(m.weight.data_ptr() for m in convs)
+        plan = self._plan
+        if plan is None or plan[0] != sig:
+            items = [(m.weight, m.bias if kind == 'f' else None, kind == 'b') for m in convs for kind in (('f', 'b') if dgrad else ('f',))]
+            pp = _PackPlan(items)
+            if not pp.live:                                # non-fp32 / non-contiguous parameters: the per-use path handles them
+                self._plan = None
+                return
+            slots = [(kind, m.weight.data_ptr()) for m in convs for kind in (('f', 'b') if dgrad else ('f',))]
+            if self._plan is not None:
+                for slot in self._plan[5]:
+                    self._c.pop(slot, None)
+            n = len(slots) // len(convs)
+            for q, (slot, pk) in enumerate(zip(slots, pp.packed)):
+                self._c[slot] = (q // n, pk)                # index of the module: its versions live in plan[3] / plan[4]
+            plan = self._plan = [sig, pp, list(convs), None, None, slots]
+        wv = [m.weight._version for m in convs]
+        bv = [-1 if m.bias is None else m.bias._version for m in convs]
+        if self.always or wv != plan[3] or bv != plan[4]:
+            plan[1].run()
+            plan[3], plan[4] = wv, bv
 
     def invalidate(self):
         self._c.clear()
+        self._plan = None
 
 
 def _wgrad(x, x_off, cin, x_stride, gy, gy_off, cout, gy_stride, k, H, W, weight_shape, with_bias):
@@ -286,7 +304,11 @@ def forward_train(net, x, cond):
 
     fused = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'               # 'convs': one Function per convolution + elementwise autograd (A/B, tests)
     if os.environ.get('K4_TRAIN_PREPACK', '1') != '0':                       # '0': every operand packed by its own launch on first use (A/B)
-        cache.prepack([m for name, m in net.named_modules() if isinstance(m, torch.nn.Conv2d) and not (fused and '.SFT_' in '.' + name)])
+        convs = net._k4.get(('train_convs', fused))
+        if convs is None:                                                     # the SFT layers' 1x1 convolutions are not packed when fused
+            convs = net._k4[('train_convs', fused)] = [m for name, m in net.named_modules()
+                                                       if isinstance(m, torch.nn.Conv2d) and not (fused and '.SFT_' in '.' + name)]
+        cache.prepack(convs)
 
     xi = x[0].permute(1, 2, 0).contiguous().float()
     ci = cond[0].permute(1, 2, 0).contiguous().float()

@@ -30,3 +30,14 @@ for i in range(n):
     tr.step(*batch(3 + i), global_step=4 + i)
 torch.cuda.synchronize()
 print('joint iteration ms', round((time.perf_counter() - t) / n * 1e3, 2), 'first losses', [round(v, 5) for v in losses])
+if os.environ.get('PROFILE_HOST') == '1':
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(n):
+        tr.step(*batch(20 + i), global_step=30 + i)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr, stream=sys.stdout)
+    st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('cumulative').print_stats(45)
