@@ -75,6 +75,7 @@ _SIGS = {
     'k4_grid_sample_3d': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
     'k4_segment_sum': [_P, _P, _I64, _I32, _I64, _P, _P],
     'k4_grid_sample_3d_backward': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
+    'k4_grid_sample_3d_backward_cl': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P],
     'k4_segment_sum_backward': [_P, _P, _I64, _I32, _P, _P],
     'k4_get_rays_of_a_view': [_I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P],
     'k4_to8b': [_P, _I64, _P, _P],
@@ -125,6 +126,7 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc_bf16x6': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                                _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
+    'k4_grid_sample_3d_backward_workspace_bytes': ([_I32, _I32, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_sft_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F,
                                          C.POINTER(SftEpilogue), _P], C.c_int),

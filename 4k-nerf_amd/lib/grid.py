@@ -6,6 +6,8 @@ arguments, parameter / buffer names (``grid``, ``xyz_min``, ``xyz_max``, ``mask`
 ``TensoRFGrid`` / ``VQGrid`` are not selected by any BASELINE configuration
 (configs/default.py:85-86) and are out of the hot-path scope.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -40,9 +42,37 @@ class GridSample3D(torch.autograd.Function):
         _, C_, X, Y, Z = ctx.grid_shape
         gg = torch.zeros(ctx.grid_shape, dtype=torch.float32, device=grad_out.device)
         go = grad_out.float().contiguous()
-        N.check(N.lib().k4_grid_sample_3d_backward(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max),
-                                                   pts.shape[0], N.f32(gg), N.stream()), 'grid_sample_3d_backward')
+        grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg)
         return gg, None, None, None
+
+
+_GSB_WS = {}          # device -> ((C, X, Y, Z), all-zero workspace of k4_grid_sample_3d_backward_cl); one grid shape per device at a time
+
+
+def grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg):
+    """gg [1|-, C, X, Y, Z] += d(trilinear lookup)/d(grid) for grad_out `go` [n, C] at `pts` [n, 3].  More than one channel: through the
+    channel-last scratch image (k4_grid_sample_3d_backward_cl; the workspace, as large as the gradient, is allocated and cleared once
+    per device and grid shape and kept -- K4_GSB_CL=0 or an allocation failure selects the channel-major atomic scatter)."""
+    L = N.lib()
+    n = pts.shape[0]
+    nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if os.environ.get('K4_GSB_CL', '1') != '0' else -1
+    ws = None
+    if nbytes > 0 and n > 0:
+        hit = _GSB_WS.get(go.device)
+        if hit is None or hit[0] != (C_, X, Y, Z):
+            _GSB_WS.pop(go.device, None)
+            try:
+                hit = _GSB_WS[go.device] = ((C_, X, Y, Z), torch.zeros([nbytes // 4], dtype=torch.int32, device=go.device))
+            except torch.OutOfMemoryError:
+                hit = None
+        ws = None if hit is None else hit[1]
+    if ws is not None:
+        ws.record_stream(torch.cuda.current_stream(go.device))
+        N.check(L.k4_grid_sample_3d_backward_cl(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.f32(gg), N.ptr(ws),
+                                                N.stream()), 'grid_sample_3d_backward_cl')
+    else:
+        N.check(L.k4_grid_sample_3d_backward(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.f32(gg), N.stream()),
+                'grid_sample_3d_backward')
 
 
 def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):

@@ -538,20 +538,31 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
     bpp = 12 * 4 + 12 + 8 * 12 * 4 * 2
 
     def scatter(pts, mn, mx):
-        g.zero_()
-        return timed(lambda: N_.check(N_.lib().k4_grid_sample_3d_backward(N_.f32(gout), 12, 417, 353, 256, N_.f32(pts), N_.f32(mn), N_.f32(mx),
-                                                                          npts, N_.f32(g), N_.stream()), 'grid_sample_3d_backward'))
+        # the product path (lib/grid.grid_sample_3d_backward: channel-last scratch + sweep, workspace kept across calls) and the
+        # channel-major atomic scatter it replaced (K4_GSB_CL=0)
+        res = {}
+        for name, env in (('', '1'), ('_channel_major_atomics', '0')):
+            os.environ['K4_GSB_CL'] = env
+            g.zero_()
+            res[name] = timed(lambda: G.grid_sample_3d_backward(gout, 12, 417, 353, 256, pts, mn, mx, g))
+        os.environ.pop('K4_GSB_CL', None)
+        G._GSB_WS.clear()                                                   # 1.8 GB of workspace: not needed by the rest of the bench
+        return res
+
+    def entry(ms):
+        return {'ms': round(ms, 3), 'B_per_point': bpp, 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1),
+                'frac_hbm': round(npts * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
     pts = torch.rand([npts, 3], device=dev, generator=gen) * 2 - 1
     one = torch.tensor([1., 1., 1.], device=dev)
-    ms = scatter(pts, -one, one)
-    out['grid_sample_bwd_2M_random_points'] = {'ms': round(ms, 3), 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
+    for k, ms in scatter(pts, -one, one).items():
+        out['grid_sample_bwd_2M_random_points' + k] = entry(ms)
     if frame_rays is not None and model is not None:
         # the coherent case: 8192 rays of the frame x 256 NDC samples each (what a training batch scatters)
         ro, rd = frame_rays[0][:8192], frame_rays[1][:8192]
         t = torch.linspace(0, 1, 256, device=dev)
         pts = (ro[:, None, :] + rd[:, None, :] * t[None, :, None]).reshape(-1, 3).contiguous()
-        ms = scatter(pts, model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous())
-        out['grid_sample_bwd_8192_rays_x_256'] = {'ms': round(ms, 3), 'B_per_point': bpp, 'GBs': round(npts * bpp / (ms * 1e-3) / 1e9, 1)}
+        for k, ms in scatter(pts, model.xyz_min.float().contiguous(), model.xyz_max.float().contiguous()).items():
+            out['grid_sample_bwd_8192_rays_x_256' + k] = entry(ms)
     return out
 
 

@@ -219,6 +219,14 @@ int k4_segment_sum(const float* src, const int64_t* index, int64_t n_pts, int32_
 int k4_grid_sample_3d_backward(const float* grad_out, int32_t channels, int32_t X, int32_t Y, int32_t Z,
                                const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
                                float* grad_grid, void* stream);
+/* The same gradient for channels > 1 through a channel-last scratch image (lanes = (sample, channel): a corner's contributions are
+ * consecutive floats, which is what the atomic units are fast at -- 2x on ray-coherent batches, ~10x on random points) and a sweep
+ * that moves the touched voxels into grad_grid [C][X][Y][Z] (+=).  `workspace` (k4_grid_sample_3d_backward_workspace_bytes, 16-byte
+ * aligned) must be ALL ZERO on entry and is all zero again on return: allocate and clear it once, not per call. */
+int64_t k4_grid_sample_3d_backward_workspace_bytes(int32_t channels, int32_t X, int32_t Y, int32_t Z);      /* < 0: use the plain entry */
+int k4_grid_sample_3d_backward_cl(const float* grad_out, int32_t channels, int32_t X, int32_t Y, int32_t Z,
+                                  const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
+                                  float* grad_grid, void* workspace, void* stream);
 int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n_pts, int32_t channels,
                             float* grad_src, void* stream);
 /* get_rays_of_a_view (lib/dvgo.py:516-582: get_rays + viewdirs + ndc_rays with near = 1) in one launch.  K_dev: [3][3]

@@ -49,6 +49,56 @@ def test_grid_sample_backward_matches_torch_autograd(C, dims):
     _close(gd.grad, gt.grad, 'grad_grid')
 
 
+@pytest.mark.parametrize('C', [2, 4, 9, 12, 16, 20, 32])
+@pytest.mark.parametrize('coherent', [False, True])
+def test_grid_sample_backward_channel_last_path_matches_the_atomic_scatter(C, coherent):
+    """k4_grid_sample_3d_backward_cl (channel-last scratch + sweep) against the channel-major atomic scatter and against fp64
+    index_add of the same trilinear weights; ray-coherent samples (the z-merge across lanes fires) and random ones; two calls
+    accumulate; the workspace is all zero again afterwards (it is never cleared between calls)."""
+    from nerf4k_amd import _native as N
+    g = torch.Generator().manual_seed(C * 2 + int(coherent))
+    X, Y, Z = 11, 9, 33
+    mn, mx = torch.tensor([-1., -1., -1.]), torch.tensor([1., 1., 1.])
+    if coherent:
+        R, S = 37, 33                                                    # z step of exactly one voxel, slow lateral drift
+        o = torch.rand([R, 1, 3], generator=g) * 1.6 - 0.8
+        d = torch.cat([torch.rand([R, 1, 2], generator=g) * 0.3 - 0.15, torch.full([R, 1, 1], 2.0)], -1)
+        o[..., 2] = -1.0
+        pts = (o + d * torch.linspace(0, 1, S).reshape(1, S, 1)).reshape(-1, 3)
+    else:
+        pts = torch.rand([2999, 3], generator=g) * 2.4 - 1.2              # some outside the box
+    n = pts.shape[0]
+    gout = torch.randn([n, C], generator=g)
+    # fp64 reference: scatter of the trilinear weights (align_corners=True, zero padding)
+    u = (pts.double() + 1) / 2 * torch.tensor([X - 1, Y - 1, Z - 1], dtype=torch.float64)
+    b = torch.floor(u)
+    f = u - b
+    want = torch.zeros([C, X * Y * Z], dtype=torch.float64)
+    for c in range(8):
+        dx, dy, dz = (c >> 2) & 1, (c >> 1) & 1, c & 1
+        ix, iy, iz = b[:, 0].long() + dx, b[:, 1].long() + dy, b[:, 2].long() + dz
+        ok = (ix >= 0) & (ix < X) & (iy >= 0) & (iy < Y) & (iz >= 0) & (iz < Z)
+        w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+        lin = ((ix * Y + iy) * Z + iz)[ok]
+        want.index_add_(1, lin, (gout.double()[ok] * w[ok, None]).T)
+    want = want.reshape(1, C, X, Y, Z)
+    L = N.lib()
+    dv = [t.cuda().contiguous() for t in (gout, pts, mn, mx)]             # kept alive: the entry points take raw pointers
+    args = (N.f32(dv[0]), C, X, Y, Z, N.f32(dv[1]), N.f32(dv[2]), N.f32(dv[3]), n)
+    plain = torch.zeros([1, C, X, Y, Z], device='cuda')
+    N.check(L.k4_grid_sample_3d_backward(*args, N.f32(plain), N.stream()), 'plain')
+    nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C, X, Y, Z))
+    assert nbytes >= X * Y * Z * (4 * C + 1) and int(L.k4_grid_sample_3d_backward_workspace_bytes(1, X, Y, Z)) < 0
+    ws = torch.zeros([nbytes // 4], dtype=torch.int32, device='cuda')
+    cl = torch.zeros([1, C, X, Y, Z], device='cuda')
+    for _ in range(2):
+        N.check(L.k4_grid_sample_3d_backward_cl(*args, N.f32(cl), N.ptr(ws), N.stream()), 'cl')
+    assert int(ws.count_nonzero()) == 0
+    _close(plain, want.float(), 'atomic scatter')
+    _close(cl, 2 * want.float(), 'channel-last path, two calls')
+    assert torch.equal(cl == 0, plain == 0)                              # the same set of touched voxels
+
+
 def test_segment_sum_backward_is_a_gather():
     g = torch.Generator().manual_seed(1)
     index = torch.sort(torch.randint(0, 50, [3000], generator=g)).values
