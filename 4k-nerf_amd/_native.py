@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 5
+K4_ABI_VERSION = 6
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
@@ -33,11 +33,6 @@ class MlpDesc(C.Structure):
 
 class ConvJob(C.Structure):          # k4_conv_job
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('res', C.c_void_p), ('mod_x', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
-
-
-class SftEpilogue(C.Structure):      # k4_sft_epilogue
-    _fields_ = [('w_packed', C.c_void_p), ('cond_stride', C.c_int32), ('y_sft_stride', C.c_int32),
-                ('cond', C.c_void_p * 8), ('y_sft', C.c_void_p * 8)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -75,6 +70,7 @@ _SIGS = {
     'k4_grid_sample_3d': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
     'k4_segment_sum': [_P, _P, _I64, _I32, _I64, _P, _P],
     'k4_grid_sample_3d_backward': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
+    'k4_touched_voxels': [_P, _I32, _I64, _P, _I64, _P, _P],
     'k4_grid_sample_3d_backward_cl': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P],
     'k4_segment_sum_backward': [_P, _P, _I64, _I32, _P, _P],
     'k4_get_rays_of_a_view': [_I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P],
@@ -128,8 +124,6 @@ _EXTRA_SIGS = {
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_grid_sample_3d_backward_workspace_bytes': ([_I32, _I32, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
-    'k4_conv2d_sft_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F,
-                                         C.POINTER(SftEpilogue), _P], C.c_int),
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),

@@ -120,20 +120,15 @@ static inline int k4_check_launch() {
 // constant in k4_march.hip); launches never call getenv.  Per-device facts (CU count, "dynamic LDS attribute already raised
 // for kernel F") are cached in fixed arrays indexed by the HIP device ordinal; concurrent first calls write the same values.
 struct K4Env {
-    int geom_occ;        // K4_GEOM_OCC     (5) waves per SIMD the geometry kernel's register allocation is bounded for (5 | 6)
-    int geom_ldspad;     // K4_GEOM_LDSPAD  (0) extra dynamic LDS bytes for the geometry kernel (occupancy experiments)
     int geom_skip;       // K4_GEOM_SKIP    (1) 0: do not use the coarse occupancy summary (A/B of the empty-space skipping)
     int shade_grid_wg;   // K4_SHADE_GRID_WG    persistent shading workgroups per CU
-    int debug;           // K4_DEBUG        (0) ablation bits, profiling only
-    int serp;            // K4_SERP         (1) serpentine ray order inside an 8x8 tile
-    int sr_small;        // K4_SR_SMALL     (1) 0: never use the 8-row tile form of the 3x3 convolution for small launches
-    int geom_band;       // K4_GEOM_BAND    (1) rows of workgroup tiles per XCD band of the geometry kernel (0: one contiguous band per XCD)
-    int shade_grid_tenths; // K4_SHADE_GRID_TENTHS (0) > 0: persistent shading workgroups = CUs x tenths / 10 (overrides K4_SHADE_GRID_WG; pipelined-rate A/B)
-    int sr_3t_rpw;       // K4_SR_3T_RPW    (4) the same knob for the default 3-term kernel
-    int sr_2t_rpw;       // K4_SR_2T_RPW    (2) output rows per wave of the 2-term (bf16x3 / f16x3) 3x3 convolution for launches beyond the small-launch rule (2 | 3 | 4):
-                         //                     8-row tiles measured 37.1 ms per 4K frame, 12-row 39.3, 16-row 38.5-38.8; 3 workgroups per CU: no gain / spills
+    int debug;           // K4_DEBUG        (0) ablation bits of the marcher kernels, profiling only
     int sr_debug;        // K4_SR_DEBUG     (0) profiling bits of the decoder kernels (1: input channel stride 0 = no memory traffic, WRONG results)
 };
+// Settled by measurement and no longer switchable (the evidence is in profiles/ and DESIGN.md): geometry kernel bounded for 5 waves per
+// SIMD (6 spilled), serpentine ray order inside an 8x8 tile, one row of workgroup tiles per XCD band, persistent shading grid sized in
+// whole workgroups per CU, small-launch tile rule of the 3x3 convolution on, 16-row tiles for the 3-term kernel and 8-row tiles for the
+// 2-term (f16x3) kernel beyond it (8-row 37.1 ms per 4K frame, 12-row 39.3, 16-row 38.5-38.8).
 const K4Env& k4_env();
 #define K4_MAX_DEVICES 64
 static inline int k4_device_ordinal() {

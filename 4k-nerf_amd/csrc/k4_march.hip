@@ -1201,12 +1201,10 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const dim3 grid(nwg), block(256);
     const int n_cu = k4_num_cus();
     {
-        // one workgroup (4 waves = 4 depth quarters) per bundle; K4_GEOM_LDSPAD pads LDS to cap occupancy (experiments)
-        // MINW = waves per SIMD the register allocation is bounded for: 5 (85 VGPRs, no spills) or 6 (80 VGPRs, 6 spilled) -- K4_GEOM_OCC
-        const int ldspad = k4_env().geom_ldspad;
-        if (P.counters) hipLaunchKernelGGL((k4_geom3_kernel<MODE, true, 5>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else if (k4_env().geom_occ >= 6) hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 6>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
-        else hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, ldspad, st, P);
+        // one workgroup (4 waves = 4 depth quarters) per bundle
+        // MINW = waves per SIMD the register allocation is bounded for: 5 (85 VGPRs, no spills); 6 (80 VGPRs, 6 spilled) measured slower
+        if (P.counters) hipLaunchKernelGGL((k4_geom3_kernel<MODE, true, 5>), dim3((unsigned)nwg * 4), block, 0, st, P);
+        else hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, 0, st, P);
     }
     int rc = k4_check_launch();
     if (rc) return rc;
@@ -1218,8 +1216,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
     const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 8 + (width ? (size_t)P.k1p * 64 : 0)));
-    const int shade_wg = k4_env().shade_grid_wg, tenths = k4_env().shade_grid_tenths;
-    const dim3 sgrid((unsigned)min(nwg, tenths > 0 ? max(1, n_cu * tenths / 10) : n_cu * shade_wg));
+    const dim3 sgrid((unsigned)min(nwg, n_cu * k4_env().shade_grid_wg));
     const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
@@ -1291,11 +1288,11 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.qhead = P.counts + nb;
     P.order = P.qhead + 8;
     P.n_bundles = (int)nb;
-    P.debug = k4_env().debug; P.serp = k4_env().serp;
-    // XCD bands of the geometry kernel: K4_GEOM_BAND rows of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to
+    P.debug = k4_env().debug; P.serp = 1;
+    // XCD bands of the geometry kernel: ONE row of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to
     // the 8 XCDs.  One contiguous band per XCD (0) left the XCDs 0.61..1.31 of the mean work on the LLFF frames -- the kernel ran at
     // the pace of the heaviest eighth of the image.
-    P.band_blocks = img_w > 0 ? k4_env().geom_band * ((img_w + 15) / 16) * 4 : k4_env().geom_band * 64;
+    P.band_blocks = img_w > 0 ? ((img_w + 15) / 16) * 4 : 64;
     if (max_steps > 65536) return K4_ERR_UNSUPPORTED;                                   // group index of the skip list is 10 bits per depth quarter
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
@@ -1306,8 +1303,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
-    env_int("K4_GEOM_OCC", 5), env_int("K4_GEOM_LDSPAD", 0), env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU),
-    env_int("K4_DEBUG", 0), env_int("K4_SERP", 1), env_int("K4_SR_SMALL", 1), env_int("K4_GEOM_BAND", 1), env_int("K4_SHADE_GRID_TENTHS", 0), env_int("K4_SR_3T_RPW", 4), env_int("K4_SR_2T_RPW", 2), env_int("K4_SR_DEBUG", 0)};
+    env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU), env_int("K4_DEBUG", 0), env_int("K4_SR_DEBUG", 0)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

@@ -41,8 +41,6 @@ struct ConvParams {
     const float* res; int res_stride; float res_scale;
     const float* modx; int mod_stride;
     int tiles_x, tiles_y;
-    // fused SFTLayer epilogue of the v2 3x3 kernel (k4_conv2d_sft_nhwc_bf16x6_multi): packed SFT weights, strides of cond / second output
-    const float* sft_w; int sft_cond_stride; int sft_y_stride;
     int debug;           // K4_SR_DEBUG ablation bits of the v2 3x3 kernel (profiling only, WRONG results; 0 in production): 2 = no epilogue stores,
                          // 4 = no MFMA phase, 8 = no split / LDS stores after the first chunk, 16 = no activation loads after the first chunk
 };
@@ -55,7 +53,6 @@ struct ConvMulti {
     int n;
     int blk_end[K4_MAX_JOBS];              // exclusive prefix of the jobs' workgroup counts
     const float* x[K4_MAX_JOBS]; float* y[K4_MAX_JOBS]; const float* res[K4_MAX_JOBS]; const float* modx[K4_MAX_JOBS];
-    const float* sft_cond[K4_MAX_JOBS]; float* sft_y[K4_MAX_JOBS];     // fused SFT epilogue: condition map, optional second output
     int H[K4_MAX_JOBS], W[K4_MAX_JOBS], tiles_x[K4_MAX_JOBS];
     int total;                             // workgroup-tiles of the launch
 };
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) 
 #endif
 typedef float k4_f4 __attribute__((ext_vector_type(4)));
 // per-tile scalars (workgroup-uniform)
-struct V2Tile { const float* x; float* y; const float* res; const float* cond; float* y2; int H, W, srcW, x0, y0, nb; };
+struct V2Tile { const float* x; float* y; const float* res; int H, W, srcW, x0, y0, nb; };
 template <int TROWS>
 __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_count, bool ups) {
     int g = 0;
@@ -489,7 +486,7 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
     const int tile = local / nb_count;
     V2Tile T;
     T.nb = local - tile * nb_count;
-    T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.cond = M.sft_cond[g]; T.y2 = M.sft_y[g]; T.H = M.H[g]; T.W = M.W[g];
+    T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.H = M.H[g]; T.W = M.W[g];
     T.srcW = ups ? T.W / 2 : T.W;
     const int tiles_x = M.tiles_x[g];
     T.x0 = (tile % tiles_x) * TILE_W; T.y0 = (tile / tiles_x) * TROWS;
@@ -498,10 +495,8 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
 
 // RPW = output rows per wave: 4 (16-row tiles) by default; 2 (8-row tiles, half the serial work per workgroup) for launches too
 // small to fill the chip with 16-row tiles -- the 209x209 windows of the 8-GPU job are 98 tiles per layer each.
-// SFT: the layer's output goes through the SFTLayer that follows it in the network (lib/sr_esrnet.py:120-123, 149-158) before it
-// leaves the registers -- y = v*(scale(cond)+1) + shift(cond), the two 1x1-conv pairs of the condition map evaluated per output row
-// on the matrix cores exactly as k4_sft_b6_kernel does (same operands, same product order: bit-identical to the separate launch).
-// The decoder's 36 SFT launches per frame were 12 % of its time for 6 % of its FLOPs: each re-read and re-wrote a whole feature map.
+// (A form with the following SFTLayer fused into this kernel's epilogue was bit-identical and measured neutral -- 51.35 / 52.09 ms per
+// 4K frame against 51.88 / 51.92 layer by layer, round 2 -- and was removed in round 3: DESIGN.md.)
 // NTERM = 2 (flag K4_ARITH_2TERM, the decoder's opt-in 'bf16x3' arithmetic): only the two leading split terms of both operands are
 // staged / loaded and 3 of the 6 products are formed (a1 b0 + a0 b1 + a0 b0, ~2^-16 relative per product) -- half the matrix
 // instructions, a third less LDS and register traffic, same packed weights (their third term is simply not read).
@@ -552,11 +547,11 @@ __device__ unsigned long long k4_sr_timing[16];
 #else
 #define K4_SR_TSTAMP(SLOT) do { } while (0)
 #endif
-template <int RPW, bool SFT = false, int NTERM = 3, bool F16 = false, bool WL = false>
+template <int RPW, int NTERM = 3, bool F16 = false, bool WL = false>
 __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTERM == 2 ? K4_V2_MINWG_2T : 2)) void k4_conv_b6v2_kernel(const ConvMulti M) {
     constexpr int NBK = 1;                                    // 32-channel output blocks per workgroup (two were measured neutral: profiles/r03_sr_kernel_stats.md)
-    static_assert(!WL || (F16 && !SFT), "weights through LDS: fp16 form");
-    static_assert(NTERM == 3 || (NTERM == 2 && !SFT), "the fused SFT epilogue reuses the full input tile's LDS");
+    static_assert(!WL || F16, "weights through LDS: fp16 form");
+    static_assert(NTERM == 3 || NTERM == 2, "3-term (6 products) or 2-term (3 products) splits");
     static_assert(!F16 || NTERM == 2, "the fp16 arithmetic is a 2-term split");
     constexpr int THREADS = 256;
     constexpr int TROWS = 4 * RPW;
@@ -825,105 +820,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
             K4_SR_TSTAMP(6);                             // barrier B
         }
         // ---- epilogue of tile T: lane holds output channel nb*32 + l31 of pixels x0 + row(reg, half) in rows y0 + wv*4 + r ----
-        if constexpr (SFT) {
-            // The input tile in LDS is dead (barrier after the last MFMA phase): it now holds the SFT operands of this workgroup's
-            // 32-channel block.  Split section of the packed SFT buffer (see k4_sft_b6_kernel): WA6 | WS6[CB] | WH6[CB] | BA | BS[CB] | BH[CB].
-            // this wave's condition vectors of its RPW rows (lane = pixel x0 + l31, 8 channels per K half): requested first, they
-            // arrive while the workgroup stages the SFT operands
-            float4 cnd[RPW][2][2];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int gy = T.y0 + wv * RPW + r, px = T.x0 + l31;
-                const bool pok = gy < T.H && px < T.W;
-                const float4* src = reinterpret_cast<const float4*>(T.cond + (pok ? ((size_t)gy * T.W + px) * P.sft_cond_stride : 0) + 8 * half);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const float4 c0 = src[kb * 4], c1 = src[kb * 4 + 1];
-                    cnd[r][kb][0] = pok ? c0 : make_float4(0.f, 0.f, 0.f, 0.f);
-                    cnd[r][kb][1] = pok ? c1 : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            const int CB = nb_count;
-            const float* const s6 = P.sft_w + (2 + 2 * CB) * 17 * 64;
-            const uint4* const g6 = reinterpret_cast<const uint4*>(s6);
-            for (int i = tid; i < 768; i += THREADS) in_s[i] = g6[i];                                              // WA6
-            for (int i = tid; i < 384; i += THREADS) {
-                in_s[768 + i] = g6[768 + T.nb * 384 + i];                                                          // WS6[nb]
-                in_s[1152 + i] = g6[768 + CB * 384 + T.nb * 384 + i];                                              // WH6[nb]
-            }
-            float* const bl = reinterpret_cast<float*>(in_s + 1536);
-            const float* const gb = s6 + (2 + 2 * CB) * 2 * 3 * 64 * 4;
-            if (tid < 64) bl[tid] = gb[tid];                                                                       // BA
-            else if (tid < 96) bl[tid] = gb[64 + T.nb * 32 + (tid - 64)];                                          // BS[nb]
-            else if (tid < 128) bl[tid] = gb[64 + CB * 32 + T.nb * 32 + (tid - 96)];                               // BH[nb]
-            __syncthreads();
-            const int co = T.nb * 32 + l31;
-            const float bias = P.bias[co];
-            // bias of output channel l31 in the [half][16] accumulator-register order of the packed BS / BH
-            const int bsel = ((l31 >> 2) & 1) * 16 + (l31 & 3) + 4 * (l31 >> 3);
-            const float bsc = bl[64 + bsel], bsh = bl[96 + bsel];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int gy = T.y0 + wv * RPW + r;
-                // GEMM 1: hidden^T[64][pixel] = lrelu(WA . cond^T + ba), lane = pixel x0 + l31 of row gy.  The two 32-neuron blocks (and
-                // below the scale / shift accumulators) take their MFMAs alternately: no instruction waits for the one before it.
-                f32x16 h[2];
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) h[mb][q] = bl[(mb * 2 + half) * 16 + q];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const float v[8] = {cnd[r][kb][0].x, cnd[r][kb][0].y, cnd[r][kb][0].z, cnd[r][kb][0].w,
-                                        cnd[r][kb][1].x, cnd[r][kb][1].y, cnd[r][kb][1].z, cnd[r][kb][1].w};
-                    uint4 x0_, x1_, x2_;
-                    k4s_split3(v, x0_, x1_, x2_);
-                    const uint4* wp = in_s + (kb * 3) * 64 + lane;
-                    const uint4* wq = in_s + ((2 + kb) * 3) * 64 + lane;
-                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
-#define K4_MF(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
-                    K4_MF(h[0], a2, x0_); K4_MF(h[1], c2, x0_); K4_MF(h[0], a0, x2_); K4_MF(h[1], c0, x2_); K4_MF(h[0], a1, x1_); K4_MF(h[1], c1, x1_);
-                    K4_MF(h[0], a1, x0_); K4_MF(h[1], c1, x0_); K4_MF(h[0], a0, x1_); K4_MF(h[1], c0, x1_); K4_MF(h[0], a0, x0_); K4_MF(h[1], c0, x0_);
-                }
-                // GEMM 2 in the orientation of the convolution's accumulators, D[pixel][channel]: A = the hidden activations (the
-                // accumulator layout of GEMM 1 is an A-operand layout when K is walked in register order), B = the packed weights
-                // (their A-fragment layout of the transposed form is the B-fragment layout here).  Same pairs of terms, same order.
-                f32x16 cs, ch;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { cs[q] = bsc; ch[q] = bsh; }
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    float vs[8], vh[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float q0 = h[0][8 * kb + e], q1 = h[1][8 * kb + e];
-                        vs[e] = q0 > 0.f ? q0 : q0 * P.slope; vh[e] = q1 > 0.f ? q1 : q1 * P.slope;
-                    }
-                    uint4 s0, s1, s2, t0, t1, t2;
-                    k4s_split3(vs, s0, s1, s2);
-                    k4s_split3(vh, t0, t1, t2);
-                    const uint4* wp = in_s + 768 + (kb * 3) * 64 + lane;
-                    const uint4* wq = in_s + 1152 + (kb * 3) * 64 + lane;
-                    const uint4 w0 = wp[0], w1 = wp[64], w2 = wp[128], u0 = wq[0], u1 = wq[64], u2 = wq[128];
-                    K4_MF(cs, s0, w2); K4_MF(ch, t0, u2); K4_MF(cs, s2, w0); K4_MF(ch, t2, u0); K4_MF(cs, s1, w1); K4_MF(ch, t1, u1);
-                    K4_MF(cs, s0, w1); K4_MF(ch, t0, u1); K4_MF(cs, s1, w0); K4_MF(ch, t1, u0); K4_MF(cs, s0, w0); K4_MF(ch, t0, u0);
-#undef K4_MF
-                }
-                if (gy >= T.H || co >= P.cout) continue;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int gx = T.x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    if (gx >= T.W) continue;
-                    const size_t pix = (size_t)gy * T.W + gx;
-                    float v = acc[0][r][e] + bias;
-                    if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
-                    if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, T.res[pix * P.res_stride + co]);
-                    const float m = k4s_mul_add(v, cs[e] + 1.f, ch[e]);                             // x*(scale+1)+shift
-                    if (T.y2) { T.y[pix * P.cout_stride + co] = v; T.y2[pix * P.sft_y_stride + co] = m; }
-                    else T.y[pix * P.cout_stride + co] = m;
-                }
-            }
-        } else if (P.debug & 2) {
+        if (P.debug & 2) {
             float sum_ = 0.f;
 #pragma unroll
             for (int j = 0; j < NBK; ++j)
@@ -994,10 +891,9 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         if ((int64_t)M.H[g] * M.W[g] * M.base.cin_stride > 0x7fffffffLL) return K4_ERR_UNSUPPORTED;
     int total = count(16);
     // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
-    // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead); K4_SR_SMALL=0 disables
+    // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead)
     int rpw = 4;
-    const int small_rounds = k4_env().sr_small == 1 ? 2 : k4_env().sr_small;      // experiment knob: K4_SR_SMALL=N applies the choice up to N rounds
-    if (total <= small_rounds * slots && k4_env().sr_small) {
+    if (total <= 2 * slots) {
         float best = 1e30f;
         for (int cand = 4; cand >= 2; --cand) {
             const int c = count(4 * cand);
@@ -1007,9 +903,8 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         total = count(4 * rpw);
     }
     const bool two = (M.base.flags & (K4_ARITH_2TERM | K4_ARITH_F16X3)) != 0;
-    const int rpw_big = two ? k4_env().sr_2t_rpw : k4_env().sr_3t_rpw;      // tile height of launches beyond the small-launch rule
-    if (rpw == 4 && (rpw_big == 2 || rpw_big == 3)) {
-        rpw = rpw_big;
+    if (rpw == 4 && two) {                                   // beyond the small-launch rule: 8-row tiles for the 2-term kernel (3 workgroups per CU), 16-row for 3-term
+        rpw = 2;
         total = count(4 * rpw);
     }
     M.total = total;
@@ -1020,10 +915,9 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, __VA_ARGS__>), grid, block, 0, st, M); \
         else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<3, __VA_ARGS__>), grid, block, 0, st, M); \
         else hipLaunchKernelGGL((k4_conv_b6v2_kernel<4, __VA_ARGS__>), grid, block, 0, st, M); } while (0)
-    if (M.base.sft_w) K4_V2_LAUNCH(true, 3, false);
-    else if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(false, 2, true, true);      // fp16 form: weight fragments through LDS
-    else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(false, 2, false);
-    else K4_V2_LAUNCH(false, 3, false);
+    if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(2, true, true);      // fp16 form: weight fragments through LDS
+    else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(2, false);
+    else K4_V2_LAUNCH(3, false);
 #undef K4_V2_LAUNCH
     return k4_check_launch();
 }
@@ -1193,13 +1087,8 @@ extern "C" int64_t k4_conv_weight_bf16x6_bytes(int32_t cout, int32_t cin, int32_
 static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                          const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
                          uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
-                         void* stream, const k4_sft_epilogue* sft = nullptr) {
+                         void* stream) {
     if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_split || !bias || cin <= 0 || cout <= 0) return K4_ERR_BAD_ARG;
-    if (sft) {
-        // the fused SFTLayer epilogue: 3x3 layers of 32 or 64 output channels (= the SFT layer's channels), plain GEMM form
-        if (ksize != 3 || (cout != 32 && cout != 64) || !sft->w_packed || sft->cond_stride < 32 || (sft->cond_stride & 3)) return K4_ERR_BAD_ARG;
-        if (flags & (K4_EPI_MODULATE | K4_W_TAPS_AS_COUT)) return K4_ERR_BAD_ARG;
-    }
     if (cin_stride < cin || (ksize != 1 && ksize != 3) || cout_stride < cout) return K4_ERR_BAD_ARG;
     const bool modulate = (flags & K4_EPI_MODULATE) != 0;
     if (modulate && (mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
@@ -1219,21 +1108,11 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
         if (modulate && !j.mod_x) return K4_ERR_BAD_ARG;
         if ((flags & K4_PRE_UPSAMPLE2X) && ((j.H & 1) || (j.W & 1))) return K4_ERR_BAD_ARG;
         M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.modx[g] = j.mod_x; M.H[g] = j.H; M.W[g] = j.W;
-        if (sft) {
-            if (!sft->cond[g] || (((size_t)sft->cond[g]) & 15) != 0) return K4_ERR_BAD_ARG;
-            if (sft->y_sft[g] && sft->y_sft_stride < cout) return K4_ERR_BAD_ARG;
-            M.sft_cond[g] = sft->cond[g]; M.sft_y[g] = sft->y_sft[g];
-        }
     }
-    if (sft) { P.sft_w = sft->w_packed; P.sft_cond_stride = sft->cond_stride; P.sft_y_stride = sft->y_sft_stride; }
     hipStream_t st = (hipStream_t)stream;
     if (flags & K4_W_TAPS_AS_COUT) {
         if (ksize != 3 || cout > 3 || modulate || (flags & K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
         return launch_conv_taps_b6(M, st);
-    }
-    if (sft) {
-        if (flags & (K4_ARITH_2TERM | K4_ARITH_F16X3)) return K4_ERR_BAD_ARG;
-        return launch_conv_b6v2(M, st);
     }
     if ((flags & K4_ARITH_2TERM) && (flags & K4_ARITH_F16X3)) return K4_ERR_BAD_ARG;
     if (ksize == 3) {
@@ -1267,15 +1146,6 @@ extern "C" int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jo
                                            void* stream) {
     return conv_b6_multi(jobs, n_jobs, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale,
                          mod_stride, stream);
-}
-
-extern "C" int k4_conv2d_sft_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
-                                               const void* w_split, const float* bias, int32_t cout, int32_t cout_stride,
-                                               uint32_t flags, float slope, int32_t res_stride, float res_scale,
-                                               const k4_sft_epilogue* sft, void* stream) {
-    if (!sft) return K4_ERR_BAD_ARG;
-    return conv_b6_multi(jobs, n_jobs, cin, cin_stride, w_split, bias, 3, cout, cout_stride, flags, slope, res_stride, res_scale, 0,
-                         stream, sft);
 }
 
 extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_stride,

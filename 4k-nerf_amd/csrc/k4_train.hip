@@ -5,8 +5,9 @@
 //   * the distortion loss of the joint training step (run_sr.py:976-988 calls torch_efficient_distloss.flatten_eff_distloss,
 //     a third-party CUDA extension that is not vendored: the published prefix-sum form is restated here), forward value and
 //     gradient in one launch;
-//   * compaction / expansion of the sparsely touched voxel-grid gradients for the data-parallel exchange (SURVEY.md 8e
-//     "Training (config 5)": dense k0 grad 1.36 GB, a 64x64 patch touches < 1 % of it).
+//   * the touched-voxel list of a grid gradient for the data-parallel exchange (k4_touched_voxels; SURVEY.md 8e "Training (config 5)":
+//     dense k0 grad 1.36 GB, a 64x64 patch touches < 1 % of it);
+//   * the SFTLayer of the decoder's training graph, forward and backward fused (k4_sft_train_*), and LeakyReLU backward on channel slices.
 // gfx950 only (wave64).  A training batch is ~10^5 points x (15..39 -> 64..128 -> 64..128 -> 3): ~1 GFLOP, far below the
 // matrix cores' interest; what matters is launch count and that nothing but x / h / grad streams through HBM once.
 #include "k4_common.h"
@@ -821,5 +822,40 @@ extern "C" int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y,
     const int64_t n = n_pix * (channels / 4);
     hipLaunchKernelGGL(k_lrelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, g_stride, y, y_stride, n_pix, channels / 4, slope,
                        out, out_stride);
+    return k4_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Touched voxels of a grid gradient [C][nvox] (any channel non-zero) as a compact int32 index list: what the data-parallel exchange of
+// the joint step sends instead of the dense 1.36 GB tensor (joint_train.sparse_grad_allreduce).  One pass over the gradient, no
+// temporaries; the list is in arbitrary order (wave-aggregated append), *counter receives the TOTAL number of touched voxels even when
+// it exceeds `cap` (the caller retries with a larger list).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_touched_voxels(const float* __restrict__ g, int C, int64_t nvox, int32_t* __restrict__ out, int64_t cap,
+                                                        unsigned long long* __restrict__ counter) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool t = false;
+    if (v < nvox)
+        for (int ch = 0; ch < C; ++ch) t |= g[(size_t)ch * nvox + v] != 0.f;
+    const unsigned long long m = __ballot(t);
+    if (m == 0) return;
+    const int lane = k4_lane();
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (t) {
+        const unsigned long long pos = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if ((int64_t)pos < cap) out[pos] = (int32_t)v;
+    }
+}
+
+extern "C" int k4_touched_voxels(const float* grad, int32_t channels, int64_t n_vox, int32_t* idx_out, int64_t cap, int64_t* counter, void* stream) {
+    if (!grad || channels <= 0 || n_vox < 0 || n_vox >= (1ll << 31) || cap < 0 || (cap > 0 && !idx_out) || !counter) return K4_ERR_BAD_ARG;
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(int64_t), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n_vox == 0) return 0;
+    hipLaunchKernelGGL(k_touched_voxels, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, channels, n_vox, idx_out, cap,
+                       reinterpret_cast<unsigned long long*>(counter));
     return k4_check_launch();
 }

@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _native as N
 from .lib import sr_train, train_ops, utils
 from .lib.masked_adam import MaskedAdam
 
@@ -32,6 +33,24 @@ SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged 
 
 def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def touched_voxels(g, cap=None):
+    """Sorted int32 indices of the columns of g [C, V] with a non-zero entry.  On the GPU: one pass of k4_touched_voxels over the gradient
+    (no [C, V] boolean temporary -- 340 MB next to the 1.36 GB k0 gradient -- and one host synchronisation, for the count)."""
+    C, V = g.shape
+    if not g.is_cuda:
+        return (g != 0).any(0).nonzero().flatten().to(torch.int32)
+    assert g.is_contiguous() and g.dtype == torch.float32
+    cap = max(1024, V // 16) if cap is None else cap
+    counter = torch.empty([1], dtype=torch.int64, device=g.device)
+    while True:
+        idx = torch.empty([cap], dtype=torch.int32, device=g.device)
+        N.check(N.lib().k4_touched_voxels(N.f32(g), C, V, N.ptr(idx), cap, N.ptr(counter), N.stream()), 'k4_touched_voxels')
+        n = int(counter)
+        if n <= cap:
+            return idx[:n].sort().values
+        cap = n
 
 
 def sparse_grad_allreduce(params, group=None, average=True):
@@ -49,7 +68,7 @@ def sparse_grad_allreduce(params, group=None, average=True):
         g = p.grad.view(C, -1)
         V = g.shape[1]
         assert V < 2 ** 31
-        idx = (g != 0).any(0).nonzero().flatten().to(torch.int32)
+        idx = touched_voxels(g)
         n = torch.tensor([idx.numel()], dtype=torch.int64, device=g.device)
         counts = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(counts, n, group=group)
@@ -122,6 +141,12 @@ class JointTrainer:
         self.use_graph = (os.environ.get('K4_TRAIN_GRAPH', '0') == '1') if use_graph is None else bool(use_graph)
         self._graphed = None
 
+    def rebuild_optimizer(self, global_step=0):
+        """Re-create the marcher's optimizer after ``model.scale_volume_grid`` replaced the grid parameters (run_sr.py:812-818 does the
+        same after every progressive-growing step): the old MaskedAdam would keep stepping the dead tensors."""
+        self.optimizer = utils.create_optimizer_or_freeze_model(self.model, self.cfg, global_step=global_step)
+        return self.optimizer
+
     def losses(self, rr, rgb_sr, target, target_4x, pr, pc, n_rays):
         """run_sr.py:877-995: the scalar terms of one iteration (dict of tensors; 'total' is what is back-propagated)."""
         cfg, s = self.cfg, self.sr_ratio
@@ -135,7 +160,8 @@ class JointTrainer:
         if cfg.weight_nearclip > 0:
             raise NotImplementedError("weight_nearclip needs the 't' / 'raw_density' keys no BASELINE configuration produces")
         if cfg.weight_distortion > 0:
-            out['distortion'] = cfg.weight_distortion * train_ops.flatten_eff_distloss(rr['weights'], rr['s'], 1 / rr['n_max'], rr['ray_id'])
+            out['distortion'] = cfg.weight_distortion * train_ops.flatten_eff_distloss(rr['weights'], rr['s'], 1 / rr['n_max'], rr['ray_id'],
+                                                                                        n_rays=rr['alphainv_last'].shape[0])
         if cfg.weight_rgbper > 0:
             per = (rr['raw_rgb'] - target[rr['ray_id']]).pow(2).sum(-1)
             out['rgbper'] = cfg.weight_rgbper * (per * rr['weights'].detach()).sum() / n_rays
@@ -154,7 +180,11 @@ class JointTrainer:
             if self._graphed is None:
                 N_patch = self.cfg.N_rand // self.cfg.N_patch
                 if tuple(x.shape[2:]) == (N_patch, N_patch):                 # capture once, for the full-size patch (edge patches stay eager)
-                    self._graphed = sr_train.GraphedDecoder(self.net_sr, x.shape, cond.shape)
+                    try:
+                        self._graphed = sr_train.GraphedDecoder(self.net_sr, x.shape, cond.shape)
+                    except Exception as e:                                    # capture failed (e.g. an op that synchronises): stay eager
+                        print(f'JointTrainer: hipGraph capture of the decoder failed ({type(e).__name__}: {e}); using the eager path', flush=True)
+                        self.use_graph = False
             if self._graphed is not None and self._graphed.matches(x, cond):
                 return self._graphed(x, cond)
         return self.net_sr(x, cond)

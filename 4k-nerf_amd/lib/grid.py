@@ -134,11 +134,13 @@ class DenseGrid(nn.Module):
             data = torch.zeros([1, 0, *size], device=old.device)
         else:
             if not old.is_cuda:
-                raise N.K4Error('scale_volume_grid: the grid must be on the GPU (no CPU path)')
+                # deliberately no F.interpolate fallback: nothing in this package computes on the CPU (move the model to the GPU first)
+                raise N.K4Error('scale_volume_grid: the grid must be on the GPU -- call model.to(device) before growing it (no CPU path)')
             src = old.float().contiguous()
             data = torch.empty([1, self.channels, *size], dtype=torch.float32, device=old.device)
             N.check(N.lib().k4_resample_trilinear(N.f32(src), self.channels, src.shape[2], src.shape[3], src.shape[4],
                                                   N.f32(data), size[0], size[1], size[2], N.stream()), 'k4_resample_trilinear')
+        # a NEW parameter, as upstream: optimizers holding the old tensor must be re-created (run_sr.py:818; JointTrainer.rebuild_optimizer)
         self.grid = nn.Parameter(data)
         self.world_size = new_world_size
 

@@ -136,7 +136,7 @@ class _Packed:
             w[:, :cin, :cout] = wf.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
             self.w = w.reshape(k * k, nch, kc, nt * 32).permute(1, 0, 2, 3).contiguous()
             assert self.w.numel() == N.lib().k4_conv_weight_floats(cout, cin, k)
-        elif mode == 'bf16x6' and k == 3 and cout <= 3 and os.environ.get('K4_CONV_TAPS', '1') != '0':
+        elif mode == 'bf16x6' and k == 3 and cout <= 3:
             # few output channels (conv_last): the 9 taps become the GEMM's N dimension, packed as a 1x1 layer
             # [n = tap*cout + co][cin] (k4nerf.h, K4_W_TAPS_AS_COUT)
             w1 = wf.permute(2, 3, 0, 1).reshape(9 * cout, cin, 1, 1)             # [(dy,dx,co)][cin]
@@ -187,7 +187,7 @@ class _Packed:
     def _native_plan(weight, dgrad):
         """(form, flags_extra, packed bytes, bias floats, logical cin) of the device packer for this layer / operand."""
         cout, cin, k, _ = weight.shape
-        taps_ok = k == 3 and os.environ.get('K4_CONV_TAPS', '1') != '0'
+        taps_ok = k == 3
         flags_extra = 0
         if dgrad and taps_ok and cin <= 3:                  # the dgrad layer has <= 3 outputs (conv_first, CondNet.0): taps form of it
             form, lc_out, lc_in, lk = 3, 9 * cin, cout, 1
@@ -412,7 +412,7 @@ class SFTNet(nn.Module):
         ``slot``: independent buffer set (one per concurrently used stream)."""
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         spec = {'feat': (1, nf), 'cond': (1, g), 'c64a': (1, 64), 'c64b': (1, 64), 'trunk': (1, nf), 'rrdb_in': (1, nf),
-                'blk': (1, nf + 4 * g), 'blk2': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3),
+                'blk': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3),
                 'xin': (1, self.conv_first.in_channels), 'cnd': (1, self.CondNet[0].in_channels)}
         if s > 1:
             spec['up1'] = (2, nf)
@@ -443,12 +443,9 @@ class SFTNet(nn.Module):
             plan.append((fn, args, 'k4_conv2d_nhwc'))
         N.check(fn(*args, N.stream()), 'k4_conv2d_nhwc')
 
-    def _conv_multi(self, pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags=0, res=None, plan=None, sft=None):
+    def _conv_multi(self, pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags=0, res=None, plan=None):
         """One layer of every window.  bf16x6: ONE grouped launch (k4_conv2d_nhwc_bf16x6_multi); other arithmetics: one launch per
-        window.  `up`: output size = window size x up.  res = (buffer name, channel offset, stride, scale).
-        sft = (packed SFT weights, None | (buffer name, channel offset, stride)): the SFTLayer that follows this convolution runs in
-        its epilogue (k4_conv2d_sft_nhwc_bf16x6_multi); with a second buffer the plain result goes to y and the modulated one there."""
-        assert sft is None or pkc.mode == 'bf16x6'
+        window.  `up`: output size = window size x up.  res = (buffer name, channel offset, stride, scale)."""
         if pkc.mode != 'bf16x6':
             for B, (h, w) in zip(Bs, hws):
                 self._conv(pkc, B[xname], x_off, x_stride, B[yname], y_off, y_stride, cout, h * up, w * up, flags,
@@ -462,22 +459,6 @@ class SFTNet(nn.Module):
             jobs[j].mod_x = None
             jobs[j].H, jobs[j].W = h * up, w * up
         rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
-        if sft is not None:
-            wp, y2 = sft
-            epi = N.SftEpilogue()
-            epi.w_packed = wp.data_ptr()
-            epi.cond_stride = self.num_grow_ch
-            epi.y_sft_stride = 0 if y2 is None else y2[2]
-            for j, B in enumerate(Bs):
-                epi.cond[j] = B['cond'].data_ptr()
-                epi.y_sft[j] = None if y2 is None else B[y2[0]].data_ptr() + 4 * y2[1]
-            fn = N.lib().k4_conv2d_sft_nhwc_bf16x6_multi
-            args = (jobs, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), cout, y_stride, flags | pkc.flags_extra, 0.2,
-                    rs, rscale, N.C.pointer(epi))
-            if plan is not None:
-                plan.append((fn, args, 'k4_conv2d_sft_nhwc_bf16x6_multi'))
-            N.check(fn(*args, N.stream()), 'k4_conv2d_sft_nhwc_bf16x6_multi')
-            return
         fn = N.lib().k4_conv2d_nhwc_bf16x6_multi
         args = (jobs, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), pkc.k, cout, y_stride, flags | pkc.flags_extra, 0.2,
                 rs, rscale, 0)
@@ -497,7 +478,7 @@ class SFTNet(nn.Module):
             jobs[j].n_pix = h * w
         rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
         fn = N.lib().k4_sft_nhwc_multi
-        arith = 0 if (self.k4_mode == 'fp32' or os.environ.get('K4_SFT_FP32', '0') == '1') else 1     # K4_SFT_ARITH_*
+        arith = 0 if self.k4_mode == 'fp32' else 1     # K4_SFT_ARITH_*
         args = (jobs, len(Bs), self.num_grow_ch, N.f32(wp), x_stride, y_stride, cfeat, 0.2, rs, rscale, arith)
         if plan is not None:
             plan.append((fn, args, 'k4_sft_nhwc_multi'))
@@ -526,11 +507,11 @@ class SFTNet(nn.Module):
             B['cnd'].copy_(cond[0].permute(1, 2, 0))
             Bs.append(B)
             hws.append((h, w))
-        key = (tuple(hws), self._k4.get('key'), self.k4_mode, os.environ.get('K4_SR_FUSE_SFT', '0'), os.environ.get('K4_SFT_FP32', '0')) \
+        key = (tuple(hws), self._k4.get('key'), self.k4_mode) \
             + tuple(t.data_ptr() for B in Bs for t in B.values())
         plans = self._k4.setdefault(('plans', slot0), {})
         plan = plans.get(key)
-        if plan is None or os.environ.get('K4_SR_PLAN', '1') == '0':
+        if plan is None:
             plan = []
             self._record_hip(pk, Bs, hws, plan)
             if len(plans) > 16:
@@ -551,8 +532,8 @@ class SFTNet(nn.Module):
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         cin, ccond = Bs[0]['xin'].shape[2], Bs[0]['cnd'].shape[2]
 
-        def cv(pkc, xname, x_off, x_stride, yname, y_off, y_stride, cout, up=1, flags=0, res=None, sft=None):
-            self._conv_multi(pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags, res=res, plan=plan, sft=sft)
+        def cv(pkc, xname, x_off, x_stride, yname, y_off, y_stride, cout, up=1, flags=0, res=None):
+            self._conv_multi(pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags, res=res, plan=plan)
 
         def sft(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=None):
             self._sft_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=res, plan=plan)
@@ -569,29 +550,15 @@ class SFTNet(nn.Module):
         cv(pk['CondNet.6'], 'c64a', 0, 64, 'cond', 0, g, g)
         copy('trunk', 'feat')
         bw = nf + 4 * g
-        # K4_SR_FUSE_SFT=1 (opt-in): sft1 runs in the epilogue of conv4, the next dense block's sft0 in the epilogue of conv5 (which
-        # then writes the block's plain output to the trunk AND the modulated one into the next block's buffer: two buffers alternate
-        # because conv5 still reads the current one).  25 of the 36 SFT launches of a frame disappear, same pixels bit for bit
-        # (tests/test_sr_gpu.py).  Measured on the 4K frame: 51.35 / 52.09 ms fused vs 51.88 / 51.92 ms layer by layer -- the 0.7 GB
-        # round trip each SFT launch saves costs as much as its two GEMMs do when they run exposed at the end of every conv workgroup
-        # instead of under the memory traffic of a separate launch.  Not the default.
-        fuse = self.k4_mode == 'bf16x6' and os.environ.get('K4_SR_FUSE_SFT', '0') == '1' and os.environ.get('K4_SFT_FP32', '0') != '1'
         for b in range(self.num_block):
             copy('rrdb_in', 'trunk')
             for r in (1, 2, 3):
                 p = f'body.{b}.rdb{r}'
-                blk, nxt = ('blk', 'blk2') if r != 2 else ('blk2', 'blk')
-                if r == 1 or not fuse:
-                    sft(p + '.sft0', 'trunk', 0, nf, blk, 0, bw, nf)                                  # xc0
-                for k in range(1, 4):                                                               # x1..x3
-                    cv(pk[f'{p}.conv{k}'], blk, 0, bw, blk, nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
-                if fuse:
-                    cv(pk[f'{p}.conv4'], blk, 0, bw, blk, nf + 3 * g, bw, g, flags=EPI_LRELU, sft=(pk[p + '.sft1'], None))      # xc1 = sft1(x4)
-                else:
-                    cv(pk[f'{p}.conv4'], blk, 0, bw, blk, nf + 3 * g, bw, g, flags=EPI_LRELU)
-                    sft(p + '.sft1', blk, nf + 3 * g, bw, blk, nf + 3 * g, bw, g)                     # xc1 in place
-                cv(pk[f'{p}.conv5'], blk, 0, bw, 'trunk', 0, nf, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2),               # x5*0.2 + x
-                   sft=(pk[f'body.{b}.rdb{r + 1}.sft0'], (nxt, 0, bw)) if fuse and r < 3 else None)
+                sft(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf)                                    # xc0
+                for k in range(1, 5):                                                               # x1..x4
+                    cv(pk[f'{p}.conv{k}'], 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
+                sft(p + '.sft1', 'blk', nf + 3 * g, bw, 'blk', nf + 3 * g, bw, g)                     # xc1 in place
+                cv(pk[f'{p}.conv5'], 'blk', 0, bw, 'trunk', 0, nf, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))              # x5*0.2 + x
             sft(f'body.{b}.sft0', 'trunk', 0, nf, 'trunk', 0, nf, nf, res=('rrdb_in', 0, nf, 0.2))  # sft(out)*0.2 + x
         sft('sftbody', 'trunk', 0, nf, 'trunk', 0, nf, nf)
         cv(pk['conv_body'], 'trunk', 0, nf, 'rrdb_in', 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))            # body_feat += feat

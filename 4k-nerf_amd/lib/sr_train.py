@@ -303,12 +303,11 @@ def forward_train(net, x, cond):
         return F.leaky_relu(t, 0.2)
 
     fused = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'               # 'convs': one Function per convolution + elementwise autograd (A/B, tests)
-    if os.environ.get('K4_TRAIN_PREPACK', '1') != '0':                       # '0': every operand packed by its own launch on first use (A/B)
-        convs = net._k4.get(('train_convs', fused))
-        if convs is None:                                                     # the SFT layers' 1x1 convolutions are not packed when fused
-            convs = net._k4[('train_convs', fused)] = [m for name, m in net.named_modules()
-                                                       if isinstance(m, torch.nn.Conv2d) and not (fused and '.SFT_' in '.' + name)]
-        cache.prepack(convs)
+    convs = net._k4.get(('train_convs', fused))
+    if convs is None:                                                     # the SFT layers' 1x1 convolutions are not packed when fused
+        convs = net._k4[('train_convs', fused)] = [m for name, m in net.named_modules()
+                                                   if isinstance(m, torch.nn.Conv2d) and not (fused and '.SFT_' in '.' + name)]
+    cache.prepack(convs)
 
     xi = x[0].permute(1, 2, 0).contiguous().float()
     ci = cond[0].permute(1, 2, 0).contiguous().float()
@@ -391,7 +390,7 @@ class GraphedDecoder:
         sample = (torch.rand(self.x_shape, device=dev, requires_grad=True), torch.rand(self.cond_shape, device=dev))
         cache.always = True
         try:
-            self.fn = torch.cuda.make_graphed_callables(_Fwd(net), sample)
+            self.fn = torch.cuda.make_graphed_callables(_Fwd(net), sample, allow_unused_input=True)    # scale 2 / dswise leave parameters unused
         finally:
             cache.always = False
 

@@ -95,40 +95,46 @@ def rgbnet_sigmoid(rgbnet, x, add=None):
 
 
 class FlattenEffDistLoss(torch.autograd.Function):
-    """sum_rays [ sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval ] / (ray_id.max() + 1), gradient w.r.t. w only."""
+    """sum_rays [ sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval ] / (ray_id.max() + 1), gradient w.r.t. w only.
+    ray_id: int64, on the device, ASCENDING (samples grouped by ray in marching order, as the marcher emits them): the kernel finds a
+    ray's segment by binary search."""
 
     @staticmethod
-    def forward(ctx, w, s, interval, ray_id):
+    def forward(ctx, w, s, interval, ray_id, n_rays_bound):
         if not w.is_cuda:
             raise N.K4Error('flatten_eff_distloss: tensor must be on the GPU (no CPU path exists for this op)')
         if torch.is_tensor(interval):
             raise NotImplementedError('per-sample interval tensors: run_sr.py:985 passes the scalar 1/n_max')
+        if ray_id.dtype != torch.int64 or not ray_id.is_cuda or ray_id.shape != w.shape:
+            raise ValueError('flatten_eff_distloss: ray_id must be an int64 device tensor of the shape of w (sorted ascending)')
         wc, sc, idx = w.detach().float().contiguous(), s.detach().float().contiguous(), ray_id.contiguous()
         n = wc.shape[0]
         if n == 0:
             ctx.empty = True
             return wc.new_zeros([])
         ctx.empty = False
-        n_rays_t = idx.max() + 1                                  # the package's normaliser; stays on the device
-        # ray_id < n_rays of the batch; bounding the launch needs a host integer: the segment search makes any upper bound correct
-        n_rays = int(n_rays_t)
+        n_rays_t = (idx[-1] + 1).to(torch.float32)               # the package's normaliser ray_id.max() + 1 (sorted: the last entry); stays on the device
+        # the launch bound must be a host integer: any bound > max(ray_id) is correct (rays without samples contribute 0).  Without one
+        # from the caller it costs a host synchronisation per step.
+        n_rays = int(n_rays_bound) if n_rays_bound is not None else int(idx[-1]) + 1
         ray_loss = torch.empty([n_rays], dtype=torch.float32, device=wc.device)
-        grad = torch.empty_like(wc)
+        grad = torch.zeros_like(wc)                                # zeros: samples of rays beyond a too-small bound get no gradient, not garbage
         N.check(N.lib().k4_distortion_loss(N.f32(wc), N.f32(sc), N.ptr(idx), n, n_rays, float(interval), N.f32(ray_loss), N.f32(grad),
                                            N.stream()), 'k4_distortion_loss')
-        ctx.save_for_backward(grad)
-        ctx.n_rays = n_rays
-        return ray_loss.sum() / n_rays
+        ctx.save_for_backward(grad, n_rays_t)
+        return ray_loss.sum() / n_rays_t
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_back):
         if ctx.empty:
-            return None, None, None, None
-        grad, = ctx.saved_tensors
-        return grad * (grad_back / ctx.n_rays), None, None, None
+            return None, None, None, None, None
+        grad, n_rays_t = ctx.saved_tensors
+        return grad * (grad_back / n_rays_t), None, None, None, None
 
 
-def flatten_eff_distloss(w, s, interval, ray_id):
-    """Drop-in for ``torch_efficient_distloss.flatten_eff_distloss`` as run_sr.py:985 calls it."""
-    return FlattenEffDistLoss.apply(w, s, interval, ray_id)
+def flatten_eff_distloss(w, s, interval, ray_id, n_rays=None):
+    """Drop-in for ``torch_efficient_distloss.flatten_eff_distloss`` as run_sr.py:985 calls it.  ``n_rays`` (optional, not in the
+    package's signature): the number of rays of the batch -- any integer > max(ray_id) -- saves the host synchronisation that reading
+    ``ray_id.max()`` back costs."""
+    return FlattenEffDistLoss.apply(w, s, interval, ray_id, n_rays)

@@ -630,32 +630,13 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     n_samples = int(rr['weights'].numel())
-    graph = 'not run (K4_BENCH_TRAIN_GRAPH=1 enables it)'
-    if os.environ.get('K4_BENCH_TRAIN_GRAPH', '0') == '1':
-        # the decoder's forward + backward replayed as hipGraphs (lib/sr_train.GraphedDecoder), same iteration otherwise
-        graph = _timed_graph_iterations(tr, batch, iters)
-    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'ms_per_iteration_decoder_as_hipgraph': graph,
+    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 23.7 ms against 16.8 eager (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 3)',
             'rays_per_iteration': pr * pc,
             'shaded_samples': n_samples, 'first_loss': round(first, 5),
             'breakdown_ms': {'forward (march train + SFTNet + losses)': round((t1 - t0) * 1e3, 2), 'backward': round((t2 - t1) * 1e3, 2),
                              'TV add-grad (dense, both grids) + MaskedAdam x 2': round((t3 - t2) * 1e3, 2)},
             'workload': 'configs[4] fern_lg_joint_l1 on 1 GPU: 64x64 patch, 417x353x256 grids (k0 9 ch), rgbnet 15->64->64->3 on k4_rgbnet_*, '
                         'SFTNet 5 blocks on the MFMA conv kernels (fwd / dgrad / wgrad), synthetic targets'}
-
-
-def _timed_graph_iterations(tr, batch, iters):
-    try:
-        tr.use_graph = True
-        for i in range(2):
-            tr.step(*batch(20 + i), global_step=20 + i)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for i in range(iters):
-            tr.step(*batch(30 + i), global_step=30 + i)
-        torch.cuda.synchronize()
-        return round((time.perf_counter() - t) / iters * 1e3, 2)
-    except Exception as e:                # capture support differs between ROCm builds: the eager number stands on its own
-        return f'unavailable: {type(e).__name__}: {str(e)[:120]}'
 
 
 def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      5       /* 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      6       /* 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -312,20 +312,6 @@ int k4_conv2d_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t
                                 const void* w_split, const float* bias, int32_t ksize, int32_t cout, int32_t cout_stride,
                                 uint32_t flags, float slope, int32_t res_stride, float res_scale, int32_t mod_stride,
                                 void* stream);
-/* 3x3 convolution + the SFTLayer that follows it in the network, in ONE launch (lib/sr_esrnet.py:149-158: conv4 -> sft1, conv5 of one
- * dense block -> sft0 of the next): with v = the convolution's result after bias / K4_EPI_LRELU / K4_EPI_RES and
- * m = v*(scale(cond)+1) + shift(cond) (the arithmetic of k4_sft_nhwc_multi with K4_SFT_ARITH_BF16X6, bit-identical to running it
- * as a separate launch on v):   y_sft[g] == NULL:  y <- m;     otherwise:  y <- v  and  y_sft[g] <- m.
- * cout = the SFT layer's channels (32 | 64); w_packed = that layer's k4_sft_weight_floats(cout) buffer; cond[g]: [H*W][cond_stride]
- * condition map of window g (32 channels, 16-byte aligned). */
-typedef struct k4_sft_epilogue {
-    const float* w_packed; int32_t cond_stride; int32_t y_sft_stride;
-    const float* cond[K4_MAX_JOBS]; float* y_sft[K4_MAX_JOBS];
-} k4_sft_epilogue;
-int k4_conv2d_sft_nhwc_bf16x6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
-                                    const void* w_split, const float* bias, int32_t cout, int32_t cout_stride,
-                                    uint32_t flags, float slope, int32_t res_stride, float res_scale,
-                                    const k4_sft_epilogue* sft, void* stream);
 typedef struct k4_sft_job { const float* cond; const float* x; float* y; const float* res; int64_t n_pix; } k4_sft_job;
 #define K4_SFT_ARITH_FP32   0      /* v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (what k4_sft_nhwc computes)                    */
 #define K4_SFT_ARITH_BF16X6 1      /* exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16 (fp32-equivalent)    */
@@ -440,6 +426,11 @@ int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, in
  * The package's value is sum(ray_loss) / (ray_id.max() + 1): that division stays on the host. */
 int k4_distortion_loss(const float* w, const float* s, const int64_t* ray_id, int64_t n_pts, int64_t n_rays, float interval,
                        float* ray_loss, float* grad_w, void* stream);
+
+/* Touched voxels (any of the `channels` planes non-zero) of a grid gradient [channels][n_vox] as a compact index list in arbitrary
+ * order: what the data-parallel exchange of the joint step sends instead of the dense tensor.  *counter (device) = the total number of
+ * touched voxels, also when it exceeds `cap` (then only `cap` indices were written: retry with a larger list). */
+int k4_touched_voxels(const float* grad, int32_t channels, int64_t n_vox, int32_t* idx_out, int64_t cap, int64_t* counter, void* stream);
 
 /* SFTLayer of the VC-Decoder in the training graph (lib/sr_esrnet.py:112-123 under autograd, run_sr.py:869-1014):
  *   y = x * (scale + 1) + shift,   scale = W1s lrelu(W0s c + b0s) + b1s,   shift = W1h lrelu(W0h c + b0h) + b1h

@@ -119,10 +119,31 @@ def test_distortion_loss_matches_the_definition():
     _close(wd.grad, wr.grad * 3.0, 'grad_w', rel=1e-5, abs_=1e-7)
     # the last ray being empty does not change the normaliser (ray_id.max() + 1 = 9 here, as the package computes it)
     assert int(ray_id.max()) + 1 == 9
+    # with the batch's ray count as launch bound (no read-back of ray_id.max()): same value, same gradient
+    wb = w.cuda().requires_grad_(True)
+    gotb = train_ops.flatten_eff_distloss(wb, s.cuda(), interval, ray_id.cuda(), n_rays=len(per) + 7)
+    (gotb * 3.0).backward()
+    assert float(gotb) == float(got) and torch.equal(wb.grad, wd.grad)
+    with pytest.raises(ValueError):
+        train_ops.flatten_eff_distloss(wd, s.cuda(), interval, ray_id.cuda().int())
     # no samples at all
     e = train_ops.flatten_eff_distloss(torch.zeros([0], device='cuda', requires_grad=True), torch.zeros([0], device='cuda'), interval,
                                        torch.zeros([0], dtype=torch.long, device='cuda'))
     assert float(e) == 0.0
+
+
+@pytest.mark.parametrize('C,V,frac', [(12, 100003, 0.01), (1, 4097, 0.5), (9, 70000, 0.0), (3, 513, 1.0)])
+def test_touched_voxels_matches_the_dense_scan(C, V, frac):
+    """k4_touched_voxels (one pass, wave-aggregated append, retry when the list overflows) == (g != 0).any(0).nonzero()."""
+    g = torch.Generator().manual_seed(C + V)
+    grad = torch.zeros([C, V])
+    hit = torch.rand([V], generator=g) < frac
+    grad[torch.randint(0, C, [int(hit.sum())], generator=g), hit.nonzero().flatten()] = 1.5
+    grad = grad.cuda()
+    want = (grad != 0).any(0).nonzero().flatten().to(torch.int32)
+    for cap in (None, 7):                                             # 7: forces the overflow / retry path
+        got = joint_train.touched_voxels(grad, cap=cap)
+        assert got.dtype == torch.int32 and torch.equal(got, want)
 
 
 def _load_joint():
