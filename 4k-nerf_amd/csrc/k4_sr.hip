@@ -538,7 +538,7 @@ __device__ __forceinline__ float k4s_wave_max_nonneg(float v) {
 // from L1 / L2 one tap ahead -- 192 cycles of matrix work at 8-row tiles with 3 products, against an L2 hit of ~500+ cycles (a layer's
 // weights, 18 KB per chunk x 4..12 chunks, do not stay in the 32 KB L1 beside three workgroups' activation traffic): every layer shape
 // of the decoder sat at ~30 % of its matrix floor whatever its size (profiles/r03_sr_kernel_stats.md).
-// K4_SR_TIMING (profiling builds only, tools/r03_call8.sh): s_memtime stamps at the phase boundaries of the chunk loop, summed over all
+// K4_SR_TIMING (profiling builds only, profiles/r03_commands/r03_call8.sh): s_memtime stamps at the phase boundaries of the chunk loop, summed over all
 // waves into k4_sr_timing[] (read and reset through k4_debug_sr_timing).  Not compiled into the product library.
 #ifdef K4_SR_TIMING
 __device__ unsigned long long k4_sr_timing[16];

@@ -1,5 +1,5 @@
 """Phase breakdown of the shading kernel (k4_shade_kernel) on the bench frame: run with K4_LIB=<library built with -DK4_SHADE_TIMING>
-(tools/r03_call4.sh).  The kernel adds per-wave s_memtime sums to out_counters[8..15]."""
+(profiles/r03_commands/r03_call4.sh).  The kernel adds per-wave s_memtime sums to out_counters[8..15]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
