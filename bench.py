@@ -375,7 +375,23 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
     dt = float(tt.item())
     tflops = flop_per_px * px / dt / 1e12
     base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'n_gpus': world, 'test_tile': tile,
-            'effective_tflops': round(tflops, 2)}
+            'effective_tflops': round(tflops, 2), 'gather': 'fp32 HR pixels, 146 MB per frame (bit-identical to the single-GPU frame)'}
+    if world > 1:
+        # the same job with 8-bit pixels on the wire (render_frame_tiles(out_dtype=torch.uint8): every rank applies the reference's
+        # to8b rule to its own tiles before the all-gather, 36.6 MB per frame -- what run_sr.py finally writes to disk)
+        with torch.no_grad():
+            hr8 = tp.render_frame_tiles(frames[0], H, W, march_fn, sr_fn, tile, out_dtype=torch.uint8)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n_frames):
+                hr8 = tp.render_frame_tiles(frames[i % len(frames)], H, W, march_fn, sr_fn, tile, out=hr8, out_dtype=torch.uint8)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t8 = torch.tensor([(time.perf_counter() - t) / n_frames], dtype=torch.float64, device=dev)
+        dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+        base['uint8_gather'] = {'ms_per_frame': round(float(t8.item()) * 1e3, 2), 'frames_per_s': round(1.0 / float(t8.item()), 3),
+                                'bytes_per_frame': int(hr8.numel())}
     primary = keep is not None and 'hr' not in keep       # the first arithmetic timed is the default one: the others are compared with its frame
     if keep is not None and primary:
         keep['hr'], keep['mode'] = hr.clone(), mode

@@ -58,7 +58,8 @@ def _worker(rank, world, port, tile, q):
         ck, H, W, rays, sd = _scene()
         march_fn, sr_fn = _fns(ck, sd)
         out = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size=tile)
-        q.put((rank, out.numpy()))
+        out8 = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size=tile, out_dtype=torch.uint8)      # 8-bit pixels cross the wire
+        q.put((rank, (out.numpy(), out8.numpy())))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -80,7 +81,9 @@ def test_tile_sharded_frame_equals_single_process(world, tile):
         assert p.exitcode == 0
     for r in range(world):
         # tile windows are marched separately: identical samples, identical SR tiles -> identical pixels
-        assert np.array_equal(got[r], want), (r, float(np.abs(got[r] - want).max()))
+        assert np.array_equal(got[r][0], want), (r, float(np.abs(got[r][0] - want).max()))
+        # quantised before the exchange with the reference's to8b rule: byte-identical to to8b of the fp32 frame
+        assert got[r][1].dtype == np.uint8 and np.array_equal(got[r][1], (255 * np.clip(want, 0, 1)).astype(np.uint8))
 
 
 def test_assignment_covers_all_tiles_and_balances():
@@ -106,3 +109,7 @@ def test_single_process_path_without_process_group():
     out = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size=12)
     want = _reference_frame(ck, H, W, rays, sd, 12)
     assert torch.equal(out, want)
+    out8 = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size=12, out_dtype=torch.uint8)
+    assert out8.dtype == torch.uint8 and torch.equal(out8, (255.0 * want.clamp(0, 1)).to(torch.uint8))
+    with pytest.raises(ValueError):
+        tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size=12, out_dtype=torch.float16)
