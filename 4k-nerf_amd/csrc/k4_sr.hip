@@ -469,6 +469,9 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) 
 #ifndef K4_V2_ARING
 #define K4_V2_ARING 3      // A-fragment ring: filled ARING-1 sub-stages ahead
 #endif
+#ifndef K4_SMALL_SLOTS3
+#define K4_SMALL_SLOTS3 1  // small-launch tile rule: count 3 resident workgroups per CU for the fp16 form's 8-row tiles (A/B builds: 0)
+#endif
 #ifndef K4_V2_BRING
 #define K4_V2_BRING 2      // weight-fragment ring: filled BRING-1 taps ahead
 #endif
@@ -892,12 +895,14 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     int total = count(16);
     // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
     // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead)
+    // (the 8-row tiles of the fp16 form run THREE workgroups per CU, every other form two)
     int rpw = 4;
     if (total <= 2 * slots) {
         float best = 1e30f;
         for (int cand = 4; cand >= 2; --cand) {
             const int c = count(4 * cand);
-            const float cost = (float)((c + slots - 1) / slots) * ((float)cand + 0.6f);
+            const int sl = (K4_SMALL_SLOTS3 && cand == 2 && (M.base.flags & K4_ARITH_F16X3)) ? 3 * k4_num_cus() : slots;
+            const float cost = (float)((c + sl - 1) / sl) * ((float)cand + 0.6f);
             if (cost < best - 1e-3f) { best = cost; rpw = cand; }
         }
         total = count(4 * rpw);
