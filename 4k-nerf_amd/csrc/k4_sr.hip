@@ -279,18 +279,41 @@ __device__ __forceinline__ void k4s_split3(const float (&v)[8], uint4& t0, uint4
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 k4s_f16x2 __attribute__((ext_vector_type(2)));
 // 4 channels, scaled by the power of two `sc` -> fp16 hi (RNE) and fp16 lo = RNE(x*sc - hi): x*sc == hi + lo up to 2^-22 relative
+// hi = RNE_fp16(v * sc), lo = RNE_fp16(v * sc - hi) for four values, sc a power of two: 8 x v_fma_mix{lo,hi}_f16 (the fp32 FMA is exact here,
+// one rounding to fp16 each; the high term adds -0.0 so that a negative zero keeps its sign).  The plain C++ form compiles to 16
+// instructions (hipcc does not form fma_mix), and vector instructions do not hide under matrix instructions on gfx950
+// (tools/micro/mfma_valu_overlap.hip): bit-identical results (tools/micro/fma_mix_split.hip).
+#ifndef K4S_ASM_SPLIT
+#define K4S_ASM_SPLIT 1
+#endif
+#ifndef K4S_INT_MAX
+#define K4S_INT_MAX 1
+#endif
 __device__ __forceinline__ void k4s_split2h_x4(const float4& v, float sc, uint2& hi, uint2& lo) {
+#if !K4S_ASM_SPLIT
     const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
     unsigned ph[2], pl[2];
-#pragma unroll
     for (int i = 0; i < 2; ++i) {
         const k4s_f32x2 x = {f[2 * i], f[2 * i + 1]};
         const k4s_f16x2 h = __builtin_convertvector(x, k4s_f16x2);
-        const k4s_f32x2 r = x - __builtin_convertvector(h, k4s_f32x2);        // exact: hi is x rounded to 11 bits
+        const k4s_f32x2 r = x - __builtin_convertvector(h, k4s_f32x2);
         const k4s_f16x2 l = __builtin_convertvector(r, k4s_f16x2);
         ph[i] = __builtin_bit_cast(unsigned, h); pl[i] = __builtin_bit_cast(unsigned, l);
     }
     hi = make_uint2(ph[0], ph[1]); lo = make_uint2(pl[0], pl[1]);
+    return;
+#endif
+    unsigned h0, h1, l0, l1;
+    const float nz = -0.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(h0) : "v"(v.x), "v"(sc), "v"(nz));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(h0) : "v"(v.y), "v"(sc), "v"(nz));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(h1) : "v"(v.z), "v"(sc), "v"(nz));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(h1) : "v"(v.w), "v"(sc), "v"(nz));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v.x), "v"(sc), "v"(h0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v.y), "v"(sc), "v"(h0));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v.z), "v"(sc), "v"(h1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v.w), "v"(sc), "v"(h1));
+    hi = make_uint2(h0, h1); lo = make_uint2(l0, l1);
 }
 
 __device__ __forceinline__ void k4s_split3x4(const float4& v, uint2& t0, uint2& t1, uint2& t2) {   // 4 channels -> 3 terms x 4 bf16
@@ -466,6 +489,7 @@ __global__ __launch_bounds__(64 * NW) void k4_conv_b6_kernel(const ConvMulti M) 
 //   * 2 waves per SIMD, nothing spills.
 // Same arithmetic, same operand order per accumulator as above: results are bit-identical to the v1 kernel (tests).
 // ------------------------------------------------------------------------------------------------------------------
+typedef unsigned k4s_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef K4_V2_ARING
 #define K4_V2_ARING 3      // A-fragment ring: filled ARING-1 sub-stages ahead
 #endif
@@ -536,6 +560,12 @@ __device__ __forceinline__ float k4s_wave_max_nonneg(float v) {
 #undef K4_DPP_MAX
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)x, 63));
 }
+// largest finite magnitude of four values on their bit patterns (non-negative floats order like unsigned integers): 4 x v_and + 2 x v_max3_u32.
+// A non-finite value (bits >= 0x7f800000) makes the result >= 0x7f800000: the caller then takes the slow path below.
+__device__ __forceinline__ unsigned k4s_absmax4_bits(const float4& v, unsigned m) {
+    const unsigned a0 = __float_as_uint(v.x) & 0x7fffffffu, a1 = __float_as_uint(v.y) & 0x7fffffffu, a2 = __float_as_uint(v.z) & 0x7fffffffu, a3 = __float_as_uint(v.w) & 0x7fffffffu;
+    return max(max(max(m, a0), max(a1, a2)), a3);
+}
 // WL = the chunk's weight fragments go through LDS: fetched ONCE per workgroup together with the next chunk's activations (a whole MFMA phase
 // ahead), stored beside the input tile, read by every wave with ds_read_b128 one tap ahead.  Without it each wave fetches its fragments
 // from L1 / L2 one tap ahead -- 192 cycles of matrix work at 8-row tiles with 3 products, against an L2 hit of ~500+ cycles (a layer's
@@ -592,13 +622,19 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     // (pixel, 8-channel) map of the v1 kernel touched 64 pieces of 16 bytes: the L1 tag rate, not bytes, bounded the staging --
     // TCP_TOTAL_CACHE_ACCESSES 2.2e8 per 2080x2080 launch, 0.7 per CU-cycle with the MFMA phase compiled out).
     // Per-thread state of the tile being STAGED (chunk independent): element offsets from the image base, an inside-the-image mask.
-    int ioff[IN_PER];
-    unsigned imask;
-    bool vec_ok;
+    // ioff: offset of the item from the image base -- in BYTES when the window's image is below 2 GB (buf_ok), else in elements -- or
+    // K4_V2_OOB for an item outside the image / past the tile.  Whole chunks of 16-byte aligned images below 2 GB are fetched through a
+    // buffer descriptor of the window: an offset beyond its range returns zeros in hardware -- no select per component, no 64-bit
+    // address arithmetic per load (vector instructions do not hide under the matrix instructions).
+#define K4_V2_OOB 0x80000000u
+    unsigned ioff[IN_PER];
+    bool vec_ok, buf_ok;
     const float* xbase;
+    __amdgpu_buffer_rsrc_t xrsrc;
     const int sq = tid & 3, sp0 = tid >> 2;
 #define K4_V2_SETUP(TT) do { \
-        imask = 0u; \
+        const long long xbytes_ = (long long)(ups ? (TT).H / 2 : (TT).H) * (TT).srcW * P.cin_stride * 4; \
+        buf_ok = xbytes_ <= (long long)K4_V2_OOB; \
         _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
             const int pp = sp0 + 64 * i; \
             const int ppc = pp < NPIX ? pp : 0; \
@@ -606,10 +642,14 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
             const int gy = (TT).y0 - 1 + py, gx = (TT).x0 - 1 + px; \
             const bool inside = pp < NPIX && gy >= 0 && gy < (TT).H && gx >= 0 && gx < (TT).W; \
             const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx; \
-            ioff[i] = inside ? (sy * (TT).srcW + sx) * P.cin_stride + sq * 4 : 0; \
-            imask |= inside ? (1u << i) : 0u; \
+            ioff[i] = inside ? (unsigned)((sy * (TT).srcW + sx) * P.cin_stride + sq * 4) << (buf_ok ? 2 : 0) : K4_V2_OOB;      /* elements < 2^31 (launch check) */ \
         } \
-        vec_ok = vec_base && (((size_t)(TT).x) & 15) == 0; xbase = (TT).x; } while (0)
+        xbase = (TT).x; \
+        vec_ok = vec_base && (((size_t)(TT).x) & 15) == 0; \
+        const unsigned long long xa_ = (unsigned long long)(TT).x; \
+        const unsigned xlo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa_), xhi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa_ >> 32)); \
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)xhi_ << 32) | xlo_), 0, \
+                                                  __builtin_amdgcn_readfirstlane((int)(unsigned)(buf_ok ? xbytes_ : 0)), 0x00020000); } while (0)
     K4_V2_SETUP(T);
 
     // raw fp32 of the NEXT chunk's tile items: fetched before the MFMA phase of the current chunk, split + stored after it, so that
@@ -618,17 +658,22 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     float4 rv[IN_PER];
 #define K4_V2_LOADRAW(CH) do { \
         const int c0_ = (CH) * KC2; \
-        if (vec_ok && c0_ + KC2 <= P.cin) { \
+        if (vec_ok && !buf_ok && c0_ + KC2 <= P.cin) { \
+            _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) {          /* images of 2 GB and more: flat loads + select */ \
+                const bool in_ = ioff[i] != K4_V2_OOB; \
+                const k4_f4 va = *reinterpret_cast<const k4_f4*>(xbase + (in_ ? ioff[i] : 0u) + c0_); \
+                rv[i] = in_ ? make_float4(va.x, va.y, va.z, va.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            } \
+        } else if (vec_ok && c0_ + KC2 <= P.cin) { \
             _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
-                const k4_f4* src = reinterpret_cast<const k4_f4*>(xbase + ioff[i] + c0_); \
-                const k4_f4 va = K4_V2_NT ? __builtin_nontemporal_load(src) : *src; \
-                rv[i] = (imask >> i) & 1u ? make_float4(va.x, va.y, va.z, va.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                const k4s_u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)ioff[i], c0_ * 4, 0); \
+                rv[i] = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w)); \
             } \
         } else { \
             _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
-                const bool in_ = (imask >> i) & 1u; \
+                const bool in_ = ioff[i] != K4_V2_OOB; \
                 const int cb = c0_ + sq * 4; \
-                const float* src = xbase + ioff[i] + c0_; \
+                const float* src = xbase + (in_ ? (ioff[i] >> (buf_ok ? 2 : 0)) : 0u) + c0_; \
                 float e4[4]; \
                 _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
                     const bool ok_ = in_ && cb + c < P.cin; \
@@ -660,12 +705,28 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     static_assert(W_PER <= 9, "weight staging registers");
     uint4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7, wr8;
 #define K4_V2_WR_LIST(X) X(0, wr0) X(1, wr1) X(2, wr2) X(3, wr3) X(4, wr4) X(5, wr5) X(6, wr6) X(7, wr7) X(8, wr8)
+    // byte offsets of this thread's items inside a chunk's fragments (chunk independent); the chunk's base rides in the scalar offset of a
+    // buffer load over the packed weights (< 4 GB): no per-chunk address arithmetic in vector registers
+    unsigned woffb[WL ? W_PER : 1];
+    __amdgpu_buffer_rsrc_t wrsrc;
+    if constexpr (WL) {
+#pragma unroll
+        for (int k = 0; k < W_PER; ++k) { const int it_ = tid + k * THREADS, itc_ = it_ < WCH ? it_ : 0; woffb[k] = (unsigned)(((itc_ / (32 * NBK)) * NOUT + itc_ % (32 * NBK) + T.nb * 32 * NBK) * 16); }
+        const unsigned long long wa_ = (unsigned long long)P.w;
+        const unsigned wlo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa_), whi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa_ >> 32));
+        wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)whi_ << 32) | wlo_), 0,
+                                                  __builtin_amdgcn_readfirstlane(nchunks * W_ITEMS * 16), 0x00020000);
+    }
+#ifndef K4_V2_WBUF
+#define K4_V2_WBUF 1
+#endif
 #define K4_V2_LOADW_ONE(K, R) if constexpr (W_PER > K) { \
-            const int it_ = tid + K * THREADS, itc_ = it_ < WCH ? it_ : 0; \
-            R = wc_[(itc_ / (32 * NBK)) * NOUT + itc_ % (32 * NBK)]; }
+            if (K4_V2_WBUF) { const k4s_u32x4 wv_ = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)woffb[K], wsoff_, 0); \
+                              R = make_uint4(wv_.x, wv_.y, wv_.z, wv_.w); } \
+            else R = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.w) + (size_t)wsoff_ + woffb[K]); }
 #define K4_V2_STOREW_ONE(K, R) if constexpr (W_PER > K) { if (tid + K * THREADS < WCH) w_s[tid + K * THREADS] = R; }
 #define K4_V2_LOADW(CH) do { \
-        const uint4* wc_ = reinterpret_cast<const uint4*>(P.w) + (size_t)(CH) * W_ITEMS + T.nb * 32 * NBK; \
+        const int wsoff_ = (CH) * W_ITEMS * 16; \
         K4_V2_WR_LIST(K4_V2_LOADW_ONE) } while (0)
     if constexpr (WL) K4_V2_LOADW(0);
     else {
@@ -692,14 +753,22 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     // The weights carry their own power-of-two factors (packing time): 2^a[co] per output channel (undone per lane in the epilogue) and
     // 2^b[chunk] per 16-input-channel chunk, which simply adds to the chunk's activation exponent: t = sexp + b is what the
     // accumulators are based on.
+    // largest FINITE magnitude of this wave's share of the staged chunk -> smax[SLOT][wave]: on the bit patterns (6 instructions per four
+    // values); only when a non-finite value is among them (the wave maximum says so, uniformly) the filtering form runs
+#define K4_V2_CHUNKMAX(SLOT) do { \
+        unsigned mb_ = 0u; \
+        _Pragma("unroll") for (int i_ = 0; i_ < IN_PER; ++i_) mb_ = k4s_absmax4_bits(rv[i_], mb_); \
+        float m_ = k4s_wave_max_nonneg(__uint_as_float(mb_)); \
+        if (__float_as_uint(m_) >= 0x7f800000u || !K4S_INT_MAX) { \
+            float mf_ = 0.f; \
+            _Pragma("unroll") for (int i_ = 0; i_ < IN_PER; ++i_) mf_ = fmaxf(fmaxf(fmaxf(mf_, k4s_finite_abs(rv[i_].x)), k4s_finite_abs(rv[i_].y)), fmaxf(k4s_finite_abs(rv[i_].z), k4s_finite_abs(rv[i_].w))); \
+            m_ = k4s_wave_max_nonneg(mf_); \
+        } \
+        if (lane == 0) smax[SLOT][wv] = m_; } while (0)
     int sexp = 0, tcur = 0, tmin = 1000;
     const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(P.w) + (size_t)nchunks * W_ITEMS);     // [NOUT] 2^-a | [nchunks] b
     if constexpr (F16) {
-        float m = 0.f;
-#pragma unroll
-        for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, k4s_finite_abs(rv[i].x)), k4s_finite_abs(rv[i].y)), fmaxf(k4s_finite_abs(rv[i].z), k4s_finite_abs(rv[i].w)));
-        m = k4s_wave_max_nonneg(m);
-        if (lane == 0) smax[0][wv] = m;
+        K4_V2_CHUNKMAX(0);
         __syncthreads();
     }
     K4_SR_TSTAMP(0);                                     // prologue: tile setup, first chunk's loads issued, (F16) its maximum + barrier
@@ -811,11 +880,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
             K4_SR_TSTAMP(4);                             // the MFMA phase
             if constexpr (F16) {
                 if (ch + 1 < nchunks) {              // the next chunk's largest magnitude (its raw values have landed under the MFMAs)
-                    float m = 0.f;
-#pragma unroll
-                    for (int i = 0; i < IN_PER; ++i) m = fmaxf(fmaxf(fmaxf(m, k4s_finite_abs(rv[i].x)), k4s_finite_abs(rv[i].y)), fmaxf(k4s_finite_abs(rv[i].z), k4s_finite_abs(rv[i].w)));
-                    m = k4s_wave_max_nonneg(m);
-                    if (lane == 0) smax[(ch + 1) & 1][wv] = m;
+                    K4_V2_CHUNKMAX((ch + 1) & 1);
                 }
             }
             K4_SR_TSTAMP(5);                             // next chunk's maximum (waits for its raw values)
@@ -875,6 +940,8 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
 #undef K4_V2_WR_LIST
 #undef K4_V2_READA
 #undef K4_V2_LOADRAW
+#undef K4_V2_CHUNKMAX
+#undef K4_V2_OOB
 #undef K4_V2_SETUP
 }
 
