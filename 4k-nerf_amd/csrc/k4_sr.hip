@@ -897,6 +897,56 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sum_ += acc[j][r][e];
             if (sum_ == 123.456f) T.y[lane] = sum_;
+        } else if (T.x0 + TILE_W <= T.W && P.slope >= 0.f && P.slope <= 1.f && (long long)T.H * T.W * P.cout_stride * 4 <= 0x80000000LL &&
+                   (!(P.flags & K4_EPI_RES) || (long long)T.H * T.W * P.res_stride * 4 <= 0x80000000LL)) {
+            // Fast path (every tile but the last column of an image): the tile is whole in x and the images are below 2 GB -> buffer
+            // stores / residual loads with the lane's offset computed ONCE per row and the element's pixel offset as a scalar (e is a
+            // compile-time index).  The general path below spends ~10 vector instructions per stored element on 64-bit addresses, and
+            // vector instructions do not hide under matrix instructions on this chip.  Same values: max(v, v * slope) == LeakyReLU for
+            // 0 <= slope <= 1.
+            const unsigned long long ya_ = (unsigned long long)T.y, ra_ = (unsigned long long)T.res;
+            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ya_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ya_)),
+                0, __builtin_amdgcn_readfirstlane(T.H * T.W * P.cout_stride * 4), 0x00020000);
+            const bool has_res = (P.flags & K4_EPI_RES) != 0;
+            const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ra_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ra_)),
+                0, __builtin_amdgcn_readfirstlane(has_res ? T.H * T.W * P.res_stride * 4 : 0), 0x00020000);
+            const float sl = (P.flags & K4_EPI_LRELU) ? P.slope : 1.f;
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                const int co = (T.nb * NBK + j) * 32 + l31;
+                const bool co_ok = co < P.cout;
+                const float bias = P.bias[co_ok ? co : 0];
+                float unscale = 1.f;
+                if constexpr (F16) unscale = ldexpf(wtail[co_ok ? co : 0], -tcur);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int gy = T.y0 + wv * RPW + r;                                  // wave-uniform
+                    if (gy >= T.H) continue;
+                    const int pix0 = gy * T.W + T.x0 + 4 * half;
+                    const unsigned yoff = co_ok ? (unsigned)((pix0 * P.cout_stride + co) * 4) : 0x80000000u;      // lanes past cout: out of range, dropped
+                    const unsigned roff = co_ok ? (unsigned)((pix0 * P.res_stride + co) * 4) : 0x80000000u;
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dp = (e & 3) + 8 * (e >> 2);
+                            float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
+                            v = fmaxf(v, v * sl);
+                            v = k4s_mul_add(v, P.res_scale, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, (int)roff, dp * P.res_stride * 4, 0)));
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)yoff, dp * P.cout_stride * 4, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int dp = (e & 3) + 8 * (e >> 2);
+                            float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
+                            v = fmaxf(v, v * sl);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)yoff, dp * P.cout_stride * 4, 0);
+                        }
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NBK; ++j) {
