@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     const int sq = tid & 3, sp0 = tid >> 2;
 #define K4_V2_SETUP(TT) do { \
         const long long xbytes_ = (long long)(ups ? (TT).H / 2 : (TT).H) * (TT).srcW * P.cin_stride * 4; \
-        buf_ok = xbytes_ <= (long long)K4_V2_OOB; \
+        buf_ok = F16 && xbytes_ <= (long long)K4_V2_OOB;           /* the bf16 instantiations keep flat loads: their register budgets are full */ \
         _Pragma("unroll") for (int i = 0; i < IN_PER; ++i) { \
             const int pp = sp0 + 64 * i; \
             const int ppc = pp < NPIX ? pp : 0; \
@@ -897,7 +897,8 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sum_ += acc[j][r][e];
             if (sum_ == 123.456f) T.y[lane] = sum_;
-        } else if (T.x0 + TILE_W <= T.W && P.slope >= 0.f && P.slope <= 1.f && (long long)T.H * T.W * P.cout_stride * 4 <= 0x80000000LL &&
+        } else if (!(RPW == 4 && NTERM == 3) &&                       // (that instantiation has no register left for it: it would spill)
+                   T.x0 + TILE_W <= T.W && P.slope >= 0.f && P.slope <= 1.f && (long long)T.H * T.W * P.cout_stride * 4 <= 0x80000000LL &&
                    (!(P.flags & K4_EPI_RES) || (long long)T.H * T.W * P.res_stride * 4 <= 0x80000000LL)) {
             // Fast path (every tile but the last column of an image): the tile is whole in x and the images are below 2 GB -> buffer
             // stores / residual loads with the lane's offset computed ONCE per row and the element's pixel offset as a scalar (e is a
