@@ -140,9 +140,11 @@ class MarcherRun:
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # per-frame completion intervals inside the overlapped region (end event of frame i - end event of frame i-1): a single slow
-        # frame shows in the spread, the median is what a long run converges to
-        self.frame_intervals_ms = [ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, steps)]
+        # per-frame completion intervals inside the overlapped region.  The S streams finish their frames in bursts, so the interval is
+        # taken over one round of the streams, (end of frame i - end of frame i-S) / S: a slow round shows in the spread, the median is
+        # what a long run converges to
+        S = len(self.streams)
+        self.frame_intervals_ms = [ev[i - S][1].elapsed_time(ev[i][1]) / S for i in range(S, steps)]
         return float(t.item()), float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     def isolated(self, n):
