@@ -427,8 +427,15 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
                        'exact 3-term bf16 splits'),
         'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
                         'frac': round(tflops / peak, 4), 'flop_per_frame': flop_per_px * px,
+                        # the other roof: every layer reads its inputs and writes its outputs ONCE as fp32 (no halo, no re-reads): channel
+                        # accesses per padded LR pixel x 4 bytes -- conv_first 67, CondNet 417, 5 RRDBs x (3 dense blocks x 1152 + 224),
+                        # sftbody 160, conv_body 192, up1 320, up2 1280, conv_hr 2048, conv_last 1072
+                        'algorithmic_bytes_per_frame': 23956 * 4 * px,
+                        'hbm_floor_ms': round(23956 * 4 * px / (HBM_PEAK_GBS * 1e9 * world) * 1e3, 2),
+                        'mfma_floor_ms': round(flop_per_px * px / (peak * 1e12) * 1e3, 2),
                         'note': f'peak = 2.5 PFLOP/s dense bf16|fp16 / {per_product} MFMA per product x n_gpus; time includes the '
-                                'marcher, layout copies and the all-gather'}})
+                                'marcher, layout copies and the all-gather.  With fp32 activations the decoder sits where the two roofs '
+                                'meet for the 3-product arithmetic (hbm_floor_ms vs mfma_floor_ms)'}})
     if world == 1:                               # rank 0's share of the 8-GPU job (3 tiles of tile_size 189), timed on this GPU
         t189 = tp.tile_geometry(H, W, 189, 10)
         mine = tp.assign_tiles(t189, 8)[0]
