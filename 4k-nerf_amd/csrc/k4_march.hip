@@ -729,6 +729,13 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
 #define K4_TARGS
 #define K4_TPASS
 #endif
+// max(x, 0) in ONE instruction, on the bit pattern: v_max_i32(bits, 0) -- a negative float is a negative integer, a non-negative one keeps
+// its bits.  fmaxf(x, 0.f) compiles to a canonicalising v_max_f32 plus the max (and v_med3_f32 is folded back into that pair), and vector
+// instructions do not hide under the matrix instructions on this chip (tools/micro/mfma_valu_overlap.hip): 128 of the ~1400 vector
+// instructions of a 64-record batch were the second half of a ReLU.  Same values for every non-NaN input (-0 -> +0 either way); a NaN
+// with a clear sign bit stays NaN as in torch.relu (fmaxf turned it into 0).  Not inline asm: the compiler must see the instruction
+// to insert the wait states between an MFMA writing a register and a vector instruction reading it.
+__device__ __forceinline__ float k4_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 template <int W, int NHID>
 __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, int k1p, int lane, int half, int debug, int nproc,
                                             float& out0, float& out1, float& out2 K4_TARGS) {
@@ -785,7 +792,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
             for (int kb = 0; kb < KB2; ++kb) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(h1[kb >> 1][8 * (kb & 1) + e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = k4_relu(h1[kb >> 1][8 * (kb & 1) + e]);
                 k4_split3(v, hs[kb][0], hs[kb][1], hs[kb][2]);
             }
             f32x16 c[NB];
@@ -818,7 +825,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
-                    const float a0 = fmaxf(c[mb2][r], 0.f);
+                    const float a0 = k4_relu(c[mb2][r]);
                     const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
                     pt01 = __builtin_elementwise_fma(w01, aa, pt01);                  // v_pk_fma_f32: channels 0 and 1 in one instruction
                     pt2 = fmaf(wo.z, a0, pt2);
@@ -829,7 +836,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, const float* feat, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
-                    const float a0 = fmaxf(h1[mb][r], 0.f);
+                    const float a0 = k4_relu(h1[mb][r]);
                     const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
                     pt01 = __builtin_elementwise_fma(w01, aa, pt01);
                     pt2 = fmaf(wo.z, a0, pt2);
