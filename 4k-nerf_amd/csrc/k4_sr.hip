@@ -1568,6 +1568,160 @@ __global__ __launch_bounds__(256) void k4_sft_b6_kernel(const SftMulti M) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same layer, same arithmetic, same bits, with the memory round trips taken off the critical path.  The kernel above issues
+// cond -> (wait) -> GEMM 1 / 2 -> x [, res] -> (wait) -> modulation -> store three times per 32-pixel tile at two waves per SIMD:
+// 194 us per 64-channel layer of a 4K frame against an HBM floor of ~66 us.  Here one tile is ONE basic block (the second output
+// block unrolled, the residual a template parameter, bounds by buffer descriptors: a pixel past the end loads zeros and its store is
+// dropped, so there is no branch and hipcc counts its waits instead of draining the queue): the x rows of the tile are requested
+// before GEMM 1, the next tile's condition rows right after GEMM 1 consumed the current ones, the residual rows of an output block
+// before that block's matrix instructions.  Needs 16-byte aligned rows and images below 2 GB (buffer offsets); anything else runs
+// on the kernel above.
+// ------------------------------------------------------------------------------------------------------------------
+#define K4_SFT_OOB 0x80000000u
+// Channel offsets go into the LANE offset (hipcc folds the constant into the instruction's immediate field), never into the scalar-offset
+// operand: with an SGPR there, hipcc's hazard recogniser assumes a 16-byte store has read its data registers when the next instruction
+// issues and lets a vector instruction overwrite them right behind the store -- on gfx950 lanes 12..15 of every 16 then stored the NEW
+// values (second output block wrong in exactly those pixels; with the offset in the immediate field the recogniser inserts the wait state).
+#define K4_SFT_CH(MB2, Q) ((unsigned)(((MB2) * 32 + 8 * (Q)) * 4))
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k4s_rsrc(const void* p, int bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a)),
+        0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int CB, bool RES>
+__global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
+    constexpr int NW6 = K4_SFT6_FLOATS(CB);
+    constexpr int NW32 = (2 + 2 * CB) * 17 * 64;
+    __shared__ __attribute__((aligned(16))) float wl[NW6];
+    SftParams P = M.base;
+    int blk = (int)blockIdx.x;
+    {
+        int g = 0;
+        while (g + 1 < M.n && blk >= M.blk_end[g]) ++g;
+        blk -= g ? M.blk_end[g - 1] : 0;
+        P.cond = M.cond[g]; P.x = M.x[g]; P.y = M.y[g]; P.res = M.res[g]; P.n_pix = M.n_pix[g];
+    }
+    const int lane = k4_lane();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const __amdgpu_buffer_rsrc_t crs = k4s_rsrc(P.cond, P.n_pix * P.cond_stride * 4);
+    const __amdgpu_buffer_rsrc_t xrs = k4s_rsrc(P.x, P.n_pix * P.x_stride * 4);
+    const __amdgpu_buffer_rsrc_t yrs = k4s_rsrc(P.y, P.n_pix * P.y_stride * 4);
+    const __amdgpu_buffer_rsrc_t rrs = k4s_rsrc(RES ? P.res : P.x, RES ? P.n_pix * P.res_stride * 4 : 0);
+    const int base = (blk * 4 + wv) * 64;
+    k4s_u32x4 cn[4];                                   // condition channels kb*16 + 8*half + 0..7 of the lane's pixel, kb = 0, 1
+    {
+        const int pix = base + l31;
+        const unsigned coff = pix < P.n_pix ? (unsigned)(pix * P.cond_stride * 4 + half * 32) : K4_SFT_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cn[i] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(coff + (unsigned)((i >> 1) * 64 + (i & 1) * 16)), 0, 0);
+    }
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.w + NW32);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = (int)threadIdx.x; i < NW6 / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint4* const wa6 = reinterpret_cast<const uint4*>(wl);
+    const uint4* const ws6 = wa6 + 2 * 2 * 3 * 64;
+    const uint4* const wh6 = ws6 + CB * 2 * 3 * 64;
+    const float* const ba = wl + (2 + 2 * CB) * 2 * 3 * 64 * 4;
+    const float* const bs = ba + 2 * 2 * 16;
+    const float* const bh = bs + CB * 2 * 16;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        asm volatile("" ::: "memory");                 // keeps the loop-invariant weight fragments in LDS (hoisted, they take 190 registers and a wave slot)
+        const int pix = base + t * 32 + l31;
+        const bool pok = pix < P.n_pix;
+        const unsigned xoff = pok ? (unsigned)(pix * P.x_stride * 4 + half * 16) : K4_SFT_OOB;
+        const unsigned yoff = pok ? (unsigned)(pix * P.y_stride * 4 + half * 16) : K4_SFT_OOB;
+        const unsigned roff = (RES && pok) ? (unsigned)(pix * P.res_stride * 4 + half * 16) : K4_SFT_OOB;
+        const unsigned cnext = (t == 0 && pix + 32 < P.n_pix) ? (unsigned)((pix + 32) * P.cond_stride * 4 + half * 32) : K4_SFT_OOB;
+        k4s_u32x4 xq[4 * CB];                          // x channels mb2*32 + 8q + 4*half + 0..3
+#pragma unroll
+        for (int i = 0; i < 4 * CB; ++i) xq[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xoff + K4_SFT_CH(i >> 2, i & 3)), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);             // the scheduler otherwise sinks the requests to their first use, behind the matrix work
+        // ---- GEMM 1: hidden^T = lrelu(WA . cond^T + ba) ----
+        f32x16 h[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[mb][r] = ba[(mb * 2 + half) * 16 + r];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const k4s_u32x4 c0 = cn[2 * kb], c1 = cn[2 * kb + 1];
+            const float v[8] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w),
+                                __uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+            uint4 x0, x1, x2;
+            k4s_split3(v, x0, x1, x2);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const uint4* wp = wa6 + ((mb * 2 + kb) * 3) * 64 + lane;
+                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                K4_B6(h[mb], a0, a1, a2, x0, x1, x2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cn[i] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(cnext + (unsigned)((i >> 1) * 64 + (i & 1) * 16)), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // lrelu + split of the hidden activations: K chunk kb = accumulator registers 8*kb .. 8*kb+7
+        uint4 hs[2][2][3];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float q = h[mb][8 * kb + e]; v[e] = q > 0.f ? q : q * P.slope; }
+                k4s_split3(v, hs[mb][kb][0], hs[mb][kb][1], hs[mb][kb][2]);
+            }
+        // ---- GEMM 2 + modulation, 32 output channels at a time ----
+#pragma unroll
+        for (int mb2 = 0; mb2 < CB; ++mb2) {
+            k4s_u32x4 rq[4];
+            if constexpr (RES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rq[q] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + K4_SFT_CH(mb2, q)), 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16 cs, ch;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cs[r] = bs[(mb2 * 2 + half) * 16 + r]; ch[r] = bh[(mb2 * 2 + half) * 16 + r]; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint4* wps = ws6 + ((mb2 * 2 + kb) * 3) * 64 + lane;
+                const uint4* wph = wh6 + ((mb2 * 2 + kb) * 3) * 64 + lane;
+                const uint4 s0 = wps[0], s1 = wps[64], s2 = wps[128];
+                const uint4 g0 = wph[0], g1 = wph[64], g2 = wph[128];
+                K4_B6(cs, s0, s1, s2, hs[0][kb][0], hs[0][kb][1], hs[0][kb][2]);
+                K4_B6(ch, g0, g1, g2, hs[1][kb][0], hs[1][kb][1], hs[1][kb][2]);
+            }
+            // accumulator registers 4q..4q+3 are 4 CONSECUTIVE channels (co = 8q + 4*half + 0..3): 16-byte accesses
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const k4s_u32x4 x4 = xq[mb2 * 4 + q];
+                const float xv[4] = {__uint_as_float(x4.x), __uint_as_float(x4.y), __uint_as_float(x4.z), __uint_as_float(x4.w)};
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = k4s_mul_add(xv[e], cs[4 * q + e] + 1.f, ch[4 * q + e]);               // x*(scale+1)+shift
+                if constexpr (RES) {
+                    const float rv[4] = {__uint_as_float(rq[q].x), __uint_as_float(rq[q].y), __uint_as_float(rq[q].z), __uint_as_float(rq[q].w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = k4s_mul_add(ov[e], P.res_scale, rv[e]);
+                }
+                const k4s_u32x4 o4 = {__float_as_uint(ov[0]), __float_as_uint(ov[1]), __float_as_uint(ov[2]), __float_as_uint(ov[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, (int)(yoff + K4_SFT_CH(mb2, q)), 0, 0);
+            }
+        }
+    }
+}
+#undef K4_SFT_OOB
+#undef K4_SFT_CH
+
 extern "C" int64_t k4_sft_weight_floats(int32_t channels) {
     if (channels != 32 && channels != 64) return -1;
     const int cb = channels / 32;
@@ -1587,8 +1741,13 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
     int total = 0;
     bool any_res = false, all_res = true;
     size_t align = 0;
+    long long max_bytes = 0;
+    int max_stride = cond_stride > x_stride ? cond_stride : x_stride;
+    if (y_stride > max_stride) max_stride = y_stride;
+    if (res_stride > max_stride) max_stride = res_stride;
     for (int g = 0; g < n_jobs; ++g) {
         const k4_sft_job& j = jobs[g];
+        if ((long long)j.n_pix * max_stride * 4 > max_bytes) max_bytes = (long long)j.n_pix * max_stride * 4;
         if (!j.cond || !j.x || !j.y || j.n_pix <= 0 || j.n_pix > 0x7fffffff || (((size_t)j.cond) & 15) != 0) return K4_ERR_BAD_ARG;
         any_res |= j.res != nullptr; all_res &= j.res != nullptr;
         align |= (size_t)j.x | (size_t)j.y | (size_t)(j.res ? j.res : j.x);
@@ -1601,7 +1760,15 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
     P.vec4 = ((x_stride | y_stride | (any_res ? res_stride : 0)) & 3) == 0 && (align & 15) == 0;
     const dim3 grid((unsigned)total), block(256);
     if (arith == K4_SFT_ARITH_BF16X6) {
-        if (channels == 64) hipLaunchKernelGGL((k4_sft_b6_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
+        // the pipelined form addresses through 32-bit buffer offsets: 16-byte rows, every image below 2 GB (K4_SR_DEBUG bit 5: A/B)
+        const bool piped = P.vec4 && max_bytes < (1ll << 31) && !(k4_env().sr_debug & 32);
+        if (piped && channels == 64) {
+            if (any_res) hipLaunchKernelGGL((k4_sft_b6p_kernel<2, true>), grid, block, 0, (hipStream_t)stream, M);
+            else hipLaunchKernelGGL((k4_sft_b6p_kernel<2, false>), grid, block, 0, (hipStream_t)stream, M);
+        } else if (piped) {
+            if (any_res) hipLaunchKernelGGL((k4_sft_b6p_kernel<1, true>), grid, block, 0, (hipStream_t)stream, M);
+            else hipLaunchKernelGGL((k4_sft_b6p_kernel<1, false>), grid, block, 0, (hipStream_t)stream, M);
+        } else if (channels == 64) hipLaunchKernelGGL((k4_sft_b6_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
         else hipLaunchKernelGGL((k4_sft_b6_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
     } else {
         if (channels == 64) hipLaunchKernelGGL((k4_sft_kernel<2>), grid, block, 0, (hipStream_t)stream, M);
