@@ -1573,9 +1573,8 @@ __global__ __launch_bounds__(256) void k4_sft_b6_kernel(const SftMulti M) {
 // cond -> (wait) -> GEMM 1 / 2 -> x [, res] -> (wait) -> modulation -> store three times per 32-pixel tile at two waves per SIMD:
 // 194 us per 64-channel layer of a 4K frame against an HBM floor of ~66 us.  Here one tile is ONE basic block (the second output
 // block unrolled, the residual a template parameter, bounds by buffer descriptors: a pixel past the end loads zeros and its store is
-// dropped, so there is no branch and hipcc counts its waits instead of draining the queue): the x rows of the tile are requested
-// before GEMM 1, the next tile's condition rows right after GEMM 1 consumed the current ones, the residual rows of an output block
-// before that block's matrix instructions.  Needs 16-byte aligned rows and images below 2 GB (buffer offsets); anything else runs
+// dropped, so there is no branch and hipcc counts its waits instead of draining the queue): the x (and residual) rows of the tile are
+// requested before GEMM 1, the next tile's condition rows right after GEMM 1 consumed the current ones.  Needs 16-byte aligned rows and images below 2 GB (buffer offsets); anything else runs
 // on the kernel above.
 // ------------------------------------------------------------------------------------------------------------------
 #define K4_SFT_OOB 0x80000000u
@@ -1596,7 +1595,8 @@ template <int CB, bool RES>
 __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
     constexpr int NW6 = K4_SFT6_FLOATS(CB);
     constexpr int NW32 = (2 + 2 * CB) * 17 * 64;
-    __shared__ __attribute__((aligned(16))) float wl[NW6];
+    constexpr int NIT = (NW6 / 4 + 255) / 256;           // rounds of 256 x 16 bytes that fill the weight image
+    __shared__ __attribute__((aligned(16))) float wl[NIT * 256 * 4];
     SftParams P = M.base;
     int blk = (int)blockIdx.x;
     {
@@ -1621,9 +1621,16 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
         for (int i = 0; i < 4; ++i) cn[i] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(coff + (unsigned)((i >> 1) * 64 + (i & 1) * 16)), 0, 0);
     }
     {
+        // the weight image goes global -> LDS directly (global_load_lds_dwordx4: lane l of a wave writes base + 16 l), every request of
+        // the workgroup in flight at once and no staging registers: as a load / ds_write loop the fill was ~10 dependent L2 round trips,
+        // as long as the two tiles that follow it.  The last round re-reads the image's first rows into the padding.
         const float4* src = reinterpret_cast<const float4*>(P.w + NW32);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = (int)threadIdx.x; i < NW6 / 4; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = i * 256 + (int)threadIdx.x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (idx < NW6 / 4 ? idx : idx - NW6 / 4)),
+                                             (__attribute__((address_space(3))) void*)(wl + (i * 256 + wv * 64) * 4), 16, 0, 0);
+        }
     }
     __syncthreads();
     const uint4* const wa6 = reinterpret_cast<const uint4*>(wl);
@@ -1644,6 +1651,11 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
         k4s_u32x4 xq[4 * CB];                          // x channels mb2*32 + 8q + 4*half + 0..3
 #pragma unroll
         for (int i = 0; i < 4 * CB; ++i) xq[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xoff + K4_SFT_CH(i >> 2, i & 3)), 0, 0);
+        k4s_u32x4 rq[RES ? 4 * CB : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < 4 * CB; ++i) rq[i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + K4_SFT_CH(i >> 2, i & 3)), 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);             // the scheduler otherwise sinks the requests to their first use, behind the matrix work
         // ---- GEMM 1: hidden^T = lrelu(WA . cond^T + ba) ----
         f32x16 h[2];
@@ -1682,12 +1694,6 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
         // ---- GEMM 2 + modulation, 32 output channels at a time ----
 #pragma unroll
         for (int mb2 = 0; mb2 < CB; ++mb2) {
-            k4s_u32x4 rq[4];
-            if constexpr (RES) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rq[q] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + K4_SFT_CH(mb2, q)), 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             f32x16 cs, ch;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { cs[r] = bs[(mb2 * 2 + half) * 16 + r]; ch[r] = bh[(mb2 * 2 + half) * 16 + r]; }
@@ -1709,7 +1715,8 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = k4s_mul_add(xv[e], cs[4 * q + e] + 1.f, ch[4 * q + e]);               // x*(scale+1)+shift
                 if constexpr (RES) {
-                    const float rv[4] = {__uint_as_float(rq[q].x), __uint_as_float(rq[q].y), __uint_as_float(rq[q].z), __uint_as_float(rq[q].w)};
+                    const k4s_u32x4 r4 = rq[mb2 * 4 + q];
+                    const float rv[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = k4s_mul_add(ov[e], P.res_scale, rv[e]);
                 }
