@@ -1104,8 +1104,59 @@ __global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvMulti M)
 
     const int nchunks = (P.cin + KC2 - 1) / KC2;
     const uint4* const wsrc_all = reinterpret_cast<const uint4*>(P.w);
+    // the 16-channel chunks of the haloed tile: chunk c + 1 is requested before the matrix instructions of chunk c (16-byte rows, whole
+    // chunks); each thread owns up to three (pixel, 8-channel group) items, their addresses are computed once
+    const bool piped = vec_ok && (P.cin % KC2) == 0;
+    const float* isrc[3];
+    bool iin[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int it = tid + 512 * j;
+        const int kg = it & 1, pp = it >> 1;
+        const int py = pp / K4_TAPS_COLS, px = pp - py * K4_TAPS_COLS;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        iin[j] = it < K4_TAPS_PPAD * 2 && pp < K4_TAPS_NPIX && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        isrc[j] = iin[j] ? P.x + ((size_t)gy * P.W + gx) * P.cin_stride + kg * 8 : P.x;
+    }
+    float4 pa[3], pb[3];
+    uint4 wpre = make_uint4(0, 0, 0, 0);
+    const int wtid = tid < 3 * 2 * 32 ? tid : 0;
+    if (piped) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pa[j] = *reinterpret_cast<const float4*>(isrc[j]);
+            pb[j] = *reinterpret_cast<const float4*>(isrc[j] + 4);
+        }
+        wpre = wsrc_all[wtid];
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * KC2;
+        if (piped) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int it = tid + 512 * j;
+                const float v[8] = {iin[j] ? pa[j].x : 0.f, iin[j] ? pa[j].y : 0.f, iin[j] ? pa[j].z : 0.f, iin[j] ? pa[j].w : 0.f,
+                                    iin[j] ? pb[j].x : 0.f, iin[j] ? pb[j].y : 0.f, iin[j] ? pb[j].z : 0.f, iin[j] ? pb[j].w : 0.f};
+                uint4 t0, t1, t2;
+                k4s_split3(v, t0, t1, t2);
+                if (it < K4_TAPS_PPAD * 2) {
+                    const int kg = it & 1, pp = it >> 1;
+                    in_s[(0 * 2 + kg) * K4_TAPS_PPAD + pp] = t0;
+                    in_s[(1 * 2 + kg) * K4_TAPS_PPAD + pp] = t1;
+                    in_s[(2 * 2 + kg) * K4_TAPS_PPAD + pp] = t2;
+                }
+            }
+            if (tid < 3 * 2 * 32) w_s[tid] = wpre;
+            __syncthreads();
+            const int chn = ch + 1 < nchunks ? ch + 1 : ch;                 // the last round re-reads its own chunk (unused)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float* q = iin[j] ? isrc[j] + chn * KC2 : P.x;
+                pa[j] = *reinterpret_cast<const float4*>(q);
+                pb[j] = *reinterpret_cast<const float4*>(q + 4);
+            }
+            wpre = wsrc_all[(size_t)chn * 3 * 2 * 32 + wtid];
+        } else {
         for (int it = tid; it < K4_TAPS_PPAD * 2; it += 512) {
             const int kg = it & 1, pp = it >> 1;
             const int py = pp / K4_TAPS_COLS, px = pp - py * K4_TAPS_COLS;
@@ -1136,6 +1187,7 @@ __global__ __launch_bounds__(512) void k4_conv_taps_b6_kernel(const ConvMulti M)
         }
         if (tid < 3 * 2 * 32) w_s[tid] = wsrc_all[(size_t)ch * 3 * 2 * 32 + tid];
         __syncthreads();
+        }
         bf16x8 b[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, w_s[(q * 2 + half) * 32 + l31]);
