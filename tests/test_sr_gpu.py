@@ -213,6 +213,51 @@ def test_fused_sft_layer(C, arith):
     assert torch.equal(buf[:, :, :16], keep[:, :, :16]) and torch.equal(buf[:, :, 16 + C:], keep[:, :, 16 + C:])
 
 
+@pytest.mark.parametrize('with_res', [False, True])
+@pytest.mark.parametrize('C', [64, 32])
+def test_sft_layer_pipelined_and_general_kernels_agree(C, with_res):
+    """k4_sft_nhwc_multi (bf16x6) picks the pipelined kernel (k4_sft_b6p_kernel: buffer-descriptor bounds, 16-byte accesses) when every row
+    is 16-byte aligned and the general one otherwise.  Same arithmetic: x at channel offset 16 (aligned) and at channel offset 17
+    (unaligned) of a wider buffer must give the SAME BITS, over several workgroups, two jobs of different ragged sizes, and match the
+    module graph; pixels past a job's end and the channels around the slice stay untouched."""
+    from nerf4k_amd import _native as N
+    torch.manual_seed(100 + C)
+    layer = sr_esrnet.SFTLayer(C, 32).cuda()
+    for p in layer.parameters():
+        p.data.normal_(0, 0.3)
+    wp = sr_esrnet.pack_sft(layer)
+    sizes = (1000, 333)                                  # 4 and 2 workgroups of 256 pixels, both ragged
+    outs = []
+    for off in (16, 17):
+        torch.manual_seed(7)
+        got = []
+        keep_refs = []
+        job = (N.SftJob * len(sizes))()
+        for g, n in enumerate(sizes):
+            cond = torch.randn([n, 32]).cuda()
+            buf = torch.randn([n + 3, 100]).cuda()       # 3 spare pixel rows behind the job
+            res = torch.randn([n, C]).cuda()
+            keep = buf.clone()
+            job[g].cond, job[g].x, job[g].y, job[g].n_pix = cond.data_ptr(), buf.data_ptr() + 4 * off, buf.data_ptr() + 4 * off, n
+            job[g].res = res.data_ptr() if with_res else 0
+            keep_refs.append((cond, buf, res, keep))
+        N.check(N.lib().k4_sft_nhwc_multi(job, len(sizes), 32, N.f32(wp), 100, 100, C, 0.2, C if with_res else 0, 0.2, 1, N.stream()), 'sft_multi')
+        torch.cuda.synchronize()
+        for (cond, buf, res, keep), n in zip(keep_refs, sizes):
+            x = keep[:n, off:off + C]
+            with torch.no_grad():
+                want = layer(x.t().reshape(1, C, 1, n), cond.t().reshape(1, 32, 1, n))[0, :, 0].t()
+                if with_res:
+                    want = want * 0.2 + res
+            y = buf[:n, off:off + C]
+            assert torch.allclose(y, want, atol=3e-5, rtol=1e-5), float((y - want).abs().max())
+            assert torch.equal(buf[:, :off], keep[:, :off]) and torch.equal(buf[:, off + C:], keep[:, off + C:]) and torch.equal(buf[n:], keep[n:])
+            got.append(y.clone())
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _conv_ref64(x, w, b):
     import torch.nn.functional as F
     return F.conv2d(x.double().permute(2, 0, 1).unsqueeze(0), w.double(), b.double(), padding=1)[0].permute(1, 2, 0)
