@@ -237,6 +237,7 @@ def test_sft_layer_pipelined_and_general_kernels_agree(C, with_res):
             cond = torch.randn([n, 32]).cuda()
             buf = torch.randn([n + 3, 100]).cuda()       # 3 spare pixel rows behind the job
             res = torch.randn([n, C]).cuda()
+            buf[:n, off:off + C] = torch.randn([n, C], generator=torch.Generator().manual_seed(g)).cuda()      # the same x at both placements
             keep = buf.clone()
             job[g].cond, job[g].x, job[g].y, job[g].n_pix = cond.data_ptr(), buf.data_ptr() + 4 * off, buf.data_ptr() + 4 * off, n
             job[g].res = res.data_ptr() if with_res else 0
