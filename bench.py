@@ -287,7 +287,7 @@ def main():
         default_mode = _sr.DEFAULT_MODE
         other_mode = 'bf16x6' if default_mode == 'f16x3' else 'f16x3'
         four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=default_mode,
-                               check=not args.no_cpu_baseline, keep=keep)
+                               check=not args.no_cpu_baseline and world == 1, keep=keep)
         if not args.no_extras:
             four_k_alt = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=other_mode, keep=keep)
             four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32', keep=keep)
@@ -316,7 +316,7 @@ def main():
             res['joint_train_step'] = _side(joint_train_step, ck, run.rays[0], H, W, dev)
             res['reference_pipeline_rocm'] = _side(reference_pipeline_rocm, ck, run.rays[0], dev)
             res['dvgo_config0'] = _side(dvgo_config0, dev, not args.no_cpu_baseline)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU legs run at N = 1 only (bench contract): at N > 1 the other ranks would idle behind rank 0's host work
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
                 res['parity_vs_oracle'] = parity
