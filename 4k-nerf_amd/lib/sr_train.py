@@ -282,7 +282,7 @@ class K4RDB(torch.autograd.Function):
         return (gt, gc, None, *grads)
 
 
-_TAP = None        # tools/sr_rdb_debug3.py: callback(block, input, cond, output) per dense block
+_TAP = None        # tests/debug/sr_rdb_debug3.py: callback(block, input, cond, output) per dense block
 
 
 def _up2(t):

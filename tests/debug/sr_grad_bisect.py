@@ -1,12 +1,12 @@
 """Which gradients of the golden SFTNet backward (tests/golden/grad_sr.npz) differ, per parameter in network order.  GPU box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 import numpy as np, torch, torch.nn.functional as F
 import nerf4k_amd  # noqa
 from nerf4k_amd.lib import sr_esrnet
 from oracle import sr as osr
-z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'grad_sr.npz'))
+z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests', 'golden', 'grad_sr.npz'))
 nb = int(z['num_block'])
 sd = osr.make_state_dict(seed=int(z['seed']), num_block=nb)
 def rel(a, b):

@@ -1,6 +1,6 @@
 """Per dense block of the golden network: gradient entering (d out) and leaving (d input) in both training graphs.  GPU box."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch, torch.nn.functional as F
 import nerf4k_amd  # noqa

@@ -1,6 +1,6 @@
 """LeakyReLU masks of the decoder's 4x path in both training graphs: elements whose sign differs, and their magnitudes.  GPU box."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch, torch.nn.functional as F
 import nerf4k_amd  # noqa

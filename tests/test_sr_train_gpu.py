@@ -9,7 +9,7 @@ parameter gradients.
 LeakyReLU kinks: the network holds ~10^6 activations, so a few LeakyReLU inputs lie within an ulp of zero; an arithmetic change that moves
 forward values by one ulp (e.g. contracting `x5 * 0.2 + x` into an FMA, which the reference's separate ops do not do) can send one of them
 down the other branch, and the input gradients then differ by ~5e-4 of their maximum around that pixel while every parameter gradient
-still agrees.  tools/sr_rdb_debug4.py lists such elements (both training graphs, mask flips of the 4x path); tools/sr_grad_bisect.py
+still agrees.  tests/debug/sr_rdb_debug4.py lists such elements (both training graphs, mask flips of the 4x path); tests/debug/sr_grad_bisect.py
 prints which gradients of this fixture differ."""
 import os
 
