@@ -57,7 +57,9 @@ def test_rgbnet_kernels_match_fp64_autograd(dim0, width, depth, n, with_add):
             amb |= (z.abs() < 1e-5).any(1)
             h = torch.relu(z)
         gy[amb] = 0
-        assert int(amb.sum()) <= max(2, n // 20)
+        # expected share: P(|z| < 1e-5) ~ 1.6e-5 per unit (z ~ N(0, 0.5)) x up to 256 hidden units = 0.2-0.7 % of the samples (467 of 70000 in
+        # the largest case; the band is ~20x the fp32 chain's own error in z, the smallest that keeps the comparison free of rounding ties)
+        assert int(amb.sum()) <= max(2, n // 100)
     wr = [(l.weight.detach().double().requires_grad_(True), l.bias.detach().double().requires_grad_(True)) for l in lins]
     xr = x.double().requires_grad_(True)
     ar = None if add is None else add.double().requires_grad_(True)
