@@ -70,6 +70,30 @@ def test_no_cpu_fallback():
         render_utils_cuda.raw2alpha(torch.zeros(4), 0, 1.0)
 
 
+def test_oracle_and_reference_stay_behind_the_test_boundary():
+    """Static check of the scope contract: the product package and tools/ never import oracle/ (test infrastructure), and nothing
+    that runs on the GPU box (product, tools, bench.py, __graft_entry__.py, tests) opens /root/reference except the two
+    build-container scripts under oracle/ that make the goldens / the reference-compiled checker."""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imp = re.compile(r'^\s*(from\s+oracle\b|import\s+oracle\b)', re.M)
+    product = glob.glob(os.path.join(root, '4k-nerf_amd', '**', '*.py'), recursive=True) + [os.path.join(root, 'nerf4k_amd.py')]
+    tools = glob.glob(os.path.join(root, 'tools', '**', '*.py'), recursive=True)
+    assert product and tools
+    for f in product + tools:
+        assert not imp.search(open(f).read()), f'{os.path.relpath(f, root)} imports oracle/'
+    # bench.py: the oracle only inside the legs that check or time it (never at module level)
+    bench = open(os.path.join(root, 'bench.py')).read()
+    assert not re.search(r'^(from\s+oracle|import\s+oracle)', bench, re.M)
+    runs_on_gpu_box = product + tools + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')] + \
+        glob.glob(os.path.join(root, 'tests', '**', '*.py'), recursive=True)
+    import ast
+    for f in runs_on_gpu_box:
+        for node in ast.walk(ast.parse(open(f).read())):        # a PATH literal (citations in docstrings / comments are prose, not paths)
+            if isinstance(node, ast.Constant) and isinstance(node.value, str) and re.fullmatch(r'/root/reference[\w/.\-]*', node.value.strip()):
+                raise AssertionError(f'{os.path.relpath(f, root)}:{node.lineno} holds the path {node.value!r}')
+
+
 def test_rays_match_reference_golden():
     z = np.load(os.path.join(GOLDEN, 'rays_views.npz'))
     H, W = int(z['H']), int(z['W'])
