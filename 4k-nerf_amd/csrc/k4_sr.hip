@@ -493,9 +493,6 @@ typedef unsigned k4s_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef K4_V2_ARING
 #define K4_V2_ARING 3      // A-fragment ring: filled ARING-1 sub-stages ahead
 #endif
-#ifndef K4_SMALL_SLOTS3
-#define K4_SMALL_SLOTS3 1  // small-launch tile rule: count 3 resident workgroups per CU for the fp16 form's 8-row tiles (A/B builds: 0)
-#endif
 #ifndef K4_V2_BRING
 #define K4_V2_BRING 2      // weight-fragment ring: filled BRING-1 taps ahead
 #endif
@@ -1013,14 +1010,16 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     int total = count(16);
     // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
     // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead)
-    // (the 8-row tiles of the fp16 form run THREE workgroups per CU, every other form two)
     int rpw = 4;
-    if (total <= 2 * slots) {
+    // fp16 form: ALWAYS 8-row tiles.  Its activation scale is found per haloed workgroup tile, and elements 2^-16 below a chunk's maximum
+    // round their low term as fp16 subnormals -- with a tile height picked from the launch size (below), the bits of a window would
+    // depend on how many other windows share its launch and on the CU count.  One tile geometry => a window's result is a function of the
+    // window alone (tile_parallel's frame == the single-GPU frame, whatever the grouping).
+    if (!(M.base.flags & K4_ARITH_F16X3) && total <= 2 * slots) {
         float best = 1e30f;
         for (int cand = 4; cand >= 2; --cand) {
             const int c = count(4 * cand);
-            const int sl = (K4_SMALL_SLOTS3 && cand == 2 && (M.base.flags & K4_ARITH_F16X3)) ? 3 * k4_num_cus() : slots;
-            const float cost = (float)((c + sl - 1) / sl) * ((float)cand + 0.6f);
+            const float cost = (float)((c + slots - 1) / slots) * ((float)cand + 0.6f);
             if (cost < best - 1e-3f) { best = cost; rpw = cand; }
         }
         total = count(4 * rpw);

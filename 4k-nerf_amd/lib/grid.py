@@ -46,30 +46,46 @@ class GridSample3D(torch.autograd.Function):
         return gg, None, None, None
 
 
-_GSB_WS = {}          # device -> ((C, X, Y, Z), all-zero workspace of k4_grid_sample_3d_backward_cl); one grid shape per device at a time
+_GSB_WS = {}          # device -> [(C, X, Y, Z), all-zero workspace of k4_grid_sample_3d_backward_cl, event of its last use]; one grid shape per device
+
+
+def release_grid_sample_workspace(device=None):
+    """Free the cached scratch image(s) of the channel-last grid_sample_3d backward (as large as the gradient: 1.4 GB for the LLFF k0)."""
+    for d in list(_GSB_WS) if device is None else [torch.device(device)]:
+        _GSB_WS.pop(d, None)
 
 
 def grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg):
     """gg [1|-, C, X, Y, Z] += d(trilinear lookup)/d(grid) for grad_out `go` [n, C] at `pts` [n, 3].  More than one channel: through the
     channel-last scratch image (k4_grid_sample_3d_backward_cl; the workspace, as large as the gradient, is allocated and cleared once
-    per device and grid shape and kept -- K4_GSB_CL=0 or an allocation failure selects the channel-major atomic scatter)."""
+    per device and grid shape and kept -- K4_GSB_CL=0 or an allocation failure selects the channel-major atomic scatter).
+    The workspace must be all-zero on entry and is left all-zero by the sweep; it is ONE buffer per device, so a use on another HIP
+    stream waits for the previous use (event), and a failed launch drops it (the next call allocates a cleared one)."""
     L = N.lib()
     n = pts.shape[0]
     nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if os.environ.get('K4_GSB_CL', '1') != '0' else -1
-    ws = None
+    hit = None
     if nbytes > 0 and n > 0:
         hit = _GSB_WS.get(go.device)
         if hit is None or hit[0] != (C_, X, Y, Z):
             _GSB_WS.pop(go.device, None)
             try:
-                hit = _GSB_WS[go.device] = ((C_, X, Y, Z), torch.zeros([nbytes // 4], dtype=torch.int32, device=go.device))
+                hit = _GSB_WS[go.device] = [(C_, X, Y, Z), torch.zeros([nbytes // 4], dtype=torch.int32, device=go.device), None]
             except torch.OutOfMemoryError:
                 hit = None
-        ws = None if hit is None else hit[1]
-    if ws is not None:
-        ws.record_stream(torch.cuda.current_stream(go.device))
-        N.check(L.k4_grid_sample_3d_backward_cl(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.f32(gg), N.ptr(ws),
-                                                N.stream()), 'grid_sample_3d_backward_cl')
+    if hit is not None:
+        ws, cur = hit[1], torch.cuda.current_stream(go.device)
+        if hit[2] is not None:
+            cur.wait_event(hit[2])                     # scatter + sweep of the previous call (possibly on another stream) have finished
+        ws.record_stream(cur)
+        try:
+            N.check(L.k4_grid_sample_3d_backward_cl(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.f32(gg), N.ptr(ws),
+                                                    N.stream()), 'grid_sample_3d_backward_cl')
+        except Exception:
+            _GSB_WS.pop(go.device, None)               # scatter done but sweep not: the image may hold non-zero sums
+            raise
+        hit[2] = torch.cuda.Event()
+        hit[2].record(cur)
     else:
         N.check(L.k4_grid_sample_3d_backward(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.f32(gg), N.stream()),
                 'grid_sample_3d_backward')

@@ -56,7 +56,7 @@ def adam_upd_multi(items, masked, step, beta1, beta2, lr, eps):
         return
     key = tuple(id(ts[0]) for ts in items)
     plan = _MULTI_PLANS.get(key)
-    if plan is not None and any(a[0].data_ptr() != q or a[2].data_ptr() != r for a, (q, r) in zip(items, plan[3])):
+    if plan is not None and any((a[0].data_ptr(), a[2].data_ptr(), a[3].data_ptr()) != ptrs for a, ptrs in zip(items, plan[3])):
         plan = None                                             # a parameter or its state was re-allocated (scale_volume_grid, load_state_dict)
     if plan is None:
         jobs = (N.AdamJob * len(items))()
@@ -67,7 +67,7 @@ def adam_upd_multi(items, masked, step, beta1, beta2, lr, eps):
             jobs[j].param, jobs[j].grad, jobs[j].exp_avg, jobs[j].exp_avg_sq = (t.data_ptr() for t in ts)
             jobs[j].n = ts[0].numel()
         touched = [t for ts in items for t in (ts[0], ts[2], ts[3])]
-        plan = (jobs, [tuple(ts[i] for i in (0, 2, 3)) for ts in items], touched, [(ts[0].data_ptr(), ts[2].data_ptr()) for ts in items])
+        plan = (jobs, [tuple(ts[i] for i in (0, 2, 3)) for ts in items], touched, [(ts[0].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr()) for ts in items])
         if len(_MULTI_PLANS) > 16:
             _MULTI_PLANS.clear()
         _MULTI_PLANS[key] = plan

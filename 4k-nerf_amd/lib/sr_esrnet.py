@@ -358,23 +358,6 @@ class SFTNet(nn.Module):
         # 'bf16x3': 2-term bf16 splits, 3 products, ~2^-16 per product (opt-in fast path, ~100 dB)
         self.k4_mode = os.environ.get('K4_SR_MODE', DEFAULT_MODE)
 
-    # ------------------------------------------------------------------ reference graph (autograd path)
-    def _forward_torch(self, x, cond, fea=None):
-        if fea is None:
-            feat = self.conv_first(x)
-        else:
-            feat = self.conv_prefea(torch.cat((self.conv_first(x), fea), dim=1))
-        cond = self.CondNet(cond)
-        body_feat = self.body((feat, cond))
-        body_feat = self.sftbody(body_feat[0], body_feat[1])
-        body_feat = self.conv_body(body_feat)
-        body_feat = body_feat + feat
-        if self.scale > 1:
-            body_feat = self.lrelu(self.conv_up1(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
-            if self.scale == 4:
-                body_feat = self.lrelu(self.conv_up2(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
-        return self.conv_last(self.lrelu(self.conv_hr(body_feat)))
-
     # ------------------------------------------------------------------ HIP path
     def _packed(self):
         """Pack every conv once per parameter version (load-time repack; names/values of parameters never change)."""
@@ -575,11 +558,13 @@ class SFTNet(nn.Module):
     def forward(self, x, cond, fea=None):
         if not x.is_cuda:
             raise N.K4Error('SFTNet input must be on the GPU: the MI355X-native decoder has no CPU path')
-        if torch.is_grad_enabled() or fea is not None or self.dswise:
-            if fea is None and not self.dswise and os.environ.get('K4_SR_TRAIN', 'hip') != 'torch':
-                from . import sr_train                     # autograd graph with every convolution (fwd, dgrad, wgrad) on the HIP kernels
-                return sr_train.forward_train(self, x, cond)
-            return self._forward_torch(x, cond, fea)
+        if fea is not None or self.dswise:
+            # n_in_colors > 3 with a feature input / the 1x1 conv_first variant: selected by no configuration of the reference's
+            # run_sr.py (it builds SFTNet(3, scale=4) and calls forward(x, cond)); there is no PyTorch fallback to route them to
+            raise N.K4Error('SFTNet.forward(fea=...) / dswise=True are outside the HIP decoder (SURVEY.md section 2: not on the hot path)')
+        if torch.is_grad_enabled():
+            from . import sr_train                     # autograd graph with every convolution (fwd, dgrad, wgrad) on the HIP kernels
+            return sr_train.forward_train(self, x, cond)
         return self._forward_hip(x, cond).clone()
 
     # ------------------------------------------------------------------ tiling (lib/sr_esrnet.py:467-527)

@@ -43,17 +43,20 @@ class _WeightCache:
 
     def _get(self, kind, weight, bias, make):
         hit = self._c.get((kind, weight.data_ptr()))
+        slot = (kind, weight.data_ptr())
         if hit is not None and type(hit[0]) is int:       # an operand of the prepack plan: current iff prepack() saw these versions
             q, plan = hit[0], self._plan
-            if self.always or (plan[3][q] == weight._version and (bias is None or plan[4][q] == bias._version)):
+            if plan is not None and (self.always or (plan[3][q] == weight._version and (bias is None or plan[4][q] == bias._version))):
                 return hit[1]
-            hit = None
+            # stale plan operand (a step without prepack()): pack for this use under a SEPARATE key -- the plan's slot stays, so the
+            # next prepack() brings the operand back onto the persistent buffers
+            hit, slot = self._c.get(('stale',) + slot), ('stale',) + slot
         if self.always:
             return make()
         key = self._key(kind, weight, bias)
         if hit is None or hit[0] != key:
             hit = (key, make())
-            self._c[(kind, weight.data_ptr())] = hit
+            self._c[slot] = hit
         return hit[1]
 
     def fwd(self, weight, bias):
@@ -73,6 +76,9 @@ class _WeightCache:
             items = [(m.weight, m.bias if kind == 'f' else None, kind == 'b') for m in convs for kind in (('f', 'b') if dgrad else ('f',))]
             pp = _PackPlan(items)
             if not pp.live:                                # non-fp32 / non-contiguous parameters: the per-use path handles them
+                if self._plan is not None:                 # ... and the old plan's integer-tagged slots must not outlive it (_get reads plan[3])
+                    for slot in self._plan[5]:
+                        self._c.pop(slot, None)
                 self._plan = None
                 return
             slots = [(kind, m.weight.data_ptr()) for m in convs for kind in (('f', 'b') if dgrad else ('f',))]

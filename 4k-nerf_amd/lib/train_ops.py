@@ -7,9 +7,11 @@
 ``flatten_eff_distloss`` the distortion loss of the joint training step (run_sr.py:976-988; third-party
                         ``torch_efficient_distloss``, not vendored upstream): value and gradient in one launch.
 
-There is no CPU path: CPU tensors raise ``K4Error``.  MLP shapes the kernels do not cover (width not in {32, 64, 128}, more than
-one hidden->hidden layer, dim0 > 64) stay on the ``nn.Sequential`` (rocBLAS) -- ``rgbnet_supported`` tells which.
+There is no CPU path and no PyTorch path: CPU tensors raise ``K4Error``, and so do MLP shapes the kernels do not cover (width not in
+{32, 64, 128}, more than one hidden->hidden layer, dim0 > 64) -- ``rgbnet_supported`` tells which.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -117,6 +119,11 @@ class FlattenEffDistLoss(torch.autograd.Function):
         # the launch bound must be a host integer: any bound > max(ray_id) is correct (rays without samples contribute 0).  Without one
         # from the caller it costs a host synchronisation per step.
         n_rays = int(n_rays_bound) if n_rays_bound is not None else int(idx[-1]) + 1
+        if os.environ.get('K4_CHECK_DISTLOSS') == '1':              # debug check of the two preconditions of the fast path (costs a host sync)
+            if n > 1 and bool((idx[1:] < idx[:-1]).any()):
+                raise ValueError('flatten_eff_distloss: ray_id is not ascending')
+            if int(idx[-1]) >= n_rays:
+                raise ValueError(f'flatten_eff_distloss: n_rays={n_rays} <= max(ray_id)={int(idx[-1])}')
         ray_loss = torch.empty([n_rays], dtype=torch.float32, device=wc.device)
         grad = torch.zeros_like(wc)                                # zeros: samples of rays beyond a too-small bound get no gradient, not garbage
         N.check(N.lib().k4_distortion_loss(N.f32(wc), N.f32(sc), N.ptr(idx), n, n_rays, float(interval), N.f32(ray_loss), N.f32(grad),

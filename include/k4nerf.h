@@ -288,7 +288,7 @@ int k4_conv2d_nhwc(const float* x, int32_t cin, int32_t cin_stride,
                    const float* res, int32_t res_stride, float res_scale,
                    const float* mod_x, int32_t mod_stride, void* stream);
 
-/* 3-term split ("bf16x6", default decoder arithmetic): same contract as k4_conv2d_nhwc, fp32-equivalent results.
+/* 3-term split ("bf16x6": the strictly fp32-equivalent decoder arithmetic; the decoder's default is "f16x3", K4_ARITH_F16X3 below): same contract as k4_conv2d_nhwc, fp32-equivalent results.
  * x = x0 + x1 + x2 exactly (bf16 terms), 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
  * the dropped terms are <= 2^-23 |x w| per product.  w_split : k4_conv_weight_bf16x6_bytes() bytes =
  * [ceil(cin/16)][3 terms][ksize*ksize][2 channel groups][32*NT][8] bf16 (zero padded, term t = RNE_bf16 of the remainder

@@ -121,3 +121,19 @@ def check_native(got, G, what):
         err = np.abs(g[fin].astype(np.float64) - want[fin].astype(np.float64))
         bound = atol + rtol * np.abs(want[fin].astype(np.float64))
         assert (err <= bound).all(), (what, key, float(err.max()), float((err - bound).max()))
+
+
+def sftnet_forward_torch(net, x, cond):
+    """The reference's op sequence (lib/sr_esrnet.py:446-465, fea=None) on the module's nn.Conv2d layers with PyTorch-ROCm ops: a
+    CHECKER for the HIP graphs (the product has no PyTorch path: SFTNet.forward raises where the HIP kernels do not apply)."""
+    import torch.nn.functional as F
+    feat = net.conv_first(x)
+    c = net.CondNet(cond)
+    body_feat = net.body((feat, c))
+    body_feat = net.sftbody(body_feat[0], body_feat[1])
+    body_feat = net.conv_body(body_feat) + feat
+    if net.scale > 1:
+        body_feat = net.lrelu(net.conv_up1(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
+        if net.scale == 4:
+            body_feat = net.lrelu(net.conv_up2(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
+    return net.conv_last(net.lrelu(net.conv_hr(body_feat)))

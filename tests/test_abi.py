@@ -68,6 +68,30 @@ def test_no_cpu_fallback():
         model(r['rays_o'], r['rays_d'], r['viewdirs'], **g['render_kwargs'])
     with pytest.raises(N.K4Error):
         render_utils_cuda.raw2alpha(torch.zeros(4), 0, 1.0)
+    # no PyTorch back doors either: an rgbnet shape the HIP kernels do not cover, SFTNet's fea / dswise variants and CPU inputs raise
+    from nerf4k_amd.lib import sr_esrnet
+    import torch.nn as nn
+    model.rgbnet = nn.Sequential(nn.Linear(15, 48), nn.ReLU(inplace=True), nn.Linear(48, 3))
+    with pytest.raises(N.K4Error):
+        model._k4_rgbnet_sigmoid(torch.zeros(4, 15))
+    net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
+    with pytest.raises(N.K4Error):
+        net(torch.zeros(1, 3, 8, 8), torch.zeros(1, 1, 8, 8))
+
+
+def test_no_pytorch_fallback_in_the_product_source():
+    """Static: the product package holds no path that evaluates the rgbnet or the decoder with PyTorch modules."""
+    import ast, glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, '4k-nerf_amd', '**', '*.py'), recursive=True):
+        rel = os.path.relpath(f, root)
+        for node in ast.walk(ast.parse(open(f).read())):          # code, not prose: docstrings may cite the reference's expressions
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute):
+                assert node.func.attr not in ('rgbnet', '_forward_torch'), (rel, node.lineno)
+            if isinstance(node, ast.FunctionDef):
+                assert node.name != '_forward_torch', (rel, node.lineno)
+            if isinstance(node, ast.Constant) and isinstance(node.value, str):
+                assert node.value not in ('K4_SR_TRAIN', 'K4_RGBNET'), (rel, node.lineno)
 
 
 def test_oracle_and_reference_stay_behind_the_test_boundary():

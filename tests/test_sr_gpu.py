@@ -12,6 +12,7 @@ import torch
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd.lib import sr_esrnet
 from oracle import sr as osr
+import helpers
 from helpers import GOLDEN, psnr
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +67,7 @@ def test_sr_vs_oracle_ragged_sizes(hw):
         got = net(x.cuda(), cond.cuda())
     _check(got, want)
     # the autograd (PyTorch-ROCm) graph computes the same function
-    got_t = net._forward_torch(x.cuda(), cond.cuda())
+    got_t = helpers.sftnet_forward_torch(net, x.cuda(), cond.cuda())
     _check(got_t, want, min_psnr=90.0, max_abs=1e-3)
 
 
@@ -343,29 +344,32 @@ def test_f16x3_network_on_swinging_layer_scales():
 
 def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkeypatch):
     """BASELINE-size frame (1008x756 -> 4032x3024, test_tile=510): (1) the grouped schedule (all 4 windows per layer in one launch)
-    returns bit-identical pixels to the window-by-window one (tiles are independent); (2) the default 3-term split arithmetic
-    stays within 110 dB of the exact-fp32 MFMA arithmetic on the whole frame."""
+    returns bit-identical pixels to the window-by-window one (tiles are independent), for the exact 3-term form AND the default f16x3 form; (2) both
+    stay within 110 dB of the exact-fp32 MFMA arithmetic on the whole frame."""
     torch.manual_seed(777)
     net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).cuda().eval()
     g = torch.Generator().manual_seed(9)
     x = torch.rand([1, 3, 756, 1008], generator=g).cuda()
     c = torch.rand([1, 756, 1008], generator=g).cuda()
-    net.k4_mode = 'bf16x6'
-    monkeypatch.setenv('K4_SR_GROUP', '8')
-    a = net.tile_process_device(x, c, 510, 10).clone()
-    monkeypatch.setenv('K4_SR_GROUP', '1')
-    b = net.tile_process_device(x, c, 510, 10).clone()
-    monkeypatch.setenv('K4_SR_GROUP', '3')               # ragged grouping: 3 + 1 windows
-    b3 = net.tile_process_device(x, c, 510, 10)
-    assert torch.equal(a, b3)
-    monkeypatch.delenv('K4_SR_GROUP')
-    assert a.shape == (1, 3, 3024, 4032) and torch.equal(a, b)
+    frames = {}
+    for mode in ('bf16x6', 'f16x3'):                     # f16x3 = the default: its per-tile activation scale must not depend on the launch
+        net.k4_mode = mode
+        monkeypatch.setenv('K4_SR_GROUP', '8')
+        a = net.tile_process_device(x, c, 510, 10).clone()
+        monkeypatch.setenv('K4_SR_GROUP', '1')
+        b = net.tile_process_device(x, c, 510, 10).clone()
+        monkeypatch.setenv('K4_SR_GROUP', '3')           # ragged grouping: 3 + 1 windows
+        b3 = net.tile_process_device(x, c, 510, 10)
+        assert torch.equal(a, b3), mode
+        monkeypatch.delenv('K4_SR_GROUP')
+        assert a.shape == (1, 3, 3024, 4032) and torch.equal(a, b), mode
+        frames[mode] = a
+    a = frames['bf16x6']
     net.k4_mode = 'fp32'
     f = net.tile_process_device(x, c, 510, 10).clone()
     p = psnr(a.cpu(), f.cpu())
     assert p >= 110.0, p
-    net.k4_mode = 'f16x3'
-    h = net.tile_process_device(x, c, 510, 10)
+    h = frames['f16x3']
     ph = psnr(h.cpu(), f.cpu())
     print(f'full frame vs fp32-MFMA: bf16x6 {p:.1f} dB, f16x3 {ph:.1f} dB')
     assert ph >= 110.0, ph

@@ -1,5 +1,5 @@
 """Marcher-only training iteration (4096-ray patch, full LLFF scene): forward + backward time, colour MLP on k4_rgbnet_* vs on the
-nn.Sequential (K4_RGBNET=torch).  Usage: python tools/train_step_time.py   (GPU box)"""
+nn.Sequential.  Usage: python tools/train_step_time.py   (GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,4 +36,4 @@ n = 0
 for i in range(10):
     n += it(3 + i)
 torch.cuda.synchronize()
-print(f"rgbnet={os.environ.get('K4_RGBNET', 'native')}: {(time.perf_counter() - t) / 10 * 1e3:.2f} ms per marcher train iteration (fwd+bwd), {n // 10} shaded samples")
+print(f"{(time.perf_counter() - t) / 10 * 1e3:.2f} ms per marcher train iteration (fwd+bwd), {n // 10} shaded samples")
