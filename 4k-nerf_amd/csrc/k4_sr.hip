@@ -17,6 +17,7 @@
 // fp32 MFMA issues at the fp32 vector rate (157 TFLOP/s peak), so LDS/HBM are far from limiting: the kernel is
 // matrix-pipe bound; bf16 would be 16x faster but breaks the fp32 parity contract.
 #include "k4_common.h"
+#include "k4_p16.h"
 
 // a * b + c with TWO roundings, as the reference's separate PyTorch ops (`x5 * 0.2 + x`, `x * (scale + 1) + shift`, lib/sr_esrnet.py:123 /
 // :158 / :182) -- hipcc would contract the expression into one FMA.  One rounding less is not "wrong", but a LeakyReLU input within an ulp
@@ -1351,6 +1352,7 @@ struct SftParams {
     const float* res; int res_stride; float res_scale;
     int n_pix; float slope;
     int vec4;                                  // all of x / y / res rows are 16-byte aligned (strides % 4 == 0, bases % 16 == 0)
+    float out_scale; uint32_t* overflow;       // p16 output (k4_sft_nhwc_p16_multi): 2^E of the produced tensor, the windows' overflow words
 };
 struct SftMulti {                              // grouped launch over the windows of a frame (see ConvMulti)
     SftParams base;
@@ -1642,7 +1644,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t k4s_rsrc(const void* p, int by
         0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int CB, bool RES>
+// OUT16: y is written PRE-SPLIT (k4_p16.h: fp16 hi / lo units under the tensor's scale 2^E = P.out_scale) for the 3x3 convolutions of
+// k4_sr_p16.hip -- the lane arrangement (4 consecutive channels of one pixel, lanes l / l + 32 = the two halves of an 8-channel group) is the
+// one p16_unit expects; a value beyond fp16 raises the window's overflow word.
+template <int CB, bool RES, bool OUT16 = false>
 __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
     constexpr int NW6 = K4_SFT6_FLOATS(CB);
     constexpr int NW32 = (2 + 2 * CB) * 17 * 64;
@@ -1650,12 +1655,15 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
     __shared__ __attribute__((aligned(16))) float wl[NIT * 256 * 4];
     SftParams P = M.base;
     int blk = (int)blockIdx.x;
+    int gjob = 0;
     {
         int g = 0;
         while (g + 1 < M.n && blk >= M.blk_end[g]) ++g;
         blk -= g ? M.blk_end[g - 1] : 0;
         P.cond = M.cond[g]; P.x = M.x[g]; P.y = M.y[g]; P.res = M.res[g]; P.n_pix = M.n_pix[g];
+        gjob = g;
     }
+    float amax = 0.f;
     const int lane = k4_lane();
     const int wv = (int)(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -1771,10 +1779,22 @@ __global__ __launch_bounds__(256) void k4_sft_b6p_kernel(const SftMulti M) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = k4s_mul_add(ov[e], P.res_scale, rv[e]);
                 }
-                const k4s_u32x4 o4 = {__float_as_uint(ov[0]), __float_as_uint(ov[1]), __float_as_uint(ov[2]), __float_as_uint(ov[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, (int)(yoff + K4_SFT_CH(mb2, q)), 0, 0);
+                if constexpr (OUT16) {
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
+                    unsigned Hh[2], Ll[2];
+                    p16_split4(ov, P.out_scale, Hh, Ll);
+                    const p16_u32x4 unit = p16_unit(Hh, Ll);
+                    const unsigned ypix = pok ? (unsigned)(pix * P.y_stride * 4) : K4_SFT_OOB;          // the unit offset is relative to the pixel's 32-channel block
+                    __builtin_amdgcn_raw_buffer_store_b128(unit, yrs, (int)(ypix + (unsigned)(mb2 * 128) + P16_UNIT_OFF(q, half)), 0, 0);
+                } else {
+                    const k4s_u32x4 o4 = {__float_as_uint(ov[0]), __float_as_uint(ov[1]), __float_as_uint(ov[2]), __float_as_uint(ov[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, (int)(yoff + K4_SFT_CH(mb2, q)), 0, 0);
+                }
             }
         }
+    }
+    if constexpr (OUT16) {
+        if (__builtin_amdgcn_ballot_w64(!(amax * P.out_scale <= 65504.f)) != 0ull && lane == 0) atomicOr(P.overflow + gjob, 1u);
     }
 }
 #undef K4_SFT_OOB
@@ -1787,7 +1807,8 @@ extern "C" int64_t k4_sft_weight_floats(int32_t channels) {
 }
 
 static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
-                     int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith, void* stream) {
+                     int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith, void* stream,
+                     float out_scale = 0.f, uint32_t* overflow = nullptr) {
     if (arith != K4_SFT_ARITH_FP32 && arith != K4_SFT_ARITH_BF16X6) return K4_ERR_BAD_ARG;
     if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_packed || cond_stride < 32 || (cond_stride & 3)) return K4_ERR_BAD_ARG;
     if ((channels != 32 && channels != 64) || x_stride < channels || y_stride < channels) return K4_ERR_BAD_ARG;
@@ -1795,6 +1816,7 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
     SftParams& P = M.base;
     P.cond_stride = cond_stride; P.w = w_packed; P.x_stride = x_stride; P.y_stride = y_stride;
     P.res_stride = res_stride; P.res_scale = res_scale; P.slope = slope;
+    P.out_scale = out_scale; P.overflow = overflow;
     M.n = n_jobs;
     int total = 0;
     bool any_res = false, all_res = true;
@@ -1820,7 +1842,12 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
     if (arith == K4_SFT_ARITH_BF16X6) {
         // the pipelined form addresses through 32-bit buffer offsets: 16-byte rows, every image below 2 GB (K4_SR_DEBUG bit 5: A/B)
         const bool piped = P.vec4 && max_bytes < (1ll << 31) && !(k4_env().sr_debug & 32);
-        if (piped && channels == 64) {
+        if (out_scale != 0.f) {                                      // p16 output: the pipelined kernel only (aligned rows, images below 2 GB), no residual
+            if (!piped || any_res || (y_stride & 15)) return K4_ERR_UNSUPPORTED;
+            for (int g = 0; g < n_jobs; ++g) if (((size_t)jobs[g].y) & 63) return K4_ERR_BAD_ARG;       // the slice starts on a 16-channel chunk
+            if (channels == 64) hipLaunchKernelGGL((k4_sft_b6p_kernel<2, false, true>), grid, block, 0, (hipStream_t)stream, M);
+            else hipLaunchKernelGGL((k4_sft_b6p_kernel<1, false, true>), grid, block, 0, (hipStream_t)stream, M);
+        } else if (piped && channels == 64) {
             if (any_res) hipLaunchKernelGGL((k4_sft_b6p_kernel<2, true>), grid, block, 0, (hipStream_t)stream, M);
             else hipLaunchKernelGGL((k4_sft_b6p_kernel<2, false>), grid, block, 0, (hipStream_t)stream, M);
         } else if (piped) {
@@ -1833,6 +1860,13 @@ static int sft_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride
         else hipLaunchKernelGGL((k4_sft_kernel<1>), grid, block, 0, (hipStream_t)stream, M);
     }
     return k4_check_launch();
+}
+
+// SFTLayer with PRE-SPLIT output (K4_SFT_ARITH_BF16X6 arithmetic; no residual): the producer side of k4_conv3x3_p16_multi.
+extern "C" int k4_sft_nhwc_p16_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
+                                     int32_t y_stride, int32_t channels, float slope, float out_scale, uint32_t* overflow, void* stream) {
+    if (!(out_scale > 0.f) || !overflow) return K4_ERR_BAD_ARG;
+    return sft_multi(jobs, n_jobs, cond_stride, w_packed, x_stride, y_stride, channels, slope, 0, 0.f, K4_SFT_ARITH_BF16X6, stream, out_scale, overflow);
 }
 
 extern "C" int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,

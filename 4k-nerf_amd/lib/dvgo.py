@@ -125,14 +125,14 @@ class _FusedMarcher:
 
     def _k4_rgbnet_sigmoid(self, feat, add=None):
         """``torch.sigmoid(self.rgbnet(feat) [+ add])`` of the staged / training forward (lib/dmpigo.py:375-379, lib/dvgo.py:407-412)
-        on k4_rgbnet_fwd / k4_rgbnet_bwd (lib/train_ops.py).  MLP shapes outside the kernels' range raise: there is no PyTorch path."""
+        on k4_rgbnet_fwd / k4_rgbnet_bwd (lib/train_ops.py); Linear-ReLU stacks outside those kernels' shapes (deeper, other widths) run
+        layer by layer on the exact-fp32 MFMA 1x1 convolution (inference only).  There is no PyTorch path: anything else raises."""
         c = self._k4_cache()
         if 'rgbnet_native' not in c:
             c['rgbnet_native'] = train_ops.rgbnet_supported(self.rgbnet)
-        if not c['rgbnet_native']:
-            raise N.K4Error('rgbnet shape outside k4_rgbnet_fwd / k4_rgbnet_bwd (Linear-ReLU stack, width 64 or 128, 3 outputs): '
-                            'the MI355X-native marcher has no PyTorch fallback')
-        return train_ops.rgbnet_sigmoid(self.rgbnet, feat, add)
+        if c['rgbnet_native']:
+            return train_ops.rgbnet_sigmoid(self.rgbnet, feat, add)
+        return train_ops.rgbnet_sigmoid_layers(self.rgbnet, feat, add)
 
     def _k4_workspace(self, n_rays, img_w, max_steps, device, slot=0):
         """Scratch between the geometry and the shading kernel: worst-case sized (every sample of every ray

@@ -16,6 +16,7 @@ residual / nearest-x2 upsampling are fused into the conv, an SFTLayer is one lau
 (joint training, run_sr.py:869-1014) ``forward`` evaluates the graph of ``lib/sr_train.py``: every convolution forward, dgrad and
 wgrad on the MFMA kernels.  No CPU path.
 """
+import contextlib
 import math
 import os
 import time
@@ -30,7 +31,9 @@ from torch.nn import init as init
 from .. import _native as N
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
-DEFAULT_MODE = 'f16x3'          # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
+DEFAULT_MODE = 'f16x3p'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
+DEFAULT_STREAMS = 1             # HIP streams the windows of a decoder pass are dealt to (K4_SR_STREAMS)
+P16_TARGET_EXP = 9              # calibration maps a tensor's largest magnitude into [2^9, 2^10): 64-128x head room below fp16's 65504
 
 
 @torch.no_grad()
@@ -45,6 +48,16 @@ def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
                 m.weight.data *= scale
                 if m.bias is not None:
                     m.bias.data.fill_(bias_fill)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    pool = _SIDE_STREAMS.setdefault(str(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 class SFTLayer(nn.Module):
@@ -261,6 +274,31 @@ class _PackPlan:
         return self
 
 
+class _PackedP16:
+    """Weights of a 3x3 layer whose INPUT is pre-split ("p16", include/k4nerf.h): k4_conv3x3_p16_multi's ``w_p16`` operand
+    [cin/16][cout/32][hi|lo][9][2][32][8] fp16 of w 2^a[co] 2^-E[ci] + [cout] floats 2^-a[co]; ``e_in``: the exponents of the p16
+    tensors the input channels belong to (one per 16-channel chunk)."""
+
+    def __init__(self, weight, bias, e_chunks):
+        cout, cin, k, _ = weight.shape
+        assert k == 3 and cout % 32 == 0 and cin % 16 == 0 and len(e_chunks) == cin // 16
+        dev = weight.device
+        e_in = torch.tensor(e_chunks, dtype=torch.int32, device=dev).repeat_interleave(16)
+        w = torch.ldexp(weight.detach().float(), -e_in.view(1, -1, 1, 1))
+        m = w.abs().amax((1, 2, 3)).double()
+        a = torch.where((m > 0) & torch.isfinite(m), 13 - torch.floor(torch.log2(m.clamp_min(1e-300))), torch.zeros_like(m)).clamp(-100, 100).to(torch.int32)
+        ws = torch.ldexp(w, a.view(-1, 1, 1, 1))
+        hi = ws.to(torch.float16)                                    # round to nearest even, as the producers split activations
+        lo = (ws - hi.float()).to(torch.float16)
+        both = torch.stack([hi, lo], 0).reshape(2, cout // 32, 32, cin // 16, 2, 8, 9)       # [term][nb][co][chunk][kg][j][tap]
+        both = both.permute(3, 1, 0, 6, 4, 2, 5).contiguous()                                  # [chunk][nb][term][tap][kg][co][j]
+        unscale = torch.ldexp(torch.ones([cout], dtype=torch.float32, device=dev), -a)
+        self.w = torch.cat([both.view(torch.int16).reshape(-1), unscale.view(torch.int16)])
+        assert self.w.numel() * 2 == N.lib().k4_conv_weight_p16_bytes(cout, cin)
+        self.b = bias.detach().float().contiguous().clone()
+        self.cin, self.cout, self.k = cin, cout, 3
+
+
 def pack_sft(layer):
     """SFTLayer weights in the operand order of the fused kernel (include/k4nerf.h, k4_sft_nhwc)."""
     dev = layer.SFT_scale_conv0.weight.device
@@ -351,18 +389,22 @@ class SFTNet(nn.Module):
             nn.Conv2d(64, 64, 1), nn.LeakyReLU(0.2, True),
             nn.Conv2d(64, 32, 1))
         object.__setattr__(self, '_k4', {})
-        # 'bf16x6' (default): exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation --
-        #            fp32-equivalent (dropped terms <= 2^-23 per product; 126 dB vs the fp32 oracle) at 2.67x less matrix time;
+        # 'f16x3p' (default): the arithmetic of 'f16x3' -- 2-term fp16 splits, 3 products per 3x3 tap on v_mfma_f32_32x32x16_f16, fp32
+        #            accumulation, ~2^-21 relative per product (NOT bit-for-bit fp32) -- with every dense-block / upsampling activation
+        #            written PRE-SPLIT by its producer under one calibrated power-of-two scale per tensor (csrc/k4_sr_p16.hip); a window
+        #            whose values leave fp16's range is re-evaluated in 'f16x3' (overflow words, checked once per pass);
+        # 'f16x3' : the same products with the split done by every consumer per haloed tile (fp32 activations in HBM);
+        # 'bf16x6': exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16 -- fp32-equivalent (dropped terms <= 2^-23
+        #            per product; 126 dB vs the fp32 oracle);
         # 'fp32'  : v_mfma_f32_32x32x2_f32, exact fp32 FMA chains;
-        # 'f16x3' : 2-term fp16 splits with power-of-two scaling (22 significant bits per operand), 3 products on the 3x3 layers;
-        # 'bf16x3': 2-term bf16 splits, 3 products, ~2^-16 per product (opt-in fast path, ~100 dB)
+        # 'bf16x3': 2-term bf16 splits, 3 products, ~2^-16 per product (opt-in, ~100 dB)
         self.k4_mode = os.environ.get('K4_SR_MODE', DEFAULT_MODE)
 
     # ------------------------------------------------------------------ HIP path
     def _packed(self):
         """Pack every conv once per parameter version (load-time repack; names/values of parameters never change)."""
-        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device), self.k4_mode)
-        mode = self.k4_mode
+        mode = 'f16x3' if self.k4_mode == 'f16x3p' else self.k4_mode       # 'f16x3p' = the 'f16x3' operands + the p16 ones of _p16_state
+        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device), mode)
         c = self._k4
         if c.get('key') == key:
             return c['packed']
@@ -467,6 +509,125 @@ class SFTNet(nn.Module):
             plan.append((fn, args, 'k4_sft_nhwc_multi'))
         N.check(fn(*args, N.stream()), 'k4_sft_nhwc_multi')
 
+    def _conv_p16_multi(self, pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, up, flags, res, out_exp, ovf, plan):
+        """One 3x3 layer of every window on PRE-SPLIT input (k4_conv3x3_p16_multi).  out_exp: exponent E of the produced p16 tensor, or None for
+        plain fp32 output.  res = (buffer name, channel offset, stride, scale)."""
+        jobs = (N.ConvJob * len(Bs))()
+        for j, (B, (h, w)) in enumerate(zip(Bs, hws)):
+            jobs[j].x = B[xname].data_ptr() + 4 * x_off
+            jobs[j].y = B[yname].data_ptr() + 4 * y_off
+            jobs[j].res = None if res is None else B[res[0]].data_ptr() + 4 * res[1]
+            jobs[j].mod_x = None
+            jobs[j].H, jobs[j].W = h * up, w * up
+        rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
+        fn = N.lib().k4_conv3x3_p16_multi
+        args = (jobs, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), pkc.cout, y_stride, flags, 0.2, rs, rscale,
+                0.0 if out_exp is None else float(2.0 ** out_exp), N.ptr(ovf))
+        plan.append((fn, args, 'k4_conv3x3_p16_multi'))
+        N.check(fn(*args, N.stream()), 'k4_conv3x3_p16_multi')
+
+    def _sft_p16_multi(self, pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, out_exp, ovf, plan):
+        """SFTLayer of every window with PRE-SPLIT output (k4_sft_nhwc_p16_multi)."""
+        jobs = (N.SftJob * len(Bs))()
+        for j, (B, (h, w)) in enumerate(zip(Bs, hws)):
+            jobs[j].cond = B['cond'].data_ptr()
+            jobs[j].x = B[xname].data_ptr() + 4 * x_off
+            jobs[j].y = B[yname].data_ptr() + 4 * y_off
+            jobs[j].res = None
+            jobs[j].n_pix = h * w
+        fn = N.lib().k4_sft_nhwc_p16_multi
+        args = (jobs, len(Bs), self.num_grow_ch, N.f32(pk[prefix]), x_stride, y_stride, cfeat, 0.2, float(2.0 ** out_exp), N.ptr(ovf))
+        plan.append((fn, args, 'k4_sft_nhwc_p16_multi'))
+        N.check(fn(*args, N.stream()), 'k4_sft_nhwc_p16_multi')
+
+    # ------------------------------------------------------------------ pre-split activations ('f16x3p')
+    def _p16_names(self):
+        """The tensors the 'f16x3p' pass writes pre-split, in network order."""
+        names = []
+        for b in range(self.num_block):
+            for r in (1, 2, 3):
+                names += [f'body.{b}.rdb{r}.{t}' for t in ('xc0', 'x1', 'x2', 'x3', 'xc1')]
+        names += ['sftbody', 'body_feat']
+        if self.scale > 1:
+            names.append('up1')
+            if self.scale == 4:
+                names.append('up2')
+        return names
+
+    @staticmethod
+    def _calibration_input(n_in, n_cond, dev, size=96):
+        """A fixed, image-like probe in [0, 1] (smooth fields, hard edges, texture, the extremes): the same on every process, so every replica
+        of a model derives the same exponents (the frame a tile-parallel job assembles does not depend on which rank decoded a window)."""
+        g = torch.Generator().manual_seed(20240777)
+        u = torch.linspace(0, 1, size).view(1, -1).expand(size, size)
+        v = torch.linspace(0, 1, size).view(-1, 1).expand(size, size)
+        chans = []
+        for c in range(n_in + n_cond):
+            f = torch.rand([4], generator=g) * 9 + 1
+            smooth = 0.5 + 0.5 * torch.sin(f[0] * u + f[1] * v + c) * torch.cos(f[2] * v - f[3] * u)
+            edges = ((u * (3 + c)).floor() + (v * (4 + c)).floor()) % 2
+            noise = torch.rand([size, size], generator=g)
+            img = 0.55 * smooth + 0.3 * edges + 0.15 * noise
+            img[: size // 8, : size // 8] = 0.0
+            img[-size // 8:, -size // 8:] = 1.0
+            chans.append(img.clamp(0, 1))
+        t = torch.stack(chans, 0).unsqueeze(0).float()
+        return t[:, :n_in].contiguous().to(dev), t[:, n_in:].contiguous().to(dev)
+
+    @torch.no_grad()
+    def k4_calibrate(self, x=None, cond=None):
+        """Choose the power-of-two scale of every pre-split tensor: one 'f16x3' pass (fp32 activations) over ``x, cond`` -- default: the fixed
+        probe of ``_calibration_input`` -- records each tensor's largest magnitude; E maps it into [2^P16_TARGET_EXP, 2^(P16_TARGET_EXP+1)).
+        Replicas that must produce identical bits have to calibrate on identical inputs (the default does)."""
+        dev = self.conv_first.weight.device
+        if x is None:
+            x, cond = self._calibration_input(self.conv_first.in_channels, self.CondNet[0].in_channels, dev)
+        pk = self._packed()
+        names = self._p16_names()
+        amax = torch.zeros([len(names)], dtype=torch.int32, device=dev)
+        h, w = int(x.shape[2]), int(x.shape[3])
+        B = self._k4_buffers(h, w, dev, ('cal', 0))
+        B['xin'].copy_(x[0].permute(1, 2, 0))
+        B['cnd'].copy_(cond[0].permute(1, 2, 0))
+        self._record_hip(pk, [B], [(h, w)], [], probe=(amax, {n: i for i, n in enumerate(names)}))
+        m = amax.cpu().view(torch.float32).double()
+        E = {}
+        for n, v in zip(names, m.tolist()):
+            E[n] = 0 if not (v > 0 and math.isfinite(v)) else max(-100, min(100, P16_TARGET_EXP - int(math.floor(math.log2(v)))))
+        self._k4['p16'] = {'key': self._k4['key'], 'E': E, 'amax': dict(zip(names, m.tolist())), 'pk': None}
+        return E
+
+    def _p16_state(self):
+        """Exponents + p16-packed weights for the current parameter versions (calibrates on first use)."""
+        self._packed()
+        st = self._k4.get('p16')
+        if st is None or st['key'] != self._k4['key']:
+            self.k4_calibrate()
+            st = self._k4['p16']
+        if st['pk'] is None:
+            E, pkp = st['E'], {}
+            for b, rr in enumerate(self.body):
+                for r in (1, 2, 3):
+                    p = f'body.{b}.rdb{r}'
+                    rdb = getattr(rr, f'rdb{r}')
+                    ch = [E[p + '.xc0']] * 4 + [E[p + '.x1']] * 2 + [E[p + '.x2']] * 2 + [E[p + '.x3']] * 2 + [E[p + '.xc1']] * 2
+                    for k in range(1, 6):
+                        m = getattr(rdb, f'conv{k}')
+                        pkp[f'{p}.conv{k}'] = _PackedP16(m.weight, m.bias, ch[:m.weight.shape[1] // 16])
+            chain = [('conv_body', 'sftbody'), ('conv_up1', 'body_feat'), ('conv_up2', 'up1'), ('conv_hr', 'up2' if self.scale == 4 else ('up1' if self.scale > 1 else 'body_feat'))]
+            for name, src in chain:
+                if hasattr(self, name):
+                    m = getattr(self, name)
+                    pkp[name] = _PackedP16(m.weight, m.bias, [E[src]] * (m.weight.shape[1] // 16))
+            st['pk'] = pkp
+        return st
+
+    def k4_warm(self):
+        """Build the load-time state (packed weights; 'f16x3p': calibration + pre-split weight operands) on the CURRENT stream."""
+        self._packed()
+        if self.k4_mode == 'f16x3p':
+            self._p16_state()
+
     @torch.no_grad()
     def _forward_hip(self, x, cond, slot=0):
         """One window through the decoder on the HIP kernels (see _forward_hip_multi)."""
@@ -477,10 +638,11 @@ class SFTNet(nn.Module):
         """Up to K4_MAX_JOBS windows through the decoder TOGETHER: every layer is one grouped launch over all windows (111 launches
         for the whole set; a window alone leaves a quarter of the CUs idle in its last round of workgroups).  The launch sequence
         of a window set is recorded once as a list of (entry point, prepared ctypes arguments) and replayed afterwards: all
-        buffers are capacity-cached at fixed addresses.  Returns views [1,3,s*h,s*w] of the windows' NHWC results."""
+        buffers are capacity-cached at fixed addresses.  Returns views [1,3,s*h,s*w] of the windows' NHWC results.
+        'f16x3p': the pass on pre-split activations, then ONE read-back of the windows' overflow words; a window that raised its word
+        (a value beyond fp16 under the calibrated scale) is decoded again in 'f16x3' -- a window's pixels depend on the window alone."""
         assert len(xs) == len(conds) and 0 < len(xs) <= N.K4_MAX_JOBS
         dev = xs[0].device
-        pk = self._packed()
         Bs, hws = [], []
         for j, (x, cond) in enumerate(zip(xs, conds)):
             assert x.shape[0] == 1 and cond.shape[0] == 1, 'batch 1 (as every call site of the reference)'
@@ -490,13 +652,52 @@ class SFTNet(nn.Module):
             B['cnd'].copy_(cond[0].permute(1, 2, 0))
             Bs.append(B)
             hws.append((h, w))
-        key = (tuple(hws), self._k4.get('key'), self.k4_mode) \
+        # (the pre-split kernels address an image through 32-bit byte offsets: windows whose 4x images reach 2 GB stay on 'f16x3')
+        p16 = self.k4_mode == 'f16x3p' and all(h * w * 4 * max(self.num_feat + 4 * self.num_grow_ch, self.scale ** 2 * self.num_feat) < 2 ** 31 for h, w in hws)
+        st = self._p16_state() if p16 else None
+        # K4_SR_STREAMS = S > 1: the windows are dealt to S groups, each group's layer sequence runs on its own HIP stream -- the last,
+        # partly filled round of workgroups of one group's layer overlaps the other group's next layer (a layer of a 4K frame is 6 rounds)
+        S = max(1, min(len(Bs), int(os.environ.get('K4_SR_STREAMS', str(DEFAULT_STREAMS)))))
+        order = sorted(range(len(Bs)), key=lambda j: (-hws[j][0] * hws[j][1], j))
+        groups = [sorted(order[g::S]) for g in range(S)]
+        cur = torch.cuda.current_stream(dev)
+        pool = _side_streams(dev, S) if S > 1 else [None]
+        ovfs = []
+        for gi, idx in enumerate(groups):
+            if S > 1:
+                pool[gi].wait_stream(cur)
+            with (torch.cuda.stream(pool[gi]) if S > 1 else contextlib.nullcontext()):
+                ovf = None
+                if p16:
+                    ovf = self._k4.setdefault(('ovf', slot0, gi, str(dev)), torch.zeros([N.K4_MAX_JOBS], dtype=torch.int32, device=dev))
+                    if S > 1:
+                        ovf.record_stream(pool[gi])
+                self._run_plan([Bs[j] for j in idx], [hws[j] for j in idx], (slot0, gi, S),
+                               p16=None if not p16 else {'E': st['E'], 'pk': st['pk'], 'ovf': ovf})
+                ovfs.append(ovf)
+        if S > 1:
+            for q in pool:
+                cur.wait_stream(q)
+            for B in Bs:
+                for t in B.values():
+                    t.record_stream(cur)
+        if p16:
+            flags = torch.stack(ovfs).cpu().tolist()                       # the one host synchronisation of the pass
+            bad = sorted(groups[gi][q] for gi in range(S) for q in range(len(groups[gi])) if flags[gi][q])
+            if bad:
+                self._k4['p16_reruns'] = self._k4.get('p16_reruns', 0) + len(bad)
+                self._run_plan([Bs[j] for j in bad], [hws[j] for j in bad], (slot0, 'redo'))
+        return [B['out'].permute(2, 0, 1).unsqueeze(0) for B in Bs]       # views [1,3,H,W] of the NHWC results
+
+    def _run_plan(self, Bs, hws, slot0, p16=None):
+        pk = self._packed()
+        key = (tuple(hws), self._k4.get('key'), self.k4_mode, p16 is not None) \
             + tuple(t.data_ptr() for B in Bs for t in B.values())
         plans = self._k4.setdefault(('plans', slot0), {})
         plan = plans.get(key)
         if plan is None:
             plan = []
-            self._record_hip(pk, Bs, hws, plan)
+            self._record_hip(pk, Bs, hws, plan, p16=p16)
             if len(plans) > 16:
                 plans.clear()
             plans[key] = plan
@@ -506,26 +707,47 @@ class SFTNet(nn.Module):
                 if fn is None:
                     if what == 'copy':
                         args[0].copy_(args[1])
+                    elif what == 'zero':
+                        args[0].zero_()
                 else:
                     N.check(fn(*args, st), what)
-        return [B['out'].permute(2, 0, 1).unsqueeze(0) for B in Bs]       # views [1,3,H,W] of the NHWC results
 
-    def _record_hip(self, pk, Bs, hws, plan):
-        """Run the launch sequence of SFTNet.forward (lib/sr_esrnet.py:446-465) once for the window set, appending every step to `plan`."""
+    def _record_hip(self, pk, Bs, hws, plan, p16=None, probe=None):
+        """Run the launch sequence of SFTNet.forward (lib/sr_esrnet.py:446-465) once for the window set, appending every step to `plan`.
+        p16 = {'E', 'pk', 'ovf'}: the 'f16x3p' sequence (dense-block / trunk-tail activations pre-split; conv4 and the SFT inputs stay fp32);
+        probe = (amax int32 tensor, name -> index): the calibration pass -- after every layer that produces a tensor of `_p16_names`, its
+        largest magnitude is folded into amax (k4_absmax_slice)."""
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         cin, ccond = Bs[0]['xin'].shape[2], Bs[0]['cnd'].shape[2]
+        E, pkp, ovf = (p16['E'], p16['pk'], p16['ovf']) if p16 is not None else (None, None, None)
 
         def cv(pkc, xname, x_off, x_stride, yname, y_off, y_stride, cout, up=1, flags=0, res=None):
             self._conv_multi(pkc, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cout, up, flags, res=res, plan=plan)
 
+        def cvp(lname, xname, x_off, x_stride, yname, y_off, y_stride, up=1, flags=0, res=None, out=None):
+            self._conv_p16_multi(pkp[lname], Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, up, flags, res,
+                                 None if out is None else E[out], ovf, plan)
+
         def sft(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=None):
             self._sft_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, res=res, plan=plan)
+
+        def sftp(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, out):
+            self._sft_p16_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, E[out], ovf, plan)
 
         def copy(dname, sname):
             for B in Bs:
                 plan.append((None, (B[dname], B[sname]), 'copy'))
                 B[dname].copy_(B[sname])
 
+        def seen(name, bname, off, stride, ch, up=1):
+            if probe is not None:
+                for B, (h, w) in zip(Bs, hws):
+                    N.check(N.lib().k4_absmax_slice(N.C.c_void_p(B[bname].data_ptr() + 4 * off), h * up * w * up, stride, ch,
+                                                    N.C.c_void_p(probe[0].data_ptr() + 4 * probe[1][name]), N.stream()), 'k4_absmax_slice')
+
+        if p16 is not None:
+            plan.append((None, (ovf,), 'zero'))
+            ovf.zero_()
         cv(pk['conv_first'], 'xin', 0, cin, 'feat', 0, nf, nf)
         cv(pk['CondNet.0'], 'cnd', 0, ccond, 'c64a', 0, 64, 64, flags=EPI_LRELU)
         cv(pk['CondNet.2'], 'c64a', 0, 64, 'c64b', 0, 64, 64, flags=EPI_LRELU)
@@ -537,22 +759,51 @@ class SFTNet(nn.Module):
             copy('rrdb_in', 'trunk')
             for r in (1, 2, 3):
                 p = f'body.{b}.rdb{r}'
+                if p16 is not None:
+                    sftp(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf, p + '.xc0')                     # xc0, pre-split
+                    for k in range(1, 4):                                                           # x1..x3, pre-split
+                        cvp(f'{p}.conv{k}', 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, flags=EPI_LRELU, out=f'{p}.x{k}')
+                    cvp(f'{p}.conv4', 'blk', 0, bw, 't', 0, 2 * g, flags=EPI_LRELU)                    # x4 stays fp32: the SFT layer reads it
+                    sftp(p + '.sft1', 't', 0, 2 * g, 'blk', nf + 3 * g, bw, g, p + '.xc1')              # xc1, pre-split (not in place)
+                    cvp(f'{p}.conv5', 'blk', 0, bw, 'trunk', 0, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))
+                    continue
                 sft(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf)                                    # xc0
+                seen(p + '.xc0', 'blk', 0, bw, nf)
                 for k in range(1, 5):                                                               # x1..x4
                     cv(pk[f'{p}.conv{k}'], 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
+                    if k < 4:
+                        seen(f'{p}.x{k}', 'blk', nf + (k - 1) * g, bw, g)
                 sft(p + '.sft1', 'blk', nf + 3 * g, bw, 'blk', nf + 3 * g, bw, g)                     # xc1 in place
+                seen(p + '.xc1', 'blk', nf + 3 * g, bw, g)
                 cv(pk[f'{p}.conv5'], 'blk', 0, bw, 'trunk', 0, nf, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))              # x5*0.2 + x
             sft(f'body.{b}.sft0', 'trunk', 0, nf, 'trunk', 0, nf, nf, res=('rrdb_in', 0, nf, 0.2))  # sft(out)*0.2 + x
-        sft('sftbody', 'trunk', 0, nf, 'trunk', 0, nf, nf)
-        cv(pk['conv_body'], 'trunk', 0, nf, 'rrdb_in', 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))            # body_feat += feat
+        if p16 is not None:
+            sftp('sftbody', 'trunk', 0, nf, 'c64a', 0, 64, nf, 'sftbody')
+            cvp('conv_body', 'c64a', 0, 64, 'rrdb_in', 0, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0), out='body_feat')   # body_feat += feat
+        else:
+            sft('sftbody', 'trunk', 0, nf, 'trunk', 0, nf, nf)
+            seen('sftbody', 'trunk', 0, nf, nf)
+            cv(pk['conv_body'], 'trunk', 0, nf, 'rrdb_in', 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))            # body_feat += feat
+            seen('body_feat', 'rrdb_in', 0, nf, nf)
         cur, up = 'rrdb_in', 1
         if s > 1:
-            cv(pk['conv_up1'], cur, 0, nf, 'up1', 0, nf, nf, up=2, flags=EPI_LRELU | PRE_UP2X)
+            if p16 is not None:
+                cvp('conv_up1', cur, 0, nf, 'up1', 0, nf, up=2, flags=EPI_LRELU | PRE_UP2X, out='up1')
+            else:
+                cv(pk['conv_up1'], cur, 0, nf, 'up1', 0, nf, nf, up=2, flags=EPI_LRELU | PRE_UP2X)
+                seen('up1', 'up1', 0, nf, nf, up=2)
             cur, up = 'up1', 2
             if s == 4:
-                cv(pk['conv_up2'], cur, 0, nf, 'up2', 0, nf, nf, up=4, flags=EPI_LRELU | PRE_UP2X)
+                if p16 is not None:
+                    cvp('conv_up2', cur, 0, nf, 'up2', 0, nf, up=4, flags=EPI_LRELU | PRE_UP2X, out='up2')
+                else:
+                    cv(pk['conv_up2'], cur, 0, nf, 'up2', 0, nf, nf, up=4, flags=EPI_LRELU | PRE_UP2X)
+                    seen('up2', 'up2', 0, nf, nf, up=4)
                 cur, up = 'up2', 4
-        cv(pk['conv_hr'], cur, 0, nf, 'hr', 0, nf, nf, up=up, flags=EPI_LRELU)
+        if p16 is not None:
+            cvp('conv_hr', cur, 0, nf, 'hr', 0, nf, up=up, flags=EPI_LRELU)
+        else:
+            cv(pk['conv_hr'], cur, 0, nf, 'hr', 0, nf, nf, up=up, flags=EPI_LRELU)
         cv(pk['conv_last'], 'hr', 0, nf, 'out', 0, 3, 3, up=up)
 
     def forward(self, x, cond, fea=None):

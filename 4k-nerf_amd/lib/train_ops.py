@@ -96,6 +96,52 @@ def rgbnet_sigmoid(rgbnet, x, add=None):
     return RgbNetSigmoid.apply(x, add, lins[0].weight, lins[0].bias, w2, b2, lins[-1].weight, lins[-1].bias)
 
 
+_GENERIC_PACKS = {}
+
+
+@torch.no_grad()
+def rgbnet_sigmoid_layers(rgbnet, x, add=None):
+    """``torch.sigmoid(rgbnet(x) [+ add])`` for Linear-ReLU stacks OUTSIDE the shapes of k4_rgbnet_fwd (more hidden layers, other widths
+    up to 128, dim0 up to 192): every Linear is one launch of the exact-fp32 MFMA convolution kernel as a 1x1 layer over the samples
+    (k4_conv2d_nhwc, ReLU = its LeakyReLU epilogue with slope 0).  Inference only: under autograd these shapes raise."""
+    from .sr_esrnet import _Packed, EPI_LRELU
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rgbnet.parameters())):
+        raise N.K4Error('training an rgbnet of this shape is outside k4_rgbnet_fwd / k4_rgbnet_bwd (Linear-ReLU stack of <= 3 layers, width 32 / 64 / 128)')
+    def flat(m):                                                   # execution order; a shared activation instance counts every time it is applied
+        return [q for c in m.children() for q in flat(c)] if isinstance(m, nn.Sequential) else [m]
+    mods = flat(rgbnet)
+    lins = [m for m in mods if isinstance(m, nn.Linear)]
+    ok = bool(lins) and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in mods) and lins[-1].out_features == 3 and mods[-1] is lins[-1] \
+        and all(l.bias is not None and l.out_features <= 128 and l.in_features <= 192 for l in lins) \
+        and len(mods) == 2 * len(lins) - 1 and all(isinstance(m, nn.Linear) == (i % 2 == 0) for i, m in enumerate(mods))
+    if not ok:
+        raise N.K4Error('rgbnet is not a Linear-ReLU stack the HIP kernels cover (no PyTorch fallback)')
+    n = x.shape[0]
+    dev = x.device
+    if n == 0:
+        return torch.empty([0, 3], dtype=torch.float32, device=dev)
+    key = tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in lins)
+    hit = _GENERIC_PACKS.get(id(rgbnet))
+    if hit is None or hit[0] != key:
+        hit = (key, [_Packed(l.weight.detach()[:, :, None, None], l.bias, 'fp32') for l in lins])
+        if len(_GENERIC_PACKS) > 8:
+            _GENERIC_PACKS.clear()
+        _GENERIC_PACKS[id(rgbnet)] = hit
+    Wd = 256                                                       # the samples as an image of 256-pixel rows (1x1 layer: any shape does)
+    Hh = (n + Wd - 1) // Wd
+    cur = torch.zeros([Hh * Wd, lins[0].in_features], dtype=torch.float32, device=dev)
+    cur[:n] = x.detach().float()
+    L = N.lib()
+    for i, (l, pk) in enumerate(zip(lins, hit[1])):
+        cout = l.out_features
+        nxt = torch.empty([Hh * Wd, cout], dtype=torch.float32, device=dev)
+        N.check(L.k4_conv2d_nhwc(N.f32(cur), l.in_features, l.in_features, N.f32(pk.w), N.f32(pk.b), 1, N.f32(nxt), cout, cout, Hh, Wd,
+                                 EPI_LRELU if i + 1 < len(lins) else 0, 0.0, None, 0, 0.0, None, 0, N.stream()), 'k4_conv2d_nhwc (rgbnet layer)')
+        cur = nxt
+    logit = cur[:n]
+    return torch.sigmoid(logit if add is None else logit + add.detach().float())
+
+
 class FlattenEffDistLoss(torch.autograd.Function):
     """sum_rays [ sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval ] / (ray_id.max() + 1), gradient w.r.t. w only.
     ray_id: int64, on the device, ASCENDING (samples grouped by ray in marching order, as the marcher emits them): the kernel finds a

@@ -189,7 +189,7 @@ def hip_sr_fn(net_sr):
         return net_sr._forward_hip_multi(imgs, conds)
     multi.max_jobs = N.K4_MAX_JOBS
     fn.k4_slots = True
-    fn.k4_warm = net_sr._packed
+    fn.k4_warm = net_sr.k4_warm
     fn.k4_multi = multi
     return fn
 

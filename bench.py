@@ -67,7 +67,7 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='marcher line only: skip the side measurements (profiling runs)')
     ap.add_argument('--backend', default='nccl', help=argparse.SUPPRESS)          # gloo + --same-device: 1-GPU logic smoke test
     ap.add_argument('--same-device', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--sr-frames', type=int, default=3, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
+    ap.add_argument('--sr-frames', type=int, default=12, help='4K frames (march + SFTNet x4, test_tile=510) timed for the '
                     'secondary frames/s figure (0 disables)')
     return ap.parse_args()
 
@@ -280,18 +280,20 @@ def main():
         }
         if secondary is not None:
             res['frames_sharded' if by_rows else 'rows_sharded'] = secondary
-    four_k = four_k_fp32 = four_k_fast = four_k_alt = None
+    four_k = four_k_fp32 = four_k_fast = four_k_alt = four_k_b6 = None
     if args.sr_frames > 0 and not args.small:
         keep = {}
         from nerf4k_amd.lib import sr_esrnet as _sr
         default_mode = _sr.DEFAULT_MODE
-        other_mode = 'bf16x6' if default_mode == 'f16x3' else 'f16x3'
+        other_mode = 'f16x3'                  # the same products with every consumer splitting fp32 activations per tile: what 'f16x3p' falls back to
         four_k = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=default_mode,
                                check=not args.no_cpu_baseline and world == 1, keep=keep)
         if not args.no_extras:
-            four_k_alt = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode=other_mode, keep=keep)
-            four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='fp32', keep=keep)
-            four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, args.sr_frames, world, rank, mode='bf16x3', keep=keep)
+            few = max(3, args.sr_frames // 4)         # the side arithmetics: a few frames each (they are context, not the headline)
+            four_k_alt = four_k_frames(model, ck, poses, rk, H, W, K, dev, few, world, rank, mode=other_mode, keep=keep)
+            four_k_b6 = four_k_frames(model, ck, poses, rk, H, W, K, dev, few, world, rank, mode='bf16x6', keep=keep)
+            four_k_fp32 = four_k_frames(model, ck, poses, rk, H, W, K, dev, 3, world, rank, mode='fp32', keep=keep)
+            four_k_fast = four_k_frames(model, ck, poses, rk, H, W, K, dev, few, world, rank, mode='bf16x3', keep=keep)
         keep.clear()
     joint_dp = None
     if world > 1 and not args.small and not args.no_extras:
@@ -308,7 +310,7 @@ def main():
         if four_k is not None:
             res['four_k'] = four_k
         if four_k_fp32 is not None:
-            res['four_k_fp32mfma'], res['four_k_bf16x3'], res['four_k_' + other_mode] = four_k_fp32, four_k_fast, four_k_alt
+            res['four_k_fp32mfma'], res['four_k_bf16x3'], res['four_k_' + other_mode], res['four_k_bf16x6'] = four_k_fp32, four_k_fast, four_k_alt, four_k_b6
         if world == 1 and not args.small and not args.no_extras:
             # side measurements (single process, no collectives): a failure in one of them must not take the headline line with it
             res['own_staged_pipeline'] = _side(own_staged_pipeline, model, run.rays[0], rk)
@@ -316,6 +318,7 @@ def main():
             res['joint_train_step'] = _side(joint_train_step, ck, run.rays[0], H, W, dev)
             res['reference_pipeline_rocm'] = _side(reference_pipeline_rocm, ck, run.rays[0], dev)
             res['dvgo_config0'] = _side(dvgo_config0, dev, not args.no_cpu_baseline)
+            res['scene_sweep'] = _side(scene_sweep, dev, H, W, K, poses)
         if not args.no_cpu_baseline and world == 1:          # the CPU legs run at N = 1 only (bench contract): at N > 1 the other ranks would idle behind rank 0's host work
             res['cpu_baseline'], parity = cpu_baseline(ck, poses[0], args.cpu_stride, model)
             if parity is not None:
@@ -364,20 +367,28 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_frames + 1)]
         t = time.perf_counter()
+        ev[0].record()
         for i in range(n_frames):
             hr = tp.render_frame_tiles(frames[i % len(frames)], H, W, march_fn, sr_fn, tile, out=hr)
+            ev[i + 1].record()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / n_frames
+        per_frame = [ev[i].elapsed_time(ev[i + 1]) for i in range(n_frames)]          # frame-to-frame intervals on the launch stream
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     tflops = flop_per_px * px / dt / 1e12
-    base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'n_gpus': world, 'test_tile': tile,
+    base = {'frames_per_s': round(1.0 / dt, 3), 'ms_per_frame': round(dt * 1e3, 2), 'frames_timed': n_frames,
+            'ms_per_frame_median': round(float(np.median(per_frame)), 2), 'ms_per_frame_p90': round(float(np.percentile(per_frame, 90)), 2),
+            'n_gpus': world, 'test_tile': tile,
             'effective_tflops': round(tflops, 2), 'gather': 'fp32 HR pixels, 146 MB per frame (bit-identical to the single-GPU frame)'}
+    if mode == 'f16x3p':
+        base['k4_p16_reruns'] = int(net._k4.get('p16_reruns', 0))          # windows redone on the per-tile kernel (overflow words) over all frames above
     if world > 1:
         # the same job with 8-bit pixels on the wire (render_frame_tiles(out_dtype=torch.uint8): every rank applies the reference's
         # to8b rule to its own tiles before the all-gather, 36.6 MB per frame -- what run_sr.py finally writes to disk)
@@ -394,12 +405,15 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
         dist.all_reduce(t8, op=dist.ReduceOp.MAX)
         base['uint8_gather'] = {'ms_per_frame': round(float(t8.item()) * 1e3, 2), 'frames_per_s': round(1.0 / float(t8.item()), 3),
                                 'bytes_per_frame': int(hr8.numel())}
+    with torch.no_grad():                                 # the frame the arithmetics are compared on: pose 0, whatever number of frames was timed
+        hr_cmp = tp.render_frame_tiles(frames[0], H, W, march_fn, sr_fn, tile) if world == 1 else hr
     primary = keep is not None and 'hr' not in keep       # the first arithmetic timed is the default one: the others are compared with its frame
     if keep is not None and primary:
-        keep['hr'], keep['mode'] = hr.clone(), mode
+        keep['hr'], keep['mode'] = hr_cmp.clone(), mode
     if not primary:
-        per_product = {'bf16x3': 3, 'f16x3': 3, 'bf16x6': 6}.get(mode)
+        per_product = {'bf16x3': 3, 'f16x3': 3, 'f16x3p': 3, 'bf16x6': 6}.get(mode)
         base['arithmetic'] = {
+            'f16x3p': 'SR 3x3 convs: the f16x3 products on activations PRE-SPLIT by their producer under calibrated per-tensor scales (K4_SR_MODE=f16x3p)',
             'bf16x3': 'SR 3x3 convs: the two leading bf16 split terms, 3 of the 6 MFMA products (opt-in K4_SR_MODE=bf16x3; >= 75 dB vs the fp32 oracle in tests/test_sr_gpu.py)',
             'f16x3': 'SR 3x3 convs: 2-term fp16 splits with power-of-two scaling, 3 products on v_mfma_f32_32x32x16_f16 (K4_SR_MODE=f16x3; >= 110 dB vs fp32 in tests/test_sr_gpu.py)',
             'bf16x6': 'SR convs: exact 3-term bf16 splits, 6 products on v_mfma_f32_32x32x16_bf16 (K4_SR_MODE=bf16x6)',
@@ -409,12 +423,12 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
         else:
             base['frac_of_fp32_mfma_peak'] = round(tflops / (157.3 * world), 4)
         if keep is not None and 'hr' in keep:      # same pose, same weights: the whole 4032x3024 frame against the default arithmetic's
-            d = (hr.double() - keep['hr'].double())
+            d = (hr_cmp.double() - keep['hr'].double())
             mse = float((d ** 2).mean())
             base[f'psnr_vs_{keep["mode"]}_frame_db'] = round(200.0 if mse == 0 else -10.0 * float(np.log10(mse)), 1)
             base[f'max_abs_vs_{keep["mode"]}_frame'] = float(d.abs().max())
         return base
-    per_product = 3 if mode == 'f16x3' else 6
+    per_product = 3 if mode in ('f16x3', 'f16x3p') else 6
     peak = 2500.0 / per_product * world
     base.update({
         'output': list(hr.shape), 'scaling': 'strong',
@@ -423,8 +437,11 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
         'arithmetic': ('marcher fp32; SR convs: exact 3-term bf16 splits, 6 of 9 partial products on v_mfma_f32_32x32x16_bf16, '
                        'fp32 accumulation (fp32-equivalent, dropped terms <= 2^-23 per product)') if mode == 'bf16x6' else
                       ('marcher fp32; SR 3x3 convs: 2-term fp16 splits with power-of-two scaling (22 significant bits per operand), 3 of 4 '
-                       'partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation (~2^-21 per product); 1x1 / SFT / conv_last layers: '
-                       'exact 3-term bf16 splits'),
+                       'partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation (~2^-21 per product, NOT bit-for-bit fp32; the '
+                       'strictly fp32-equivalent decoder is four_k_bf16x6); 1x1 / SFT / conv_last layers: exact 3-term bf16 splits'
+                       + ('; dense-block / upsampling activations are written PRE-SPLIT (fp16 hi + lo) by their producer under one '
+                          'calibrated power-of-two scale per tensor and go global -> LDS by DMA; a window that leaves fp16 range is '
+                          'redone on the per-tile kernel (k4_p16_reruns counts them)' if mode == 'f16x3p' else '')),
         'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
                         'frac': round(tflops / peak, 4), 'flop_per_frame': flop_per_px * px,
                         # the other roof: every layer reads its inputs and writes its outputs ONCE as fp32 (no halo, no re-reads): channel
@@ -436,20 +453,45 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
                         'note': f'peak = 2.5 PFLOP/s dense bf16|fp16 / {per_product} MFMA per product x n_gpus; time includes the '
                                 'marcher, layout copies and the all-gather.  With fp32 activations the decoder sits where the two roofs '
                                 'meet for the 3-product arithmetic (hbm_floor_ms vs mfma_floor_ms)'}})
-    if world == 1:                               # rank 0's share of the 8-GPU job (3 tiles of tile_size 189), timed on this GPU
-        t189 = tp.tile_geometry(H, W, 189, 10)
-        mine = tp.assign_tiles(t189, 8)[0]
-        sub = _SubsetGeometry(t189, mine)
+    if world == 1:
+        # The N-GPU job's critical path, measured on THIS GPU (no multi-GPU node was available to the builder: every figure below is a
+        # PROJECTION, unmeasured on hardware): for N = 2 / 4 / 8 and a few tile sizes, the heaviest rank's share of the frame (its tiles'
+        # padded windows marched + decoded exactly as tile_parallel does) + a device-to-device copy of its all-gather slot as a
+        # stand-in for the collective.  Parity of a tile size is checked against the oracle with the SAME tile size (tests).
+        proj = {}
         with torch.no_grad():
-            sub.render(frames[0], march_fn, sr_fn)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(3):
-                sub.render(frames[0], march_fn, sr_fn)
-            torch.cuda.synchronize()
-        share = (time.perf_counter() - t) / 3
-        base['rank_share_8gpu'] = {'ms': round(share * 1e3, 2), 'tiles': len(mine), 'tile_size': 189,
-                                   'projected_speedup_before_gather': round(dt / share, 2)}
+            for n, cands in ((2, (510, 378)), (4, (252, 378)), (8, (189, 168, 126, 252))):
+                rows = []
+                for ts in cands:
+                    tl = tp.tile_geometry(H, W, ts, 10)
+                    owned = tp.assign_tiles(tl, n)
+                    area = [sum((tl[i][5] - tl[i][4]) * (tl[i][7] - tl[i][6]) for i in o) for o in owned]
+                    r = max(range(n), key=lambda q: area[q])
+                    sub = _SubsetGeometry(tl, owned[r])
+                    slot = max(sum((tl[i][1] - tl[i][0]) * (tl[i][3] - tl[i][2]) * 16 for i in o) for o in owned)
+                    src, dst = torch.empty([3, slot], device=dev), torch.empty([3, slot], device=dev)
+                    sub.render(frames[0], march_fn, sr_fn)
+                    torch.cuda.synchronize()
+                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+                    evs[0].record()
+                    for q in range(8):
+                        sub.render(frames[0], march_fn, sr_fn)
+                        evs[q + 1].record()
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record(); dst.copy_(src); g1.record()
+                    torch.cuda.synchronize()
+                    ms = float(np.median([evs[q].elapsed_time(evs[q + 1]) for q in range(8)]))
+                    gms = g0.elapsed_time(g1)
+                    rows.append({'tile_size': ts, 'tiles_of_heaviest_rank': len(owned[r]), 'halo_factor': round(area[r] * n / (H * W), 3),
+                                 'share_ms_median': round(ms, 2), 'gather_standin_ms': round(gms, 3),
+                                 'projected_speedup': round(dt * 1e3 / (ms + gms), 2)})
+                best = max(rows, key=lambda q: q['projected_speedup'])
+                proj[str(n)] = {'best': best, 'candidates': rows}
+        base['rank_share_projection'] = dict(proj, note='UNMEASURED ON HARDWARE: one GPU timing the heaviest rank\'s tiles + a D2D copy of its '
+                                                        'all-gather slot; speedup = this GPU\'s whole frame (tile 510) / that')
+        b8 = proj['8']['best']
+        base['rank_share_8gpu'] = {'ms': b8['share_ms_median'], 'tiles': b8['tiles_of_heaviest_rank'], 'tile_size': b8['tile_size'],
+                                   'projected_speedup_before_gather': round(dt * 1e3 / b8['share_ms_median'], 2)}
     if check and rank == 0:
         base.update(four_k_parity_and_cpu(ck, net, poses[(n_frames - 1) % len(frames)], hr, tiles, H, W))
     return base
@@ -667,7 +709,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
 def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):
     """The reference's pipeline STRUCTURE on this MI355X -- 8192-ray chunks (run_sr.py:121-124), one launch per op, boolean-mask
     compactions with their host syncs, the op sequence of lib/dmpigo.py:300-427 -- on THIS package's staged gfx950 kernels
-    (`k4_staged=True`; rgbnet on rocBLAS).  Context only: it is our own slow path, not the reference's kernels."""
+    (`k4_staged=True`; rgbnet on k4_rgbnet_fwd).  Context only: it is our own slow path, not the reference's kernels."""
     ro, rd, vd = rays
 
     def frame():
@@ -683,6 +725,45 @@ def own_staged_pipeline(model, rays, rk, chunk=8192, frames=2):
         dt = (time.perf_counter() - t) / frames
     return {'value': round(ro.shape[0] / dt / 1e6, 3), 'unit': 'Mrays/s', 'ms_per_frame': round(dt * 1e3, 2),
             'what': 'reference op sequence, per-op launches of our own staged kernels, 8192-ray chunks, same GPU'}
+
+
+def scene_sweep(dev, H, W, K, poses):
+    """The marcher on OTHER density fields than the one every kernel was tuned on (K1's live mask and skip groups, K2's longest-first
+    queue depend on sparsity): SURVEY 8d's second scene ("horns": the same generator, seed 778, 8 test views), a 3x denser field
+    (72 blobs) and a 3x sparser one (8 blobs).  Stream-synchronised per-call rate (median of the views), the algorithm's sample counts
+    and the same algorithmic-byte roofline fraction as the headline."""
+    from nerf4k_amd import scene
+    from nerf4k_amd.lib import utils, dvgo
+    out = {}
+    for name, kw, n_views in (('horns_seed778', dict(seed=778), 8), ('dense_72_blobs', dict(seed=779, n_blobs=72), 4),
+                              ('sparse_8_blobs', dict(seed=780, n_blobs=8), 4)):
+        ck = scene.make_llff_checkpoint(**kw)
+        model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
+        rk = ck['render_kwargs']
+        views = scene.llff_spiral_poses()[::max(1, 20 // n_views)][:n_views]
+        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+        ms = []
+        with torch.no_grad():
+            for i, p in enumerate(views):
+                ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(p).to(dev), True, False, False, False)]
+                model(ro, rd, vd, k4_img_w=W, k4_counters=cnt, **rk)
+                model(ro, rd, vd, k4_img_w=W, **rk)
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); model(ro, rd, vd, k4_img_w=W, **rk); b.record()
+                    torch.cuda.synchronize()
+                    ms.append(a.elapsed_time(b))
+        inb, msk, alp, shd = [c / len(views) for c in cnt.cpu().tolist()]
+        m = float(np.median(ms))
+        b_alg = H * W * 56 + inb + msk * 32 + shd * 8 * model.k0_dim * 4
+        out[name] = {'views': len(views), 'ms_per_call_median': round(m, 4), 'mrays_isolated': round(H * W / (m * 1e-3) / 1e6, 1),
+                     'samples_per_frame': {'in_bbox': int(inb), 'mask': int(msk), 'alpha': int(alp), 'shaded': int(shd)},
+                     'shaded_fraction': round(shd / (H * W * 256), 4),
+                     'roofline_frac': round(b_alg / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del model, ck
+        torch.cuda.empty_cache()
+    return out
 
 
 def reference_pipeline_rocm(ck, frame_rays, dev, frames=2, chunk=8192):

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      6       /* 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      7       /* 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -317,6 +317,31 @@ typedef struct k4_sft_job { const float* cond; const float* x; float* y; const f
 #define K4_SFT_ARITH_BF16X6 1      /* exact 3-term bf16 splits, 6 partial products on v_mfma_f32_32x32x16_bf16 (fp32-equivalent)    */
 int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
                       int32_t y_stride, int32_t channels, float slope, int32_t res_stride, float res_scale, int32_t arith, void* stream);
+
+/* ---- PRE-SPLIT activations ("p16"; the decoder's 'f16x3p' arithmetic = K4_ARITH_F16X3's three fp16 products with the split done ONCE by
+ * the producing layer) -----------------------------------------------------------------------------------------------------------------------
+ * A p16 tensor is a channel slice (offset and width multiples of 16 channels; 16-byte aligned rows) of an NHWC image of 4-byte elements.
+ * Per pixel and 16-channel chunk (64 bytes) it holds four 16-byte units
+ *     [hi ch 0-7][hi ch 8-15][lo ch 0-7][lo ch 8-15],   hi = RNE_fp16(v 2^E), lo = RNE_fp16(v 2^E - hi)
+ * under ONE exponent E per tensor, fixed by the caller before the tensor is written (22 significant bits while |v| 2^E >= 2^-3, an
+ * absolute error <= 2^-25 2^-E below).  Producers: k4_sft_nhwc_p16_multi and k4_conv3x3_p16_multi with out_scale = 2^E; each ORs 1 into
+ * overflow[job] when a value of that window does not fit fp16 (|v| 2^E > 65504, or non-finite): the caller then re-evaluates the window on
+ * the fp32-activation entry points (SFTNet does).  Consumer: k4_conv3x3_p16_multi (3x3, stride 1, zero padding; cin % 16 == 0,
+ * cout % 32 == 0; flags from {K4_EPI_LRELU (0 <= slope <= 1), K4_EPI_RES, K4_PRE_UPSAMPLE2X}); out_scale == 0 writes plain fp32.
+ *   w_p16 : k4_conv_weight_p16_bytes(cout, cin) bytes = [cin/16][cout/32][hi|lo][9 taps][2 channel groups][32 co][8] fp16 of
+ *           w[co][ci][tap] 2^a[co] 2^-E[ci] (E[ci] = exponent of the p16 tensor input channel ci belongs to; a[co] brings the largest scaled
+ *           magnitude of output channel co into [2^13, 2^14)), followed by [cout] floats 2^-a[co]; 16-byte aligned.  bias: [cout] floats,
+ *           16-byte aligned.  The result does not depend on which other windows share the launch.
+ * k4_absmax_slice: *out_bits = max(*out_bits, bits of the largest |x| of the channel slice) (atomicMax; zero it first) -- what a
+ * calibration pass on the fp32 entry points uses to choose the exponents. */
+int64_t k4_conv_weight_p16_bytes(int32_t cout, int32_t cin);
+int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                         const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
+                         uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                         float out_scale, uint32_t* overflow, void* stream);
+int k4_sft_nhwc_p16_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
+                          int32_t y_stride, int32_t channels, float slope, float out_scale, uint32_t* overflow, void* stream);
+int k4_absmax_slice(const float* x, int64_t n_pix, int32_t stride, int32_t channels, uint32_t* out_bits, void* stream);
 
 /* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then
  * *res_scale + res if res != NULL), scale/shift = conv1x1(lrelu(conv1x1(cond))) evaluated in one launch, the hidden

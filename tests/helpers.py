@@ -137,3 +137,24 @@ def sftnet_forward_torch(net, x, cond):
         if net.scale == 4:
             body_feat = net.lrelu(net.conv_up2(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
     return net.conv_last(net.lrelu(net.conv_hr(body_feat)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pre-split activations ("p16", include/k4nerf.h): the format restated on the CPU, for the tests of its producers / consumers.
+# ---------------------------------------------------------------------------------------------------------------------
+def to_p16(x, E):
+    """fp32 [..., C] (C % 16 == 0) -> int32 [..., C]: per 16-channel chunk the four units [hi 0-7][hi 8-15][lo 0-7][lo 8-15] of
+    hi = RNE_fp16(x 2^E), lo = RNE_fp16(x 2^E - hi)."""
+    xs = torch.ldexp(x.float().cpu(), torch.tensor(E))
+    hi = xs.to(torch.float16)
+    lo = (xs - hi.float()).to(torch.float16)
+    lead, C = x.shape[:-1], x.shape[-1]
+    units = torch.stack([hi.reshape(*lead, C // 16, 16), lo.reshape(*lead, C // 16, 16)], -2)        # [..., chunk, term, 16]
+    return units.contiguous().view(torch.int16).reshape(*lead, C // 16, 32).view(torch.int32).reshape(*lead, C)
+
+
+def from_p16(p, E):
+    """Inverse of to_p16: (hi + lo) 2^-E as fp64."""
+    lead, C = p.shape[:-1], p.shape[-1]
+    h = p.cpu().contiguous().view(torch.int16).reshape(*lead, C // 16, 2, 16).view(torch.float16).double()
+    return torch.ldexp(h[..., 0, :] + h[..., 1, :], torch.tensor(-E)).reshape(*lead, C)

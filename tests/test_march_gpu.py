@@ -90,6 +90,11 @@ def test_golden_fused_and_staged(name):
     dict(seed=32, num_voxels=56 * 56 * 40, mpi_depth=40, viewbase_pe=3, spatial_pe=2, rgbnet_dim=6, rgbnet_width=32),
     dict(seed=33, num_voxels=56 * 56 * 40, mpi_depth=40, rgbnet_depth=2, rgbnet_width=128, rgbnet_dim=12),
     dict(seed=34, num_voxels=56 * 56 * 64, mpi_depth=64, stepsize=0.5),
+    # other density fields than the tuned one ("horns" = the same generator, seed 778; 3x denser; 3x sparser): the live mask,
+    # the skip groups and the longest-first shading queue must not depend on one field's statistics
+    dict(seed=778, num_voxels=64 * 64 * 48, mpi_depth=48),
+    dict(seed=779, num_voxels=64 * 64 * 48, mpi_depth=48, n_blobs=72),
+    dict(seed=780, num_voxels=64 * 64 * 48, mpi_depth=48, n_blobs=8),
 ])
 def test_mpi_frame_vs_oracle(cfg):
     ck = scene.make_llff_checkpoint(**cfg)

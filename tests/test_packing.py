@@ -159,3 +159,35 @@ def test_conv_packers_reproduce_the_weights(cout, cin, k, mode):
     want = torch.zeros_like(got)
     want[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
     assert torch.equal(got, want)
+
+
+def test_p16_format_roundtrip_and_weight_packing():
+    """The pre-split activation format (tests/helpers.py restates include/k4nerf.h) keeps 22 bits inside its window, and the p16 weight
+    operand decodes to w 2^a[co] 2^-E[chunk] with every output channel's largest magnitude in [2^13, 2^14)."""
+    import helpers
+    from nerf4k_amd.lib.sr_esrnet import _PackedP16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([5, 7, 48], generator=g) * torch.logspace(-3, 1, 48)
+    for E in (-3, 0, 9):
+        p = helpers.to_p16(x, E)
+        assert p.dtype == torch.int32 and p.shape == x.shape
+        back = helpers.from_p16(p, E)
+        big = (x.abs() * 2.0 ** E) >= 2.0 ** -3
+        rel = ((back - x.double()).abs() / x.abs().double().clamp_min(1e-30))[big]
+        assert float(rel.max()) <= 2.0 ** -21.5, (E, float(rel.max()))
+        assert float((back - x.double()).abs()[~big].max()) <= 2.0 ** -25 * 2.0 ** -E * 1.0001 if (~big).any() else True
+    cout, cin = 64, 96
+    w = torch.randn([cout, cin, 3, 3], generator=g) * 0.05
+    b = torch.randn([cout], generator=g)
+    e_chunks = [3, 3, 3, 3, -2, 7]
+    pk = _PackedP16(w, b, e_chunks)
+    nbytes = (cin // 16) * (cout // 32) * 18432
+    raw = pk.w[: nbytes // 2].view(torch.float16).reshape(cin // 16, cout // 32, 2, 9, 2, 32, 8).double()        # [chunk][nb][term][tap][kg][co][j]
+    unscale = pk.w[nbytes // 2:].view(torch.float32).double()
+    dec = (raw[:, :, 0] + raw[:, :, 1]).permute(1, 4, 0, 3, 5, 2).reshape(cout, cin, 9)                            # [nb][co][chunk][kg][j][tap]
+    e_in = torch.tensor(e_chunks).repeat_interleave(16).double()
+    want = w.double().reshape(cout, cin, 9) * (2.0 ** -e_in).view(1, -1, 1) / unscale.view(-1, 1, 1)
+    assert float(((dec - want).abs() / want.abs().amax((1, 2), keepdim=True)).max()) <= 2.0 ** -22
+    top = (raw[:, :, 0].abs().permute(1, 4, 0, 3, 5, 2).reshape(cout, -1)).amax(1)
+    assert bool(((top >= 2.0 ** 13) & (top < 2.0 ** 14)).all())
+    assert torch.equal(pk.b, b)

@@ -352,7 +352,7 @@ def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkey
     x = torch.rand([1, 3, 756, 1008], generator=g).cuda()
     c = torch.rand([1, 756, 1008], generator=g).cuda()
     frames = {}
-    for mode in ('bf16x6', 'f16x3'):                     # f16x3 = the default: its per-tile activation scale must not depend on the launch
+    for mode in ('bf16x6', 'f16x3', 'f16x3p'):           # per-tile (f16x3) / per-tensor (f16x3p, the default) scales must not depend on the launch
         net.k4_mode = mode
         monkeypatch.setenv('K4_SR_GROUP', '8')
         a = net.tile_process_device(x, c, 510, 10).clone()
@@ -369,7 +369,158 @@ def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkey
     f = net.tile_process_device(x, c, 510, 10).clone()
     p = psnr(a.cpu(), f.cpu())
     assert p >= 110.0, p
-    h = frames['f16x3']
-    ph = psnr(h.cpu(), f.cpu())
-    print(f'full frame vs fp32-MFMA: bf16x6 {p:.1f} dB, f16x3 {ph:.1f} dB')
-    assert ph >= 110.0, ph
+    ph = psnr(frames['f16x3'].cpu(), f.cpu())
+    pp = psnr(frames['f16x3p'].cpu(), f.cpu())
+    print(f'full frame vs fp32-MFMA: bf16x6 {p:.1f} dB, f16x3 {ph:.1f} dB, f16x3p {pp:.1f} dB')
+    assert ph >= 110.0 and pp >= 110.0, (ph, pp)
+    assert net._k4.get('p16_reruns', 0) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pre-split activations ('f16x3p', csrc/k4_sr_p16.hip): producers, consumer, whole network, overflow path
+# ---------------------------------------------------------------------------------------------------------------------
+def _p16_conv(pk, xp, x_off, x_stride, y, y_off, y_stride, H, W, flags=0, res=None, out_exp=None, ovf=None):
+    from nerf4k_amd import _native as N
+    jobs = (N.ConvJob * 1)()
+    jobs[0].x = xp.data_ptr() + 4 * x_off
+    jobs[0].y = y.data_ptr() + 4 * y_off
+    jobs[0].res = None if res is None else res[0].data_ptr() + 4 * res[1]
+    jobs[0].mod_x = None
+    jobs[0].H, jobs[0].W = H, W
+    rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
+    if ovf is None:
+        ovf = torch.zeros([8], dtype=torch.int32, device='cuda')
+    N.check(N.lib().k4_conv3x3_p16_multi(jobs, 1, pk.cin, x_stride, N.ptr(pk.w), N.f32(pk.b), pk.cout, y_stride, flags, 0.2, rs, rscale,
+                                         0.0 if out_exp is None else float(2.0 ** out_exp), N.ptr(ovf), N.stream()), 'k4_conv3x3_p16_multi')
+    return ovf
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 32), (160, 32), (192, 64), (64, 64)])
+def test_p16_conv_layer(cin, cout):
+    """k4_conv3x3_p16_multi on hand-packed pre-split input (two slices under different exponents, read from the middle of a wider image)
+    against an fp64 convolution: fp32 output with LeakyReLU + residual, pre-split output (decoded), the x2-upsampling loader, ragged
+    sizes, and the overflow word."""
+    import torch.nn.functional as F
+    from nerf4k_amd.lib.sr_esrnet import _PackedP16, EPI_LRELU, EPI_RES, PRE_UP2X
+    g = torch.Generator().manual_seed(cin + cout)
+    for (H, W) in ((19, 41), (8, 32), (1, 1), (33, 70)):
+        x = torch.randn([H, W, cin], generator=g)
+        x[..., 64:] *= 0.03                                      # the second "tensor" is 30x smaller and carries its own exponent
+        e_chunks = [4] * 4 + [9] * ((cin - 64) // 16)
+        xp = torch.zeros([H, W, 224], dtype=torch.int32)
+        xp[..., 16:16 + 64] = helpers.to_p16(x[..., :64], 4)
+        if cin > 64:
+            xp[..., 80:16 + cin] = helpers.to_p16(x[..., 64:], 9)
+        xd = torch.cat([helpers.from_p16(xp[..., 16:80], 4)] + ([helpers.from_p16(xp[..., 80:16 + cin], 9)] if cin > 64 else []), -1)
+        w = torch.randn([cout, cin, 3, 3], generator=g) / (cin * 9) ** 0.5
+        b = torch.randn([cout], generator=g)
+        res = torch.randn([H, W, 72], generator=g)
+        pk = _PackedP16(w.cuda(), b.cuda(), e_chunks)
+        ref = F.conv2d(xd.permute(2, 0, 1).unsqueeze(0), w.double(), b.double(), padding=1)
+        want = (F.leaky_relu(ref, 0.2)[0].permute(1, 2, 0) * 0.2 + res[..., 4:4 + cout].double())
+        y = torch.zeros([H, W, 112]).cuda()
+        ovf = _p16_conv(pk, xp.cuda(), 16, 224, y, 32, 112, H, W, EPI_LRELU | EPI_RES, res=(res.cuda(), 4, 72, 0.2))
+        err = float((y[..., 32:32 + cout].cpu().double() - want).abs().max())
+        assert err < 5e-6, (cin, cout, H, W, err)
+        assert float(y[..., :32].abs().max()) == 0 and float(y[..., 32 + cout:].abs().max()) == 0 and int(ovf.sum()) == 0
+        # pre-split output (no residual), decoded
+        E_out = 7
+        yp = torch.zeros([H, W, 112], dtype=torch.int32).cuda()
+        ovf = _p16_conv(pk, xp.cuda(), 16, 224, yp, 32, 112, H, W, EPI_LRELU, out_exp=E_out)
+        wantp = F.leaky_relu(ref, 0.2)[0].permute(1, 2, 0)
+        got = helpers.from_p16(yp[..., 32:32 + cout], E_out)
+        assert float((got - wantp).abs().max()) < 5e-6 and int(ovf.sum()) == 0 and int(yp[..., :32].abs().max()) == 0
+        # and it is exactly the split of the fp32 output of the same launch arithmetic
+        y32 = torch.zeros([H, W, 112]).cuda()
+        _p16_conv(pk, xp.cuda(), 16, 224, y32, 32, 112, H, W, EPI_LRELU)
+        assert torch.equal(yp[..., 32:32 + cout].cpu(), helpers.to_p16(y32[..., 32:32 + cout].cpu(), E_out))
+        # a scale that does not fit fp16 raises the window's overflow word
+        ovf = _p16_conv(pk, xp.cuda(), 16, 224, yp, 32, 112, H, W, EPI_LRELU, out_exp=30)
+        assert int(ovf[0]) == 1 and int(ovf[1:].sum()) == 0
+        # nearest x2 upsampling folded into the DMA addressing
+        yu = torch.zeros([2 * H, 2 * W, 112]).cuda()
+        _p16_conv(pk, xp.cuda(), 16, 224, yu, 32, 112, 2 * H, 2 * W, EPI_LRELU | PRE_UP2X)
+        refu = F.leaky_relu(F.conv2d(F.interpolate(xd.permute(2, 0, 1).unsqueeze(0), scale_factor=2, mode='nearest'), w.double(), b.double(), padding=1), 0.2)
+        assert float((yu[..., 32:32 + cout].cpu().double() - refu[0].permute(1, 2, 0)).abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize('C', [64, 32])
+def test_sft_layer_p16_output_is_the_split_of_the_fp32_output(C):
+    """k4_sft_nhwc_p16_multi == to_p16(k4_sft_nhwc_multi): same arithmetic, the producer only changes how the result is stored (pins the
+    lane exchange of the 16-byte units bit for bit), incl. a pixel count that does not fill the last wave and the overflow word."""
+    from nerf4k_amd import _native as N
+    torch.manual_seed(C + 1)
+    layer = sr_esrnet.SFTLayer(C, 32).cuda()
+    for p in layer.parameters():
+        p.data.normal_(0, 0.3)
+    wp = sr_esrnet.pack_sft(layer)
+    H, W = 13, 37
+    cond = torch.randn([H, W, 32]).cuda()
+    x = torch.randn([H, W, 64]).cuda()
+    y32 = torch.zeros([H, W, 208]).cuda()
+    yp = torch.zeros([H, W, 208], dtype=torch.int32).cuda()
+    ovf = torch.zeros([8], dtype=torch.int32).cuda()
+    off = 64 if C == 64 else 160
+    for out, p16 in ((y32, False), (yp, True)):
+        jobs = (N.SftJob * 1)()
+        jobs[0].cond, jobs[0].x, jobs[0].y, jobs[0].res, jobs[0].n_pix = cond.data_ptr(), x.data_ptr(), out.data_ptr() + 4 * off, None, H * W
+        if p16:
+            N.check(N.lib().k4_sft_nhwc_p16_multi(jobs, 1, 32, N.f32(wp), 64, 208, C, 0.2, float(2.0 ** 5), N.ptr(ovf), N.stream()), 'sft p16')
+        else:
+            N.check(N.lib().k4_sft_nhwc_multi(jobs, 1, 32, N.f32(wp), 64, 208, C, 0.2, 0, 0.0, 1, N.stream()), 'sft')
+    assert torch.equal(yp[..., off:off + C].cpu(), helpers.to_p16(y32[..., off:off + C].cpu(), 5))
+    assert int(yp[..., :off].abs().max()) == 0 and int(yp[..., off + C:].abs().max()) == 0 and int(ovf.sum()) == 0
+    jobs[0].y = yp.data_ptr() + 4 * off
+    N.check(N.lib().k4_sft_nhwc_p16_multi(jobs, 1, 32, N.f32(wp), 64, 208, C, 0.2, float(2.0 ** 40), N.ptr(ovf), N.stream()), 'sft p16')
+    assert int(ovf[0]) == 1
+
+
+@pytest.mark.parametrize('hw', [(40, 56), (33, 65), (8, 32), (1, 1)])
+def test_f16x3p_network_vs_oracle(hw):
+    """The default decoder arithmetic (pre-split activations under calibrated per-tensor scales) against the CPU oracle: >= 110 dB as
+    'f16x3', no overflow re-run on in-range inputs, and the same function through tile_process."""
+    sd = osr.make_state_dict(seed=7, num_block=5)
+    net = _net(sd, 5)
+    assert net.k4_mode == 'f16x3p' or os.environ.get('K4_SR_MODE')
+    net.k4_mode = 'f16x3p'
+    g = torch.Generator().manual_seed(hw[0] * 100 + hw[1])
+    x = torch.rand([1, 3, *hw], generator=g)
+    cond = torch.rand([1, 1, *hw], generator=g)
+    want = osr.sftnet_forward(sd, x, cond)
+    with torch.no_grad():
+        got = net(x.cuda(), cond.cuda()).cpu()
+        net.k4_mode = 'f16x3'
+        safe = net(x.cuda(), cond.cuda()).cpu()
+    p, ps = psnr(got, want), psnr(safe, want)
+    print(f'{hw}: f16x3p {p:.1f} dB, f16x3 {ps:.1f} dB vs oracle; max|err| {float((got - want).abs().max()):.2e}')
+    assert p >= 110.0 and float((got - want).abs().max()) <= 2e-5, (p, ps)
+    assert net._k4.get('p16_reruns', 0) == 0
+    E = net._k4['p16']['E']
+    assert len(E) == len(net._p16_names()) and all(-100 <= e <= 100 for e in E.values())
+
+
+def test_f16x3p_overflow_windows_are_redone_in_f16x3(monkeypatch):
+    """Exponents that push every tensor beyond fp16 (calibration target 2^40): every window raises its overflow word and is decoded again on
+    the per-tile kernels -- the result is the 'f16x3' result, bit for bit; inputs 1000x the calibration probe do the same through the
+    real mechanism."""
+    sd = osr.make_state_dict(seed=11, num_block=2)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand([1, 3, 72, 90], generator=g).cuda()
+    c = torch.rand([1, 72, 90], generator=g).cuda()
+    net = _net(sd, 2)
+    with torch.no_grad():
+        net.k4_mode = 'f16x3'
+        want = net.tile_process_device(x, c, 40, 10).clone()
+        big = net.tile_process_device(x * 3e4, c, 40, 10).clone()
+        net.k4_mode = 'f16x3p'
+        ok = net.tile_process_device(x, c, 40, 10).clone()
+        assert net._k4.get('p16_reruns', 0) == 0 and psnr(ok.cpu(), want.cpu()) >= 110.0
+        gotbig = net.tile_process_device(x * 3e4, c, 40, 10).clone()
+        n_big = net._k4.get('p16_reruns', 0)
+        assert n_big > 0 and torch.equal(gotbig, big), n_big
+    monkeypatch.setattr(sr_esrnet, 'P16_TARGET_EXP', 40)
+    net2 = _net(sd, 2)
+    net2.k4_mode = 'f16x3p'
+    with torch.no_grad():
+        got = net2.tile_process_device(x, c, 40, 10)
+    assert net2._k4.get('p16_reruns', 0) == 6 and torch.equal(got, want)
