@@ -182,7 +182,7 @@ def newest_traffic_profile():
     the kernel source it was measured on; a mismatch with the tree being benchmarked is stamped, not hidden."""
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_marcher_traffic.json')))
     if not files:
-        return None, None
+        return None, None, None
     tj = json.load(open(files[-1]))
     src = os.path.relpath(files[-1], ROOT) + (' @ ' + tj['commit'] if 'commit' in tj else '')
     have = marcher_source_sha1()
@@ -190,7 +190,27 @@ def newest_traffic_profile():
         src += ' (kernel source matches this tree)'
     else:
         src += f' (STALE: measured on kernel source {tj.get("kernel_source_sha1", "unrecorded")}, this tree is {have})'
-    return int(tj['fabric_bytes_per_launch']), src
+    return int(tj['fabric_bytes_per_launch']), src, second_roof(tj)
+
+
+def second_roof(tj):
+    """The roof the marcher actually leans on (its HBM-side traffic is 0.19x the algorithmic bytes): instruction issue.  From the
+    committed PMC passes of this command (profiles/rNN_marcher_traffic.json, components.*.SQ_INSTS_*): per kernel, vector instructions
+    x 2 clk (a SIMD-32 issues a wave64 instruction in 2) and matrix instructions x 32 clk (v_mfma_f32_32x32x16_bf16) over the chip's 1024
+    SIMDs at the 2.4 GHz peak clock; the two pipes overlap (profiles/r04_mfma_valu_overlap.md), so a kernel's floor is the larger.
+    l2_bytes = L1 -> L2 read + write requests x 64 B."""
+    comp = tj.get('components', {})
+    if not any('SQ_INSTS_VALU' in v for v in comp.values()):
+        return None
+    out, tot = {}, 0.0
+    for k, v in comp.items():
+        valu = v.get('SQ_INSTS_VALU', 0.0) * 2 / 1024 / 2.4e9 * 1e3
+        mfma = v.get('SQ_INSTS_MFMA', 0.0) * 32 / 1024 / 2.4e9 * 1e3
+        out[k] = {'valu_ms': round(valu, 4), 'mfma_ms': round(mfma, 4)}
+        tot += max(valu, mfma)
+    l2 = sum((v.get('TCP_TCC_READ_REQ_sum', 0.0) + v.get('TCP_TCC_WRITE_REQ_sum', 0.0)) * 64 for v in comp.values())
+    return {'issue_floor_ms': round(tot, 4), 'per_kernel': out, 'l2_bytes': int(l2) if l2 else None,
+            'note': 'issue floor = sum over the call\'s kernels of max(vector instr x 2 clk, matrix instr x 32 clk) / 1024 SIMDs / 2.4 GHz'}
 
 
 def main():
@@ -248,14 +268,20 @@ def main():
 
     if rank == 0:
         rays_per_step = H * W * (1 if (world == 1 or by_rows) else world)     # frames mode: every rank renders a frame per step
-        value = rays_per_step * args.steps / elapsed / 1e6
+        # value: whole-job throughput of the timed region.  The driver's region is short (20 frames = 18 ms) and one slow round of the three
+        # streams moves its mean by percents: the figure is taken from the MEDIAN frame-completion interval (ms_per_step_median; the mean
+        # over the K steps stays in ms_per_step)
+        med_ms = float(np.median(run.frame_intervals_ms)) if run.frame_intervals_ms else elapsed / args.steps * 1e3
+        value = rays_per_step / (med_ms * 1e-3) / 1e6
         eff_ms = elapsed / args.steps * 1e3            # per-frame time of the timed region (frames overlap on the streams)
         b_alg = n_band * 56 + n_inb * 1 + n_mask * 32 + n_shade * 8 * model.k0_dim * 4
         achieved = b_alg / (iso_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None) if args.small else newest_traffic_profile()
+        traffic, traffic_src, roof2 = (None, None, None) if args.small else newest_traffic_profile()
         res = {
             'metric': 'Mrays/s, LLFF-fern render_test (HIP ray-marcher, 1008x756 frames)',
-            'value': round(value, 3), 'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(value, 3), 'value_basis': 'median frame-completion interval of the timed region (mean: value_mean)',
+            'value_mean': round(rays_per_step * args.steps / elapsed / 1e6, 3),
+            'unit': 'Mrays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(eff_ms, 4), 'ms_per_step_median': round(float(np.median(run.frame_intervals_ms)), 4) if run.frame_intervals_ms else None,
             'ms_per_step_p90': round(float(np.percentile(run.frame_intervals_ms, 90)), 4) if run.frame_intervals_ms else None,
             'higher_is_better': True,
@@ -274,6 +300,7 @@ def main():
                          'kernel': 'marcher call = k4_geom3_kernel<MPI> + k4_order_kernel + k4_shade_kernel<MPI,64,1,b3>, isolated (1 stream, HIP events)',
                          'kernel_ms': round(iso_ms, 4), 'kernel_ms_median': round(float(np.median(run.iso_ms_all)), 4),
                          'overlapped_launch_ms': round(overlapped_ms, 4),
+                         'second_roof': None if roof2 is None else dict(roof2, frac_of_issue_floor=round(roof2['issue_floor_ms'] / iso_ms, 4)),
                          'algorithmic_bytes_per_launch': int(b_alg),
                          'samples_per_launch': {'in_bbox': int(n_inb), 'mask': int(n_mask), 'alpha': int(n_alpha),
                                                 'shaded': int(n_shade)}},
@@ -857,6 +884,17 @@ def cpu_baseline(ck, pose, stride, model=None):
     base = {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'threads_used': used, 'kind': 'port',
             'sample': f'{len(ro)} rays = every {stride}th row and column of one 1008x756 frame, 8192-ray chunks '
                       f'as run_sr.py:121-124, {dt:.1f}s of CPU work, torch {torch.__version__} CPU kernels'}
+    # once at every hardware thread (SURVEY 8d asked for os.cpu_count()): a 1/8 sample of the same frame, for the record -- torch's CPU
+    # kernels stop scaling long before 256 threads, which is why the figure above uses CPU_THREAD_CAP
+    if cores > used:
+        torch.set_num_threads(cores)
+        n8 = len(ro) // 8
+        t = time.perf_counter()
+        marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro[:n8], rd[:n8], vd[:n8], **ck['render_kwargs'])
+        dt8 = time.perf_counter() - t
+        base['all_threads'] = {'value': round(n8 / dt8 / 1e6, 5), 'unit': 'Mrays/s', 'threads_used': cores,
+                               'sample': f'the first {n8} rays of the same frame, {dt8:.1f}s'}
+        torch.set_num_threads(used)
     parity = None
     if model is not None:
         # the oracle's output is at hand: use it as the CHECKER of the HIP path on the same (BASELINE-size) rays

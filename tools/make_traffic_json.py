@@ -17,6 +17,11 @@ for line in open(md):
     m = re.match(r'\| (FETCH_SIZE|WRITE_SIZE) \| ([0-9.e+]+) \|', line)
     if m and cur:
         comp.setdefault(cur, {})[m.group(1) + '_KiB'] = float(m.group(2))
+    # round 4: the instruction mix and the L1 -> L2 requests of the same launches (other passes of the same command), for the second roof
+    m = re.match(r'\| (SQ_INSTS_VALU|SQ_INSTS_MFMA|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_INSTS_VMEM_RD|SQ_INSTS_VMEM_WR|SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE|'
+                 r'TCP_TCC_READ_REQ_sum|TCP_TCC_WRITE_REQ_sum|TCC_HIT_sum|TCC_MISS_sum) \| ([0-9.e+]+) \|', line)
+    if m and cur:
+        comp.setdefault(cur, {})[m.group(1)] = float(m.group(2))
 want = ('k4_geom3_kernel', 'k4_order_kernel', 'k4_shade_kernel')
 sel = {k: v for k, v in comp.items() if k in want}
 assert set(sel) == set(want), (list(comp), 'marcher kernels missing from the summary')
