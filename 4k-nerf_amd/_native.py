@@ -127,6 +127,7 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv_weight_p16_bytes': ([_I32, _I32], C.c_int64),
+    'k4_conv_weight_p16_up2x_bytes': ([_I32, _I32], C.c_int64),
     'k4_conv3x3_p16_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F, _F, _P, _P], C.c_int),
     'k4_sft_nhwc_p16_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _F, _P, _P], C.c_int),
     'k4_absmax_slice': ([_P, _I64, _I32, _I32, _P, _P], C.c_int),

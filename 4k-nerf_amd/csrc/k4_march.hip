@@ -730,9 +730,9 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
 #define K4_TPASS
 #endif
 // max(x, 0) in ONE instruction, on the bit pattern: v_max_i32(bits, 0) -- a negative float is a negative integer, a non-negative one keeps
-// its bits.  fmaxf(x, 0.f) compiles to a canonicalising v_max_f32 plus the max (and v_med3_f32 is folded back into that pair), and vector
-// instructions do not hide under the matrix instructions on this chip (tools/micro/mfma_valu_overlap.hip): 128 of the ~1400 vector
-// instructions of a 64-record batch were the second half of a ReLU.  Same values for every non-NaN input (-0 -> +0 either way); a NaN
+// its bits.  fmaxf(x, 0.f) compiles to a canonicalising v_max_f32 plus the max (and v_med3_f32 is folded back into that pair), and the
+// kernel is bound by its vector work (a wave hides at most ~5 vector instructions per MFMA, profiles/r04_mfma_valu_overlap.md; this
+// stream carries ~17): 128 of the ~1400 vector instructions of a 64-record batch were the second half of a ReLU.  Same values for every non-NaN input (-0 -> +0 either way); a NaN
 // with a clear sign bit stays NaN as in torch.relu (fmaxf turned it into 0).  Not inline asm: the compiler must see the instruction
 // to insert the wait states between an MFMA writing a register and a vector instruction reading it.
 __device__ __forceinline__ float k4_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }

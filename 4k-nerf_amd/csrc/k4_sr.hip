@@ -282,8 +282,8 @@ typedef _Float16 k4s_f16x2 __attribute__((ext_vector_type(2)));
 // 4 channels, scaled by the power of two `sc` -> fp16 hi (RNE) and fp16 lo = RNE(x*sc - hi): x*sc == hi + lo up to 2^-22 relative
 // hi = RNE_fp16(v * sc), lo = RNE_fp16(v * sc - hi) for four values, sc a power of two: 8 x v_fma_mix{lo,hi}_f16 (the fp32 FMA is exact here,
 // one rounding to fp16 each; the high term adds -0.0 so that a negative zero keeps its sign).  The plain C++ form compiles to 16
-// instructions (hipcc does not form fma_mix), and vector instructions do not hide under matrix instructions on gfx950
-// (tools/micro/mfma_valu_overlap.hip): bit-identical results (tools/micro/fma_mix_split.hip).
+// instructions (hipcc does not form fma_mix); the staging phase they sit in runs between two barriers, outside the matrix phase, so every
+// instruction there is exposed (profiles/r04_mfma_valu_overlap.md): bit-identical results (tools/micro/fma_mix_split.hip).
 #ifndef K4S_ASM_SPLIT
 #define K4S_ASM_SPLIT 1
 #endif
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
     // ioff: offset of the item from the image base -- in BYTES when the window's image is below 2 GB (buf_ok), else in elements -- or
     // K4_V2_OOB for an item outside the image / past the tile.  Whole chunks of 16-byte aligned images below 2 GB are fetched through a
     // buffer descriptor of the window: an offset beyond its range returns zeros in hardware -- no select per component, no 64-bit
-    // address arithmetic per load (vector instructions do not hide under the matrix instructions).
+    // address arithmetic per load (the staging phase is not covered by matrix work: every vector instruction in it is exposed).
 #define K4_V2_OOB 0x80000000u
     unsigned ioff[IN_PER];
     bool vec_ok, buf_ok;
@@ -900,8 +900,8 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                    (!(P.flags & K4_EPI_RES) || (long long)T.H * T.W * P.res_stride * 4 <= 0x80000000LL)) {
             // Fast path (every tile but the last column of an image): the tile is whole in x and the images are below 2 GB -> buffer
             // stores / residual loads with the lane's offset computed ONCE per row and the element's pixel offset as a scalar (e is a
-            // compile-time index).  The general path below spends ~10 vector instructions per stored element on 64-bit addresses, and
-            // vector instructions do not hide under matrix instructions on this chip.  Same values: max(v, v * slope) == LeakyReLU for
+            // compile-time index).  The general path below spends ~10 vector instructions per stored element on 64-bit addresses, none of
+            // them covered by matrix work (the epilogue has none).  Same values: max(v, v * slope) == LeakyReLU for
             // 0 <= slope <= 1.
             const unsigned long long ya_ = (unsigned long long)T.y, ra_ = (unsigned long long)T.res;
             const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(

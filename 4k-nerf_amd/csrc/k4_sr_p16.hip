@@ -30,6 +30,7 @@
 #define P16_ACT_INSTR ((P16_ACT_ITEMS + 63) / 64)   /* 22 wave-instructions of 1 KB (the last one 16 lanes) */
 #define P16_W_BYTES (2 * 9 * 2 * 32 * 16)           /* 18432: [term][tap][channel group][32 co] x 8 fp16 */
 #define P16_W_INSTR (P16_W_BYTES / 1024)            /* 18 */
+#define P16_W_BYTES_UP (2 * 4 * 2 * 32 * 16)        /* 8192: [term][2 x 2 tap][channel group][32 co] x 8 fp16, per phase */
 
 struct P16Conv {
     int n;
@@ -46,8 +47,18 @@ struct P16Conv {
                              // chunk 0 only, 256 = no MFMAs, 512 = every pixel reads pixel 0 (no HBM traffic)
 };
 
-template <bool OUT16>
+// UP (K4_PRE_UPSAMPLE2X): the layer reads its input through a nearest x2 upsampling (lib/sr_esrnet.py:461-463).  Output pixel (2Y + py, 2X + px)
+// then sees only a 2 x 2 neighbourhood of LR pixels -- the 3 x 3 taps that land on the same LR pixel add up: per PHASE (py, px) the layer is a
+// 2 x 2 convolution with the weights W'[a][b] = sum of the taps (dy, dx) with (py + dy - 1) >> 1 == a + py - 1 (rows; same for columns), 16
+// tap matrices instead of 36 per 2 x 2 output pixels: 2.25x fewer matrix instructions, exact algebra (the tap sums are formed in fp32 by the
+// packer: the products differ from the 9-tap form by one rounding of a weight sum).  A workgroup = 8 x 32 LR positions of ONE phase; the four
+// phase workgroups of a tile are adjacent in launch order (the tile's activations come from L2 three times out of four).
+template <bool OUT16, bool UP>
 __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
+    constexpr int W_CH = UP ? P16_W_BYTES_UP : P16_W_BYTES;           // weight bytes of one (chunk, output block[, phase])
+    constexpr int W_NI = W_CH / 1024;                                  // DMA instructions
+    constexpr int NSUB = UP ? 8 : 18;                                  // sub-stages (tap x row) per chunk
+    constexpr int NTAP = UP ? 4 : 9;
     __shared__ __attribute__((aligned(16))) unsigned char wbuf0[P16_W_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf1[P16_W_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char abuf0[P16_ACT_BYTES];
@@ -61,17 +72,18 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     while (g + 1 < M.n && b >= M.blk_end[g]) ++g;
     const int local = b - (g ? M.blk_end[g - 1] : 0);
     const int nb_count = M.cout >> 5;
-    const int tile = local / nb_count, nb = local - tile * nb_count;
-    const int H = M.H[g], W = M.W[g];
-    const bool ups = (M.flags & K4_PRE_UPSAMPLE2X) != 0;
-    const int srcH = ups ? H >> 1 : H, srcW = ups ? W >> 1 : W;
+    const int phase = UP ? (local & 3) : 0, py = phase >> 1, px = phase & 1;
+    const int lt = UP ? (local >> 2) : local;
+    const int tile = lt / nb_count, nb = lt - tile * nb_count;
+    const int H = M.H[g], W = M.W[g];                                  // OUTPUT size; the tile grid and the DMA plan live on the input (LR) image
+    const int srcH = UP ? H >> 1 : H, srcW = UP ? W >> 1 : W;
     const int tiles_x = M.tiles_x[g];
-    const int x0 = (tile % tiles_x) * 32, y0 = (tile / tiles_x) * 8;
+    const int x0 = (tile % tiles_x) * 32, y0 = (tile / tiles_x) * 8;   // input-image coordinates of the tile
     const int nchunks = M.cin >> 4;
 
     // ---- DMA plan of this thread (chunk independent): activation instructions k = wv + 4 i, weight instructions k = wv + 4 i ----
     const __amdgpu_buffer_rsrc_t xrs = p16_rsrc(M.x[g], (unsigned)(((long long)(srcH * srcW - 1) * M.cin_stride + M.cin) * 4));
-    const __amdgpu_buffer_rsrc_t wrs = p16_rsrc(M.w, (unsigned)(nchunks * nb_count * P16_W_BYTES));
+    const __amdgpu_buffer_rsrc_t wrs = p16_rsrc(M.w, (unsigned)(nchunks * nb_count * (UP ? 4 : 1) * W_CH));
     unsigned aoff[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -79,17 +91,16 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         const int p = item >> 2, j = item & 3;
         const int row = p / P16_COLS, col = p - row * P16_COLS;
         const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-        const bool inside = item < P16_ACT_ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const int sy = ups ? gy >> 1 : gy, sx = ups ? gx >> 1 : gx;
-        aoff[i] = inside ? (unsigned)(((M.debug & 512) ? 0 : (sy * srcW + sx) * M.cin_stride * 4) + ((j ^ ((col >> 2) & 3)) << 4)) : P16_OOB;
+        const bool inside = item < P16_ACT_ITEMS && gy >= 0 && gy < srcH && gx >= 0 && gx < srcW;
+        aoff[i] = inside ? (unsigned)(((M.debug & 512) ? 0 : (gy * srcW + gx) * M.cin_stride * 4) + ((j ^ ((col >> 2) & 3)) << 4)) : P16_OOB;
     }
     const unsigned woff = (unsigned)(lane * 16);
 #define P16_ISSUE(CH, WB, AB) do { \
-        const int wso_ = ((CH) * nb_count + nb) * P16_W_BYTES; \
+        const int wso_ = (((CH) * nb_count + nb) * (UP ? 4 : 1) + phase) * W_CH; \
         const int aso_ = (CH) * 64; \
         _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) { \
             const int k_ = wv + 4 * i_; \
-            if (k_ < P16_W_INSTR && (!(M.debug & 128) || (CH) == 0)) \
+            if (k_ < W_NI && (!(M.debug & 128) || (CH) == 0)) \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(WB + k_ * 1024), 16, (int)woff, wso_ + k_ * 1024, 0, 0); \
         } \
         _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { \
@@ -105,15 +116,15 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = l31 + dx;
-            ard[dx][t] = (unsigned)((wv * 2 * P16_COLS + col) * 64 + (((2 * t + half) ^ ((col >> 2) & 3)) << 4));
+            const int col = l31 + dx + (UP && dx < 2 ? px : 0);           // UP: column taps b = 0, 1 read haloed columns l31 + b + px (ard[2] unused)
+            ard[dx][t] = (unsigned)(((wv * 2 + (UP ? py : 0)) * P16_COLS + col) * 64 + (((2 * t + half) ^ ((col >> 2) & 3)) << 4));
         }
 
     // per-lane epilogue tables: output channels co(q, e) = nb*32 + 8q + 4 half + e
     const int cob = nb * 32 + 4 * half;
     p16_f32x4 us[4], bs[4];
     {
-        const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(M.w) + (size_t)nchunks * nb_count * P16_W_BYTES);
+        const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(M.w) + (size_t)nchunks * nb_count * (UP ? 4 : 1) * W_CH);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             us[q] = *reinterpret_cast<const p16_f32x4*>(wtail + cob + 8 * q);
@@ -126,13 +137,17 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 
     P16_ISSUE(0, wbuf0, abuf0);
 
+    // tap t -> (row, column) offset in the haloed tile: 3 x 3 taps (dy, dx) = (t / 3, t % 3); UP: 2 x 2 taps (a, b) = (t / 2, t % 2), the phase's
+    // offset already sits in ard
+#define P16_TROW(T) (UP ? (T) / 2 : (T) / 3)
+#define P16_TCOL(T) (UP ? (T) % 2 : (T) % 3)
 #define P16_RDW(DST, WB, T) do { \
-        DST[0] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (0 * 9 + (T)) * 1024); \
-        DST[1] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (1 * 9 + (T)) * 1024); } while (0)
+        DST[0] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (0 * NTAP + (T)) * 1024); \
+        DST[1] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (1 * NTAP + (T)) * 1024); } while (0)
 #define P16_RDX(DST, AB, U) do { \
         const int t_ = (U) >> 1, r_ = (U) & 1; \
-        DST[0] = *reinterpret_cast<const p16_u32x4*>(AB + ard[t_ % 3][0] + (r_ + t_ / 3) * (P16_COLS * 64)); \
-        DST[1] = *reinterpret_cast<const p16_u32x4*>(AB + ard[t_ % 3][1] + (r_ + t_ / 3) * (P16_COLS * 64)); } while (0)
+        DST[0] = *reinterpret_cast<const p16_u32x4*>(AB + ard[P16_TCOL(t_)][0] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); \
+        DST[1] = *reinterpret_cast<const p16_u32x4*>(AB + ard[P16_TCOL(t_)][1] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); } while (0)
     // one chunk: its DMA has been issued an iteration ago; wait, barrier, issue the next chunk's DMA into the other buffers, 18 sub-stages
     // (tap x row) of 3 MFMAs with the fragments of sub-stage u + 2 / tap t + 1 read under the MFMAs of u
 #define P16_CHUNK(CH, WB, AB, WBN, ABN) do { \
@@ -143,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         P16_RDX(xb[0], AB, 0); \
         P16_RDX(xb[1], AB, 1); \
         if (!(M.debug & 256)) \
-        _Pragma("unroll") for (int u = 0; u < 18; ++u) { \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u) { \
             const int t = u >> 1, r = u & 1; \
-            if (r == 0 && t + 1 < 9) P16_RDW(wa[(t + 1) & 1], WB, t + 1); \
-            if (u + 2 < 18) P16_RDX(xb[(u + 2) % 3], AB, u + 2); \
+            if (r == 0 && t + 1 < NTAP) P16_RDW(wa[(t + 1) & 1], WB, t + 1); \
+            if (u + 2 < NSUB) P16_RDX(xb[(u + 2) % 3], AB, u + 2); \
             __builtin_amdgcn_sched_barrier(0); \
             const p16_f16x8 wh = __builtin_bit_cast(p16_f16x8, wa[t & 1][0]), wl = __builtin_bit_cast(p16_f16x8, wa[t & 1][1]); \
             const p16_f16x8 xh = __builtin_bit_cast(p16_f16x8, xb[u % 3][0]), xl = __builtin_bit_cast(p16_f16x8, xb[u % 3][1]); \
@@ -163,10 +178,12 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 #undef P16_CHUNK
 #undef P16_RDX
 #undef P16_RDW
+#undef P16_TROW
+#undef P16_TCOL
 #undef P16_ISSUE
 
     // ---- epilogue: lane = pixel (x0 + l31, row y0 + 2 wv + r), registers 4q .. 4q+3 = channels cob + 8q + 0..3 ----
-    const int gx = x0 + l31;
+    const int gx = UP ? 2 * (x0 + l31) + px : x0 + l31;               // output column of this lane
     const float sl = (M.flags & K4_EPI_LRELU) ? M.slope : 1.f;
     const bool has_res = (M.flags & K4_EPI_RES) != 0;
     const __amdgpu_buffer_rsrc_t yrs = p16_rsrc(M.y[g], (unsigned)(((long long)(H * W - 1) * M.cout_stride + M.cout) * 4));
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int gy = y0 + wv * 2 + r;
+        const int gy = UP ? 2 * (y0 + wv * 2 + r) + py : y0 + wv * 2 + r;
         if (gy >= H) continue;                                               // wave-uniform
         const bool ok = gx < W;
         const unsigned pix = (unsigned)(gy * W + gx);
@@ -220,6 +237,10 @@ extern "C" int64_t k4_conv_weight_p16_bytes(int32_t cout, int32_t cin) {
     if (cout <= 0 || cin <= 0 || (cout & 31) || (cin & 15)) return -1;
     return (int64_t)(cin / 16) * (cout / 32) * P16_W_BYTES + (int64_t)cout * 4;
 }
+extern "C" int64_t k4_conv_weight_p16_up2x_bytes(int32_t cout, int32_t cin) {       // the K4_PRE_UPSAMPLE2X operand: four phases of 2 x 2 taps
+    if (cout <= 0 || cin <= 0 || (cout & 31) || (cin & 15)) return -1;
+    return (int64_t)(cin / 16) * (cout / 32) * 4 * P16_W_BYTES_UP + (int64_t)cout * 4;
+}
 
 extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                                     const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
@@ -245,14 +266,19 @@ extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int
         const long long strd = cin_stride > cout_stride ? cin_stride : cout_stride;
         if ((long long)j.H * j.W * (strd > res_stride ? strd : res_stride) * 4 >= 0x80000000LL) return K4_ERR_UNSUPPORTED;      // 32-bit buffer offsets
         M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.H[g] = j.H; M.W[g] = j.W;
-        M.tiles_x[g] = (j.W + 31) / 32;
-        total += M.tiles_x[g] * ((j.H + 7) / 8) * nbc;
+        const bool up = (flags & K4_PRE_UPSAMPLE2X) != 0;              // the tile grid lives on the INPUT image; four phase workgroups per tile
+        const int gw = up ? j.W / 2 : j.W, gh = up ? j.H / 2 : j.H;
+        M.tiles_x[g] = (gw + 31) / 32;
+        total += M.tiles_x[g] * ((gh + 7) / 8) * nbc * (up ? 4 : 1);
         M.blk_end[g] = total;
     }
     M.total = total;
     const dim3 grid((unsigned)total), block(256);
-    if (out_scale != 0.f) hipLaunchKernelGGL((k4_conv_p16_kernel<true>), grid, block, 0, (hipStream_t)stream, M);
-    else hipLaunchKernelGGL((k4_conv_p16_kernel<false>), grid, block, 0, (hipStream_t)stream, M);
+    if (flags & K4_PRE_UPSAMPLE2X) {
+        if (out_scale != 0.f) hipLaunchKernelGGL((k4_conv_p16_kernel<true, true>), grid, block, 0, (hipStream_t)stream, M);
+        else hipLaunchKernelGGL((k4_conv_p16_kernel<false, true>), grid, block, 0, (hipStream_t)stream, M);
+    } else if (out_scale != 0.f) hipLaunchKernelGGL((k4_conv_p16_kernel<true, false>), grid, block, 0, (hipStream_t)stream, M);
+    else hipLaunchKernelGGL((k4_conv_p16_kernel<false, false>), grid, block, 0, (hipStream_t)stream, M);
     return k4_check_launch();
 }
 

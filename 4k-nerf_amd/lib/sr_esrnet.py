@@ -16,7 +16,6 @@ residual / nearest-x2 upsampling are fused into the conv, an SFTLayer is one lau
 (joint training, run_sr.py:869-1014) ``forward`` evaluates the graph of ``lib/sr_train.py``: every convolution forward, dgrad and
 wgrad on the MFMA kernels.  No CPU path.
 """
-import contextlib
 import math
 import os
 import time
@@ -32,7 +31,6 @@ from .. import _native as N
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
 DEFAULT_MODE = 'f16x3p'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
-DEFAULT_STREAMS = 1             # HIP streams the windows of a decoder pass are dealt to (K4_SR_STREAMS)
 P16_TARGET_EXP = 9              # calibration maps a tensor's largest magnitude into [2^9, 2^10): 64-128x head room below fp16's 65504
 
 
@@ -48,16 +46,6 @@ def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
                 m.weight.data *= scale
                 if m.bias is not None:
                     m.bias.data.fill_(bias_fill)
-
-
-_SIDE_STREAMS = {}
-
-
-def _side_streams(dev, n):
-    pool = _SIDE_STREAMS.setdefault(str(dev), [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
 
 
 class SFTLayer(nn.Module):
@@ -295,6 +283,43 @@ class _PackedP16:
         unscale = torch.ldexp(torch.ones([cout], dtype=torch.float32, device=dev), -a)
         self.w = torch.cat([both.view(torch.int16).reshape(-1), unscale.view(torch.int16)])
         assert self.w.numel() * 2 == N.lib().k4_conv_weight_p16_bytes(cout, cin)
+        self.b = bias.detach().float().contiguous().clone()
+        self.cin, self.cout, self.k = cin, cout, 3
+
+
+class _PackedP16Up(_PackedP16):
+    """The same for a layer that reads its input through a nearest x2 upsampling (K4_PRE_UPSAMPLE2X, lib/sr_esrnet.py:461-463): output pixel
+    (2Y + py, 2X + px) sees a 2 x 2 block of input pixels, the 3 x 3 taps landing on the same input pixel are added (fp32) -- four phases of
+    2 x 2 taps, 16 tap matrices instead of 36 per 2 x 2 outputs.  Operand: [cin/16][cout/32][phase py*2+px][hi|lo][tap a*2+b][2][32][8] fp16
+    + [cout] floats 2^-a[co]; tap (a, b) of phase (py, px) multiplies input pixel (Y - 1 + py + a, X - 1 + px + b)."""
+
+    def __init__(self, weight, bias, e_chunks):
+        cout, cin, k, _ = weight.shape
+        assert k == 3 and cout % 32 == 0 and cin % 16 == 0 and len(e_chunks) == cin // 16
+        dev = weight.device
+        e_in = torch.tensor(e_chunks, dtype=torch.int32, device=dev).repeat_interleave(16)
+        w = torch.ldexp(weight.detach().float(), -e_in.view(1, -1, 1, 1))
+        rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}                  # phase -> taps (dy or dx) that land on input offset a = 0 / 1
+        wc = torch.zeros([cout, cin, 4, 4], dtype=torch.float32, device=dev)
+        for py in (0, 1):
+            for px in (0, 1):
+                for a in (0, 1):
+                    for b in (0, 1):
+                        acc = None
+                        for dy in rows[py][a]:
+                            for dx in rows[px][b]:
+                                acc = w[:, :, dy, dx] if acc is None else acc + w[:, :, dy, dx]
+                        wc[:, :, py * 2 + px, a * 2 + b] = acc
+        m = wc.abs().amax((1, 2, 3)).double()
+        a_ = torch.where((m > 0) & torch.isfinite(m), 13 - torch.floor(torch.log2(m.clamp_min(1e-300))), torch.zeros_like(m)).clamp(-100, 100).to(torch.int32)
+        ws = torch.ldexp(wc, a_.view(-1, 1, 1, 1))
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.float()).to(torch.float16)
+        both = torch.stack([hi, lo], 0).reshape(2, cout // 32, 32, cin // 16, 2, 8, 4, 4)      # [term][nb][co][chunk][kg][j][phase][tap]
+        both = both.permute(3, 1, 6, 0, 7, 4, 2, 5).contiguous()                                # [chunk][nb][phase][term][tap][kg][co][j]
+        unscale = torch.ldexp(torch.ones([cout], dtype=torch.float32, device=dev), -a_)
+        self.w = torch.cat([both.view(torch.int16).reshape(-1), unscale.view(torch.int16)])
+        assert self.w.numel() * 2 == N.lib().k4_conv_weight_p16_up2x_bytes(cout, cin)
         self.b = bias.detach().float().contiguous().clone()
         self.cin, self.cout, self.k = cin, cout, 3
 
@@ -618,7 +643,8 @@ class SFTNet(nn.Module):
             for name, src in chain:
                 if hasattr(self, name):
                     m = getattr(self, name)
-                    pkp[name] = _PackedP16(m.weight, m.bias, [E[src]] * (m.weight.shape[1] // 16))
+                    cls = _PackedP16Up if name in ('conv_up1', 'conv_up2') else _PackedP16
+                    pkp[name] = cls(m.weight, m.bias, [E[src]] * (m.weight.shape[1] // 16))
             st['pk'] = pkp
         return st
 
@@ -655,38 +681,18 @@ class SFTNet(nn.Module):
         # (the pre-split kernels address an image through 32-bit byte offsets: windows whose 4x images reach 2 GB stay on 'f16x3')
         p16 = self.k4_mode == 'f16x3p' and all(h * w * 4 * max(self.num_feat + 4 * self.num_grow_ch, self.scale ** 2 * self.num_feat) < 2 ** 31 for h, w in hws)
         st = self._p16_state() if p16 else None
-        # K4_SR_STREAMS = S > 1: the windows are dealt to S groups, each group's layer sequence runs on its own HIP stream -- the last,
-        # partly filled round of workgroups of one group's layer overlaps the other group's next layer (a layer of a 4K frame is 6 rounds)
-        S = max(1, min(len(Bs), int(os.environ.get('K4_SR_STREAMS', str(DEFAULT_STREAMS)))))
-        order = sorted(range(len(Bs)), key=lambda j: (-hws[j][0] * hws[j][1], j))
-        groups = [sorted(order[g::S]) for g in range(S)]
-        cur = torch.cuda.current_stream(dev)
-        pool = _side_streams(dev, S) if S > 1 else [None]
-        ovfs = []
-        for gi, idx in enumerate(groups):
-            if S > 1:
-                pool[gi].wait_stream(cur)
-            with (torch.cuda.stream(pool[gi]) if S > 1 else contextlib.nullcontext()):
-                ovf = None
-                if p16:
-                    ovf = self._k4.setdefault(('ovf', slot0, gi, str(dev)), torch.zeros([N.K4_MAX_JOBS], dtype=torch.int32, device=dev))
-                    if S > 1:
-                        ovf.record_stream(pool[gi])
-                self._run_plan([Bs[j] for j in idx], [hws[j] for j in idx], (slot0, gi, S),
-                               p16=None if not p16 else {'E': st['E'], 'pk': st['pk'], 'ovf': ovf})
-                ovfs.append(ovf)
-        if S > 1:
-            for q in pool:
-                cur.wait_stream(q)
-            for B in Bs:
-                for t in B.values():
-                    t.record_stream(cur)
+        # (dealing the windows to two or four HIP streams so that one group's last, partly filled round of workgroups overlaps the other's
+        # next layer measured neutral on the 4K frame and slower on the 8-GPU rank share: profiles/r04_decoder_streams_neutral.md)
         if p16:
-            flags = torch.stack(ovfs).cpu().tolist()                       # the one host synchronisation of the pass
-            bad = sorted(groups[gi][q] for gi in range(S) for q in range(len(groups[gi])) if flags[gi][q])
+            ovf = self._k4.setdefault(('ovf', slot0, str(dev)), torch.zeros([N.K4_MAX_JOBS], dtype=torch.int32, device=dev))
+            self._run_plan(Bs, hws, slot0, p16={'E': st['E'], 'pk': st['pk'], 'ovf': ovf})
+            flags = ovf.cpu().tolist()                                     # the one host synchronisation of the pass
+            bad = [j for j in range(len(Bs)) if flags[j]]
             if bad:
                 self._k4['p16_reruns'] = self._k4.get('p16_reruns', 0) + len(bad)
                 self._run_plan([Bs[j] for j in bad], [hws[j] for j in bad], (slot0, 'redo'))
+        else:
+            self._run_plan(Bs, hws, slot0)
         return [B['out'].permute(2, 0, 1).unsqueeze(0) for B in Bs]       # views [1,3,H,W] of the NHWC results
 
     def _run_plan(self, Bs, hws, slot0, p16=None):

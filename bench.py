@@ -170,10 +170,12 @@ class MarcherRun:
 
 def marcher_source_sha1():
     """Fingerprint of the marcher's kernel source: profiles/*_marcher_traffic.json records the one it was measured on."""
-    import hashlib
+    import hashlib, re
     h = hashlib.sha1()
     for f in ('k4_march.hip', 'k4_common.h'):
-        h.update(open(os.path.join(ROOT, '4k-nerf_amd', 'csrc', f), 'rb').read())
+        src = open(os.path.join(ROOT, '4k-nerf_amd', 'csrc', f), 'r').read()
+        src = re.sub(r'//[^\n]*', '', src)                         # the CODE: comment edits do not make a measurement stale
+        h.update('\n'.join(l.strip() for l in src.splitlines() if l.strip()).encode())
     return h.hexdigest()[:12]
 
 

@@ -332,9 +332,15 @@ int k4_sft_nhwc_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_strid
  *           w[co][ci][tap] 2^a[co] 2^-E[ci] (E[ci] = exponent of the p16 tensor input channel ci belongs to; a[co] brings the largest scaled
  *           magnitude of output channel co into [2^13, 2^14)), followed by [cout] floats 2^-a[co]; 16-byte aligned.  bias: [cout] floats,
  *           16-byte aligned.  The result does not depend on which other windows share the launch.
+ *   K4_PRE_UPSAMPLE2X: the input image is (H/2) x (W/2) and is read through a nearest x2 upsampling (lib/sr_esrnet.py:461-463).  The entry point
+ *           evaluates the layer per output PHASE (py, px) = (y & 1, x & 1) as a 2 x 2 convolution of the input: the 3 x 3 taps that land on the
+ *           same input pixel are added by the packer (fp32) -- 2.25x fewer matrix instructions, the same sums up to one rounding of a weight sum.
+ *           w_p16 then is k4_conv_weight_p16_up2x_bytes(cout, cin) bytes = [cin/16][cout/32][phase py*2+px][hi|lo][tap a*2+b][2][32][8] fp16 +
+ *           [cout] floats 2^-a[co]; tap (a, b) of phase (py, px) multiplies input pixel (Y - 1 + py + a, X - 1 + px + b), output pixel (2Y + py, 2X + px).
  * k4_absmax_slice: *out_bits = max(*out_bits, bits of the largest |x| of the channel slice) (atomicMax; zero it first) -- what a
  * calibration pass on the fp32 entry points uses to choose the exponents. */
 int64_t k4_conv_weight_p16_bytes(int32_t cout, int32_t cin);
+int64_t k4_conv_weight_p16_up2x_bytes(int32_t cout, int32_t cin);
 int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
                          const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
                          uint32_t flags, float slope, int32_t res_stride, float res_scale,

@@ -191,3 +191,30 @@ def test_p16_format_roundtrip_and_weight_packing():
     top = (raw[:, :, 0].abs().permute(1, 4, 0, 3, 5, 2).reshape(cout, -1)).amax(1)
     assert bool(((top >= 2.0 ** 13) & (top < 2.0 ** 14)).all())
     assert torch.equal(pk.b, b)
+
+
+def test_p16_up2x_weight_packing_is_the_phase_sum_of_the_taps():
+    """K4_PRE_UPSAMPLE2X operand: decoding it and applying the four 2 x 2 phase filters to an image equals the 3 x 3 layer on the nearest-x2
+    upsampled image (CPU, fp64), i.e. the tap sums and the (phase, tap) -> input offset map are right."""
+    import torch.nn.functional as F
+    from nerf4k_amd.lib.sr_esrnet import _PackedP16Up
+    g = torch.Generator().manual_seed(8)
+    cout, cin = 32, 32
+    w = torch.randn([cout, cin, 3, 3], generator=g) * 0.1
+    b = torch.zeros([cout])
+    pk = _PackedP16Up(w, b, [0, 2])
+    nbytes = (cin // 16) * (cout // 32) * 4 * 8192
+    raw = pk.w[: nbytes // 2].view(torch.float16).reshape(cin // 16, cout // 32, 4, 2, 4, 2, 32, 8).double()       # [chunk][nb][phase][term][tap][kg][co][j]
+    unscale = pk.w[nbytes // 2:].view(torch.float32).double()
+    dec = (raw[:, :, :, 0] + raw[:, :, :, 1]).permute(1, 5, 0, 4, 6, 2, 3).reshape(cout, cin, 4, 4)                  # [nb][co][chunk][kg][j][phase][tap]
+    e_in = torch.tensor([0, 2]).repeat_interleave(16).double()
+    wp = dec * unscale.view(-1, 1, 1, 1) * (2.0 ** e_in).view(1, -1, 1, 1)                                            # phase filters on the raw input
+    x = torch.randn([1, cin, 7, 9], generator=g).double()
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), w.double(), padding=1)
+    xp = F.pad(x, (1, 1, 1, 1))
+    got = torch.zeros_like(want)
+    for py in (0, 1):
+        for px in (0, 1):
+            k2 = wp[:, :, py * 2 + px].reshape(cout, cin, 2, 2)
+            got[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + 8, px:px + 10], k2)                                    # input pixel (Y - 1 + py + a, X - 1 + px + b)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())

@@ -401,7 +401,7 @@ def test_p16_conv_layer(cin, cout):
     against an fp64 convolution: fp32 output with LeakyReLU + residual, pre-split output (decoded), the x2-upsampling loader, ragged
     sizes, and the overflow word."""
     import torch.nn.functional as F
-    from nerf4k_amd.lib.sr_esrnet import _PackedP16, EPI_LRELU, EPI_RES, PRE_UP2X
+    from nerf4k_amd.lib.sr_esrnet import _PackedP16, _PackedP16Up, EPI_LRELU, EPI_RES, PRE_UP2X
     g = torch.Generator().manual_seed(cin + cout)
     for (H, W) in ((19, 41), (8, 32), (1, 1), (33, 70)):
         x = torch.randn([H, W, cin], generator=g)
@@ -437,11 +437,16 @@ def test_p16_conv_layer(cin, cout):
         # a scale that does not fit fp16 raises the window's overflow word
         ovf = _p16_conv(pk, xp.cuda(), 16, 224, yp, 32, 112, H, W, EPI_LRELU, out_exp=30)
         assert int(ovf[0]) == 1 and int(ovf[1:].sum()) == 0
-        # nearest x2 upsampling folded into the DMA addressing
+        # nearest x2 upsampling: four phases of 2 x 2 taps on the input image (tap sums formed by the packer)
+        pku = _PackedP16Up(w.cuda(), b.cuda(), e_chunks)
         yu = torch.zeros([2 * H, 2 * W, 112]).cuda()
-        _p16_conv(pk, xp.cuda(), 16, 224, yu, 32, 112, 2 * H, 2 * W, EPI_LRELU | PRE_UP2X)
+        _p16_conv(pku, xp.cuda(), 16, 224, yu, 32, 112, 2 * H, 2 * W, EPI_LRELU | PRE_UP2X)
         refu = F.leaky_relu(F.conv2d(F.interpolate(xd.permute(2, 0, 1).unsqueeze(0), scale_factor=2, mode='nearest'), w.double(), b.double(), padding=1), 0.2)
         assert float((yu[..., 32:32 + cout].cpu().double() - refu[0].permute(1, 2, 0)).abs().max()) < 5e-6
+        assert float(yu[..., :32].abs().max()) == 0 and float(yu[..., 32 + cout:].abs().max()) == 0
+        ypu = torch.zeros([2 * H, 2 * W, 112], dtype=torch.int32).cuda()                       # and with pre-split output
+        _p16_conv(pku, xp.cuda(), 16, 224, ypu, 32, 112, 2 * H, 2 * W, EPI_LRELU | PRE_UP2X, out_exp=E_out)
+        assert torch.equal(ypu[..., 32:32 + cout].cpu(), helpers.to_p16(yu[..., 32:32 + cout].cpu(), E_out))
 
 
 @pytest.mark.parametrize('C', [64, 32])

@@ -6,11 +6,11 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import _native as N
-from nerf4k_amd.lib.sr_esrnet import _Packed, _PackedP16, SFTNet, EPI_LRELU, PRE_UP2X
+from nerf4k_amd.lib.sr_esrnet import _Packed, _PackedP16, _PackedP16Up, SFTNet, EPI_LRELU, PRE_UP2X
 torch.manual_seed(0)
 nwin = int(os.environ.get('K4_TOOL_WINDOWS', '1'))
 cases = [(64, 32, 520, 520, 0), (96, 32, 520, 520, 0), (128, 32, 520, 520, 0), (160, 32, 520, 520, 0), (192, 64, 520, 520, 0),
-         (64, 64, 520, 520, 0), (64, 64, 1040, 1040, PRE_UP2X), (64, 64, 2080, 2080, 0), (160, 32, 209, 209, 0), (192, 64, 209, 209, 0)]
+         (64, 64, 520, 520, 0), (64, 64, 1040, 1040, PRE_UP2X), (64, 64, 2080, 2080, 0), (160, 32, 209, 209, 0), (192, 64, 209, 209, 0), (64, 64, 2080, 2080, PRE_UP2X)]
 only = os.environ.get('K4_TOOL_ONLY', '')          # 'p16': time only the pre-split kernel (profiling runs)
 if len(sys.argv) > 1:
     cases = [cases[int(a)] for a in sys.argv[1:]]
@@ -35,7 +35,7 @@ for cin, cout, H, W, fl in cases:
     ys = [torch.zeros([H, W, 64], device='cuda') for _ in range(nwin)]
     w = (torch.randn([cout, cin, 3, 3], device='cuda') / (cin * 9) ** 0.5)
     b = torch.randn([cout], device='cuda')
-    pk, pkp = _Packed(w, b, 'f16x3'), _PackedP16(w, b, [0] * (cin // 16))
+    pk, pkp = _Packed(w, b, 'f16x3'), (_PackedP16Up if fl & PRE_UP2X else _PackedP16)(w, b, [0] * (cin // 16))
     net = SFTNet.__new__(SFTNet)
     ovf = torch.zeros([8], dtype=torch.int32, device='cuda')
     Bs = [{'x': x, 'xp': xp, 'y': y} for x, xp, y in zip(xs, xps, ys)]

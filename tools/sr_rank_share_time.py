@@ -13,7 +13,7 @@ mine = [tiles[i] for i in tp.assign_tiles(tiles, 8)[0]]
 with torch.no_grad():
     out = net.tile_process_device(x, c, TS, 10, tiles=mine)
     torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(3):
+    for _ in range(10):
         out = net.tile_process_device(x, c, TS, 10, tiles=mine, out=out)
     torch.cuda.synchronize()
-print('rank-0 share of 8, tile_size %d, %d tiles:' % (TS, len(mine)), ': ms', round((time.perf_counter() - t) / 3 * 1e3, 2), [(t_[5] - t_[4], t_[7] - t_[6]) for t_ in mine])
+print('rank-0 share of 8, tile_size %d, %d tiles:' % (TS, len(mine)), ': ms', round((time.perf_counter() - t) / 10 * 1e3, 2), [(t_[5] - t_[4], t_[7] - t_[6]) for t_ in mine])
