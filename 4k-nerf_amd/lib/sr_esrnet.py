@@ -711,9 +711,7 @@ class SFTNet(nn.Module):
             st = N.stream()
             for fn, args, what in plan:
                 if fn is None:
-                    if what == 'copy':
-                        args[0].copy_(args[1])
-                    elif what == 'zero':
+                    if what == 'zero':
                         args[0].zero_()
                 else:
                     N.check(fn(*args, st), what)
@@ -740,11 +738,6 @@ class SFTNet(nn.Module):
         def sftp(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, out):
             self._sft_p16_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, E[out], ovf, plan)
 
-        def copy(dname, sname):
-            for B in Bs:
-                plan.append((None, (B[dname], B[sname]), 'copy'))
-                B[dname].copy_(B[sname])
-
         def seen(name, bname, off, stride, ch, up=1):
             if probe is not None:
                 for B, (h, w) in zip(Bs, hws):
@@ -759,39 +752,43 @@ class SFTNet(nn.Module):
         cv(pk['CondNet.2'], 'c64a', 0, 64, 'c64b', 0, 64, 64, flags=EPI_LRELU)
         cv(pk['CondNet.4'], 'c64b', 0, 64, 'c64a', 0, 64, 64, flags=EPI_LRELU)
         cv(pk['CondNet.6'], 'c64a', 0, 64, 'cond', 0, g, g)
-        copy('trunk', 'feat')
+        # the trunk lives in three rotating 64-channel images (no copies): an RRDB reads X, its dense blocks write P, Q, P (each block's
+        # residual is its own input), its SFT layer writes Q with the residual X -> the next RRDB's X
         bw = nf + 4 * g
+        X, P, Q = 'feat', 'trunk', 'rrdb_in'
         for b in range(self.num_block):
-            copy('rrdb_in', 'trunk')
-            for r in (1, 2, 3):
+            src = X
+            for r, dst in zip((1, 2, 3), (P, Q, P)):
                 p = f'body.{b}.rdb{r}'
                 if p16 is not None:
-                    sftp(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf, p + '.xc0')                     # xc0, pre-split
+                    sftp(p + '.sft0', src, 0, nf, 'blk', 0, bw, nf, p + '.xc0')                       # xc0, pre-split
                     for k in range(1, 4):                                                           # x1..x3, pre-split
                         cvp(f'{p}.conv{k}', 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, flags=EPI_LRELU, out=f'{p}.x{k}')
                     cvp(f'{p}.conv4', 'blk', 0, bw, 't', 0, 2 * g, flags=EPI_LRELU)                    # x4 stays fp32: the SFT layer reads it
                     sftp(p + '.sft1', 't', 0, 2 * g, 'blk', nf + 3 * g, bw, g, p + '.xc1')              # xc1, pre-split (not in place)
-                    cvp(f'{p}.conv5', 'blk', 0, bw, 'trunk', 0, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))
-                    continue
-                sft(p + '.sft0', 'trunk', 0, nf, 'blk', 0, bw, nf)                                    # xc0
-                seen(p + '.xc0', 'blk', 0, bw, nf)
-                for k in range(1, 5):                                                               # x1..x4
-                    cv(pk[f'{p}.conv{k}'], 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
-                    if k < 4:
-                        seen(f'{p}.x{k}', 'blk', nf + (k - 1) * g, bw, g)
-                sft(p + '.sft1', 'blk', nf + 3 * g, bw, 'blk', nf + 3 * g, bw, g)                     # xc1 in place
-                seen(p + '.xc1', 'blk', nf + 3 * g, bw, g)
-                cv(pk[f'{p}.conv5'], 'blk', 0, bw, 'trunk', 0, nf, nf, flags=EPI_RES, res=('trunk', 0, nf, 0.2))              # x5*0.2 + x
-            sft(f'body.{b}.sft0', 'trunk', 0, nf, 'trunk', 0, nf, nf, res=('rrdb_in', 0, nf, 0.2))  # sft(out)*0.2 + x
+                    cvp(f'{p}.conv5', 'blk', 0, bw, dst, 0, nf, flags=EPI_RES, res=(src, 0, nf, 0.2))  # x5*0.2 + x
+                else:
+                    sft(p + '.sft0', src, 0, nf, 'blk', 0, bw, nf)                                    # xc0
+                    seen(p + '.xc0', 'blk', 0, bw, nf)
+                    for k in range(1, 5):                                                           # x1..x4
+                        cv(pk[f'{p}.conv{k}'], 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, g, flags=EPI_LRELU)
+                        if k < 4:
+                            seen(f'{p}.x{k}', 'blk', nf + (k - 1) * g, bw, g)
+                    sft(p + '.sft1', 'blk', nf + 3 * g, bw, 'blk', nf + 3 * g, bw, g)                 # xc1 in place
+                    seen(p + '.xc1', 'blk', nf + 3 * g, bw, g)
+                    cv(pk[f'{p}.conv5'], 'blk', 0, bw, dst, 0, nf, nf, flags=EPI_RES, res=(src, 0, nf, 0.2))              # x5*0.2 + x
+                src = dst
+            sft(f'body.{b}.sft0', P, 0, nf, Q, 0, nf, nf, res=(X, 0, nf, 0.2))                      # sft(out)*0.2 + x
+            X, P, Q = Q, P, ('c64b' if X == 'feat' else X)                                          # 'feat' is kept for the trunk's last residual
         if p16 is not None:
-            sftp('sftbody', 'trunk', 0, nf, 'c64a', 0, 64, nf, 'sftbody')
-            cvp('conv_body', 'c64a', 0, 64, 'rrdb_in', 0, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0), out='body_feat')   # body_feat += feat
+            sftp('sftbody', X, 0, nf, 'c64a', 0, 64, nf, 'sftbody')
+            cvp('conv_body', 'c64a', 0, 64, P, 0, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0), out='body_feat')           # body_feat += feat
         else:
-            sft('sftbody', 'trunk', 0, nf, 'trunk', 0, nf, nf)
-            seen('sftbody', 'trunk', 0, nf, nf)
-            cv(pk['conv_body'], 'trunk', 0, nf, 'rrdb_in', 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))            # body_feat += feat
-            seen('body_feat', 'rrdb_in', 0, nf, nf)
-        cur, up = 'rrdb_in', 1
+            sft('sftbody', X, 0, nf, Q, 0, nf, nf)
+            seen('sftbody', Q, 0, nf, nf)
+            cv(pk['conv_body'], Q, 0, nf, P, 0, nf, nf, flags=EPI_RES, res=('feat', 0, nf, 1.0))                          # body_feat += feat
+            seen('body_feat', P, 0, nf, nf)
+        cur, up = P, 1
         if s > 1:
             if p16 is not None:
                 cvp('conv_up1', cur, 0, nf, 'up1', 0, nf, up=2, flags=EPI_LRELU | PRE_UP2X, out='up1')
