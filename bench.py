@@ -886,11 +886,11 @@ def cpu_baseline(ck, pose, stride, model=None):
     base = {'value': round(len(ro) / dt / 1e6, 5), 'unit': 'Mrays/s', 'cores': cores, 'threads_used': used, 'kind': 'port',
             'sample': f'{len(ro)} rays = every {stride}th row and column of one 1008x756 frame, 8192-ray chunks '
                       f'as run_sr.py:121-124, {dt:.1f}s of CPU work, torch {torch.__version__} CPU kernels'}
-    # once at every hardware thread (SURVEY 8d asked for os.cpu_count()): a 1/8 sample of the same frame, for the record -- torch's CPU
-    # kernels stop scaling long before 256 threads, which is why the figure above uses CPU_THREAD_CAP
+    # once at every hardware thread (SURVEY 8d asked for os.cpu_count()): a small sample of the same frame, for the record -- torch's CPU
+    # kernels stop scaling long before 256 threads (measured: 0.0004 Mrays/s at 256 against 0.06 at 32), which is why the figure above uses CPU_THREAD_CAP
     if cores > used:
         torch.set_num_threads(cores)
-        n8 = len(ro) // 8
+        n8 = min(len(ro), 4096)                 # half a chunk of the reference's loop: at 256 threads torch's CPU kernels run ~100x SLOWER than at 32
         t = time.perf_counter()
         marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], ro[:n8], rd[:n8], vd[:n8], **ck['render_kwargs'])
         dt8 = time.perf_counter() - t
