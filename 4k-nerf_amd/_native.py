@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 7
+K4_ABI_VERSION = 8
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
@@ -33,6 +33,10 @@ class MlpDesc(C.Structure):
 
 class ConvJob(C.Structure):          # k4_conv_job
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('res', C.c_void_p), ('mod_x', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
+
+
+class ConvSftJob(C.Structure):       # k4_conv_sft_job
+    _fields_ = [('cond', C.c_void_p), ('y2', C.c_void_p)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -129,6 +133,9 @@ _EXTRA_SIGS = {
     'k4_conv_weight_p16_bytes': ([_I32, _I32], C.c_int64),
     'k4_conv_weight_p16_up2x_bytes': ([_I32, _I32], C.c_int64),
     'k4_conv3x3_p16_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F, _F, _P, _P], C.c_int),
+    'k4_conv_sft_epilogue_bytes': ([_I32], C.c_int64),
+    'k4_conv3x3_p16_sft_multi': ([C.POINTER(ConvJob), C.POINTER(ConvSftJob), _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_uint32, _F, _I32, _F,
+                                 _I32, _F, _P, _F, _I32, _F, _P, _P], C.c_int),
     'k4_sft_nhwc_p16_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _F, _P, _P], C.c_int),
     'k4_absmax_slice': ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),

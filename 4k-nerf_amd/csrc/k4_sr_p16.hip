@@ -43,6 +43,9 @@ struct P16Conv {
     int cout, cout_stride; unsigned flags; float slope; int res_stride; float res_scale;
     float out_scale;
     uint32_t* overflow;
+    // SFT epilogue (k4_conv3x3_p16_sft_multi): the layer's result v goes through the NEXT SFTLayer before it is stored pre-split into y2
+    const float* cond[K4_MAX_JOBS]; void* y2[K4_MAX_JOBS];
+    const void* w_sfe; int cond_stride, y2_stride; float cond_scale, sft_slope;
     int debug;               // K4_SR_DEBUG ablation bits (profiling only, WRONG results; 0 in production): 64 = activation DMA for chunk 0 only, 128 = weight DMA for
                              // chunk 0 only, 256 = no MFMAs, 512 = every pixel reads pixel 0 (no HBM traffic)
 };
@@ -53,8 +56,38 @@ struct P16Conv {
 // tap matrices instead of 36 per 2 x 2 output pixels: 2.25x fewer matrix instructions, exact algebra (the tap sums are formed in fp32 by the
 // packer: the products differ from the 9-tap form by one rounding of a weight sum).  A workgroup = 8 x 32 LR positions of ONE phase; the four
 // phase workgroups of a tile are adjacent in launch order (the tile's activations come from L2 three times out of four).
-template <bool OUT16, bool UP>
+//
+// SFT (k4_conv3x3_p16_sft_multi): the SFTLayer that consumes this layer's result (lib/sr_esrnet.py:112-123,149-156: sft1 after conv4, the next
+// dense block's sft0 after conv5) runs in the epilogue instead of as a launch of its own (36 of a frame's 111 launches, HBM-bound at 75-125 us
+// each).  scale / shift depend on the condition pixel only: two 32 -> 32 -> 32 1x1 stacks per 32-channel output block, on the matrix pipe in
+// this kernel's arithmetic (three fp16 products, operands split in two fp16 terms): 24 MFMAs per 32 pixels against the layer's 270-324.  The
+// SFT operand of the (layer, output block) -- 17 KB, P16_SFE_* below -- arrives by DMA in the weight buffer the LAST chunk does not use, issued
+// where a next chunk's DMA would be; the lane's condition rows are requested before the chunk loop.  Hidden activations never leave registers:
+// GEMM 1's C layout is GEMM 2's B layout once the host walks GEMM 2's k in accumulator-register order.  Every scale rides in the operands
+// (condition 2^Ec, per-neuron 2^Eh[j] from the bound of |hidden j| over the calibrated condition range): no exponent arithmetic here.
+#define P16_SFE_A2 8192               /* A1 [path][kb][term][64 lanes] x 16 B | A2 [path][kb][term][64] x 16 B | tables [us1|b1|us2|b2][path][half][16] fp32 */
+#define P16_SFE_TAB 16384
+#define P16_SFE_BYTES 17408
+// K4_P16_TIMING (profiling builds only, tools/p16_phase_timing.py): s_memtime stamps at the phase boundaries, summed over all waves into
+// k4_p16_timing[] (read and reset through k4_debug_p16_timing).  Not compiled into the product library.
+#ifdef K4_P16_TIMING
+#define P16_TIMING_WAVES 65536
+__device__ unsigned long long k4_p16_timing[P16_TIMING_WAVES][8];      // per wave (index 4 blockIdx + wave): no atomics -- 17680 waves adding to nine words took longer than the layer
+#define P16_TSTAMP(SLOT) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                              tacc[SLOT] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define P16_TSTAMP(SLOT) do { } while (0)
+#endif
+template <bool OUT16, bool UP, bool SFT = false>
 __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
+#ifdef K4_P16_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long mt0_ = tlast, rt0_ = __builtin_amdgcn_s_memrealtime();     // (non-SFT: slots 5 / 6 = the wave's life in s_memtime / s_memrealtime (100 MHz) ticks)
+#define P16_TFLUSH() do { const unsigned wi_ = blockIdx.x * 4 + (threadIdx.x >> 6); \
+                          if ((threadIdx.x & 63) == 0 && wi_ < P16_TIMING_WAVES) { tacc[7] = 1; _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) k4_p16_timing[wi_][i_] += tacc[i_]; } } while (0)
+#else
+#define P16_TFLUSH() do { } while (0)
+#endif
     constexpr int W_CH = UP ? P16_W_BYTES_UP : P16_W_BYTES;           // weight bytes of one (chunk, output block[, phase])
     constexpr int W_NI = W_CH / 1024;                                  // DMA instructions
     constexpr int NSUB = UP ? 8 : 18;                                  // sub-stages (tap x row) per chunk
@@ -63,6 +96,12 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf1[P16_W_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char abuf0[P16_ACT_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char abuf1[P16_ACT_BYTES];
+    // LDS-typed views (the kernel selects between the buffers at run time; generic pointers that are selected and then cast back to LDS trip
+    // hipcc's backend: "Illegal instruction detected: V_CMP_NE_U32 0, src_shared_base")
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef const __attribute__((address_space(3))) p16_u32x4 lds_u32x4;
+    typedef const __attribute__((address_space(3))) p16_f32x4 lds_f32x4;
+    lds_u8* const W0 = (lds_u8*)wbuf0; lds_u8* const W1 = (lds_u8*)wbuf1; lds_u8* const A0 = (lds_u8*)abuf0; lds_u8* const A1 = (lds_u8*)abuf1;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform for the compiler too: DMA instruction indices, M0, scalar offsets
@@ -83,31 +122,59 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 
     // ---- DMA plan of this thread (chunk independent): activation instructions k = wv + 4 i, weight instructions k = wv + 4 i ----
     const __amdgpu_buffer_rsrc_t xrs = p16_rsrc(M.x[g], (unsigned)(((long long)(srcH * srcW - 1) * M.cin_stride + M.cin) * 4));
-    const __amdgpu_buffer_rsrc_t wrs = p16_rsrc(M.w, (unsigned)(nchunks * nb_count * (UP ? 4 : 1) * W_CH));
-    unsigned aoff[6];
+    const int w_tail = nchunks * nb_count * (UP ? 4 : 1) * W_CH;      // byte offset of the [cout] floats 2^-a[co] behind the weights
+    const __amdgpu_buffer_rsrc_t wrs = p16_rsrc(M.w, (unsigned)(w_tail + M.cout * 4));
+    // DMA plan of this wave: instruction k of a plan belongs to wave k % 4.  (A fifth / sixth wave that only issues the DMA -- the matrix waves
+    // then never sit on the vector-memory queue, ~20 % of their life by s_memtime stamps -- was built and measured: bit-identical, the chunk
+    // loop then waits on the producers' issue + flight time instead, no layer faster: profiles/r04_p16_producer_waves_not_faster.md)
+    constexpr int NISS = 4;
+    constexpr int AW = (P16_ACT_INSTR + NISS - 1) / NISS, WW = (W_NI + NISS - 1) / NISS, SW = (P16_SFE_BYTES / 1024 + NISS - 1) / NISS;
+    const int wi = wv;
+    unsigned aoff[AW];
+    {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int item = (wv + 4 * i) * 64 + lane;
-        const int p = item >> 2, j = item & 3;
-        const int row = p / P16_COLS, col = p - row * P16_COLS;
-        const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-        const bool inside = item < P16_ACT_ITEMS && gy >= 0 && gy < srcH && gx >= 0 && gx < srcW;
-        aoff[i] = inside ? (unsigned)(((M.debug & 512) ? 0 : (gy * srcW + gx) * M.cin_stride * 4) + ((j ^ ((col >> 2) & 3)) << 4)) : P16_OOB;
+        for (int i = 0; i < AW; ++i) {
+            const int item = (wi + NISS * i) * 64 + lane;
+            const int p = item >> 2, j = item & 3;
+            const int row = p / P16_COLS, col = p - row * P16_COLS;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            const bool inside = item < P16_ACT_ITEMS && gy >= 0 && gy < srcH && gx >= 0 && gx < srcW;
+            aoff[i] = inside ? (unsigned)(((M.debug & 512) ? 0 : (gy * srcW + gx) * M.cin_stride * 4) + ((j ^ ((col >> 2) & 3)) << 4)) : P16_OOB;
+        }
     }
     const unsigned woff = (unsigned)(lane * 16);
-#define P16_ISSUE(CH, WB, AB) do { \
+#define P16_ISSUE(CH, WB, AB) do { { \
         const int wso_ = (((CH) * nb_count + nb) * (UP ? 4 : 1) + phase) * W_CH; \
         const int aso_ = (CH) * 64; \
-        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) { \
-            const int k_ = wv + 4 * i_; \
+        _Pragma("unroll") for (int i_ = 0; i_ < WW; ++i_) { \
+            const int k_ = wi + NISS * i_; \
             if (k_ < W_NI && (!(M.debug & 128) || (CH) == 0)) \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(WB + k_ * 1024), 16, (int)woff, wso_ + k_ * 1024, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)((WB) + k_ * 1024), 16, (int)woff, wso_ + k_ * 1024, 0, 0); \
         } \
-        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { \
-            const int k_ = wv + 4 * i_; \
+        _Pragma("unroll") for (int i_ = 0; i_ < AW; ++i_) { \
+            const int k_ = wi + NISS * i_; \
             if ((k_ < P16_ACT_INSTR - 1 || (k_ == P16_ACT_INSTR - 1 && lane < P16_ACT_ITEMS - (P16_ACT_INSTR - 1) * 64)) && (!(M.debug & 64) || (CH) == 0)) \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(AB + k_ * 1024), 16, (int)aoff[i_], aso_, 0, 0); \
-        } } while (0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)((AB) + k_ * 1024), 16, (int)aoff[i_], aso_, 0, 0); \
+        } } } while (0)
+
+    const __amdgpu_buffer_rsrc_t srs = p16_rsrc(SFT ? M.w_sfe : M.w, SFT ? (unsigned)(nb_count * P16_SFE_BYTES) : 0u);
+    const __amdgpu_buffer_rsrc_t brs = p16_rsrc(M.bias, (unsigned)(M.cout * 4));
+    // (+ this block's 32 + 32 epilogue constants 2^-a[co], bias[co] behind the operand: the SFT kernel keeps them out of its registers)
+#define P16_ISSUE_SFE(WB) do { { \
+        _Pragma("unroll") for (int i_ = 0; i_ < SW; ++i_) { \
+            const int k_ = wi + NISS * i_; \
+            if (k_ < P16_SFE_BYTES / 1024) \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void*)((WB) + k_ * 1024), 16, (int)woff, nb * P16_SFE_BYTES + k_ * 1024, 0, 0); \
+        } \
+        if (wi == 0 && lane < 8) { \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)((WB) + P16_SFE_BYTES), 16, (int)woff, w_tail + nb * 128, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)((WB) + P16_SFE_BYTES + 128), 16, (int)woff, nb * 128, 0, 0); \
+        } } } while (0)
+    // every DMA of a chunk must have LANDED when its barrier releases the readers: an explicit wait -- hipcc's own count before s_barrier is
+    // not to be relied on (with the eight condition loads in flight it emitted vmcnt(8) at the loop's first barrier, which on the back edge
+    // let eight DMA instructions of the next chunk stay in flight: run-to-run different bits once the issue moved closer to the barrier)
+#define P16_BARRIER() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+    P16_ISSUE(0, W0, A0);
 
     // ---- fragment addresses: weights (A operand) lane = (channel group, co); activations (B operand) lane = (channel group, column) ----
     const unsigned wrd = (unsigned)(lane * 16);
@@ -123,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     // per-lane epilogue tables: output channels co(q, e) = nb*32 + 8q + 4 half + e
     const int cob = nb * 32 + 4 * half;
     p16_f32x4 us[4], bs[4];
-    {
+    if constexpr (!SFT) {
         const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(M.w) + (size_t)nchunks * nb_count * (UP ? 4 : 1) * W_CH);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -135,24 +202,39 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     p16_f32x16 acc[2];
     acc[0] = (p16_f32x16)(0.f); acc[1] = (p16_f32x16)(0.f);
 
-    P16_ISSUE(0, wbuf0, abuf0);
-
+    // SFT: the lane's condition channels kb*16 + 8*half + 0..7 (kb = 0, 1) of its two pixels, requested now; the operand's DMA plan
+    p16_u32x4 cq[SFT ? 2 : 1][4];
+    if constexpr (SFT) {
+        const __amdgpu_buffer_rsrc_t crs = p16_rsrc(M.cond[g], (unsigned)(((long long)(H * W - 1) * M.cond_stride + 32) * 4));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int gy = y0 + wv * 2 + r, gxc = x0 + l31;
+            const unsigned coff = (gy < H && gxc < W) ? (unsigned)((gy * W + gxc) * M.cond_stride * 4 + half * 32) : P16_OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cq[r][i] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(coff + (unsigned)((i >> 1) * 64 + (i & 1) * 16)), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // tap t -> (row, column) offset in the haloed tile: 3 x 3 taps (dy, dx) = (t / 3, t % 3); UP: 2 x 2 taps (a, b) = (t / 2, t % 2), the phase's
     // offset already sits in ard
 #define P16_TROW(T) (UP ? (T) / 2 : (T) / 3)
 #define P16_TCOL(T) (UP ? (T) % 2 : (T) % 3)
 #define P16_RDW(DST, WB, T) do { \
-        DST[0] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (0 * NTAP + (T)) * 1024); \
-        DST[1] = *reinterpret_cast<const p16_u32x4*>(WB + wrd + (1 * NTAP + (T)) * 1024); } while (0)
+        DST[0] = *reinterpret_cast<lds_u32x4*>(WB + wrd + (0 * NTAP + (T)) * 1024); \
+        DST[1] = *reinterpret_cast<lds_u32x4*>(WB + wrd + (1 * NTAP + (T)) * 1024); } while (0)
 #define P16_RDX(DST, AB, U) do { \
         const int t_ = (U) >> 1, r_ = (U) & 1; \
-        DST[0] = *reinterpret_cast<const p16_u32x4*>(AB + ard[P16_TCOL(t_)][0] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); \
-        DST[1] = *reinterpret_cast<const p16_u32x4*>(AB + ard[P16_TCOL(t_)][1] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); } while (0)
+        DST[0] = *reinterpret_cast<lds_u32x4*>(AB + ard[P16_TCOL(t_)][0] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); \
+        DST[1] = *reinterpret_cast<lds_u32x4*>(AB + ard[P16_TCOL(t_)][1] + (r_ + P16_TROW(t_)) * (P16_COLS * 64)); } while (0)
     // one chunk: its DMA has been issued an iteration ago; wait, barrier, issue the next chunk's DMA into the other buffers, 18 sub-stages
     // (tap x row) of 3 MFMAs with the fragments of sub-stage u + 2 / tap t + 1 read under the MFMAs of u
 #define P16_CHUNK(CH, WB, AB, WBN, ABN) do { \
-        __syncthreads(); \
+        P16_TSTAMP(CH == 0 ? 0 : 3); \
+        P16_BARRIER(); \
+        P16_TSTAMP(1); \
         if ((CH) + 1 < nchunks) P16_ISSUE((CH) + 1, WBN, ABN); \
+        else if (SFT) P16_ISSUE_SFE(WBN); \
+        P16_TSTAMP(2); \
         p16_u32x4 wa[2][2], xb[3][2]; \
         P16_RDW(wa[0], WB, 0); \
         P16_RDX(xb[0], AB, 0); \
@@ -172,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         } } while (0)
 
     for (int ch = 0; ch < nchunks; ch += 2) {
-        P16_CHUNK(ch, wbuf0, abuf0, wbuf1, abuf1);
-        if (ch + 1 < nchunks) P16_CHUNK(ch + 1, wbuf1, abuf1, wbuf0, abuf0);
+        P16_CHUNK(ch, W0, A0, W1, A1);
+        if (ch + 1 < nchunks) P16_CHUNK(ch + 1, W1, A1, W0, A0);
     }
 #undef P16_CHUNK
 #undef P16_RDX
@@ -181,13 +263,150 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 #undef P16_TROW
 #undef P16_TCOL
 #undef P16_ISSUE
+#undef P16_ISSUE_SFE
 
+    P16_TSTAMP(3);
     // ---- epilogue: lane = pixel (x0 + l31, row y0 + 2 wv + r), registers 4q .. 4q+3 = channels cob + 8q + 0..3 ----
     const int gx = UP ? 2 * (x0 + l31) + px : x0 + l31;               // output column of this lane
     const float sl = (M.flags & K4_EPI_LRELU) ? M.slope : 1.f;
     const bool has_res = (M.flags & K4_EPI_RES) != 0;
     const __amdgpu_buffer_rsrc_t yrs = p16_rsrc(M.y[g], (unsigned)(((long long)(H * W - 1) * M.cout_stride + M.cout) * 4));
     const __amdgpu_buffer_rsrc_t rrs = p16_rsrc(has_res ? (const void*)M.res[g] : M.y[g], has_res ? (unsigned)(((long long)(H * W - 1) * M.res_stride + M.cout) * 4) : 0u);
+    if constexpr (SFT) {
+        P16_BARRIER();                                                       // the SFT operand has landed; every wave is done with the chunk buffers
+        P16_TSTAMP(6);
+        const lds_u8* const SB = (nchunks & 1) ? W1 : W0;                    // the weight buffer the last chunk did not use
+        const lds_u8* const tab = SB + P16_SFE_TAB;                          // tables: floats
+        const __amdgpu_buffer_rsrc_t y2rs = p16_rsrc(M.y2[g], (unsigned)(((long long)(H * W - 1) * M.y2_stride + M.cout) * 4));
+        const bool dual = M.y[g] != nullptr;                                 // the layer's own result is kept too (fp32: the next block's residual)
+        const float one = 1.f;
+        float amax = 0.f, cmax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int gy = y0 + wv * 2 + r;
+            if (gy >= H) continue;                                           // wave-uniform
+            const bool ok = gx < W;
+            const unsigned pix = (unsigned)(gy * W + gx);
+            const unsigned roff = ok ? (pix * (unsigned)M.res_stride + (unsigned)cob) * 4u : P16_OOB;
+            p16_u32x4 rq[4];
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rq[q] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(roff + (unsigned)(q * 32)), 0, 0);
+            }
+            // ---- the layer's own result v (constants from the LDS image), kept fp32 when the caller wants it ----
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const p16_f32x4 usq = *reinterpret_cast<lds_f32x4*>(SB + P16_SFE_BYTES + (4 * half + 8 * q) * 4);
+                const p16_f32x4 bsq = *reinterpret_cast<lds_f32x4*>(SB + P16_SFE_BYTES + 128 + (4 * half + 8 * q) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(acc[r][4 * q + e], usq[e], bsq[e]);
+                    t = fmaxf(t, t * sl);
+                    if (has_res) t = p16_mul_add(t, M.res_scale, __uint_as_float(rq[q][e]));
+                    v[4 * q + e] = t;
+                }
+                if (dual) {
+                    const unsigned yoff = ok ? (pix * (unsigned)M.cout_stride + (unsigned)cob) * 4u + (unsigned)(q * 32) : P16_OOB;
+                    const p16_u32x4 o4 = {__float_as_uint(v[4 * q]), __float_as_uint(v[4 * q + 1]), __float_as_uint(v[4 * q + 2]), __float_as_uint(v[4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, (int)yoff, 0, 0);
+                }
+            }
+            // ---- B operand of GEMM 1: the lane's condition channels, split here ----
+            p16_u32x4 bh[2], bl[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const p16_u32x4 c0 = cq[r][2 * kb], c1 = cq[r][2 * kb + 1];
+                const float va[4] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w)};
+                const float vb[4] = {__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+                cmax = fmaxf(fmaxf(cmax, fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(va[2]), fabsf(va[3])))),
+                             fmaxf(fmaxf(fabsf(vb[0]), fabsf(vb[1])), fmaxf(fabsf(vb[2]), fabsf(vb[3]))));
+                unsigned Ha[2], La[2], Hb[2], Lb[2];
+                p16_split4(va, M.cond_scale, Ha, La);
+                p16_split4(vb, M.cond_scale, Hb, Lb);
+                bh[kb] = p16_u32x4{Ha[0], Ha[1], Hb[0], Hb[1]};
+                bl[kb] = p16_u32x4{La[0], La[1], Lb[0], Lb[1]};
+            }
+            // ---- one path at a time (scale, then shift): GEMM 1 -> hidden (registers = GEMM 2's B operand) -> GEMM 2 -> fold into v.
+            //      x (scale + 1) + shift with the reference's two roundings: v <- v * (scale + 1), then v <- v + shift ----
+#pragma unroll
+            for (int pth = 0; pth < 2; ++pth) {
+                p16_f32x16 h = (p16_f32x16)(0.f);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const p16_f16x8 ah = __builtin_bit_cast(p16_f16x8, *reinterpret_cast<lds_u32x4*>(SB + ((pth * 2 + kb) * 2 + 0) * 1024 + lane * 16));
+                    const p16_f16x8 al = __builtin_bit_cast(p16_f16x8, *reinterpret_cast<lds_u32x4*>(SB + ((pth * 2 + kb) * 2 + 1) * 1024 + lane * 16));
+                    const p16_f16x8 xh = __builtin_bit_cast(p16_f16x8, bh[kb]), xl = __builtin_bit_cast(p16_f16x8, bl[kb]);
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, h, 0, 0, 0);
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, h, 0, 0, 0);
+                    h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, h, 0, 0, 0);
+                }
+                // hidden j 2^Eh[j] = lrelu(acc us1 + b1) (tables carry 2^Eh: lrelu is positively homogeneous); registers 8 kb .. 8 kb + 7 = K block kb
+                lds_f32x4* const u1 = reinterpret_cast<lds_f32x4*>(tab + ((0 * 2 + pth) * 2 + half) * 16 * 4);
+                lds_f32x4* const b1 = reinterpret_cast<lds_f32x4*>(tab + ((1 * 2 + pth) * 2 + half) * 16 * 4);
+                p16_u32x4 hh[2], hl[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    float t8[8];
+#pragma unroll
+                    for (int e4 = 0; e4 < 2; ++e4) {
+                        const p16_f32x4 uu = u1[2 * kb + e4], bb = b1[2 * kb + e4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = fmaf(h[8 * kb + 4 * e4 + e], uu[e], bb[e]);
+                            t8[4 * e4 + e] = fmaxf(t, t * M.sft_slope);                 // LeakyReLU for 0 <= slope <= 1 (host check)
+                        }
+                    }
+                    const float ta[4] = {t8[0], t8[1], t8[2], t8[3]}, tb[4] = {t8[4], t8[5], t8[6], t8[7]};
+                    unsigned Ha[2], La[2], Hb[2], Lb[2];
+                    p16_split4(ta, one, Ha, La);
+                    p16_split4(tb, one, Hb, Lb);
+                    hh[kb] = p16_u32x4{Ha[0], Ha[1], Hb[0], Hb[1]};
+                    hl[kb] = p16_u32x4{La[0], La[1], Lb[0], Lb[1]};
+                }
+                p16_f32x16 c = (p16_f32x16)(0.f);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const p16_f16x8 ah = __builtin_bit_cast(p16_f16x8, *reinterpret_cast<lds_u32x4*>(SB + P16_SFE_A2 + ((pth * 2 + kb) * 2 + 0) * 1024 + lane * 16));
+                    const p16_f16x8 al = __builtin_bit_cast(p16_f16x8, *reinterpret_cast<lds_u32x4*>(SB + P16_SFE_A2 + ((pth * 2 + kb) * 2 + 1) * 1024 + lane * 16));
+                    const p16_f16x8 xh = __builtin_bit_cast(p16_f16x8, hh[kb]), xl = __builtin_bit_cast(p16_f16x8, hl[kb]);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, c, 0, 0, 0);
+                }
+                lds_f32x4* const u2 = reinterpret_cast<lds_f32x4*>(tab + ((2 * 2 + pth) * 2 + half) * 16 * 4);
+                lds_f32x4* const b2 = reinterpret_cast<lds_f32x4*>(tab + ((3 * 2 + pth) * 2 + half) * 16 * 4);
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const p16_f32x4 uu = u2[i4], bb = b2[i4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m = fmaf(c[4 * i4 + e], uu[e], bb[e]);
+                        v[4 * i4 + e] = pth == 0 ? __fmul_rn(v[4 * i4 + e], m + 1.f) : __fadd_rn(v[4 * i4 + e], m);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- stored pre-split ----
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float o[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                unsigned Hh[2], Ll[2];
+                p16_split4(o, M.out_scale, Hh, Ll);
+                const p16_u32x4 unit = p16_unit(Hh, Ll);
+                const unsigned y2off = ok ? (pix * (unsigned)M.y2_stride + (unsigned)(nb * 32)) * 4u + P16_UNIT_OFF(q, half) : P16_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(unit, y2rs, (int)y2off, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                               // one row at a time: interleaved, the two rows' operands double the register peak
+        }
+        // beyond fp16 (or non-finite) in the stored tensor or in the condition: the window is redone on the per-tile kernels (host).  The hidden
+        // activations cannot overflow while the condition passes (their scales come from bounds over 2^-6 of fp16's range, see the packer)
+        if (__builtin_amdgcn_ballot_w64(!(amax * M.out_scale <= 65504.f) || !(cmax * M.cond_scale <= 65504.f)) != 0ull && lane == 0) atomicOr(M.overflow + g, 1u);
+        P16_TSTAMP(5);
+        P16_TFLUSH();
+        return;
+    }
     float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -231,7 +450,24 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         // the image) come from zero-padded inputs like any other pixel's: harmless to include.
         if (__builtin_amdgcn_ballot_w64(!(amax * M.out_scale <= 65504.f)) != 0ull && lane == 0) atomicOr(M.overflow + g, 1u);
     }
+    P16_TSTAMP(4);
+#ifdef K4_P16_TIMING
+    tacc[5] = ((__builtin_amdgcn_s_memtime() - mt0_) << 32) | (__builtin_amdgcn_s_memrealtime() - rt0_);       // the wave's life in both clocks
+    tacc[6] = (rt0_ << 24) | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) << 16) | (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu);   // start (100 MHz) | XCC | HW_ID[15:0]
+#endif
+    P16_TFLUSH();
 }
+#ifdef K4_P16_TIMING
+extern "C" int k4_debug_p16_timing(unsigned long long* out, int reset) {             // out: [P16_TIMING_WAVES][8]; slot 7 = number of passes of that wave index
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(k4_p16_timing), sizeof(unsigned long long) * 8 * P16_TIMING_WAVES);
+    if (e == hipSuccess && reset) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(k4_p16_timing));
+        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * 8 * P16_TIMING_WAVES);
+    }
+    return (int)e;
+}
+#endif
 
 extern "C" int64_t k4_conv_weight_p16_bytes(int32_t cout, int32_t cin) {
     if (cout <= 0 || cin <= 0 || (cout & 31) || (cin & 15)) return -1;
@@ -242,11 +478,22 @@ extern "C" int64_t k4_conv_weight_p16_up2x_bytes(int32_t cout, int32_t cin) {   
     return (int64_t)(cin / 16) * (cout / 32) * 4 * P16_W_BYTES_UP + (int64_t)cout * 4;
 }
 
-extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
-                                    const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
-                                    uint32_t flags, float slope, int32_t res_stride, float res_scale,
-                                    float out_scale, uint32_t* overflow, void* stream) {
+extern "C" int64_t k4_conv_sft_epilogue_bytes(int32_t channels) {                      // the epilogue-SFT operand of a layer with `channels` outputs
+    if (channels <= 0 || (channels & 31)) return -1;
+    return (int64_t)(channels / 32) * P16_SFE_BYTES;
+}
+
+static int conv3x3_p16(const k4_conv_job* jobs, const k4_conv_sft_job* sjobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                       const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
+                       uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                       int32_t cond_stride, float cond_scale, const void* w_sfe, float sft_slope, int32_t y2_stride,
+                       float out_scale, uint32_t* overflow, void* stream) {
+    const bool sft = sjobs != nullptr;
     if (!jobs || n_jobs <= 0 || n_jobs > K4_MAX_JOBS || !w_p16 || !bias) return K4_ERR_BAD_ARG;
+    if (sft) {
+        if (!w_sfe || (((size_t)w_sfe) & 15) || (flags & K4_PRE_UPSAMPLE2X) || cond_stride < 32 || (cond_stride & 3) || y2_stride < cout || (y2_stride & 15)) return K4_ERR_BAD_ARG;
+        if (!(cond_scale > 0.f) || !(out_scale > 0.f) || !(sft_slope >= 0.f && sft_slope <= 1.f)) return K4_ERR_BAD_ARG;
+    }
     if (cin <= 0 || (cin & 15) || cin_stride < cin || (cin_stride & 3) || cout <= 0 || (cout & 31) || cout_stride < cout || (cout_stride & 3)) return K4_ERR_BAD_ARG;
     if (flags & ~(K4_EPI_LRELU | K4_EPI_RES | K4_PRE_UPSAMPLE2X)) return K4_ERR_BAD_ARG;
     if ((flags & K4_EPI_LRELU) && !(slope >= 0.f && slope <= 1.f)) return K4_ERR_BAD_ARG;
@@ -256,11 +503,17 @@ extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int
     P16Conv M{};
     M.n = n_jobs; M.cin = cin; M.cin_stride = cin_stride; M.w = w_p16; M.bias = bias; M.cout = cout; M.cout_stride = cout_stride;
     M.flags = flags; M.slope = slope; M.res_stride = res_stride; M.res_scale = res_scale; M.out_scale = out_scale; M.overflow = overflow; M.debug = k4_env().sr_debug;
+    M.w_sfe = w_sfe; M.cond_stride = cond_stride; M.y2_stride = y2_stride; M.cond_scale = cond_scale; M.sft_slope = sft_slope;
     const int nbc = cout / 32;
     int total = 0;
     for (int g = 0; g < n_jobs; ++g) {
         const k4_conv_job& j = jobs[g];
-        if (!j.x || !j.y || j.H <= 0 || j.W <= 0 || (((size_t)j.x | (size_t)j.y) & 15)) return K4_ERR_BAD_ARG;
+        if (!j.x || (!j.y && !sft) || j.H <= 0 || j.W <= 0 || (((size_t)j.x | (size_t)j.y) & 15)) return K4_ERR_BAD_ARG;      // SFT: y may be NULL (only y2 is produced)
+        if (sft) {
+            if (!sjobs[g].cond || !sjobs[g].y2 || (((size_t)sjobs[g].cond) & 15) || (((size_t)sjobs[g].y2) & 63)) return K4_ERR_BAD_ARG;
+            if ((long long)j.H * j.W * (cond_stride > y2_stride ? cond_stride : y2_stride) * 4 >= 0x80000000LL) return K4_ERR_UNSUPPORTED;
+            M.cond[g] = sjobs[g].cond; M.y2[g] = sjobs[g].y2;
+        }
         if ((flags & K4_EPI_RES) && (!j.res || (((size_t)j.res) & 15))) return K4_ERR_BAD_ARG;
         if ((flags & K4_PRE_UPSAMPLE2X) && ((j.H & 1) || (j.W & 1))) return K4_ERR_BAD_ARG;
         const long long strd = cin_stride > cout_stride ? cin_stride : cout_stride;
@@ -274,12 +527,34 @@ extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int
     }
     M.total = total;
     const dim3 grid((unsigned)total), block(256);
+    if (sft) {
+        hipLaunchKernelGGL((k4_conv_p16_kernel<false, false, true>), grid, block, 0, (hipStream_t)stream, M);
+        return k4_check_launch();
+    }
     if (flags & K4_PRE_UPSAMPLE2X) {
         if (out_scale != 0.f) hipLaunchKernelGGL((k4_conv_p16_kernel<true, true>), grid, block, 0, (hipStream_t)stream, M);
         else hipLaunchKernelGGL((k4_conv_p16_kernel<false, true>), grid, block, 0, (hipStream_t)stream, M);
     } else if (out_scale != 0.f) hipLaunchKernelGGL((k4_conv_p16_kernel<true, false>), grid, block, 0, (hipStream_t)stream, M);
     else hipLaunchKernelGGL((k4_conv_p16_kernel<false, false>), grid, block, 0, (hipStream_t)stream, M);
     return k4_check_launch();
+}
+
+extern "C" int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                                    const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
+                                    uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                                    float out_scale, uint32_t* overflow, void* stream) {
+    return conv3x3_p16(jobs, nullptr, n_jobs, cin, cin_stride, w_p16, bias, cout, cout_stride, flags, slope, res_stride, res_scale,
+                       0, 0.f, nullptr, 0.f, 0, out_scale, overflow, stream);
+}
+
+extern "C" int k4_conv3x3_p16_sft_multi(const k4_conv_job* jobs, const k4_conv_sft_job* sft_jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                                        const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
+                                        uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                                        int32_t cond_stride, float cond_scale, const void* w_sfe, float sft_slope, int32_t y2_stride,
+                                        float out_scale, uint32_t* overflow, void* stream) {
+    if (!sft_jobs || !overflow) return K4_ERR_BAD_ARG;
+    return conv3x3_p16(jobs, sft_jobs, n_jobs, cin, cin_stride, w_p16, bias, cout, cout_stride, flags, slope, res_stride, res_scale,
+                       cond_stride, cond_scale, w_sfe, sft_slope, y2_stride, out_scale, overflow, stream);
 }
 
 // ---- largest |x| of a channel slice, as bits, into *out_bits with atomicMax (calibration of the p16 exponents; non-finite values count) ----

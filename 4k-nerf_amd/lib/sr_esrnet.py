@@ -324,6 +324,68 @@ class _PackedP16Up(_PackedP16):
         self.cin, self.cout, self.k = cin, cout, 3
 
 
+class _PackedSfe:
+    """An SFTLayer as the EPILOGUE operand of the 3x3 layer that produces its input (k4_conv3x3_p16_sft_multi's ``w_sfe``, include/k4nerf.h):
+    per 32-channel output block [A1 | A2 | tables].  ``e_cond``: exponent of the condition tensor (|cond| 2^e_cond < 2^(P16_TARGET_EXP+1) on
+    the calibration probe); the hidden activations get one power-of-two scale PER NEURON from the bound of |hidden j| over that range, folded
+    into GEMM 1's tables and GEMM 2's weights (lrelu is positively homogeneous)."""
+
+    def __init__(self, layer, e_cond):
+        dev = layer.SFT_scale_conv0.weight.device
+        g = layer.SFT_scale_conv0.weight.shape[1]
+        assert g == 32 and layer.SFT_scale_conv0.weight.shape[0] == 32
+        C = layer.SFT_scale_conv1.weight.shape[0]
+        assert C % 32 == 0
+        lane = torch.arange(64, device=dev)
+        l31, half = lane & 31, lane >> 5
+        e = torch.arange(8, device=dev)
+        kb = torch.arange(2, device=dev)
+        r16 = torch.arange(16, device=dev)
+        hh = torch.arange(2, device=dev)
+        row = ((r16 & 3) + 8 * (r16 >> 2))[None, :] + 4 * hh[:, None]                        # [half][16] -> accumulator row
+        k1 = kb[:, None, None] * 16 + 8 * half[None, :, None] + e[None, None, :]              # [kb][lane][8]: condition channel
+        k2 = (e & 3)[None, None, :] + 8 * (2 * kb[:, None, None] + (e >> 2)[None, None, :]) + 4 * half[None, :, None]     # hidden neuron, register order
+
+        def exp_to(m, target):                                                                # integer a with m 2^a in [2^target, 2^(target+1)); 0 for m = 0 / non-finite
+            m = m.double()
+            return torch.where((m > 0) & torch.isfinite(m), target - torch.floor(torch.log2(m.clamp_min(1e-300))), torch.zeros_like(m)).clamp(-100, 100).to(torch.int32)
+
+        def split(ws):
+            hi = ws.to(torch.float16)
+            return hi, (ws - hi.float()).to(torch.float16)
+
+        cmax = 2.0 ** (P16_TARGET_EXP + 1 - e_cond)
+        a1_frag, a2_frag, tabs = [], [], {}
+        for pth, (c0, c1) in enumerate(((layer.SFT_scale_conv0, layer.SFT_scale_conv1), (layer.SFT_shift_conv0, layer.SFT_shift_conv1))):
+            W0, b0 = c0.weight.detach().float().reshape(32, 32), c0.bias.detach().float()
+            W1, b1 = c1.weight.detach().float().reshape(C, 32), c1.bias.detach().float()
+            bound = W0.abs().double().sum(1) * cmax + b0.abs().double()
+            # bound 2^Eh <= 2^P16_TARGET_EXP: a condition 2^6 beyond its calibrated range (where ITS check fires) still leaves the hidden values inside fp16
+            Eh = torch.where(bound > 0, P16_TARGET_EXP - torch.ceil(torch.log2(bound.clamp_min(1e-300))), torch.zeros_like(bound)).clamp(-100, 100).to(torch.int32)
+            w0s = torch.ldexp(W0, torch.full_like(Eh, -e_cond).view(-1, 1))
+            a1 = exp_to(w0s.abs().amax(1), 13)
+            hi, lo = split(torch.ldexp(w0s, a1.view(-1, 1)))
+            a1_frag.append(torch.stack([t[l31[None, :, None].expand(2, 64, 8), k1] for t in (hi, lo)], 1))          # [kb][term][lane][8]
+            w1s = torch.ldexp(W1, (-Eh).view(1, -1))
+            a2 = exp_to(w1s.abs().amax(1), 13)
+            hi2, lo2 = split(torch.ldexp(w1s, a2.view(-1, 1)))
+            a2_frag.append([torch.stack([t[(nb * 32 + l31)[None, :, None].expand(2, 64, 8), k2] for t in (hi2, lo2)], 1) for nb in range(C // 32)])
+            one = torch.ones([32], dtype=torch.float32, device=dev)
+            tabs[(0, pth)] = [torch.ldexp(one, Eh - a1)[row]] * (C // 32)
+            tabs[(1, pth)] = [torch.ldexp(b0, Eh)[row]] * (C // 32)
+            tabs[(2, pth)] = [torch.ldexp(torch.ones([C], dtype=torch.float32, device=dev), -a2)[nb * 32 + row] for nb in range(C // 32)]
+            tabs[(3, pth)] = [b1[nb * 32 + row] for nb in range(C // 32)]
+        blocks = []
+        for nb in range(C // 32):
+            A1 = torch.stack(a1_frag, 0).contiguous().view(torch.int16).reshape(-1)                                   # [path][kb][term][lane][8]
+            A2 = torch.stack([a2_frag[0][nb], a2_frag[1][nb]], 0).contiguous().view(torch.int16).reshape(-1)
+            T = torch.stack([torch.stack([tabs[(w_, pth)][nb] for pth in (0, 1)], 0) for w_ in range(4)], 0)           # [which][path][half][16]
+            blocks += [A1, A2, T.contiguous().view(torch.int16).reshape(-1)]
+        self.w = torch.cat(blocks)
+        assert self.w.numel() * 2 == N.lib().k4_conv_sft_epilogue_bytes(C), (self.w.numel() * 2, C)
+        self.channels, self.e_cond = C, e_cond
+
+
 def pack_sft(layer):
     """SFTLayer weights in the operand order of the fused kernel (include/k4nerf.h, k4_sft_nhwc)."""
     dev = layer.SFT_scale_conv0.weight.device
@@ -462,7 +524,7 @@ class SFTNet(nn.Module):
         ``slot``: independent buffer set (one per concurrently used stream)."""
         nf, g, s = self.num_feat, self.num_grow_ch, self.scale
         spec = {'feat': (1, nf), 'cond': (1, g), 'c64a': (1, 64), 'c64b': (1, 64), 'trunk': (1, nf), 'rrdb_in': (1, nf),
-                'blk': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3),
+                'blk': (1, nf + 4 * g), 'blk2': (1, nf + 4 * g), 't': (1, 2 * g), 'hr': (s, nf), 'out': (s, 3),
                 'xin': (1, self.conv_first.in_channels), 'cnd': (1, self.CondNet[0].in_channels)}
         if s > 1:
             spec['up1'] = (2, nf)
@@ -551,6 +613,28 @@ class SFTNet(nn.Module):
         plan.append((fn, args, 'k4_conv3x3_p16_multi'))
         N.check(fn(*args, N.stream()), 'k4_conv3x3_p16_multi')
 
+    def _conv_p16_sft_multi(self, pkc, sfe, Bs, hws, xname, x_off, x_stride, y, flags, res, y2name, y2_off, y2_stride, out_exp, ovf, plan):
+        """One 3x3 layer of every window on pre-split input whose result goes through the SFTLayer ``sfe`` (_PackedSfe) in the epilogue
+        (k4_conv3x3_p16_sft_multi): y2 = the modulated result, pre-split under 2^out_exp; y = (buffer name, channel offset, stride) keeps the
+        layer's own fp32 result as well, None drops it."""
+        assert sfe.channels == pkc.cout
+        jobs = (N.ConvJob * len(Bs))()
+        sj = (N.ConvSftJob * len(Bs))()
+        for j, (B, (h, w)) in enumerate(zip(Bs, hws)):
+            jobs[j].x = B[xname].data_ptr() + 4 * x_off
+            jobs[j].y = None if y is None else B[y[0]].data_ptr() + 4 * y[1]
+            jobs[j].res = None if res is None else B[res[0]].data_ptr() + 4 * res[1]
+            jobs[j].mod_x = None
+            jobs[j].H, jobs[j].W = h, w
+            sj[j].cond = B['cond'].data_ptr()
+            sj[j].y2 = B[y2name].data_ptr() + 4 * y2_off
+        rs, rscale = (0, 0.0) if res is None else (res[2], res[3])
+        fn = N.lib().k4_conv3x3_p16_sft_multi
+        args = (jobs, sj, len(Bs), pkc.cin, x_stride, N.ptr(pkc.w), N.f32(pkc.b), pkc.cout, pkc.cout if y is None else y[2], flags, 0.2, rs, rscale,
+                self.num_grow_ch, float(2.0 ** sfe.e_cond), N.ptr(sfe.w), 0.2, y2_stride, float(2.0 ** out_exp), N.ptr(ovf))
+        plan.append((fn, args, 'k4_conv3x3_p16_sft_multi'))
+        N.check(fn(*args, N.stream()), 'k4_conv3x3_p16_sft_multi')
+
     def _sft_p16_multi(self, pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, out_exp, ovf, plan):
         """SFTLayer of every window with PRE-SPLIT output (k4_sft_nhwc_p16_multi)."""
         jobs = (N.SftJob * len(Bs))()
@@ -568,7 +652,7 @@ class SFTNet(nn.Module):
     # ------------------------------------------------------------------ pre-split activations ('f16x3p')
     def _p16_names(self):
         """The tensors the 'f16x3p' pass writes pre-split, in network order."""
-        names = []
+        names = ['cond']                                      # (not stored pre-split: the epilogue SFT layers split it under this exponent)
         for b in range(self.num_block):
             for r in (1, 2, 3):
                 names += [f'body.{b}.rdb{r}.{t}' for t in ('xc0', 'x1', 'x2', 'x3', 'xc1')]
@@ -639,6 +723,10 @@ class SFTNet(nn.Module):
                     for k in range(1, 6):
                         m = getattr(rdb, f'conv{k}')
                         pkp[f'{p}.conv{k}'] = _PackedP16(m.weight, m.bias, ch[:m.weight.shape[1] // 16])
+                    # the SFT layers that run in a producer's epilogue: sft1 (conv4), and sft0 of the 2nd / 3rd block of an RRDB (the previous conv5)
+                    pkp[f'{p}.sft1:sfe'] = _PackedSfe(rdb.sft1, E['cond'])
+                    if r > 1:
+                        pkp[f'{p}.sft0:sfe'] = _PackedSfe(rdb.sft0, E['cond'])
             chain = [('conv_body', 'sftbody'), ('conv_up1', 'body_feat'), ('conv_up2', 'up1'), ('conv_hr', 'up2' if self.scale == 4 else ('up1' if self.scale > 1 else 'body_feat'))]
             for name, src in chain:
                 if hasattr(self, name):
@@ -738,6 +826,10 @@ class SFTNet(nn.Module):
         def sftp(prefix, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, out):
             self._sft_p16_multi(pk, prefix, Bs, hws, xname, x_off, x_stride, yname, y_off, y_stride, cfeat, E[out], ovf, plan)
 
+        def cvps(lname, sname, xname, x_off, x_stride, y, y2name, y2_off, y2_stride, out, flags=0, res=None):
+            self._conv_p16_sft_multi(pkp[lname], pkp[sname + ':sfe'], Bs, hws, xname, x_off, x_stride, y, flags, res, y2name, y2_off, y2_stride,
+                                     E[out], ovf, plan)
+
         def seen(name, bname, off, stride, ch, up=1):
             if probe is not None:
                 for B, (h, w) in zip(Bs, hws):
@@ -752,21 +844,36 @@ class SFTNet(nn.Module):
         cv(pk['CondNet.2'], 'c64a', 0, 64, 'c64b', 0, 64, 64, flags=EPI_LRELU)
         cv(pk['CondNet.4'], 'c64b', 0, 64, 'c64a', 0, 64, 64, flags=EPI_LRELU)
         cv(pk['CondNet.6'], 'c64a', 0, 64, 'cond', 0, g, g)
+        seen('cond', 'cond', 0, g, g)
         # the trunk lives in three rotating 64-channel images (no copies): an RRDB reads X, its dense blocks write P, Q, P (each block's
         # residual is its own input), its SFT layer writes Q with the residual X -> the next RRDB's X
         bw = nf + 4 * g
         X, P, Q = 'feat', 'trunk', 'rrdb_in'
+        # 'f16x3p': an SFT layer whose input is a 3x3 layer's result runs in that layer's epilogue (sft1 <- conv4; the next dense block's sft0 <-
+        # conv5, written into the OTHER dense-block image: conv5 still reads this one); K4_SR_SFT_FUSE=0: every SFT layer a launch of its own
+        fuse = p16 is not None and os.environ.get('K4_SR_SFT_FUSE', '1') != '0'
+        blk, blk_next = 'blk', 'blk2'
         for b in range(self.num_block):
             src = X
             for r, dst in zip((1, 2, 3), (P, Q, P)):
                 p = f'body.{b}.rdb{r}'
                 if p16 is not None:
-                    sftp(p + '.sft0', src, 0, nf, 'blk', 0, bw, nf, p + '.xc0')                       # xc0, pre-split
+                    if not (fuse and r > 1):
+                        sftp(p + '.sft0', src, 0, nf, blk, 0, bw, nf, p + '.xc0')                     # xc0, pre-split
                     for k in range(1, 4):                                                           # x1..x3, pre-split
-                        cvp(f'{p}.conv{k}', 'blk', 0, bw, 'blk', nf + (k - 1) * g, bw, flags=EPI_LRELU, out=f'{p}.x{k}')
-                    cvp(f'{p}.conv4', 'blk', 0, bw, 't', 0, 2 * g, flags=EPI_LRELU)                    # x4 stays fp32: the SFT layer reads it
-                    sftp(p + '.sft1', 't', 0, 2 * g, 'blk', nf + 3 * g, bw, g, p + '.xc1')              # xc1, pre-split (not in place)
-                    cvp(f'{p}.conv5', 'blk', 0, bw, dst, 0, nf, flags=EPI_RES, res=(src, 0, nf, 0.2))  # x5*0.2 + x
+                        cvp(f'{p}.conv{k}', blk, 0, bw, blk, nf + (k - 1) * g, bw, flags=EPI_LRELU, out=f'{p}.x{k}')
+                    if fuse:
+                        cvps(f'{p}.conv4', p + '.sft1', blk, 0, bw, None, blk, nf + 3 * g, bw, p + '.xc1', flags=EPI_LRELU)     # xc1 = sft1(x4), x4 never stored
+                    else:
+                        cvp(f'{p}.conv4', blk, 0, bw, 't', 0, 2 * g, flags=EPI_LRELU)                  # x4 stays fp32: the SFT layer reads it
+                        sftp(p + '.sft1', 't', 0, 2 * g, blk, nf + 3 * g, bw, g, p + '.xc1')            # xc1, pre-split (not in place)
+                    if fuse and r < 3:
+                        pn = f'body.{b}.rdb{r + 1}'
+                        cvps(f'{p}.conv5', pn + '.sft0', blk, 0, bw, (dst, 0, nf), blk_next, 0, bw, pn + '.xc0',
+                             flags=EPI_RES, res=(src, 0, nf, 0.2))                                    # x5*0.2 + x, and the next block's xc0
+                        blk, blk_next = blk_next, blk
+                    else:
+                        cvp(f'{p}.conv5', blk, 0, bw, dst, 0, nf, flags=EPI_RES, res=(src, 0, nf, 0.2))  # x5*0.2 + x
                 else:
                     sft(p + '.sft0', src, 0, nf, 'blk', 0, bw, nf)                                    # xc0
                     seen(p + '.xc0', 'blk', 0, bw, nf)

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      7       /* 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      8       /* 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -347,6 +347,29 @@ int k4_conv3x3_p16_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
                          float out_scale, uint32_t* overflow, void* stream);
 int k4_sft_nhwc_p16_multi(const k4_sft_job* jobs, int32_t n_jobs, int32_t cond_stride, const float* w_packed, int32_t x_stride,
                           int32_t y_stride, int32_t channels, float slope, float out_scale, uint32_t* overflow, void* stream);
+
+/* k4_conv3x3_p16_multi whose result v goes through the SFTLayer that CONSUMES it (lib/sr_esrnet.py:112-123; in a dense block sft1 after conv4,
+ * lib/sr_esrnet.py:154-155, and the next block's sft0 after conv5, :156 + :150) in the epilogue instead of a launch of its own:
+ *     y  (fp32, optional: jobs[g].y may be NULL) = v = the layer's result with its flags (K4_EPI_LRELU / K4_EPI_RES)
+ *     y2 (p16 under out_scale = 2^E)             = v * (scale(cond) + 1) + shift(cond)
+ * cond: [H W][cond_stride] fp32 (32 channels read); scale / shift = conv1x1(lrelu_{sft_slope}(conv1x1(cond))) as 32 -> 32 -> cout stacks in this
+ * kernel's arithmetic (fp16 hi/lo splits, three products, fp32 accumulation).  cond_scale = 2^Ec, a power of two with |cond| 2^Ec < 2^10 over
+ * the range the operand was packed for; a condition value with |cond| 2^Ec > 65504 (or a stored value beyond fp16) ORs 1 into overflow[job].
+ *   w_sfe: k4_conv_sft_epilogue_bytes(cout) bytes = per 32-channel output block nb, 17408 bytes:
+ *     A1 [path scale|shift][kb 2][hi|lo][64 lanes][8] fp16 : W0_path[m = lane & 31][k = 16 kb + 8 (lane >> 5) + e] 2^a1[m] 2^-Ec
+ *     A2 [path][kb][hi|lo][64][8] fp16 : W1_path[32 nb + (lane & 31)][j(kb, lane >> 5, e)] 2^a2[c] 2^-Eh[j],
+ *                                        j(kb, h, e) = (e & 3) + 8 (2 kb + (e >> 2)) + 4 h   (GEMM 1's accumulator-register order)
+ *     tables [us1 | b1 | us2 | b2][path][half][16] fp32, entry i of half h <-> row (i & 3) + 8 (i >> 2) + 4 h:
+ *            us1 = 2^-a1 2^Eh, b1 = bias0 2^Eh (hidden neuron), us2 = 2^-a2, b2 = bias1 (output channel 32 nb + row)
+ *   with 2^Eh[j] chosen from the bound sum_k |W0[j][k]| 2^(10 - Ec) + |bias0[j]| <= 2^(9 - Eh[j]): the hidden activations cannot leave fp16
+ *   while the condition passes its check.  Same window independence as k4_conv3x3_p16_multi. */
+typedef struct k4_conv_sft_job { const float* cond; void* y2; } k4_conv_sft_job;
+int64_t k4_conv_sft_epilogue_bytes(int32_t channels);
+int k4_conv3x3_p16_sft_multi(const k4_conv_job* jobs, const k4_conv_sft_job* sft_jobs, int32_t n_jobs, int32_t cin, int32_t cin_stride,
+                             const void* w_p16, const float* bias, int32_t cout, int32_t cout_stride,
+                             uint32_t flags, float slope, int32_t res_stride, float res_scale,
+                             int32_t cond_stride, float cond_scale, const void* w_sfe, float sft_slope, int32_t y2_stride,
+                             float out_scale, uint32_t* overflow, void* stream);
 int k4_absmax_slice(const float* x, int64_t n_pix, int32_t stride, int32_t channels, uint32_t* out_bits, void* stream);
 
 /* Fused SFTLayer (lib/sr_esrnet.py:112-123): y[p][c] = x[p][c]*(scale(cond)[p][c]+1) + shift(cond)[p][c] (then

@@ -218,3 +218,67 @@ def test_p16_up2x_weight_packing_is_the_phase_sum_of_the_taps():
             k2 = wp[:, :, py * 2 + px].reshape(cout, cin, 2, 2)
             got[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + 8, px:px + 10], k2)                                    # input pixel (Y - 1 + py + a, X - 1 + px + b)
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('C', [32, 64])
+def test_sft_epilogue_operand_evaluates_the_sft_layer(C):
+    """k4_conv3x3_p16_sft_multi's w_sfe (include/k4nerf.h): walking the operand the way the kernel's epilogue does -- GEMM 1 on the scaled
+    condition, tables, LeakyReLU, GEMM 2 with k in accumulator-register order, tables -- gives scale / shift of the SFTLayer (fp64, CPU);
+    every fp16 operand is finite and the hidden activations stay below 2^P16_TARGET_EXP over the calibrated condition range."""
+    from nerf4k_amd.lib.sr_esrnet import _PackedSfe, SFTLayer, P16_TARGET_EXP
+    torch.manual_seed(40 + C)
+    layer = SFTLayer(C, 32)
+    with torch.no_grad():
+        for m_ in layer.modules():
+            if isinstance(m_, torch.nn.Conv2d):
+                m_.weight.mul_(3.0)
+                m_.bias.normal_(0, 0.5)
+    e_cond = 7
+    sfe = _PackedSfe(layer, e_cond)
+    assert sfe.w.numel() * 2 == (C // 32) * 17408
+    cmax = 2.0 ** (P16_TARGET_EXP + 1 - e_cond)
+    cond = (torch.rand([50, 32], dtype=torch.float64) * 2 - 1) * cmax
+    with torch.no_grad():
+        c4 = cond.float().t().reshape(1, 32, 1, 50)
+        want_scale = layer.SFT_scale_conv1(torch.nn.functional.leaky_relu(layer.SFT_scale_conv0(c4), 0.2))[0, :, 0].double()       # [C][50]
+        want_shift = layer.SFT_shift_conv1(torch.nn.functional.leaky_relu(layer.SFT_shift_conv0(c4), 0.2))[0, :, 0].double()
+    lane = torch.arange(64)
+    l31, half = lane & 31, lane >> 5
+    for nb in range(C // 32):
+        blk = sfe.w[nb * 8704:(nb + 1) * 8704]
+        assert bool(torch.isfinite(blk[:8192].view(torch.float16).float()).all())
+        A1 = blk[:4096].view(torch.float16).double().reshape(2, 2, 2, 64, 8).sum(2)              # [path][kb][lane][e]  (hi + lo)
+        A2 = blk[4096:8192].view(torch.float16).double().reshape(2, 2, 2, 64, 8).sum(2)
+        T = blk[8192:].view(torch.float32).double().reshape(4, 2, 2, 16)                          # [us1|b1|us2|b2][path][half][16]
+        B = cond * 2.0 ** e_cond                                                                  # [pix][k]
+        got = []
+        for pth in (0, 1):
+            acc = torch.zeros([50, 32], dtype=torch.float64)                                      # [pix][row m]
+            for kb in range(2):
+                for e in range(8):
+                    for h in (0, 1):                                                              # lane (h, m): A1 element e multiplies condition channel 16 kb + 8 h + e
+                        sel = half == h
+                        acc[:, l31[sel]] += A1[pth, kb, sel, e][None, :] * B[:, (16 * kb + 8 * h + e)][:, None]
+            # registers of half h: entry i <-> row (i & 3) + 8 (i >> 2) + 4 h
+            hid = torch.zeros([50, 2, 16], dtype=torch.float64)
+            for h in (0, 1):
+                for i in range(16):
+                    rowi = (i & 3) + 8 * (i >> 2) + 4 * h
+                    t = acc[:, rowi] * T[0, pth, h, i] + T[1, pth, h, i]
+                    hid[:, h, i] = torch.where(t > 0, t, t * 0.2)
+            assert float(hid.abs().max()) <= 2.0 ** P16_TARGET_EXP
+            out = torch.zeros([50, 32], dtype=torch.float64)                                      # [pix][c local]
+            for kb in range(2):
+                for e in range(8):
+                    for h in (0, 1):
+                        sel = half == h
+                        out[:, l31[sel]] += A2[pth, kb, sel, e][None, :] * hid[:, h, 8 * kb + e][:, None]
+            res = torch.zeros([50, 32], dtype=torch.float64)
+            for h in (0, 1):
+                for i in range(16):
+                    rowi = (i & 3) + 8 * (i >> 2) + 4 * h
+                    res[:, rowi] = out[:, rowi] * T[2, pth, h, i] + T[3, pth, h, i]
+            got.append(res.t())                                                                   # [32][pix]
+        for g_, w_ in zip(got, (want_scale, want_shift)):
+            w_nb = w_[nb * 32:(nb + 1) * 32]
+            assert float((g_ - w_nb).abs().max()) <= 3e-6 * max(1.0, float(w_nb.abs().max())), (C, nb, float((g_ - w_nb).abs().max()))

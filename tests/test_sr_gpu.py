@@ -449,6 +449,102 @@ def test_p16_conv_layer(cin, cout):
         assert torch.equal(ypu[..., 32:32 + cout].cpu(), helpers.to_p16(yu[..., 32:32 + cout].cpu(), E_out))
 
 
+@pytest.mark.parametrize('cin,cout', [(160, 32), (192, 64)])
+def test_p16_conv_with_sft_epilogue(cin, cout):
+    """k4_conv3x3_p16_sft_multi (the SFTLayer that consumes a 3x3 layer's result evaluated in that layer's epilogue: sft1 <- conv4, next sft0 <-
+    conv5) against fp64: the layer's own fp32 result (LeakyReLU / residual), the modulated result decoded from its pre-split store, y = NULL
+    produces the same y2, ragged sizes, untouched neighbours, and the overflow word for a condition outside fp16 under its scale."""
+    import torch.nn.functional as F
+    from nerf4k_amd import _native as N
+    from nerf4k_amd.lib.sr_esrnet import _PackedP16, _PackedSfe, EPI_LRELU, EPI_RES
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    torch.manual_seed(cin + cout)
+    layer = sr_esrnet.SFTLayer(cout, 32)
+    for p_ in layer.parameters():
+        p_.data.normal_(0, 0.3)
+    e_cond = 7                                                   # |cond| 2^7 < 2^10: |cond| < 8
+    sfe = _PackedSfe(layer.cuda(), e_cond)
+    layer = layer.cpu().double()
+    for (H, W) in ((19, 41), (8, 32), (1, 1), (33, 70)):
+        x = torch.randn([H, W, cin], generator=g)
+        e_chunks = [4] * (cin // 16)
+        xp = torch.zeros([H, W, 224], dtype=torch.int32)
+        xp[..., 16:16 + cin] = helpers.to_p16(x, 4)
+        xd = helpers.from_p16(xp[..., 16:16 + cin], 4)
+        w = torch.randn([cout, cin, 3, 3], generator=g) / (cin * 9) ** 0.5
+        b = torch.randn([cout], generator=g)
+        res = torch.randn([H, W, 72], generator=g)
+        cond = (torch.rand([H, W, 40], generator=g) * 2 - 1) * 6.0
+        pk = _PackedP16(w.cuda(), b.cuda(), e_chunks)
+        ref = F.conv2d(xd.permute(2, 0, 1).unsqueeze(0), w.double(), b.double(), padding=1)
+        c4 = cond[..., 4:36].double().permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            scale = layer.SFT_scale_conv1(F.leaky_relu(layer.SFT_scale_conv0(c4), 0.2))[0].permute(1, 2, 0)
+            shift = layer.SFT_shift_conv1(F.leaky_relu(layer.SFT_shift_conv0(c4), 0.2))[0].permute(1, 2, 0)
+        E_out = 6
+        for flags, use_res in ((EPI_LRELU, False), (EPI_RES, True)):
+            v = ref[0].permute(1, 2, 0)
+            v = F.leaky_relu(v, 0.2) if flags & EPI_LRELU else v
+            if use_res:
+                v = v * 0.2 + res[..., 4:4 + cout].double()
+            want = v * (scale + 1) + shift
+            outs = []
+            for dual in (True, False):
+                y = torch.zeros([H, W, 112]).cuda()
+                y2 = torch.zeros([H, W, 208], dtype=torch.int32).cuda()
+                ovf = torch.zeros([8], dtype=torch.int32).cuda()
+                jobs, sj = (N.ConvJob * 1)(), (N.ConvSftJob * 1)()
+                xc, rc, cc = xp.cuda(), res.cuda(), cond.cuda()
+                jobs[0].x, jobs[0].y = xc.data_ptr() + 64, (y.data_ptr() + 128) if dual else None
+                jobs[0].res, jobs[0].mod_x, jobs[0].H, jobs[0].W = (rc.data_ptr() + 16) if use_res else None, None, H, W
+                sj[0].cond, sj[0].y2 = cc.data_ptr() + 16, y2.data_ptr() + 4 * 64
+                N.check(N.lib().k4_conv3x3_p16_sft_multi(jobs, sj, 1, cin, 224, N.ptr(pk.w), N.f32(pk.b), cout, 112, flags, 0.2, 72 if use_res else 0,
+                                                         0.2 if use_res else 0.0, 40, float(2.0 ** e_cond), N.ptr(sfe.w), 0.2, 208, float(2.0 ** E_out),
+                                                         N.ptr(ovf), N.stream()), 'k4_conv3x3_p16_sft_multi')
+                got = helpers.from_p16(y2[..., 64:64 + cout].cpu(), E_out)
+                err = float((got - want).abs().max())
+                assert err < 2e-5 * max(1.0, float(want.abs().max())), (cin, cout, H, W, flags, dual, err)
+                assert int(ovf.sum()) == 0
+                assert int(y2[..., :64].abs().max()) == 0 and int(y2[..., 64 + cout:].abs().max()) == 0
+                if dual:
+                    assert float((y[..., 32:32 + cout].cpu().double() - v).abs().max()) < 5e-6
+                    assert float(y[..., :32].abs().max()) == 0 and float(y[..., 32 + cout:].abs().max()) == 0
+                else:
+                    assert float(y.abs().max()) == 0
+                outs.append(y2.cpu())
+            assert torch.equal(outs[0], outs[1])
+        # a condition value beyond fp16 under its scale raises the window's overflow word
+        cc = cond.clone(); cc[H // 2, W // 2, 9] = 700.0
+        cc = cc.cuda()
+        sj[0].cond = cc.data_ptr() + 16
+        ovf = torch.zeros([8], dtype=torch.int32).cuda()
+        N.check(N.lib().k4_conv3x3_p16_sft_multi(jobs, sj, 1, cin, 224, N.ptr(pk.w), N.f32(pk.b), cout, 112, EPI_LRELU, 0.2, 0, 0.0, 40, float(2.0 ** e_cond),
+                                                 N.ptr(sfe.w), 0.2, 208, float(2.0 ** E_out), N.ptr(ovf), N.stream()), 'k4_conv3x3_p16_sft_multi')
+        assert int(ovf[0]) == 1 and int(ovf[1:].sum()) == 0
+
+
+def test_f16x3p_sft_epilogues_against_separate_sft_launches(monkeypatch):
+    """The default 'f16x3p' plan (sft1 / the inner sft0 layers in the epilogue of conv4 / conv5) against the same plan with every SFT layer as
+    its own launch (K4_SR_SFT_FUSE=0): two fp32-equivalent evaluations of the same network (>= 125 dB), 25 launches fewer."""
+    sd = osr.make_state_dict(seed=5, num_block=5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand([1, 3, 70, 100], generator=g).cuda()
+    cond = torch.rand([1, 1, 70, 100], generator=g).cuda()
+    outs, launches = [], []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('K4_SR_SFT_FUSE', fuse)
+        net = _net(sd, 5)
+        net.k4_mode = 'f16x3p'
+        with torch.no_grad():
+            outs.append(net(x, cond).cpu())
+        assert net._k4.get('p16_reruns', 0) == 0
+        plan = next(iter(net._k4[('plans', 0)].values()))
+        launches.append(sum(1 for fn, _, _ in plan if fn is not None))
+    assert launches[1] - launches[0] == 25, launches
+    p = psnr(outs[0], outs[1])
+    assert p >= 125.0 and float((outs[0] - outs[1]).abs().max()) <= 5e-6, (p, float((outs[0] - outs[1]).abs().max()))
+
+
 @pytest.mark.parametrize('C', [64, 32])
 def test_sft_layer_p16_output_is_the_split_of_the_fp32_output(C):
     """k4_sft_nhwc_p16_multi == to_p16(k4_sft_nhwc_multi): same arithmetic, the producer only changes how the result is stored (pins the
