@@ -469,8 +469,10 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
                        'partial products on v_mfma_f32_32x32x16_f16, fp32 accumulation (~2^-21 per product, NOT bit-for-bit fp32; the '
                        'strictly fp32-equivalent decoder is four_k_bf16x6); 1x1 / SFT / conv_last layers: exact 3-term bf16 splits'
                        + ('; dense-block / upsampling activations are written PRE-SPLIT (fp16 hi + lo) by their producer under one '
-                          'calibrated power-of-two scale per tensor and go global -> LDS by DMA; a window that leaves fp16 range is '
-                          'redone on the per-tile kernel (k4_p16_reruns counts them)' if mode == 'f16x3p' else '')),
+                          'calibrated power-of-two scale per tensor and go global -> LDS by DMA; the SFT layers behind conv4 / conv5 of a '
+                          'dense block run in that 3x3 layer\'s epilogue in the same 3-product fp16 arithmetic (K4_SR_SFT_FUSE=0: own launches, '
+                          'bf16 splits); a window that leaves fp16 range is redone on the per-tile kernel (k4_p16_reruns counts them)'
+                          if mode == 'f16x3p' else '')),
         'sr_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
                         'frac': round(tflops / peak, 4), 'flop_per_frame': flop_per_px * px,
                         # the other roof: every layer reads its inputs and writes its outputs ONCE as fp32 (no halo, no re-reads): channel
@@ -481,7 +483,11 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
                         'mfma_floor_ms': round(flop_per_px * px / (peak * 1e12) * 1e3, 2),
                         'note': f'peak = 2.5 PFLOP/s dense bf16|fp16 / {per_product} MFMA per product x n_gpus; time includes the '
                                 'marcher, layout copies and the all-gather.  With fp32 activations the decoder sits where the two roofs '
-                                'meet for the 3-product arithmetic (hbm_floor_ms vs mfma_floor_ms)'}})
+                                'meet for the 3-product arithmetic (hbm_floor_ms vs mfma_floor_ms).  The peak is quoted at 2.4 GHz; '
+                                'the 3x3 kernels of this frame were measured at 1,624 MHz (s_memtime / s_memrealtime per wave on an '
+                                'instrumented build, profiles/r04_p16_producer_waves_not_faster.md section 3): frac_at_measured_clock '
+                                'prices the same time against peak x 1624 / 2400',
+                        'frac_at_measured_clock': round(tflops / (peak * 1624.0 / 2400.0), 4)}})
     if world == 1:
         # The N-GPU job's critical path, measured on THIS GPU (no multi-GPU node was available to the builder: every figure below is a
         # PROJECTION, unmeasured on hardware): for N = 2 / 4 / 8 and a few tile sizes, the heaviest rank's share of the frame (its tiles'
