@@ -54,8 +54,9 @@ struct P16Conv {
 // then sees only a 2 x 2 neighbourhood of LR pixels -- the 3 x 3 taps that land on the same LR pixel add up: per PHASE (py, px) the layer is a
 // 2 x 2 convolution with the weights W'[a][b] = sum of the taps (dy, dx) with (py + dy - 1) >> 1 == a + py - 1 (rows; same for columns), 16
 // tap matrices instead of 36 per 2 x 2 output pixels: 2.25x fewer matrix instructions, exact algebra (the tap sums are formed in fp32 by the
-// packer: the products differ from the 9-tap form by one rounding of a weight sum).  A workgroup = 8 x 32 LR positions of ONE phase; the four
-// phase workgroups of a tile are adjacent in launch order (the tile's activations come from L2 three times out of four).
+// packer: the products differ from the 9-tap form by one rounding of a weight sum).  A workgroup = 8 x 32 LR positions of the two column phases
+// (py, 0), (py, 1) of one row phase: four accumulator blocks per wave, the haloed tile fetched once for both (P16_CHUNK_UP); the two row-phase
+// workgroups of a tile are adjacent in launch order.
 //
 // SFT (k4_conv3x3_p16_sft_multi): the SFTLayer that consumes this layer's result (lib/sr_esrnet.py:112-123,149-156: sft1 after conv4, the next
 // dense block's sft0 after conv5) runs in the epilogue instead of as a launch of its own (36 of a frame's 111 launches, HBM-bound at 75-125 us
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 #else
 #define P16_TFLUSH() do { } while (0)
 #endif
-    constexpr int W_CH = UP ? P16_W_BYTES_UP : P16_W_BYTES;           // weight bytes of one (chunk, output block[, phase])
+    constexpr int W_CH = UP ? 2 * P16_W_BYTES_UP : P16_W_BYTES;       // weight bytes of one (chunk, output block[, phase PAIR (py, 0), (py, 1)])
     constexpr int W_NI = W_CH / 1024;                                  // DMA instructions
-    constexpr int NSUB = UP ? 8 : 18;                                  // sub-stages (tap x row) per chunk
-    constexpr int NTAP = UP ? 4 : 9;
+    constexpr int NSUB = 18;                                           // sub-stages (tap x row) per chunk of the 3 x 3 form
+    constexpr int NTAP = 9;
     __shared__ __attribute__((aligned(16))) unsigned char wbuf0[P16_W_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char wbuf1[P16_W_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char abuf0[P16_ACT_BYTES];
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     while (g + 1 < M.n && b >= M.blk_end[g]) ++g;
     const int local = b - (g ? M.blk_end[g - 1] : 0);
     const int nb_count = M.cout >> 5;
-    const int phase = UP ? (local & 3) : 0, py = phase >> 1, px = phase & 1;
-    const int lt = UP ? (local >> 2) : local;
+    const int py = UP ? (local & 1) : 0;                               // UP: a workgroup = both column phases (py, 0), (py, 1) of its tile
+    const int lt = UP ? (local >> 1) : local;
     const int tile = lt / nb_count, nb = lt - tile * nb_count;
     const int H = M.H[g], W = M.W[g];                                  // OUTPUT size; the tile grid and the DMA plan live on the input (LR) image
     const int srcH = UP ? H >> 1 : H, srcW = UP ? W >> 1 : W;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 
     // ---- DMA plan of this thread (chunk independent): activation instructions k = wv + 4 i, weight instructions k = wv + 4 i ----
     const __amdgpu_buffer_rsrc_t xrs = p16_rsrc(M.x[g], (unsigned)(((long long)(srcH * srcW - 1) * M.cin_stride + M.cin) * 4));
-    const int w_tail = nchunks * nb_count * (UP ? 4 : 1) * W_CH;      // byte offset of the [cout] floats 2^-a[co] behind the weights
+    const int w_tail = nchunks * nb_count * (UP ? 2 : 1) * W_CH;      // byte offset of the [cout] floats 2^-a[co] behind the weights
     const __amdgpu_buffer_rsrc_t wrs = p16_rsrc(M.w, (unsigned)(w_tail + M.cout * 4));
     // DMA plan of this wave: instruction k of a plan belongs to wave k % 4.  (A fifth / sixth wave that only issues the DMA -- the matrix waves
     // then never sit on the vector-memory queue, ~20 % of their life by s_memtime stamps -- was built and measured: bit-identical, the chunk
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     }
     const unsigned woff = (unsigned)(lane * 16);
 #define P16_ISSUE(CH, WB, AB) do { { \
-        const int wso_ = (((CH) * nb_count + nb) * (UP ? 4 : 1) + phase) * W_CH; \
+        const int wso_ = (((CH) * nb_count + nb) * (UP ? 2 : 1) + py) * W_CH; \
         const int aso_ = (CH) * 64; \
         _Pragma("unroll") for (int i_ = 0; i_ < WW; ++i_) { \
             const int k_ = wi + NISS * i_; \
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = l31 + dx + (UP && dx < 2 ? px : 0);           // UP: column taps b = 0, 1 read haloed columns l31 + b + px (ard[2] unused)
+            const int col = l31 + dx;                                     // UP: column tap b of phase px reads haloed column l31 + b + px = ard[b + px]
             ard[dx][t] = (unsigned)(((wv * 2 + (UP ? py : 0)) * P16_COLS + col) * 64 + (((2 * t + half) ^ ((col >> 2) & 3)) << 4));
         }
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     const int cob = nb * 32 + 4 * half;
     p16_f32x4 us[4], bs[4];
     if constexpr (!SFT) {
-        const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(M.w) + (size_t)nchunks * nb_count * (UP ? 4 : 1) * W_CH);
+        const float* const wtail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(M.w) + (size_t)w_tail);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             us[q] = *reinterpret_cast<const p16_f32x4*>(wtail + cob + 8 * q);
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         }
     }
 
-    p16_f32x16 acc[2];
-    acc[0] = (p16_f32x16)(0.f); acc[1] = (p16_f32x16)(0.f);
+    p16_f32x16 acc[UP ? 4 : 2];                                        // [row r] (UP: [column phase px][row r])
+#pragma unroll
+    for (int i = 0; i < (UP ? 4 : 2); ++i) acc[i] = (p16_f32x16)(0.f);
 
     // SFT: the lane's condition channels kb*16 + 8*half + 0..7 (kb = 0, 1) of its two pixels, requested now; the operand's DMA plan
     p16_u32x4 cq[SFT ? 2 : 1][4];
@@ -215,10 +217,9 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // tap t -> (row, column) offset in the haloed tile: 3 x 3 taps (dy, dx) = (t / 3, t % 3); UP: 2 x 2 taps (a, b) = (t / 2, t % 2), the phase's
-    // offset already sits in ard
-#define P16_TROW(T) (UP ? (T) / 2 : (T) / 3)
-#define P16_TCOL(T) (UP ? (T) % 2 : (T) % 3)
+    // tap t -> (row, column) offset in the haloed tile: 3 x 3 taps (dy, dx) = (t / 3, t % 3)
+#define P16_TROW(T) ((T) / 3)
+#define P16_TCOL(T) ((T) % 3)
 #define P16_RDW(DST, WB, T) do { \
         DST[0] = *reinterpret_cast<lds_u32x4*>(WB + wrd + (0 * NTAP + (T)) * 1024); \
         DST[1] = *reinterpret_cast<lds_u32x4*>(WB + wrd + (1 * NTAP + (T)) * 1024); } while (0)
@@ -253,11 +254,59 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
             __builtin_amdgcn_sched_barrier(0); \
         } } while (0)
 
+    // UP: one chunk of the phase pair = 4 stages (row tap a, row r); a stage reads the THREE haloed columns l31 + 0 / 1 / 2 of input row r + a + py
+    // once -- column tap b of phase px multiplies column b + px, so the middle column serves both phases -- and issues 4 (px, b) x 3 MFMAs.
+    // LDS weight image of the pair: [px][hi | lo][tap a*2+b][64 lanes] x 16 B.  Fragments of stage s + 1 (and of row tap 1 during stage 1) are read
+    // under the MFMAs of stage s.  (Four single-phase workgroups per tile fetched the same activations four times for 24 MFMAs per chunk and
+    // wave: the layer was bound by the DMA issue.)
+#define P16_RDW_UP(DST, WB, A) do { \
+        _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) \
+        _Pragma("unroll") for (int tm_ = 0; tm_ < 2; ++tm_) \
+            DST[px_][b_][tm_] = *reinterpret_cast<lds_u32x4*>(WB + wrd + ((px_ * 2 + tm_) * 4 + (A) * 2 + b_) * 1024); } while (0)
+#define P16_RDX_UP(DST, AB, S) do { \
+        _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) \
+        _Pragma("unroll") for (int tm_ = 0; tm_ < 2; ++tm_) \
+            DST[c_][tm_] = *reinterpret_cast<lds_u32x4*>(AB + ard[c_][tm_] + (((S) & 1) + ((S) >> 1)) * (P16_COLS * 64)); } while (0)
+#define P16_CHUNK_UP(CH, WB, AB, WBN, ABN) do { \
+        P16_TSTAMP(CH == 0 ? 0 : 3); \
+        P16_BARRIER(); \
+        P16_TSTAMP(1); \
+        if ((CH) + 1 < nchunks) P16_ISSUE((CH) + 1, WBN, ABN); \
+        P16_TSTAMP(2); \
+        p16_u32x4 ww[2][2][2][2], xx[2][3][2];                   /* [buffer][px][b][term], [buffer][column][term] */ \
+        P16_RDW_UP(ww[0], WB, 0); \
+        P16_RDX_UP(xx[0], AB, 0); \
+        if (!(M.debug & 256)) \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {       /* stage s = (a = s >> 1, r = s & 1) */ \
+            const int a_ = s_ >> 1, r_ = s_ & 1; \
+            if (s_ == 1) P16_RDW_UP(ww[1], WB, 1); \
+            if (s_ + 1 < 4) P16_RDX_UP(xx[(s_ + 1) & 1], AB, s_ + 1); \
+            __builtin_amdgcn_sched_barrier(0); \
+            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) \
+            _Pragma("unroll") for (int px_ = 0; px_ < 2; ++px_) { \
+                const p16_f16x8 wh = __builtin_bit_cast(p16_f16x8, ww[a_][px_][b_][0]), wl = __builtin_bit_cast(p16_f16x8, ww[a_][px_][b_][1]); \
+                const p16_f16x8 xh = __builtin_bit_cast(p16_f16x8, xx[s_ & 1][b_ + px_][0]), xl = __builtin_bit_cast(p16_f16x8, xx[s_ & 1][b_ + px_][1]); \
+                acc[px_ * 2 + r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[px_ * 2 + r_], 0, 0, 0); \
+                acc[px_ * 2 + r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[px_ * 2 + r_], 0, 0, 0); \
+                acc[px_ * 2 + r_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[px_ * 2 + r_], 0, 0, 0); \
+            } \
+            __builtin_amdgcn_sched_barrier(0); \
+        } } while (0)
+
     for (int ch = 0; ch < nchunks; ch += 2) {
-        P16_CHUNK(ch, W0, A0, W1, A1);
-        if (ch + 1 < nchunks) P16_CHUNK(ch + 1, W1, A1, W0, A0);
+        if constexpr (UP) {
+            P16_CHUNK_UP(ch, W0, A0, W1, A1);
+            if (ch + 1 < nchunks) P16_CHUNK_UP(ch + 1, W1, A1, W0, A0);
+        } else {
+            P16_CHUNK(ch, W0, A0, W1, A1);
+            if (ch + 1 < nchunks) P16_CHUNK(ch + 1, W1, A1, W0, A0);
+        }
     }
 #undef P16_CHUNK
+#undef P16_CHUNK_UP
+#undef P16_RDW_UP
+#undef P16_RDX_UP
 #undef P16_RDX
 #undef P16_RDW
 #undef P16_TROW
@@ -267,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
 
     P16_TSTAMP(3);
     // ---- epilogue: lane = pixel (x0 + l31, row y0 + 2 wv + r), registers 4q .. 4q+3 = channels cob + 8q + 0..3 ----
-    const int gx = UP ? 2 * (x0 + l31) + px : x0 + l31;               // output column of this lane
+    const int gx = x0 + l31;                                           // output column of this lane (UP: 2 gx + px, below)
     const float sl = (M.flags & K4_EPI_LRELU) ? M.slope : 1.f;
     const bool has_res = (M.flags & K4_EPI_RES) != 0;
     const __amdgpu_buffer_rsrc_t yrs = p16_rsrc(M.y[g], (unsigned)(((long long)(H * W - 1) * M.cout_stride + M.cout) * 4));
@@ -409,11 +458,13 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
     }
     float amax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int ri = 0; ri < (UP ? 4 : 2); ++ri) {                              // accumulator ri = (column phase px, row r)
+        const int r = ri & 1, pxe = ri >> 1;
         const int gy = UP ? 2 * (y0 + wv * 2 + r) + py : y0 + wv * 2 + r;
         if (gy >= H) continue;                                               // wave-uniform
-        const bool ok = gx < W;
-        const unsigned pix = (unsigned)(gy * W + gx);
+        const int gxo = UP ? 2 * gx + pxe : gx;
+        const bool ok = gxo < W;
+        const unsigned pix = (unsigned)(gy * W + gxo);
         const unsigned roff = ok ? (pix * (unsigned)M.res_stride + (unsigned)cob) * 4u : P16_OOB;
         p16_u32x4 rq[4];
         if (has_res) {
@@ -425,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = fmaf(acc[r][4 * q + e], us[q][e], bs[q][e]);
+                float t = fmaf(acc[ri][4 * q + e], us[q][e], bs[q][e]);
                 t = fmaxf(t, t * sl);                                        // LeakyReLU for 0 <= slope <= 1 (host check); identity with sl = 1
                 if (has_res) t = p16_mul_add(t, M.res_scale, __uint_as_float(rq[q][e]));
                 v[e] = t;
@@ -519,10 +570,10 @@ static int conv3x3_p16(const k4_conv_job* jobs, const k4_conv_sft_job* sjobs, in
         const long long strd = cin_stride > cout_stride ? cin_stride : cout_stride;
         if ((long long)j.H * j.W * (strd > res_stride ? strd : res_stride) * 4 >= 0x80000000LL) return K4_ERR_UNSUPPORTED;      // 32-bit buffer offsets
         M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.H[g] = j.H; M.W[g] = j.W;
-        const bool up = (flags & K4_PRE_UPSAMPLE2X) != 0;              // the tile grid lives on the INPUT image; four phase workgroups per tile
+        const bool up = (flags & K4_PRE_UPSAMPLE2X) != 0;              // the tile grid lives on the INPUT image; two workgroups (row phases) per tile
         const int gw = up ? j.W / 2 : j.W, gh = up ? j.H / 2 : j.H;
         M.tiles_x[g] = (gw + 31) / 32;
-        total += M.tiles_x[g] * ((gh + 7) / 8) * nbc * (up ? 4 : 1);
+        total += M.tiles_x[g] * ((gh + 7) / 8) * nbc * (up ? 2 : 1);
         M.blk_end[g] = total;
     }
     M.total = total;

@@ -545,6 +545,23 @@ def test_f16x3p_sft_epilogues_against_separate_sft_launches(monkeypatch):
     assert p >= 125.0 and float((outs[0] - outs[1]).abs().max()) <= 5e-6, (p, float((outs[0] - outs[1]).abs().max()))
 
 
+def test_f16x3p_decoder_is_run_to_run_deterministic():
+    """The same window five times: identical bits.  (The chunk loop's barriers guard LDS written by DMA; a compiler-chosen `s_waitcnt vmcnt(8)` in
+    front of one of them once let DMA instructions of the next chunk stay in flight -- the result then differed from run to run on large
+    windows only.  The kernel waits explicitly now; this is the regression test: a window of several hundred workgroups, every layer shape.)"""
+    sd = osr.make_state_dict(seed=3, num_block=2)
+    net = _net(sd, 2)
+    net.k4_mode = 'f16x3p'
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand([1, 3, 300, 260], generator=g).cuda()
+    c = torch.rand([1, 300, 260], generator=g).cuda()
+    with torch.no_grad():
+        ref = net.tile_process_device(x, c, 189, 10).clone()
+        for _ in range(4):
+            assert torch.equal(net.tile_process_device(x, c, 189, 10), ref)
+    assert net._k4.get('p16_reruns', 0) == 0
+
+
 @pytest.mark.parametrize('C', [64, 32])
 def test_sft_layer_p16_output_is_the_split_of_the_fp32_output(C):
     """k4_sft_nhwc_p16_multi == to_p16(k4_sft_nhwc_multi): same arithmetic, the producer only changes how the result is stored (pins the
