@@ -39,6 +39,16 @@ class ConvSftJob(C.Structure):       # k4_conv_sft_job
     _fields_ = [('cond', C.c_void_p), ('y2', C.c_void_p)]
 
 
+class RdbTrain(C.Structure):         # k4_rdb_train
+    _fields_ = [('H', C.c_int32), ('W', C.c_int32), ('nf', C.c_int32), ('g', C.c_int32),
+                ('t', C.c_void_p), ('c', C.c_void_p), ('buf', C.c_void_p), ('x4', C.c_void_p), ('out', C.c_void_p),
+                ('w_fwd', C.c_void_p * 5), ('b_fwd', C.c_void_p * 5), ('sft0', C.c_void_p * 8), ('sft1', C.c_void_p * 8),
+                ('w_bwd', C.c_void_p * 5), ('b_bwd', C.c_void_p * 5), ('g5', C.c_void_p),
+                ('G', C.c_void_p), ('gx4', C.c_void_p), ('gx0', C.c_void_p), ('gc0', C.c_void_p), ('gc1', C.c_void_p),
+                ('dwdb', C.c_void_p * 5), ('gsft0', C.c_void_p * 8), ('gsft1', C.c_void_p * 8),
+                ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p)]
+
+
 class AdamJob(C.Structure):          # k4_adam_job
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p), ('n', C.c_int64)]
 
@@ -141,6 +151,8 @@ _EXTRA_SIGS = {
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_wgrad_dbias_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_pack_conv_weight_bf16x6_multi': ([C.POINTER(PackJob), _I32, _P], C.c_int),
+    'k4_rdb_train_fwd': ([C.POINTER(RdbTrain), _P], C.c_int),
+    'k4_rdb_train_bwd': ([C.POINTER(RdbTrain), _P], C.c_int),
     'k4_lrelu_bwd': ([_P, _I32, _P, _I32, _I64, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_conv2d_bias_grad': ([_P, _I32, _I32, _I64, _P, _P], C.c_int),
     'k4_adam_upd_multi': ([C.POINTER(AdamJob), _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),

@@ -826,6 +826,85 @@ extern "C" int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// A dense block of the training graph issued natively (include/k4nerf.h, k4_rdb_train): the launch sequences of lib/sr_train.py K4RDB.forward /
+// .backward, call for call -- the entry points below are the ones the host would call; what goes away is ~26 Python-to-C transitions per block.
+// ---------------------------------------------------------------------------------------------------------------------
+static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // everything queued on `signaller` so far completes before what `waiter` gets next
+    if (waiter == signaller) return 0;
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventRecord(ev, signaller);
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+    const hipError_t d = hipEventDestroy(ev);                              // (released by the runtime once the recorded work has completed)
+    return (int)(e != hipSuccess ? e : d);
+}
+static bool k4_rdb_ok(const k4_rdb_train* p, bool bwd) {
+    if (!p || p->H <= 0 || p->W <= 0 || p->g != 32 || (p->nf != 32 && p->nf != 64) || !p->t || !p->c || !p->buf || !p->x4) return false;
+    for (int k = 0; k < 5; ++k) if (!p->w_fwd[k] && !bwd) return false;
+    for (int k = 0; k < 8; ++k) if (!p->sft0[k] || !p->sft1[k]) return false;
+    if (!bwd) return p->out != nullptr;
+    if (!p->g5 || !p->G || !p->gx4 || !p->gx0 || !p->gc0 || !p->gc1 || !p->ws0 || !p->ws1) return false;
+    for (int k = 0; k < 5; ++k) if (!p->w_bwd[k] || !p->b_bwd[k] || !p->dwdb[k]) return false;
+    for (int k = 0; k < 8; ++k) if (!p->gsft0[k] || !p->gsft1[k]) return false;
+    return true;
+}
+#define K4_RDB_TRY(CALL) do { const int rc_ = (CALL); if (rc_ != 0) return rc_; } while (0)
+
+extern "C" int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream) {
+    if (!k4_rdb_ok(p, false)) return K4_ERR_BAD_ARG;
+    const int H = p->H, W = p->W, nf = p->nf, g = p->g, bw = nf + 4 * g;
+    const int64_t n = (int64_t)H * W;
+    K4_RDB_TRY(k4_sft_train_fwd(p->t, nf, p->c, 32, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6], p->sft0[7],
+                                0.2f, p->buf, bw, stream));
+    for (int k = 1; k <= 3; ++k)
+        K4_RDB_TRY(k4_conv2d_nhwc_bf16x6(p->buf, nf + (k - 1) * g, bw, p->w_fwd[k - 1], p->b_fwd[k - 1], 3, p->buf + nf + (k - 1) * g, g, bw, H, W,
+                                         K4_EPI_LRELU, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
+    K4_RDB_TRY(k4_conv2d_nhwc_bf16x6(p->buf, nf + 3 * g, bw, p->w_fwd[3], p->b_fwd[3], 3, p->x4, g, g, H, W, K4_EPI_LRELU, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
+    K4_RDB_TRY(k4_sft_train_fwd(p->x4, g, p->c, 32, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6], p->sft1[7],
+                                0.2f, p->buf + nf + 3 * g, bw, stream));
+    return k4_conv2d_nhwc_bf16x6(p->buf, bw, bw, p->w_fwd[4], p->b_fwd[4], 3, p->out, nf, nf, H, W, K4_EPI_RES, 0.2f, p->t, nf, 0.2f, nullptr, 0, stream);
+}
+
+extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
+    if (!k4_rdb_ok(p, true)) return K4_ERR_BAD_ARG;
+    const int H = p->H, W = p->W, nf = p->nf, g = p->g, bw = nf + 4 * g;
+    const int64_t n = (int64_t)H * W;
+    hipStream_t main_s = (hipStream_t)stream, side = p->side_stream ? (hipStream_t)p->side_stream : main_s;
+    // a weight gradient on the side stream: forked behind everything queued on the main stream so far (= the producer of the gradient slice it reads)
+#define K4_RDB_WGRAD(CIN, GY, COUT, GYS, K) do { \
+        K4_RDB_TRY(k4_wait_stream(side, main_s)); \
+        K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); } while (0)
+    // G[:, 0:COUT'] (+)= dgrad: the output is its own residual
+#define K4_RDB_DGRAD(K, SRC, SS, CIN_OF_LAYER, ACC) \
+        K4_RDB_TRY(k4_conv2d_nhwc_bf16x6((SRC), (K) == 4 ? nf : g, (SS), p->w_bwd[K], p->b_bwd[K], 3, p->G, (CIN_OF_LAYER), bw, H, W, (ACC) ? K4_EPI_RES : 0u, 0.2f, \
+                                         (ACC) ? p->G : nullptr, (ACC) ? bw : 0, 1.f, nullptr, 0, stream))
+    // conv5: out = 0.2 conv5(buf) + t
+    K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
+    K4_RDB_DGRAD(4, p->g5, nf, bw, false);                                         // G = dgrad (every channel)
+    // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
+    K4_RDB_TRY(k4_sft_train_bwd(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+                                0.2f, p->gx4, p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
+                                p->ws1, p->ws1_bytes, stream));
+    K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
+    K4_RDB_WGRAD(nf + 3 * g, p->gx4, g, g, 3);
+    K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true);                                  // G[:, 0:nf+3g] += dgrad
+    for (int k = 3; k >= 1; --k) {                                                  // x_k = lrelu(conv_k(buf[:, 0:off]))
+        const int off = nf + (k - 1) * g;
+        K4_RDB_TRY(k4_lrelu_bwd(p->G + off, bw, p->buf + off, bw, n, g, 0.2f, p->G + off, bw, stream));
+        K4_RDB_WGRAD(off, p->G + off, g, bw, k - 1);
+        K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true);
+    }
+    K4_RDB_TRY(k4_sft_train_bwd(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+                                0.2f, p->gx0, p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
+                                p->ws0, p->ws0_bytes, stream));
+#undef K4_RDB_WGRAD
+#undef K4_RDB_DGRAD
+    return k4_wait_stream(main_s, side);                                           // the wgrads are done before anything queued on `stream` after this call
+}
+#undef K4_RDB_TRY
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Touched voxels of a grid gradient [C][nvox] (any channel non-zero) as a compact int32 index list: what the data-parallel exchange of
 // the joint step sends instead of the dense 1.36 GB tensor (joint_train.sparse_grad_allreduce).  One pass over the gradient, no
 // temporaries; the list is in arbitrary order (wave-aggregated append), *counter receives the TOTAL number of touched voxels even when

@@ -95,11 +95,56 @@ class MaskedAdam(torch.optim.Optimizer):
             if not ok:
                 raise ValueError(msg)
         self.per_lr = None
+        self._fast = {}             # id(param group) -> plan of the group's small tensors (see _fast_step)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def set_pervoxel_lr(self, count):
         assert self.param_groups[0]['params'][0].shape == count.shape
         self.per_lr = (count.float() / count.max()).contiguous()
+        self._fast.clear()
+
+    def _fast_step(self, group, masked, beta1, beta2, lr, eps):
+        """The group's SMALL tensors (the decoder: 458 of them) in one pass over a plan built by the previous regular step: per tensor one
+        ``.grad`` read, one pointer refresh, one step-count store -- the regular path below spent ~2 ms of host time per iteration on them
+        (state lookups, contiguity / dtype checks, list building, job-table key), which paces the joint training iteration
+        (profiles/r04_train_wgrad_side_stream_slower.md).  Returns False (nothing done) whenever the plan's assumptions do not hold: a tensor
+        or its state re-allocated, a missing or non-contiguous gradient, step counts that differ."""
+        f = self._fast.get(id(group))
+        if f is None or f['masked'] != bool(masked) or len(group['params']) != f['n_group']:
+            return False
+        plist, states, jobs = f['params'], f['states'], f['jobs']
+        if [p.data_ptr() for p in plist] != f['pptr'] or self.state.get(plist[0]) is not states[0] or self.state.get(plist[-1]) is not states[-1]:
+            return False
+        grads = [p.grad for p in plist]
+        step = states[0]['step']
+        f32 = torch.float32
+        for g, st, nel in zip(grads, states, f['numel']):
+            if g is None or st['step'] != step or g.dtype is not f32 or not g.is_cuda or not g.is_contiguous() or g.numel() != nel:
+                return False
+        if [st['exp_avg'].data_ptr() for st in states] != f['mptr']:
+            return False
+        step += 1
+        for j, g in enumerate(grads):
+            jobs[j].grad = g.data_ptr()
+        for st in states:
+            st['step'] = step
+        N.check(N.lib().k4_adam_upd_multi(jobs, len(plist), int(bool(masked)), int(step), float(beta1), float(beta2), float(lr), float(eps),
+                                          N.stream()), 'k4_adam_upd_multi')
+        torch.autograd.graph.increment_version(f['touched'])
+        return True
+
+    def _fast_plan(self, group, masked, items):
+        """Remember the small tensors a regular step just updated (all at one step count) for _fast_step."""
+        plist = [ts[0] for ts in items]
+        states = [self.state[p] for p in plist]
+        jobs = (N.AdamJob * len(items))()
+        for j, ts in enumerate(items):
+            jobs[j].param, jobs[j].grad, jobs[j].exp_avg, jobs[j].exp_avg_sq = (t.data_ptr() for t in ts)
+            jobs[j].n = ts[0].numel()
+        self._fast[id(group)] = {'params': plist, 'states': states, 'jobs': jobs, 'masked': bool(masked), 'n_group': len(group['params']),
+                                 'pptr': [p.data_ptr() for p in plist], 'mptr': [st['exp_avg'].data_ptr() for st in states],
+                                 'numel': [p.numel() for p in plist], 'ids': {id(p) for p in plist},
+                                 'touched': [t for ts in items for t in (ts[0], ts[2], ts[3])]}
 
     @torch.no_grad()
     def step(self):
@@ -107,7 +152,10 @@ class MaskedAdam(torch.optim.Optimizer):
             (beta1, beta2), lr, eps = group['betas'], group['lr'], group['eps']
             masked = group['skip_zero_grad']                   # KeyError without it, as upstream (masked_adam.py:45)
             small = {}
+            fast_ids = self._fast[id(group)]['ids'] if self._fast_step(group, masked, beta1, beta2, lr, eps) else ()
             for param in (p for p in group['params'] if p.grad is not None):
+                if id(param) in fast_ids:
+                    continue
                 state = self.state[param]
                 if not state:                                   # lazy state, zeros in the parameter's memory format
                     state.update(step=0, exp_avg=torch.zeros_like(param, memory_format=torch.preserve_format),
@@ -128,4 +176,9 @@ class MaskedAdam(torch.optim.Optimizer):
             # the group's small tensors (the decoder: 458 of them) share hyper-parameters: a handful of launches instead of one each
             for (msk, step), items in small.items():
                 adam_upd_multi(items, msk, step, beta1, beta2, lr, eps)
+            if not fast_ids:
+                if len(small) == 1 and self.per_lr is None:     # one step count, one mask flag: the next step can take the fast path
+                    self._fast_plan(group, masked, next(iter(small.values())))
+                else:
+                    self._fast.pop(id(group), None)
             small.clear()

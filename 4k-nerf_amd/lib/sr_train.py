@@ -216,6 +216,31 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
     return gx, gc, g
 
 
+_NATIVE_RDB = os.environ.get('K4_TRAIN_NATIVE_RDB', '1') != '0'      # 0: a dense block's launches issued one by one from Python (A/B)
+_WGRAD_STREAM = os.environ.get('K4_TRAIN_WGRAD_STREAM', '1') != '0'   # 0: the block's weight gradients on the chain's own stream (A/B)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """The second HIP stream (per device) a dense block's weight-gradient launches go to (k4_rdb_train_bwd: forked / joined inside the call)."""
+    if not _WGRAD_STREAM:
+        return None
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return st.cuda_stream
+
+
+def _rdb_desc(t, c, buf, x4, P, H, W, nf, g):
+    d = N.RdbTrain()
+    d.H, d.W, d.nf, d.g = H, W, nf, g
+    d.t, d.c, d.buf, d.x4 = t.data_ptr(), c.data_ptr(), buf.data_ptr(), x4.data_ptr()
+    for i in range(8):
+        d.sft0[i] = P[i].data_ptr()
+        d.sft1[i] = P[18 + i].data_ptr()
+    return d
+
+
 class K4RDB(torch.autograd.Function):
     """ResidualDenseBlock_5C with its two SFT layers (lib/sr_esrnet.py:126-158) as ONE autograd node.
 
@@ -240,6 +265,17 @@ class K4RDB(torch.autograd.Function):
         buf = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
         x4 = torch.empty([H, W, g], dtype=torch.float32, device=t.device)
         out = torch.empty([H, W, nf], dtype=torch.float32, device=t.device)
+        if _NATIVE_RDB:                                   # the seven launches below, issued by ONE native call (include/k4nerf.h, k4_rdb_train)
+            d = _rdb_desc(t, c, buf, x4, P, H, W, nf, g)
+            d.out = out.data_ptr()
+            packs = [cache.fwd(P[8 + 2 * k], P[9 + 2 * k]) for k in range(5)]
+            for k, pk in enumerate(packs):
+                assert pk.mode == 'bf16x6' and pk.k == 3 and pk.flags_extra == 0
+                d.w_fwd[k], d.b_fwd[k] = pk.w.data_ptr(), pk.b.data_ptr()
+            N.check(L.k4_rdb_train_fwd(N.C.byref(d), N.stream()), 'k4_rdb_train_fwd')
+            ctx.save_for_backward(t, c, buf, x4, *P)
+            ctx.cache = cache
+            return out
         N.check(L.k4_sft_train_fwd(N.f32(t), nf, N.f32(c), 32, n, nf, *[N.f32(q) for q in P[0:8]], 0.2, N.f32(buf), bw, N.stream()), 'k4_sft_train_fwd')
         for k in (1, 2, 3):
             SFTNet._conv(cache.fwd(P[6 + 2 * k], P[7 + 2 * k]), buf, 0, bw, buf, nf + (k - 1) * g, bw, g, H, W, flags=EPI_LRELU)
@@ -263,6 +299,34 @@ class K4RDB(torch.autograd.Function):
         go = go.contiguous().float()
         G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
         grads = [None] * 26
+        if _NATIVE_RDB:                                   # the 19 launches of the host form below, issued by ONE native call; the weight gradients on a second stream
+            L, dev = N.lib(), t.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            d = _rdb_desc(t, c, buf, x4, P, H, W, nf, g)
+            g5 = go * 0.2
+            gx4, gx0 = torch.empty([n, g], **f32), torch.empty([n, nf], **f32)
+            gc0, gc1 = torch.empty([n, 32], **f32), torch.empty([n, 32], **f32)
+            d.g5, d.G, d.gx4, d.gx0, d.gc0, d.gc1 = g5.data_ptr(), G.data_ptr(), gx4.data_ptr(), gx0.data_ptr(), gc0.data_ptr(), gc1.data_ptr()
+            keep = []
+            for k in range(5):
+                w = P[8 + 2 * k]
+                pk = cache.bwd(w)
+                assert pk.mode == 'bf16x6' and pk.k == 3 and pk.flags_extra == 0
+                d.w_bwd[k], d.b_bwd[k] = pk.w.data_ptr(), pk.b.data_ptr()
+                dwdb = torch.empty([w.numel() + w.shape[0]], **f32)                  # zeroed by the wgrad entry point
+                d.dwdb[k] = dwdb.data_ptr()
+                grads[8 + 2 * k], grads[9 + 2 * k] = dwdb[:w.numel()].view(w.shape), dwdb[w.numel():]
+                keep.append(pk)
+            for i in range(8):
+                g0, g1 = torch.empty_like(P[i]), torch.empty_like(P[18 + i])
+                d.gsft0[i], d.gsft1[i] = g0.data_ptr(), g1.data_ptr()
+                grads[i], grads[18 + i] = g0, g1
+            nb0, nb1 = int(L.k4_sft_train_bwd_workspace_bytes(n, nf)), int(L.k4_sft_train_bwd_workspace_bytes(n, g))
+            ws0, ws1 = torch.empty([nb0 // 4], **f32), torch.empty([nb1 // 4], **f32)
+            d.ws0, d.ws0_bytes, d.ws1, d.ws1_bytes = ws0.data_ptr(), nb0, ws1.data_ptr(), nb1
+            d.side_stream = _side_stream(dev)
+            N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
+            return (go + gx0.view(H, W, nf), (gc0 + gc1).view(H, W, 32), None, *grads)
 
         def accum(pk, src, s_off, s_stride, cout):                      # G[..., :cout] += dgrad: the output is its own residual
             SFTNet._conv(pk, src, s_off, s_stride, G, 0, bw, cout, H, W, flags=EPI_RES, res=(G, 0, bw, 1.0))

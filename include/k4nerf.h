@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      8       /* 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      8       /* 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -420,6 +420,35 @@ int k4_pack_conv_weight_bf16x6_multi(const k4_pack_job* jobs, int32_t n_jobs, vo
  * input); rows of `*_stride` floats (channel slices of wider images); out may be grad (in place). */
 int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y, int32_t y_stride, int64_t n_pix, int32_t channels, float slope,
                  float* out, int32_t out_stride, void* stream);
+
+/* A whole ResidualDenseBlock_SFT (lib/sr_esrnet.py:126-158) of the training graph issued by ONE call: the same launches, in the same order, as the
+ * host issues through k4_sft_train_fwd / k4_conv2d_nhwc_bf16x6 / k4_conv2d_wgrad_dbias_bf16x6 / k4_lrelu_bwd / k4_sft_train_bwd (7 forward, 19 backward) --
+ * the joint training iteration is paced by the host's ~900 Python-to-C calls (profiles/r04_train_wgrad_side_stream_slower.md), this removes ~390 of them.
+ * Images are NHWC fp32; g = 32 growth channels, nf = 32 | 64; bw = nf + 4 g.
+ *   forward : buf[:, 0:nf] = sft0(t, c); buf[:, nf+(k-1)g : nf+kg] = lrelu(conv_k(buf[:, 0:nf+(k-1)g])), k = 1..3; x4 = lrelu(conv4(buf[:, 0:nf+3g]));
+ *             buf[:, nf+3g : bw] = sft1(x4, c); out = 0.2 conv5(buf) + t.
+ *   backward: g5 = 0.2 grad_out (caller); G = dgrad5(g5); the SFT / LeakyReLU / dgrad chain accumulates into the channel prefixes of G as the host form
+ *             does (lib/sr_train.py K4RDB); gx0 / gc0 / gc1 = gradients of t through sft0 and of the condition through both SFT layers; dwdb[k] =
+ *             [dW | dbias] of conv k+1; gsft0 / gsft1 = the eight weight / bias gradients of each SFT layer.  side_stream != NULL: every weight-gradient
+ *             launch goes to that stream, forked behind the launch that finishes the gradient slice it reads and joined before the call returns control
+ *             of `stream` (the wgrads depend on nothing the chain produces later; a 64x64 patch's launches leave most of the chip idle).
+ * w_fwd / b_fwd: forward operands of conv1..conv5 (k4_pack_conv_weight_bf16x6 form 0); w_bwd / b_bwd: dgrad operands (form 1, zero bias). */
+typedef struct k4_rdb_train {
+    int32_t H, W, nf, g;
+    const float* t; const float* c;
+    float* buf; float* x4; float* out;
+    const void* w_fwd[5]; const float* b_fwd[5];
+    const float* sft0[8]; const float* sft1[8];         /* w0s b0s w1s b1s w0h b0h w1h b1h */
+    const void* w_bwd[5]; const float* b_bwd[5];
+    const float* g5;
+    float* G; float* gx4; float* gx0; float* gc0; float* gc1;
+    float* dwdb[5];
+    float* gsft0[8]; float* gsft1[8];
+    float* ws0; int64_t ws0_bytes; float* ws1; int64_t ws1_bytes;
+    void* side_stream;
+} k4_rdb_train;
+int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
+int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
 
 /* ---- training-step streaming kernels --------------------------------------------------------
  * Replace the reference extension `adam_upd_cuda` (lib/cuda/adam_upd.cpp:10-67 -> adam_upd_kernel.cu:60-133) that

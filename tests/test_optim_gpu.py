@@ -217,3 +217,59 @@ def test_multi_tensor_adam_is_bit_identical_to_the_single_tensor_kernels(masked)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert items_a[3][0]._version > 0                                   # versions bumped like the single-tensor wrappers do
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_masked_adam_fast_path_for_small_tensors_is_the_regular_step(masked, monkeypatch):
+    """MaskedAdam.step takes a cached plan for a group's small tensors from its second step on (_fast_step: one pointer refresh per tensor):
+    five steps with fresh gradient tensors each time against an optimizer whose fast path is disabled -- identical parameters and moments, the
+    same step counts; then a missing gradient, a re-allocated moment and load_state_dict each drop back to the regular path and stay identical."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3, 3, 7), (64,), (32, 16, 3, 3), (1,), (17,)] * 12
+    init = [torch.randn(sh, generator=g) for sh in shapes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    oa = MaskedAdam([{'params': pa, 'lr': 1e-3, 'skip_zero_grad': masked}])
+    ob = MaskedAdam([{'params': pb, 'lr': 1e-3, 'skip_zero_grad': masked}])
+    monkeypatch.setattr(ob, '_fast_step', lambda *a, **k: False)
+    took = []
+    orig = oa._fast_step
+    monkeypatch.setattr(oa, '_fast_step', lambda *a, **k: took.append(orig(*a, **k)) or took[-1])
+
+    def give_grads(skip=None):
+        for j, (x, y) in enumerate(zip(pa, pb)):
+            gr = torch.randn(x.shape, generator=g)
+            if masked:
+                gr[torch.rand(x.shape, generator=g) < 0.3] = 0
+            x.grad, y.grad = (None, None) if j == skip else (gr.clone().cuda(), gr.clone().cuda())
+
+    def same():
+        for x, y in zip(pa, pb):
+            assert torch.equal(x, y)
+            sa, sb = oa.state.get(x), ob.state.get(y)
+            assert (sa is None) == (sb is None)
+            if sa:
+                assert sa['step'] == sb['step'] and torch.equal(sa['exp_avg'], sb['exp_avg']) and torch.equal(sa['exp_avg_sq'], sb['exp_avg_sq'])
+
+    for it in range(5):
+        give_grads()
+        oa.step(); ob.step()
+        same()
+    assert took[0] is False and all(took[1:])                        # first step builds the plan, the next four take it
+    v0 = pa[0]._version
+    give_grads(skip=4)                                               # a tensor without a gradient: regular path, that tensor's step count stays behind
+    oa.step(); ob.step()
+    same()
+    assert took[-1] is False and pa[0]._version > v0
+    give_grads()
+    oa.step(); ob.step()                                             # step counts now differ inside the group: still the regular path
+    same()
+    for opt, ps in ((oa, pa), (ob, pb)):
+        opt.state[ps[7]]['exp_avg'] = opt.state[ps[7]]['exp_avg'].clone()     # re-allocated moment
+    give_grads()
+    oa.step(); ob.step()
+    same()
+    oa.load_state_dict(oa.state_dict()); ob.load_state_dict(ob.state_dict())
+    give_grads()
+    oa.step(); ob.step()
+    same()
