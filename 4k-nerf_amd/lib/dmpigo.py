@@ -237,7 +237,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         gd = self._k4_grid(act_shift_grid=self.act_shift.grid,
                            live=(0.0, interval) if (k4_live_mask and k4_counters is None) else None)
         if Nr > 0:
-            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot)
+            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot, pre=(gd, md, 0))
             N.check(N.lib().k4_march_mpi_fwd(
                 N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
                 N_samples, interval, float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes,
