@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
             }
             __builtin_amdgcn_sched_barrier(0);                               // one row at a time: interleaved, the two rows' operands double the register peak
         }
-        // beyond fp16 (or non-finite) in the stored tensor or in the condition: the window is redone on the per-tile kernels (host).  The hidden
+        // beyond fp16 (+-Inf included; a NaN slips through fmaxf and simply propagates to the pixels it reaches, as it does in the fp32 reference)
+        // in the stored tensor or in the condition: the window is redone on the per-tile kernels (host).  The hidden
         // activations cannot overflow while the condition passes (their scales come from bounds over 2^-6 of fp16's range, see the packer)
         if (__builtin_amdgcn_ballot_w64(!(amax * M.out_scale <= 65504.f) || !(cmax * M.cond_scale <= 65504.f)) != 0ull && lane == 0) atomicOr(M.overflow + g, 1u);
         P16_TSTAMP(5);
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(256, 2) void k4_conv_p16_kernel(const P16Conv M) {
         }
     }
     if constexpr (OUT16) {
-        // |v| 2^E beyond fp16 (or non-finite): this window's frame is redone on the per-tile kernel (host).  Values of masked lanes (columns past
+        // |v| 2^E beyond fp16 (+-Inf included; NaN is not detected -- fmaxf drops it -- and propagates to the pixels it reaches like in the fp32
+        // reference): this window's frame is redone on the per-tile kernel (host).  Values of masked lanes (columns past
         // the image) come from zero-padded inputs like any other pixel's: harmless to include.
         if (__builtin_amdgcn_ballot_w64(!(amax * M.out_scale <= 65504.f)) != 0ull && lane == 0) atomicOr(M.overflow + g, 1u);
     }

@@ -871,6 +871,11 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     const int H = p->H, W = p->W, nf = p->nf, g = p->g, bw = nf + 4 * g;
     const int64_t n = (int64_t)H * W;
     hipStream_t main_s = (hipStream_t)stream, side = p->side_stream ? (hipStream_t)p->side_stream : main_s;
+    // every exit joins the side stream back into `stream`: after a failed launch the caller frees the gradient buffers on `stream` while weight
+    // gradients already forked to the side stream may still be running on them
+    int rc = 0;
+#undef K4_RDB_TRY
+#define K4_RDB_TRY(CALL) do { rc = (CALL); if (rc != 0) goto join; } while (0)
     // a weight gradient on the side stream: forked behind everything queued on the main stream so far (= the producer of the gradient slice it reads)
 #define K4_RDB_WGRAD(CIN, GY, COUT, GYS, K) do { \
         K4_RDB_TRY(k4_wait_stream(side, main_s)); \
@@ -898,9 +903,13 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     K4_RDB_TRY(k4_sft_train_bwd(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                 0.2f, p->gx0, p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
                                 p->ws0, p->ws0_bytes, stream));
+join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD
-    return k4_wait_stream(main_s, side);                                           // the wgrads are done before anything queued on `stream` after this call
+    {
+        const int rj = k4_wait_stream(main_s, side);                               // the wgrads are done before anything queued on `stream` after this call
+        return rc != 0 ? rc : rj;
+    }
 }
 #undef K4_RDB_TRY
 

@@ -113,15 +113,19 @@ class MaskedAdam(torch.optim.Optimizer):
         if f is None or f['masked'] != bool(masked) or len(group['params']) != f['n_group']:
             return False
         plist, states, jobs = f['params'], f['states'], f['jobs']
-        if [p.data_ptr() for p in plist] != f['pptr'] or self.state.get(plist[0]) is not states[0] or self.state.get(plist[-1]) is not states[-1]:
+        if [p.data_ptr() for p in plist] != f['pptr']:
             return False
+        sget = self.state.get
+        for p, st in zip(plist, states):                    # EVERY tensor's state dict is the one the plan was built on (a replaced state: regular path)
+            if sget(p) is not st:
+                return False
         grads = [p.grad for p in plist]
         step = states[0]['step']
         f32 = torch.float32
         for g, st, nel in zip(grads, states, f['numel']):
             if g is None or st['step'] != step or g.dtype is not f32 or not g.is_cuda or not g.is_contiguous() or g.numel() != nel:
                 return False
-        if [st['exp_avg'].data_ptr() for st in states] != f['mptr']:
+        if [st['exp_avg'].data_ptr() for st in states] != f['mptr'] or [st['exp_avg_sq'].data_ptr() for st in states] != f['vptr']:
             return False
         step += 1
         for j, g in enumerate(grads):
@@ -143,6 +147,7 @@ class MaskedAdam(torch.optim.Optimizer):
             jobs[j].n = ts[0].numel()
         self._fast[id(group)] = {'params': plist, 'states': states, 'jobs': jobs, 'masked': bool(masked), 'n_group': len(group['params']),
                                  'pptr': [p.data_ptr() for p in plist], 'mptr': [st['exp_avg'].data_ptr() for st in states],
+                                 'vptr': [st['exp_avg_sq'].data_ptr() for st in states],
                                  'numel': [p.numel() for p in plist], 'ids': {id(p) for p in plist},
                                  'touched': [t for ts in items for t in (ts[0], ts[2], ts[3])]}
 

@@ -703,7 +703,12 @@ class SFTNet(nn.Module):
         E = {}
         for n, v in zip(names, m.tolist()):
             E[n] = 0 if not (v > 0 and math.isfinite(v)) else max(-100, min(100, P16_TARGET_EXP - int(math.floor(math.log2(v)))))
-        self._k4['p16'] = {'key': self._k4['key'], 'E': E, 'amax': dict(zip(names, m.tolist())), 'pk': None}
+        # Recorded launch plans hold raw pointers into the previous calibration's packed operands and bake its exponents into their arguments:
+        # they die with it (and the plan key carries the calibration generation, so a plan recorded under another state can never be replayed).
+        for k in [k for k in self._k4 if isinstance(k, tuple) and k and k[0] == 'plans']:
+            del self._k4[k]
+        self._k4['p16_gen'] = self._k4.get('p16_gen', 0) + 1
+        self._k4['p16'] = {'key': self._k4['key'], 'E': E, 'amax': dict(zip(names, m.tolist())), 'pk': None, 'gen': self._k4['p16_gen']}
         return E
 
     def _p16_state(self):
@@ -785,7 +790,7 @@ class SFTNet(nn.Module):
 
     def _run_plan(self, Bs, hws, slot0, p16=None):
         pk = self._packed()
-        key = (tuple(hws), self._k4.get('key'), self.k4_mode, p16 is not None) \
+        key = (tuple(hws), self._k4.get('key'), self.k4_mode, p16 is not None, self._k4.get('p16_gen', 0) if p16 is not None else -1) \
             + tuple(t.data_ptr() for B in Bs for t in B.values())
         plans = self._k4.setdefault(('plans', slot0), {})
         plan = plans.get(key)

@@ -225,9 +225,10 @@ def _side_stream(device):
     """The second HIP stream (per device) a dense block's weight-gradient launches go to (k4_rdb_train_bwd: forked / joined inside the call)."""
     if not _WGRAD_STREAM:
         return None
-    st = _SIDE_STREAMS.get(device.index)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)       # one side stream per MAIN stream: callers on different streams do not share one
+    st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return st.cuda_stream
 
 

@@ -7,8 +7,12 @@
 ``flatten_eff_distloss`` the distortion loss of the joint training step (run_sr.py:976-988; third-party
                         ``torch_efficient_distloss``, not vendored upstream): value and gradient in one launch.
 
-There is no CPU path and no PyTorch path: CPU tensors raise ``K4Error``, and so do MLP shapes the kernels do not cover (width not in
-{32, 64, 128}, more than one hidden->hidden layer, dim0 > 64) -- ``rgbnet_supported`` tells which.
+``rgbnet_sigmoid_layers`` the same expression for Linear-ReLU stacks OUTSIDE those kernels' shapes (width not in {32, 64, 128}, more than one
+                        hidden->hidden layer, dim0 > 64; ``rgbnet_supported`` tells which): layer by layer on the exact-fp32 1x1 MFMA
+                        convolution, INFERENCE ONLY -- the models route such shapes here (lib/dvgo.py::_k4_rgbnet_sigmoid).
+
+There is no CPU path and no PyTorch path: CPU tensors raise ``K4Error``; so do these out-of-shape stacks under autograd, and anything that is
+not a biased Linear-ReLU stack ending in 3 outputs (another activation, a bias-free Linear, a layer wider than 128 / more than 192 inputs).
 """
 import os
 
@@ -99,14 +103,20 @@ def rgbnet_sigmoid(rgbnet, x, add=None):
 _GENERIC_PACKS = {}
 
 
-@torch.no_grad()
 def rgbnet_sigmoid_layers(rgbnet, x, add=None):
     """``torch.sigmoid(rgbnet(x) [+ add])`` for Linear-ReLU stacks OUTSIDE the shapes of k4_rgbnet_fwd (more hidden layers, other widths
     up to 128, dim0 up to 192): every Linear is one launch of the exact-fp32 MFMA convolution kernel as a 1x1 layer over the samples
     (k4_conv2d_nhwc, ReLU = its LeakyReLU epilogue with slope 0).  Inference only: under autograd these shapes raise."""
-    from .sr_esrnet import _Packed, EPI_LRELU
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rgbnet.parameters())):
+    # (checked in the CALLER's grad mode: as a `torch.no_grad()`-decorated function this test could never fire and a training loop would have
+    #  received a constant -- found by tests/test_train_ops_gpu.py::test_rgbnet_layer_by_layer_path_and_rejected_shapes in round 5)
+    if torch.is_grad_enabled() and (x.requires_grad or (add is not None and add.requires_grad) or any(p.requires_grad for p in rgbnet.parameters())):
         raise N.K4Error('training an rgbnet of this shape is outside k4_rgbnet_fwd / k4_rgbnet_bwd (Linear-ReLU stack of <= 3 layers, width 32 / 64 / 128)')
+    with torch.no_grad():
+        return _rgbnet_sigmoid_layers(rgbnet, x, add)
+
+
+def _rgbnet_sigmoid_layers(rgbnet, x, add):
+    from .sr_esrnet import _Packed, EPI_LRELU
     def flat(m):                                                   # execution order; a shared activation instance counts every time it is applied
         return [q for c in m.children() for q in flat(c)] if isinstance(m, nn.Sequential) else [m]
     mods = flat(rgbnet)

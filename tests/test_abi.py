@@ -71,7 +71,9 @@ def test_no_cpu_fallback():
     # no PyTorch back doors either: an rgbnet shape the HIP kernels do not cover, SFTNet's fea / dswise variants and CPU inputs raise
     from nerf4k_amd.lib import sr_esrnet
     import torch.nn as nn
-    model.rgbnet = nn.Sequential(nn.Linear(15, 48), nn.ReLU(inplace=True), nn.Linear(48, 3))
+    # (CPU input: raises whatever the shape; the shape checks themselves are exercised on the GPU in
+    #  tests/test_train_ops_gpu.py::test_rgbnet_layer_by_layer_path_and_rejected_shapes)
+    model.rgbnet = nn.Sequential(nn.Linear(15, 48), nn.Tanh(), nn.Linear(48, 3))           # an activation the kernels do not have
     with pytest.raises(N.K4Error):
         model._k4_rgbnet_sigmoid(torch.zeros(4, 15))
     net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
@@ -136,3 +138,25 @@ def test_llff_scene_matches_reference_config():
     # the per-plane bias our module builds equals the one in the checkpoint (lib/dmpigo.py:53-58)
     m2 = dmpigo.DirectMPIGO(**ck['model_kwargs'])
     assert torch.allclose(m2.act_shift.grid, ck['model_state_dict']['act_shift.grid'])
+
+
+def test_one_abi_number_everywhere():
+    """The header, the loader, the library and the two documents that quote the ABI version agree (round-4 verdict: INTEGRATION said 6,
+    DESIGN said 7, the header 8)."""
+    hdr = open(os.path.join(ROOT, 'include', 'k4nerf.h')).read()
+    v = int(re.search(r'#define\s+K4_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert v == N.K4_ABI_VERSION == N.lib().k4_abi_version()
+    for doc in ('INTEGRATION.md', 'DESIGN.md'):
+        quoted = [int(x) for x in re.findall(r'ABI version (\d+)', open(os.path.join(ROOT, doc)).read())]
+        assert quoted and all(q == v for q in quoted), (doc, quoted, v)
+
+
+def test_run_py_import_line_resolves():
+    """`run.py:11` of the reference imports `lib.img_encoder`, which the reference tree does not ship: the package
+    provides the (empty) module, and every in-scope name of that import line and of run_sr.py:13-17."""
+    import importlib
+    for name in ('img_encoder', 'utils', 'dvgo', 'dmpigo', 'sr_esrnet', 'masked_adam', 'grid'):
+        importlib.import_module('nerf4k_amd.lib.' + name)
+    import inspect
+    sig = inspect.signature(dvgo.mimg_patch_indices_generator)
+    assert list(sig.parameters) == ['imsz', 'num_im', 'BS', 'sz_patch', 'sr_ratio']       # lib/dvgo.py:850 (run.py:429 passes 3: a reference defect)

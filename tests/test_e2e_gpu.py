@@ -100,11 +100,11 @@ def full_scene():
     return ck, model, net.cuda(), sd
 
 
-@pytest.mark.parametrize('tile,index', [(510, 3), (189, 9)])
+@pytest.mark.parametrize('tile,index', [(510, 3), (189, 9), (168, 8)])
 def test_full_size_window_vs_oracle(full_scene, tile, index):
     """BASELINE size: 1008x756 frame of the full 417x353x256 scene, one reference tile window of test_tile=510 (the 508x256
-    window) and one of the 8-GPU geometry (189: an interior 209x209 window): HIP march + decode of the window against the
-    oracle's march + SFTNet on the same rays."""
+    window), one of the 8-GPU geometry (189: an interior 209x209 window) and one of the tile size the 8-GPU projection of bench.py
+    actually picks (168: an interior 188x188 window): HIP march + decode of the window against the oracle's march + SFTNet on the same rays."""
     ck, model, net, sd = full_scene
     H, W = scene.LLFF_HW
     pose = scene.llff_spiral_poses()[0]
@@ -153,6 +153,24 @@ def test_full_4k_frame_vs_oracle(full_scene):
     assert got.shape == want.shape == (1, 3, 4 * H, 4 * W)
     p = _close(got, want)
     print(f'whole 4K frame: HR PSNR vs oracle {p:.1f} dB, max abs {float((got.cpu() - want).abs().max()):.2e}')
+
+
+def test_render_viewpoints_horns_full_size():
+    """BASELINE configs[3]'s scene ("horns" = the generator's seed 778) through the drop-in render loop at full size: one 1008x756 view of
+    `render_viewpoints` (run_sr.py:75-182) against the CPU oracle on the same rays."""
+    ck = scene.make_llff_checkpoint(seed=778)
+    model = utils.model_from_checkpoint_dict(ck).cuda().eval()
+    H, W = scene.LLFF_HW
+    pose = scene.llff_spiral_poses()[5]
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ro, rd, vd = marcher.get_rays_of_a_view(H, W, scene.LLFF_K, pose, ndc=True)
+    want = marcher.forward(ck['model_class'], ck['model_kwargs'], ck['model_state_dict'], ro.reshape(-1, 3), rd.reshape(-1, 3), vd.reshape(-1, 3), **rk)
+    rgbs, depths, bgmaps, psnrs, viewdirs_all, feats = render.render_viewpoints(model, pose[None], np.array([[H, W]]), scene.LLFF_K[None], True, rk)
+    assert rgbs.shape == (1, H, W, 3) and feats.shape == (1, H, W, 3)
+    p = _close(torch.from_numpy(np.asarray(feats[0])).reshape(-1, 3), want['rgb_marched'], min_psnr=80.0, tol=2e-5)
+    _close(torch.from_numpy(np.asarray(depths[0])).reshape(-1), want['depth'], min_psnr=80.0, tol=2e-5)
+    print(f'horns (seed 778) full-size render_viewpoints: PSNR vs oracle {p:.1f} dB')
 
 
 def test_render_viewpoints_contract():

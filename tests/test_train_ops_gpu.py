@@ -250,3 +250,33 @@ def test_graphed_decoder_matches_eager_and_sees_weight_updates():
         with torch.no_grad():                                       # an "optimizer step": the next replay must pack the new weights
             for p in net.parameters():
                 p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02 * p.abs().mean())
+
+
+def test_rgbnet_layer_by_layer_path_and_rejected_shapes():
+    """the layer-by-layer path (`rgbnet_sigmoid_layers`: stacks outside k4_rgbnet_fwd's shapes, inference only) against the
+    module itself in fp64, including a depth-4 stack, odd widths and an input count that is not a multiple of 4 -- and the shapes that ARE
+    rejected, on the GPU under no_grad (so that it is the shape, not the device or autograd, that raises)."""
+    from torch import nn
+    torch.manual_seed(3)
+    x = torch.randn([1000, 39], device='cuda')
+    add = torch.randn([1000, 3], device='cuda')
+    for net, xin, ad in ((dmpigo._mlp(39, 128, 4, 3), x, None),                                     # two hidden->hidden layers (depth 4)
+                         (nn.Sequential(nn.Linear(15, 48), nn.ReLU(), nn.Linear(48, 3)), x[:, :15].contiguous(), add),                  # width 48
+                         (nn.Sequential(nn.Linear(13, 40), nn.ReLU(), nn.Linear(40, 24), nn.ReLU(), nn.Linear(24, 3)), x[:, :13].contiguous(), None)):  # cin % 4 != 0, uneven widths
+        net = net.cuda()
+        assert not train_ops.rgbnet_supported(net)
+        with torch.no_grad():
+            got = train_ops.rgbnet_sigmoid_layers(net, xin, ad)
+            want = torch.sigmoid(net.double()(xin.double()) + (0 if ad is None else ad.double()))
+        assert got.shape == (1000, 3) and float((got.double() - want).abs().max()) <= 2e-6
+        net.float()
+        with torch.enable_grad(), pytest.raises(N.K4Error):                                           # these shapes do not train
+            train_ops.rgbnet_sigmoid_layers(net, xin, ad)
+    rejected = [nn.Sequential(nn.Linear(15, 48), nn.Tanh(), nn.Linear(48, 3)),                        # another activation
+                nn.Sequential(nn.Linear(15, 48, bias=False), nn.ReLU(), nn.Linear(48, 3)),            # a bias-free Linear
+                nn.Sequential(nn.Linear(15, 160), nn.ReLU(), nn.Linear(160, 3)),                      # wider than 128
+                nn.Sequential(nn.Linear(15, 48), nn.ReLU(), nn.Linear(48, 4))]                        # not 3 outputs
+    with torch.no_grad():
+        for net in rejected:
+            with pytest.raises(N.K4Error):
+                train_ops.rgbnet_sigmoid_layers(net.cuda(), x[:, :15].contiguous())
