@@ -572,7 +572,7 @@ def four_k_horns(dev, poses, H, W, K, world, rank, n_frames=6):
     ck = scene.make_llff_checkpoint(seed=778)
     model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
     views = poses[::max(1, len(poses) // 8)][:8]
-    out = four_k_frames(model, ck, views, ck['render_kwargs'], H, W, K, dev, n_frames, world, rank, mode=None)
+    out = four_k_frames(model, ck, views, ck['render_kwargs'], H, W, K, dev, n_frames, world, rank, mode=None, keep={})
     keep = {k: out[k] for k in ('frames_per_s', 'ms_per_frame', 'ms_per_frame_median', 'frames_timed', 'test_tile', 'k4_p16_reruns', 'rank_share_8gpu') if k in out}
     if 'rank_share_projection' in out:
         keep['rank_share_projection_best'] = {n: v['best'] for n, v in out['rank_share_projection'].items() if isinstance(v, dict) and 'best' in v}
