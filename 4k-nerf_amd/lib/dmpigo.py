@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import _native as N
 from . import grid
+from . import dvgo as _dvgo
 from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid, _take
 
 
@@ -230,14 +231,18 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
             depth = torch.empty([Nr], dtype=torch.float32, device=dev)
             ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
-        md, _keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
-        N_samples = int((self.mpi_depth - 1) / stepsize) + 1              # lib/dmpigo.py:278
-        interval = float(stepsize * self.voxel_size_ratio)                # lib/dmpigo.py:306
-        # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
-        gd = self._k4_grid(act_shift_grid=self.act_shift.grid,
-                           live=(0.0, interval) if (k4_live_mask and k4_counters is None) else None)
+        use_live = bool(k4_live_mask and k4_counters is None)
+
+        def build():
+            md, keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)
+            n_samples = int((self.mpi_depth - 1) / stepsize) + 1          # lib/dmpigo.py:278
+            itv = float(stepsize * self.voxel_size_ratio)                 # lib/dmpigo.py:306
+            # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
+            gd = self._k4_grid(act_shift_grid=self.act_shift.grid, live=(0.0, itv) if use_live else None)
+            return (md, gd, n_samples, itv), keep
+        md, gd, N_samples, interval = self._k4_plan('mpi', (float(stepsize), use_live, float(self.fast_color_thres)), build)
         if Nr > 0:
-            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot, pre=(gd, md, 0))
+            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot, pre=(gd, md, 0) if _dvgo._MARCH_PRE else None)
             N.check(N.lib().k4_march_mpi_fwd(
                 N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
                 N_samples, interval, float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes,

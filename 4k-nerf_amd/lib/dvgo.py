@@ -43,6 +43,13 @@ class _FusedMarcher:
         return self._k4c
 
     def _k4_fusable(self):
+        c = self._k4_cache()
+        hit = c.get('fusable')
+        if hit is None or hit[0] is not self.rgbnet:
+            hit = c['fusable'] = (self.rgbnet, self._k4_fusable_uncached())
+        return hit[1]
+
+    def _k4_fusable_uncached(self):
         if self.rgbnet is None:
             return self.k0_dim == 3
         lins = [m for m in self.rgbnet.modules() if isinstance(m, nn.Linear)]
@@ -206,6 +213,37 @@ class _FusedMarcher:
         else:
             gd.occ_summary = self._k4_occ_summary().data_ptr()
         return gd
+
+    def _k4_plan(self, tag, extra_key, build):
+        """Per-call descriptors of the fused path (k4_grid_desc, k4_mlp_desc and the tensors they point into) cached on the VERSIONS of every
+        tensor they are derived from: a render loop re-derives nothing per frame but this key (~30 attribute reads) -- the per-part caches
+        below (k0 repack, live mask, packed rgbnet, host copies) each rebuilt their own key and ctypes structs on every call, ~0.2 ms of
+        Python per frame, which paces bench.py's pipelined loop on a slow host (round 5: 0.86 -> 1.3 ms per frame on some boxes).
+        ``build()`` -> (value, tensors to keep alive).  A plan is valid per HIP stream it was built or re-validated on: the first call on
+        another stream goes through ``build`` again, which orders that stream behind the load-time kernels (see _k4_live_mask)."""
+        mc = self.mask_cache
+        ts = [self.density.grid, self.k0.grid, mc.mask, self.xyz_min, self.xyz_max, mc.xyz2ijk_scale, mc.xyz2ijk_shift]
+        act = getattr(self, 'act_shift', None)
+        ts.append(act.grid if isinstance(act, nn.Module) else act)
+        if self.rgbnet is not None:
+            c = self._k4_cache()
+            lins = c.get('plan_lins')
+            if lins is None or lins[0] is not self.rgbnet:
+                lins = c['plan_lins'] = (self.rgbnet, [m for m in self.rgbnet.modules() if isinstance(m, nn.Linear)])
+            for l in lins[1]:
+                ts.append(l.weight)
+                ts.append(l.bias)
+        key = (tag, extra_key, _MARCH_PRE, _K0_BRICK, _LIVE_MASK, os.environ.get('K4_MLP')) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+        c = self._k4_cache()
+        plan = c.get(('plan', tag))
+        st = N.stream().value
+        if plan is not None and plan[0] == key and st in plan[2]:
+            return plan[1]
+        value, keep = build()
+        seen = plan[2] if (plan is not None and plan[0] == key) else set()
+        seen.add(st)
+        c[('plan', tag)] = (key, value, seen, keep)
+        return value
 
     def k4_warm(self, stepsize=None):
         """Build every load-time cache of the fused path (k0 channel-last repack, packed rgbnet, host copies of the bbox and, when the
@@ -484,21 +522,26 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
             depth = torch.empty([Nr], dtype=torch.float32, device=dev)
             ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
-        md, _keep = self._k4_mlp(k0_skip=0 if (self.rgbnet is None or self.rgbnet_direct) else 3, spatial_pe=0)
-        stepdist = float(stepsize * self.voxel_size)                       # lib/dvgo.py:310
-        interval = float(stepsize * self.voxel_size_ratio)                # lib/dvgo.py:341
-        act_shift = self._k4_host_scalar('act_shift', self.act_shift)
-        # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
-        gd = self._k4_grid(live=(act_shift, interval) if (k4_live_mask and k4_counters is None) else None)
-        depth_n = int((self.max_world_size - 1) / stepsize) + 1           # lib/dvgo.py:311
-        diag = self._k4_host_scalar('diag', (self.xyz_max - self.xyz_min).norm())
-        max_steps = int(np.ceil(diag / stepdist)) + 2
+        use_live = bool(k4_live_mask and k4_counters is None)
+
+        def build():
+            md, keep = self._k4_mlp(k0_skip=0 if (self.rgbnet is None or self.rgbnet_direct) else 3, spatial_pe=0)
+            sd = float(stepsize * self.voxel_size)                         # lib/dvgo.py:310
+            itv = float(stepsize * self.voxel_size_ratio)                  # lib/dvgo.py:341
+            ash = self._k4_host_scalar('act_shift', self.act_shift)
+            # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
+            gd = self._k4_grid(live=(ash, itv) if use_live else None)
+            dn = int((self.max_world_size - 1) / stepsize) + 1             # lib/dvgo.py:311
+            diag = float((self.xyz_max - self.xyz_min).norm())             # (one read-back per plan, not per call)
+            return (md, gd, sd, itv, ash, dn, int(np.ceil(diag / sd)) + 2), keep
+        md, gd, stepdist, interval, act_shift, depth_n, max_steps = self._k4_plan(
+            'dvgo', (float(stepsize), use_live, float(self.fast_color_thres), float(self.voxel_size), float(self.voxel_size_ratio)), build)
         if Nr == 0:
             ret = {'alphainv_last': ainv, 'rgb_marched': rgb, 'rgb_feature': rgb}
             if render_depth:
                 ret['depth'] = depth
             return ret
-        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot, pre=(gd, md, 1))
+        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot, pre=(gd, md, 1) if _MARCH_PRE else None)
         N.check(N.lib().k4_march_dvgo_fwd(
             N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
             float(near), 1e9, stepdist, max_steps, depth_n, act_shift, interval,
