@@ -992,6 +992,7 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, FS& fs, int k1p, in
 #define K4_PART_MIN 4            // smallest part_batches the workspace is sized for
 #define K4_QLEN 32               // qhead[K4_QLEN] = queue length: its own 128-byte line (the head word's line is busy with the queue's atomics)
 __device__ __forceinline__ int k4_batches_of(int count) { return (int)(((unsigned)max(count, 0) + 63u) >> 6); }
+template <bool PARTS>        // PARTS = false (part_batches == 0, the default): one job per bundle, the round-4 kernel's instruction stream
 __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int2* __restrict__ jobs, int n_bundles, int* qhead, int part_batches,
                                                         int* __restrict__ slot_of, int* __restrict__ arrive, int part_slots) {
     constexpr int NBIN = K4_ORDER_CLASSES * K4_ORDER_SUB;            // 4096 = 4 per thread
@@ -1012,15 +1013,19 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
-            if (b >= n_bundles) continue;
             const int nbat = k4_batches_of(v[i]);
-            int np = (part_batches > 0 && nbat > part_batches) ? min((nbat + part_batches - 1) / part_batches, 32767) : 1;
+            if constexpr (!PARTS) {
+                if (b < n_bundles) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
+                continue;
+            }
+            if (b >= n_bundles) continue;
+            int np = nbat > part_batches ? min((nbat + part_batches - 1) / part_batches, 32767) : 1;
             int slot = -1;
             if (np > 1) {                                            // a run of part-sum slots, while they last
                 slot = atomicAdd(&slot_head, np);
                 if (slot + np > part_slots) { slot = -1; np = 1; }
             }
-            if (part_batches > 0) { slot_of[b] = slot; arrive[b] = 0; }     // (untouched when bundles are never split: the default)
+            slot_of[b] = slot; arrive[b] = 0;
             const int q = (nbat + np - 1) / np;                       // batches per part (the last part may hold fewer)
             atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(q, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], np);
         }
@@ -1052,9 +1057,13 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
-            if (b >= n_bundles) continue;
             const int nbat = k4_batches_of(v[i]);
-            const int np = (part_batches <= 0 || slot_of[b] < 0) ? 1 : min((nbat + part_batches - 1) / part_batches, 32767);     // this thread's own decision of the first pass
+            if constexpr (!PARTS) {
+                if (b < n_bundles) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = make_int2(b, 1 << 16);
+                continue;
+            }
+            if (b >= n_bundles) continue;
+            const int np = slot_of[b] < 0 ? 1 : min((nbat + part_batches - 1) / part_batches, 32767);     // this thread's own decision of the first pass
             const int q = (nbat + np - 1) / np;
             const int pos = atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(q, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], np);
             for (int pp = 0; pp < np; ++pp) jobs[pos + pp] = make_int2(b, pp | (np << 16));
@@ -1568,7 +1577,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     }
     int rc = k4_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k4_order_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead, P.part_batches, P.slot_of, P.arrive, P.part_slots);
+    if (P.part_batches > 0) hipLaunchKernelGGL(k4_order_kernel<true>, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead, P.part_batches, P.slot_of, P.arrive, P.part_slots);
+    else hipLaunchKernelGGL(k4_order_kernel<false>, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead, 0, P.slot_of, P.arrive, P.part_slots);
     rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
