@@ -974,6 +974,114 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, FS& fs, int k1p, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: BOTH 32-sample tiles of a batch in one software pipeline (rgbnet 16 -> 64 -> 64 -> 3, the LLFF shape).
+// mlp_mfma_b3 runs a tile as split -> layer-1 MFMAs -> ReLU + split -> layer-2 MFMAs -> output layer, every phase waiting for the one
+// before it: inside ONE wave the matrix pipe and the vector pipe never work at the same time, and the measured per-SIMD cost of a batch is
+// the SUM of the two (profiles/r05_marcher_split_path.md: ~1,240 vector instructions x 2.8 cycles + 120 MFMAs x 32 cycles).  Here the
+// vector work of one stage runs under the matrix work of an INDEPENDENT stage: tile B's input split under tile A's layer 1, the ReLU +
+// split of hidden block k+1 under the layer-2 MFMAs of block k, tile A's output layer under tile B's layer 2; sched_group_barrier
+// prescribes the interleave (one MFMA, then a few vector instructions: a wave hides <= 5 per MFMA, profiles/r04_mfma_valu_overlap.md),
+// sched_barrier keeps the stages apart.  Every accumulator and every output sum receives its terms in mlp_mfma_b3's order (layer 1 and
+// layer 2 with the two 32-neuron blocks side by side, K4_MFMA_B3_X2): the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef K4_MLP_PAIR
+#define K4_MLP_PAIR 1
+#endif
+#define K4_SGB_MFMA 0x008
+#define K4_SGB_VALU 0x002
+#define K4_SGB_DSRD 0x100
+// one stage: NM MFMAs, each followed by NV vector instructions (the scheduler takes them from the stage's region in dependency order)
+#define K4_STAGE_SCHED(NM, NV) do { _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) { \
+        __builtin_amdgcn_sched_group_barrier(K4_SGB_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(K4_SGB_VALU, (NV), 0); } } while (0)
+__device__ __forceinline__ void k4_relu_split8(const f32x16& h, int hi, uint4& t0, uint4& t1, uint4& t2) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = k4_relu(h[8 * hi + e]);
+    k4_split3(v, t0, t1, t2);
+}
+template <class FS>
+__device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane, int half,
+                                              float& out0, float& out1, float& out2 K4_TARGS) {
+    typedef MlpLayoutB3<64, 1> ML;
+    const uint4* const w1s = reinterpret_cast<const uint4*>(ws + ML::w1s(16));
+    const uint4* const w2s = reinterpret_cast<const uint4*>(ws + ML::w2s(16));
+    const float* const b2s = ws + ML::b2s(16);
+    const float* const wot = ws + ML::wot(16);
+    const float* const bo = ws + ML::bo(16);
+    float vA[8], vB[8];
+    fs.load(0, 0, vA);
+    fs.load(0, 1, vB);
+    // layer-1 weight fragments (both 32-neuron blocks), shared by the two tiles
+    const uint4 a0 = w1s[lane], a1 = w1s[64 + lane], a2 = w1s[128 + lane];
+    const uint4 c0 = w1s[192 + lane], c1 = w1s[256 + lane], c2 = w1s[320 + lane];
+    uint4 xA0, xA1, xA2, xB0, xB1, xB2;
+    k4_split3(vA, xA0, xA1, xA2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S1: layer 1 of tile A  ||  input split of tile B ----
+    f32x16 hA0 = (f32x16)(0.f), hA1 = (f32x16)(0.f), hB0 = (f32x16)(0.f), hB1 = (f32x16)(0.f);
+    K4_MFMA_B3_X2(hA0, hA1, a0, a1, a2, c0, c1, c2, xA0, xA1, xA2);
+    k4_split3(vB, xB0, xB1, xB2);
+    K4_STAGE_SCHED(12, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S2: layer 1 of tile B  ||  ReLU + split of tile A's hidden block 0 ----
+    uint4 hsA[4][3], hsB[4][3];
+    K4_MFMA_B3_X2(hB0, hB1, a0, a1, a2, c0, c1, c2, xB0, xB1, xB2);
+    k4_relu_split8(hA0, 0, hsA[0][0], hsA[0][1], hsA[0][2]);
+    K4_STAGE_SCHED(12, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    // layer-2 accumulators start from the bias
+    f32x16 cA0, cA1, cB0, cB1;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 b0v = *reinterpret_cast<const float4*>(b2s + (0 * 2 + half) * 16 + r4 * 4);
+        const float4 b1v = *reinterpret_cast<const float4*>(b2s + (1 * 2 + half) * 16 + r4 * 4);
+        cA0[r4 * 4 + 0] = b0v.x; cA0[r4 * 4 + 1] = b0v.y; cA0[r4 * 4 + 2] = b0v.z; cA0[r4 * 4 + 3] = b0v.w;
+        cA1[r4 * 4 + 0] = b1v.x; cA1[r4 * 4 + 1] = b1v.y; cA1[r4 * 4 + 2] = b1v.z; cA1[r4 * 4 + 3] = b1v.w;
+    }
+    cB0 = cA0; cB1 = cA1;
+    // ---- S3..S6: layer 2 of tile A, hidden block kb  ||  ReLU + split of the next hidden block (of A, then B's first) ----
+#define K4_L2_STAGE(C0, C1, HS, KB, NEXT_STMT, NV) do { \
+        const uint4* const wp_ = w2s + ((KB) * 3) * 64 + lane; \
+        const uint4* const wq_ = w2s + ((4 + (KB)) * 3) * 64 + lane; \
+        const uint4 p0_ = wp_[0], p1_ = wp_[64], p2_ = wp_[128], q0_ = wq_[0], q1_ = wq_[64], q2_ = wq_[128]; \
+        K4_MFMA_B3_X2(C0, C1, p0_, p1_, p2_, q0_, q1_, q2_, HS[KB][0], HS[KB][1], HS[KB][2]); \
+        NEXT_STMT; \
+        K4_STAGE_SCHED(12, NV); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    K4_TSTAMP(3);                                        // (timing builds) input splits + layer 1 of both tiles + first hidden block's split
+    K4_L2_STAGE(cA0, cA1, hsA, 0, k4_relu_split8(hA0, 1, hsA[1][0], hsA[1][1], hsA[1][2]), 4);
+    K4_L2_STAGE(cA0, cA1, hsA, 1, k4_relu_split8(hA1, 0, hsA[2][0], hsA[2][1], hsA[2][2]), 4);
+    K4_L2_STAGE(cA0, cA1, hsA, 2, k4_relu_split8(hA1, 1, hsA[3][0], hsA[3][1], hsA[3][2]), 4);
+    K4_L2_STAGE(cA0, cA1, hsA, 3, k4_relu_split8(hB0, 0, hsB[0][0], hsB[0][1], hsB[0][2]), 4);
+    // ---- S7..S10: layer 2 of tile B  ||  the next hidden block of B + tile A's output layer (its accumulators are complete) ----
+    k4_f32x2 ptA01 = {0.f, 0.f}, ptB01 = {0.f, 0.f};
+    float ptA2 = 0.f, ptB2 = 0.f;
+#define K4_OUT_HALF(C, MB2, R0, PT01, PT2) do { \
+        _Pragma("unroll") for (int r_ = (R0); r_ < (R0) + 8; ++r_) { \
+            const float4 wo_ = *reinterpret_cast<const float4*>(wot + (((MB2) * 16 + r_) * 2 + half) * 4); \
+            const float a_ = k4_relu(C[r_]); \
+            const k4_f32x2 w01_ = {wo_.x, wo_.y}, aa_ = {a_, a_}; \
+            PT01 = __builtin_elementwise_fma(w01_, aa_, PT01); \
+            PT2 = fmaf(wo_.z, a_, PT2); } } while (0)
+    K4_TSTAMP(4);                                        // layer 2 of tile A (+ splits)
+    K4_L2_STAGE(cB0, cB1, hsB, 0, k4_relu_split8(hB0, 1, hsB[1][0], hsB[1][1], hsB[1][2]); K4_OUT_HALF(cA0, 0, 0, ptA01, ptA2), 5);
+    K4_L2_STAGE(cB0, cB1, hsB, 1, k4_relu_split8(hB1, 0, hsB[2][0], hsB[2][1], hsB[2][2]); K4_OUT_HALF(cA0, 0, 8, ptA01, ptA2), 5);
+    K4_L2_STAGE(cB0, cB1, hsB, 2, k4_relu_split8(hB1, 1, hsB[3][0], hsB[3][1], hsB[3][2]); K4_OUT_HALF(cA1, 1, 0, ptA01, ptA2), 5);
+    K4_L2_STAGE(cB0, cB1, hsB, 3, K4_OUT_HALF(cA1, 1, 8, ptA01, ptA2), 2);
+#undef K4_L2_STAGE
+    K4_TSTAMP(5);                                        // layer 2 of tile B (+ splits, tile A's output layer)
+    // ---- S11: tile B's output layer ----
+    K4_OUT_HALF(cB0, 0, 0, ptB01, ptB2); K4_OUT_HALF(cB0, 0, 8, ptB01, ptB2);
+    K4_OUT_HALF(cB1, 1, 0, ptB01, ptB2); K4_OUT_HALF(cB1, 1, 8, ptB01, ptB2);
+#undef K4_OUT_HALF
+    // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of a tile; sample 32 t + (l&31) belongs to lane 32 t + (l&31)
+    const float qA0 = ptA01.x + __shfl_xor(ptA01.x, 32) + bo[0], qA1 = ptA01.y + __shfl_xor(ptA01.y, 32) + bo[1], qA2 = ptA2 + __shfl_xor(ptA2, 32) + bo[2];
+    const float qB0 = ptB01.x + __shfl_xor(ptB01.x, 32) + bo[0], qB1 = ptB01.y + __shfl_xor(ptB01.y, 32) + bo[1], qB2 = ptB2 + __shfl_xor(ptB2, 32) + bo[2];
+    out0 = half ? qB0 : qA0; out1 = half ? qB1 : qA1; out2 = half ? qB2 : qA2;
+    K4_TSTAMP(2);                                        // tile B's output layer + shuffles
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Between K1 and K2: the order in which the shading kernel's persistent waves take the bundles.  A bundle is shaded by ONE
 // wave, 64 records at a time, and bundles carry 0 .. thousands of records: taken in image order, a heavy bundle pulled near
@@ -1307,7 +1415,11 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             float l0, l1, l2;
             if (B3) {
                 LdsFeat fs = {feat, P.k1p, lane & 31, half};
-                mlp_mfma_b3<W, NHID>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
+                if constexpr (K4_MLP_PAIR && W == 64 && NHID == 1) {
+                    // a full batch of the LLFF shape: both tiles through one software pipeline (same bits); anything else one tile at a time
+                    if (P.k1p == 16 && nproc > 32 && !(P.debug & 2)) mlp_pair64_b3(wl, fs, lane, half, l0, l1, l2 K4_TPASS);
+                    else mlp_mfma_b3<W, NHID>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
+                } else mlp_mfma_b3<W, NHID>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
             }
             else mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
