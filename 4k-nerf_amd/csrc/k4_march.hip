@@ -1755,7 +1755,7 @@ static WsLayout ws_layout(int64_t nb, int64_t ent_stride) {
     L.slot_of = L.arrive + nb * 4;
     L.jobs = up(L.slot_of + nb * 4);
     L.part_sums = up(L.jobs + nb * (1 + ent_stride / 64 / K4_PART_MIN) * 8);
-    L.part_slots = nb * K4_PART_SLOTS_PER_BUNDLE;
+    L.part_slots = k4_env().part_batches > 0 ? nb * K4_PART_SLOTS_PER_BUNDLE : 0;     // (the default never splits a bundle: no slots, 2 KB each)
     L.total = up(L.part_sums + L.part_slots * 256 * 8);
     return L;
 }
