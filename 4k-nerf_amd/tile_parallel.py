@@ -66,7 +66,20 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
                 quantises its own pixels with the reference's ``utils.to8b`` rule (clip to [0,1], x255, truncate: what run_sr.py writes to
                 PNG / video) BEFORE the exchange: the all-gather moves 36.6 MB per 4K frame instead of 146 MB, and the assembled frame
                 equals to8b of the fp32 frame byte for byte.
+
+    = ``decode_frame_tiles(march_frame_tiles(...))``.  A renderer of MANY frames may issue frame i+1's march before frame i's decode
+    (``march_frame_tiles`` runs on side streams that only wait for what is queued on the current stream at the time of the call): the
+    march of the next frame then runs under the decoder of the current one -- same pixels, the frames are independent (bench.py four_k,
+    ``frames_per_s_pipelined``).
     """
+    st = march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad, scale, group)
+    return decode_frame_tiles(st, out=out, out_dtype=out_dtype)
+
+
+@torch.no_grad()
+def march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scale=4, group=None):
+    """First half of ``render_frame_tiles``: this rank's tile windows marched (each on its own HIP stream on a GPU); with a decoder that
+    has no grouped form the windows are decoded here too.  -> state for ``decode_frame_tiles``."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     rk = dist.get_rank(group) if dist.is_initialized() else 0
     tiles = tile_geometry(H, W, tile_size, tile_pad)
@@ -109,9 +122,26 @@ def render_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scal
                 oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
                 send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
         off += th * tw
-    if pool:
+    events = None
+    if pool:                                               # joined by decode_frame_tiles (events: the pool's streams may carry the NEXT frame's march by then)
+        events = []
         for st in pool:
-            cur.wait_stream(st)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            events.append(ev)
+    return {'tiles': tiles, 'owned': owned, 'slot': slot, 'send': send, 'pending': pending, 'multi': multi, 'events': events, 'cur': cur,
+            'ws': ws, 'group': group, 'H': H, 'W': W, 'scale': scale, 'dev': dev}
+
+
+@torch.no_grad()
+def decode_frame_tiles(state, out=None, out_dtype=None):
+    """Second half of ``render_frame_tiles``: join the marches, decode this rank's windows (one grouped launch per layer), gather, assemble."""
+    tiles, owned, slot, send, pending, multi = (state[k] for k in ('tiles', 'owned', 'slot', 'send', 'pending', 'multi'))
+    ws, group, H, W, scale, dev = (state[k] for k in ('ws', 'group', 'H', 'W', 'scale', 'dev'))
+    if state['events']:
+        cur = torch.cuda.current_stream(dev)
+        for ev in state['events']:
+            cur.wait_event(ev)
     if multi is not None:
         for p0 in range(0, len(pending), multi.max_jobs):
             part = pending[p0:p0 + multi.max_jobs]
