@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 9
+K4_ABI_VERSION = 10
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST, K0_BRICK4 = 0, 1, 2
@@ -90,6 +90,9 @@ _SIGS = {
     'k4_get_rays_of_a_view': [_I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P],
     'k4_to8b': [_P, _I64, _P, _P],
     'k4_repack_k0': [_P, _I32, _I32, _I64, _P, _P],
+    'k4_train_select_mpi': [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32, _F, _F, _P, _P, _P, _P, _P],
+    'k4_train_compact': [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P],
+    'k4_ndc_points_of': [_P, _P, _P, _P, _I64, _I32, _P, _P],
 }
 _lib = None
 

@@ -9,6 +9,53 @@
 #define K4_THREADS 256
 static inline unsigned k4_blocks(int64_t n) { return (unsigned)((n + K4_THREADS - 1) / K4_THREADS); }
 
+// ---------------------------------------------------------------- per-sample arithmetic shared by the staged kernels below and by
+// k_train_select_mpi (one expression tree each: a decision taken there is the decision the staged op sequence takes)
+__device__ __forceinline__ void k4s_ndc_point(const float* __restrict__ o, const float* __restrict__ d, int64_t ray, int step, int n_samples, float (&p)[3]) {
+    const float dist = (float)step / (float)(n_samples - 1);                         // .cu:260
+    p[0] = fmaf(d[ray * 3 + 0], dist, o[ray * 3 + 0]);
+    p[1] = fmaf(d[ray * 3 + 1], dist, o[ray * 3 + 1]);
+    p[2] = fmaf(d[ray * 3 + 2], dist, o[ray * 3 + 2]);
+}
+__device__ __forceinline__ bool k4s_outbbox(const float (&p)[3], const float* __restrict__ mn, const float* __restrict__ mx) {
+    return (mn[0] > p[0]) | (mn[1] > p[1]) | (mn[2] > p[2]) | (mx[0] < p[0]) | (mx[1] < p[1]) | (mx[2] < p[2]);
+}
+__device__ __forceinline__ uint8_t k4s_maskcache(const uint8_t* __restrict__ world, float x, float y, float z, const float* __restrict__ sc,
+                                                 const float* __restrict__ sh, int si, int sj, int sk) {
+    const int a = k4_round_half_away(fmaf(x, sc[0], sh[0]));
+    const int b = k4_round_half_away(fmaf(y, sc[1], sh[1]));
+    const int c = k4_round_half_away(fmaf(z, sc[2], sh[2]));
+    uint8_t v = 0;
+    if ((unsigned)a < (unsigned)si && (unsigned)b < (unsigned)sj && (unsigned)c < (unsigned)sk)
+        v = world[((size_t)a * sj + b) * sk + c] != 0;
+    return v;
+}
+// corner indices / weights of F.grid_sample(bilinear, align_corners=True, zero padding) on an [X][Y][Z] grid
+__device__ __forceinline__ void k4s_grid_corners(float x, float y, float z, const float* __restrict__ mn, const float* __restrict__ mx,
+                                                 int X, int Y, int Z, size_t (&idx)[8], float (&w)[8]) {
+    const float nx = k4_norm_coord(x, mn[0], mx[0]);
+    const float ny = k4_norm_coord(y, mn[1], mx[1]);
+    const float nz = k4_norm_coord(z, mn[2], mx[2]);
+    const K4Tri t = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int xx = t.x0 + K4_CX(c), yy = t.y0 + K4_CY(c), zz = t.z0 + K4_CZ(c);
+        const bool ok = (unsigned)xx < (unsigned)X && (unsigned)yy < (unsigned)Y && (unsigned)zz < (unsigned)Z;
+        idx[c] = ok ? ((size_t)xx * Y + yy) * Z + zz : 0;
+        w[c] = ok ? t.w[c] : 0.f;
+    }
+}
+__device__ __forceinline__ float k4s_grid_blend(const float* __restrict__ g, const size_t (&idx)[8], const float (&w)[8]) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v += g[idx[c]] * w[c];
+    return v;
+}
+__device__ __forceinline__ void k4s_raw2alpha(float den, float shift, float iv, float& e, float& al) {
+    e = expf(den + shift);
+    al = (iv == 1.f) ? 1.f - 1.f / (1.f + e) : 1.f - powf(1.f + e, -iv);
+}
+
 // ---------------------------------------------------------------- sample_ndc_pts_on_rays (.cu:245-270)
 __global__ void k_sample_ndc(const float* __restrict__ o, const float* __restrict__ d,
                              const float* __restrict__ mn, const float* __restrict__ mx,
@@ -17,12 +64,10 @@ __global__ void k_sample_ndc(const float* __restrict__ o, const float* __restric
     if (idx >= n_rays * n_samples) return;
     const int64_t ray = idx / n_samples;
     const int step = (int)(idx % n_samples);
-    const float dist = (float)step / (float)(n_samples - 1);
-    const float px = fmaf(d[ray * 3 + 0], dist, o[ray * 3 + 0]);
-    const float py = fmaf(d[ray * 3 + 1], dist, o[ray * 3 + 1]);
-    const float pz = fmaf(d[ray * 3 + 2], dist, o[ray * 3 + 2]);
-    pts[idx * 3 + 0] = px; pts[idx * 3 + 1] = py; pts[idx * 3 + 2] = pz;
-    mask[idx] = (mn[0] > px) | (mn[1] > py) | (mn[2] > pz) | (mx[0] < px) | (mx[1] < py) | (mx[2] < pz);
+    float p[3];
+    k4s_ndc_point(o, d, ray, step, n_samples, p);
+    pts[idx * 3 + 0] = p[0]; pts[idx * 3 + 1] = p[1]; pts[idx * 3 + 2] = p[2];
+    mask[idx] = k4s_outbbox(p, mn, mx);
 }
 
 // ---------------------------------------------------------------- ray-AABB helpers (.cu:12-79)
@@ -115,13 +160,7 @@ __global__ void k_maskcache(const uint8_t* __restrict__ world, const float* __re
                             int si, int sj, int sk, int64_t n, uint8_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int a = k4_round_half_away(fmaf(xyz[i * 3 + 0], sc[0], sh[0]));
-    const int b = k4_round_half_away(fmaf(xyz[i * 3 + 1], sc[1], sh[1]));
-    const int c = k4_round_half_away(fmaf(xyz[i * 3 + 2], sc[2], sh[2]));
-    uint8_t v = 0;
-    if ((unsigned)a < (unsigned)si && (unsigned)b < (unsigned)sj && (unsigned)c < (unsigned)sk)
-        v = world[((size_t)a * sj + b) * sk + c] != 0;
-    out[i] = v;
+    out[i] = k4s_maskcache(world, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], sc, sh, si, sj, sk);
 }
 
 // ---------------------------------------------------------------- raw2alpha (+bwd) (.cu:431-458, 507-530)
@@ -129,10 +168,11 @@ __global__ void k_raw2alpha(const float* __restrict__ den, float shift, float in
                             int64_t n, float* __restrict__ ex, float* __restrict__ al) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float e = expf(den[i] + shift);
     const float iv = ipp ? ipp[i] : interval;
+    float e, a;
+    k4s_raw2alpha(den[i], shift, iv, e, a);
     ex[i] = e;
-    al[i] = (iv == 1.f) ? 1.f - 1.f / (1.f + e) : 1.f - powf(1.f + e, -iv);
+    al[i] = a;
 }
 __global__ void k_raw2alpha_bwd(const float* __restrict__ ex, const float* __restrict__ gb, float interval,
                                 const float* __restrict__ ipp, int64_t n, float* __restrict__ g) {
@@ -225,25 +265,108 @@ __global__ void k_grid_sample(const float* __restrict__ grid, int C, int X, int 
                               int64_t n, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float nx = k4_norm_coord(xyz[i * 3 + 0], mn[0], mx[0]);
-    const float ny = k4_norm_coord(xyz[i * 3 + 1], mn[1], mx[1]);
-    const float nz = k4_norm_coord(xyz[i * 3 + 2], mn[2], mx[2]);
-    const K4Tri t = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
     size_t idx[8]; float w[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int x = t.x0 + K4_CX(c), y = t.y0 + K4_CY(c), z = t.z0 + K4_CZ(c);
-        const bool ok = (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
-        idx[c] = ok ? ((size_t)x * Y + y) * Z + z : 0;
-        w[c] = ok ? t.w[c] : 0.f;
-    }
+    k4s_grid_corners(xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], mn, mx, X, Y, Z, idx, w);
     const size_t plane = (size_t)X * Y * Z;
-    for (int ch = 0; ch < C; ++ch) {
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v += grid[plane * ch + idx[c]] * w[c];
-        out[i * C + ch] = v;
+    for (int ch = 0; ch < C; ++ch) out[i * C + ch] = k4s_grid_blend(grid + plane * ch, idx, w);
+}
+
+// ---------------------------------------------------------------- training forward without host round trips (round 5)
+// The reference's training forward (lib/dmpigo.py:300-333) filters its sample list three times -- bounding box + mask cache, alpha >
+// fast_color_thres, weight > fast_color_thres -- and each boolean-mask indexing is a device-to-host synchronisation (4 per iteration in
+// the op-for-op mirror).  k_train_select_mpi takes ALL THREE decisions for a batch of rays in one launch, with the arithmetic of the staged
+// kernels above (k4s_*: a decision here is the decision the op sequence takes): one wave per ray, lanes = 64 consecutive samples; the
+// transmittance product is the exact sequential one of k_alpha2weight (incl. the T < 1e-3 stop: samples behind it keep weight 0).  Per ray it
+// leaves the steps of the alpha-passing samples (ascending), a flag per such sample "weight passes too", and the two counts; after one
+// cumsum per count (and ONE read-back of the two totals, to size the tensors) k_train_compact writes the global lists the differentiable
+// ops then run on: ray_id / step_id of the alpha-passing samples and, for the shaded ones, their index into that list.
+__global__ __launch_bounds__(256) void k_train_select_mpi(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ mn,
+                                                          const float* __restrict__ mx, int64_t n_rays, int n_samples,
+                                                          const uint8_t* __restrict__ world, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                          int si, int sj, int sk,
+                                                          const float* __restrict__ dens, int X, int Y, int Z,
+                                                          const float* __restrict__ act, int AD, float interval, float thres,
+                                                          int16_t* __restrict__ steps2, uint8_t* __restrict__ keep3,
+                                                          int64_t* __restrict__ cnt2, int64_t* __restrict__ cnt3) {
+    const int lane = k4_lane();
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    float T = 1.f;
+    bool stopped = false;
+    int n2 = 0, n3 = 0;
+    int16_t* const my_steps = steps2 + ray * n_samples;
+    uint8_t* const my_keep = keep3 + ray * n_samples;
+    for (int base = 0; base < n_samples; base += 64) {
+        const int step = base + lane;
+        const bool v = step < n_samples;
+        float p[3];
+        k4s_ndc_point(o, d, ray, v ? step : 0, n_samples, p);
+        bool f2 = v && !k4s_outbbox(p, mn, mx);                                           // lib/dmpigo.py:300-303
+        if (f2) f2 = k4s_maskcache(world, p[0], p[1], p[2], sc, sh, si, sj, sk) != 0;     // :308-313
+        float alpha = 0.f;
+        if (f2) {
+            size_t idx[8]; float w[8];
+            k4s_grid_corners(p[0], p[1], p[2], mn, mx, X, Y, Z, idx, w);
+            const float den = k4s_grid_blend(dens, idx, w);                              // self.density(ray_pts)
+            k4s_grid_corners(p[0], p[1], p[2], mn, mx, 1, 1, AD, idx, w);
+            const float ash = k4s_grid_blend(act, idx, w);                               // self.act_shift(ray_pts)
+            const float sum = den + ash;                                                 // :316
+            float e;
+            k4s_raw2alpha(sum, 0.f, interval, e, alpha);                                 // :317, shift 0 (lib/dmpigo.py:261)
+            f2 = alpha > thres;                                                          // :319
+        }
+        uint64_t bm = __ballot(f2);
+        const uint64_t bm2 = bm;
+        float myw = 0.f;                                                                 // weights start as zeros (.cu:624)
+        while (bm && !stopped) {                                                         // k_alpha2weight's sequential product
+            const int l = __builtin_ctzll(bm);
+            const float al = k4_readlane(alpha, l);
+            if (lane == l) myw = T * al;
+            T = fmaf(-T, al, T);
+            bm &= bm - 1;
+            if (T < 1e-3f) stopped = true;                                               // the crossing sample keeps its weight (:597-600)
+        }
+        const bool f3 = f2 && myw > thres;                                               // :329
+        if (f2) {
+            const int pos = n2 + k4_prefix(bm2);
+            my_steps[pos] = (int16_t)step;
+            my_keep[pos] = f3 ? 1 : 0;
+        }
+        n2 += __popcll(bm2);
+        n3 += __popcll(__ballot(f3));
     }
+    if (lane == 0) { cnt2[ray] = n2; cnt3[ray] = n3; }
+}
+// one wave per ray: its alpha-passing samples go to [off2[ray], off2[ray] + cnt2) of the global list, the shaded ones' list positions to idx3
+__global__ __launch_bounds__(256) void k_train_compact(const int16_t* __restrict__ steps2, const uint8_t* __restrict__ keep3,
+                                                       const int64_t* __restrict__ cnt2, const int64_t* __restrict__ inc2, const int64_t* __restrict__ inc3,
+                                                       int64_t n_rays, int n_samples, int64_t* __restrict__ ray_id, int64_t* __restrict__ step_id,
+                                                       int64_t* __restrict__ idx3) {
+    const int lane = k4_lane();
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int n2 = (int)cnt2[ray];
+    const int64_t o2 = inc2[ray] - n2;                                                   // exclusive offsets from the inclusive cumsums
+    int64_t o3 = ray > 0 ? inc3[ray - 1] : 0;
+    for (int base = 0; base < n2; base += 64) {
+        const int j = base + lane;
+        const bool v = j < n2;
+        const int st = v ? (int)steps2[ray * n_samples + j] : 0;
+        const bool k3 = v && keep3[ray * n_samples + j] != 0;
+        if (v) { ray_id[o2 + j] = ray; step_id[o2 + j] = st; }
+        const uint64_t bm = __ballot(k3);
+        if (k3) idx3[o3 + k4_prefix(bm)] = o2 + j;
+        o3 += __popcll(bm);
+    }
+}
+// ray_pts of listed samples: the sampler's formula on (ray_id, step_id)
+__global__ void k_ndc_points_of(const float* __restrict__ o, const float* __restrict__ d, const int64_t* __restrict__ ray_id,
+                                const int64_t* __restrict__ step_id, int64_t n, int n_samples, float* __restrict__ pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p[3];
+    k4s_ndc_point(o, d, ray_id[i], (int)step_id[i], n_samples, p);
+    pts[i * 3 + 0] = p[0]; pts[i * 3 + 1] = p[1]; pts[i * 3 + 2] = p[2];
 }
 
 // ---------------------------------------------------------------- segment_coo(sum), sorted index
@@ -834,6 +957,36 @@ extern "C" int k4_build_live_mask(const k4_grid_desc* g, float act_shift_scalar,
     const int64_t ncell = k4_live_mask_workspace_bytes(P.X, P.Y, P.Z);
     hipLaunchKernelGGL(k_cell_live, dim3(k4_blocks(ncell)), dim3(K4_THREADS), 0, ST, P, workspace);
     hipLaunchKernelGGL(k_live_mask, dim3(k4_blocks((int64_t)P.MX * P.MY * P.MZ)), dim3(K4_THREADS), 0, ST, P, workspace, out_mask);
+    return k4_check_launch();
+}
+extern "C" int k4_train_select_mpi(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max, int64_t n_rays, int32_t n_samples,
+                                   const uint8_t* mask, const float* xyz2ijk_scale, const float* xyz2ijk_shift, int32_t mi, int32_t mj, int32_t mk,
+                                   const float* density, int32_t X, int32_t Y, int32_t Z, const float* act_shift, int32_t act_depth,
+                                   float interval, float fast_color_thres,
+                                   int16_t* steps2, uint8_t* keep3, int64_t* cnt2, int64_t* cnt3, void* stream) {
+    REQ(n_rays >= 0 && n_samples >= 2 && n_samples <= 32767 && mi > 0 && mj > 0 && mk > 0 && X > 0 && Y > 0 && Z > 0 && act_depth > 0 && fast_color_thres > 0.f);
+    if (n_rays == 0) return K4_OK;
+    REQ(rays_o && rays_d && xyz_min && xyz_max && mask && xyz2ijk_scale && xyz2ijk_shift && density && act_shift && steps2 && keep3 && cnt2 && cnt3);
+    hipLaunchKernelGGL(k_train_select_mpi, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, ST, rays_o, rays_d, xyz_min, xyz_max, n_rays, n_samples,
+                       mask, xyz2ijk_scale, xyz2ijk_shift, mi, mj, mk, density, X, Y, Z, act_shift, act_depth, interval, fast_color_thres,
+                       steps2, keep3, cnt2, cnt3);
+    return k4_check_launch();
+}
+extern "C" int k4_train_compact(const int16_t* steps2, const uint8_t* keep3, const int64_t* cnt2, const int64_t* cumsum2, const int64_t* cumsum3,
+                                int64_t n_rays, int32_t n_samples, int64_t* ray_id, int64_t* step_id, int64_t* idx3, void* stream) {
+    REQ(n_rays >= 0 && n_samples >= 2);
+    if (n_rays == 0) return K4_OK;
+    REQ(steps2 && keep3 && cnt2 && cumsum2 && cumsum3 && ray_id && step_id && idx3);
+    hipLaunchKernelGGL(k_train_compact, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, ST, steps2, keep3, cnt2, cumsum2, cumsum3, n_rays, n_samples,
+                       ray_id, step_id, idx3);
+    return k4_check_launch();
+}
+extern "C" int k4_ndc_points_of(const float* rays_o, const float* rays_d, const int64_t* ray_id, const int64_t* step_id, int64_t n, int32_t n_samples,
+                                float* pts, void* stream) {
+    REQ(n >= 0 && n_samples >= 2);
+    if (n == 0) return K4_OK;
+    REQ(rays_o && rays_d && ray_id && step_id && pts);
+    hipLaunchKernelGGL(k_ndc_points_of, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, rays_o, rays_d, ray_id, step_id, n, n_samples, pts);
     return k4_check_launch();
 }
 extern "C" int64_t k4_k0_brick4_floats(int32_t x, int32_t y, int32_t z, int32_t cpad) {

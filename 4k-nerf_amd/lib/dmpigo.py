@@ -12,6 +12,8 @@ Reference quirks honoured: ``act_type`` / ``mode_type`` a
 (lib/dmpigo.py:392-397); ``mode_type`` 'TRANS'/'adain' reference undefined modules upstream and are
 rejected here.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -19,6 +21,8 @@ import torch.nn as nn
 from .. import _native as N
 from . import grid
 from . import dvgo as _dvgo
+
+_TRAIN_PRESEL = os.environ.get('K4_TRAIN_PRESEL', '1') != '0'      # training forward: the three sample filters decided by one launch (same values)
 from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid, _take
 
 
@@ -253,26 +257,69 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             ret['depth'] = depth
         return ret
 
+    def _select_samples(self, rays_o, rays_d, N_samples, interval):
+        """The three sample filters of lib/dmpigo.py:300-333 (bounding box + mask cache, alpha > thres, weight > thres) decided for the whole
+        batch by ONE launch (k4_train_select_mpi: the staged ops' arithmetic, so its decisions are theirs) + a compaction; ONE read-back (the
+        two list lengths) instead of one per boolean-mask indexing.  -> (ray_pts, ray_id, step_id) of the alpha-passing samples and idx3, the
+        positions of the shaded ones in that list."""
+        Nr, dev = rays_o.shape[0], rays_o.device
+        L = N.lib()
+        mc, dg, ag = self.mask_cache, self.density.grid, self.act_shift.grid
+        steps2 = torch.empty([Nr, N_samples], dtype=torch.int16, device=dev)
+        keep3 = torch.empty([Nr, N_samples], dtype=torch.uint8, device=dev)
+        cnt = torch.empty([2, Nr], dtype=torch.int64, device=dev)
+        st = N.stream()
+        N.check(L.k4_train_select_mpi(N.f32(rays_o), N.f32(rays_d), N.f32(self.xyz_min), N.f32(self.xyz_max), Nr, int(N_samples),
+                                      N.ptr(mc.mask), N.f32(mc.xyz2ijk_scale), N.f32(mc.xyz2ijk_shift), *[int(v) for v in mc.mask.shape],
+                                      N.f32(dg), *[int(v) for v in dg.shape[2:]], N.f32(ag), int(ag.numel()),
+                                      float(interval), float(self.fast_color_thres),
+                                      N.ptr(steps2), N.ptr(keep3), N.ptr(cnt[0]), N.ptr(cnt[1]), st), 'k4_train_select_mpi')
+        cum = cnt.cumsum(1)
+        n2, n3 = (int(v) for v in cum[:, -1].tolist()) if Nr > 0 else (0, 0)            # the iteration's one device-to-host read in the marcher forward
+        ray_id = torch.empty([n2 + 1], dtype=torch.int64, device=dev)[:n2]            # (+1: a valid pointer for an empty list)
+        step_id = torch.empty([n2 + 1], dtype=torch.int64, device=dev)[:n2]
+        idx3 = torch.empty([n3 + 1], dtype=torch.int64, device=dev)[:n3]
+        N.check(L.k4_train_compact(N.ptr(steps2), N.ptr(keep3), N.ptr(cnt[0]), N.ptr(cum[0]), N.ptr(cum[1]), Nr, int(N_samples),
+                                   N.ptr(ray_id), N.ptr(step_id), N.ptr(idx3), st), 'k4_train_compact')
+        ray_pts = torch.empty([n2 + 1, 3], dtype=torch.float32, device=dev)[:n2]
+        N.check(L.k4_ndc_points_of(N.f32(rays_o), N.f32(rays_d), N.ptr(ray_id), N.ptr(step_id), n2, int(N_samples), N.f32(ray_pts), st), 'k4_ndc_points_of')
+        return ray_pts, ray_id, step_id, idx3
+
     def _forward_staged(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
-                        global_step=None, rand_bkgd=False, **_ignored):
-        """The reference's op sequence (lib/dmpigo.py:300-427) on the staged gfx950 kernels."""
+                        global_step=None, rand_bkgd=False, k4_presel=None, **_ignored):
+        """The reference's op sequence (lib/dmpigo.py:300-427) on the staged gfx950 kernels.  With a mask cache and fast_color_thres > 0 (every
+        BASELINE configuration) the three sample filters are decided up front by ``_select_samples``: the differentiable ops then run on the
+        same lists the op-for-op sequence ends with (same values, same gradients), with one host synchronisation instead of four.
+        ``K4_TRAIN_PRESEL=0`` / ``k4_presel=False`` keeps the filter-by-filter form (A/B, tests)."""
         ret_dict = {}
         Nr = len(rays_o)
-        ray_pts, ray_id, step_id, N_samples, mask_inbbox = self.sample_ray(
-            rays_o=rays_o, rays_d=rays_d, near=near, far=far, stepsize=stepsize)
         interval = stepsize * self.voxel_size_ratio
-        if self.mask_cache is not None:
-            mask1 = self.mask_cache(ray_pts)
-            ray_pts, ray_id, step_id = _take(mask1, ray_pts, ray_id, step_id)
-        density = self.density(ray_pts) + self.act_shift(ray_pts)
-        alpha = self.activate_density(density, interval)
-        if self.fast_color_thres > 0:
-            mask2 = (alpha > self.fast_color_thres)
-            ray_pts, ray_id, step_id, alpha = _take(mask2, ray_pts, ray_id, step_id, alpha)
-        weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
-        if self.fast_color_thres > 0:
-            mask3 = (weights > self.fast_color_thres)
-            ray_pts, ray_id, step_id, alpha, weights = _take(mask3, ray_pts, ray_id, step_id, alpha, weights)
+        presel = (_TRAIN_PRESEL if k4_presel is None else bool(k4_presel)) and self.mask_cache is not None and self.fast_color_thres > 0
+        if presel:
+            assert near == 0 and far == 1
+            N_samples = int((self.mpi_depth - 1) / stepsize) + 1
+            presel = N_samples <= 32767
+        if presel:
+            ray_pts, ray_id, step_id, idx3 = self._select_samples(rays_o.contiguous(), rays_d.contiguous(), N_samples, interval)
+            density = self.density(ray_pts) + self.act_shift(ray_pts)
+            alpha = self.activate_density(density, interval)
+            weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
+            ray_pts, ray_id, step_id, alpha, weights = [t.index_select(0, idx3) for t in (ray_pts, ray_id, step_id, alpha, weights)]
+        else:
+            ray_pts, ray_id, step_id, N_samples, mask_inbbox = self.sample_ray(
+                rays_o=rays_o, rays_d=rays_d, near=near, far=far, stepsize=stepsize)
+            if self.mask_cache is not None:
+                mask1 = self.mask_cache(ray_pts)
+                ray_pts, ray_id, step_id = _take(mask1, ray_pts, ray_id, step_id)
+            density = self.density(ray_pts) + self.act_shift(ray_pts)
+            alpha = self.activate_density(density, interval)
+            if self.fast_color_thres > 0:
+                mask2 = (alpha > self.fast_color_thres)
+                ray_pts, ray_id, step_id, alpha = _take(mask2, ray_pts, ray_id, step_id, alpha)
+            weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, Nr)
+            if self.fast_color_thres > 0:
+                mask3 = (weights > self.fast_color_thres)
+                ray_pts, ray_id, step_id, alpha, weights = _take(mask3, ray_pts, ray_id, step_id, alpha, weights)
         vox_emb = self.k0(ray_pts)
         if vox_emb.dim() == 1:
             vox_emb = vox_emb.unsqueeze(-1)

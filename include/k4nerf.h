@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      9       /* 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      10      /* 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -181,6 +181,27 @@ int k4_march_dvgo_fwd(const float* rays_o, const float* rays_d, const float* vie
 /* sample_ndc_pts_on_rays (render_utils.cpp:87-98): pts [n_rays][n_samples][3], mask_outbbox [n_rays][n_samples] */
 int k4_sample_ndc_pts_on_rays(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
                               int64_t n_rays, int32_t n_samples, float* out_pts, uint8_t* out_mask_outbbox, void* stream);
+/* Training forward of DirectMPIGO without host round trips per filter (round 5; lib/dmpigo.py:300-333 filters the sample list by
+ * bounding box + mask cache, by alpha > fast_color_thres and by weight > fast_color_thres: three boolean-mask indexings = device-to-host
+ * synchronisations).  k4_train_select_mpi takes the three decisions for all n_rays x n_samples samples in one launch, in the arithmetic of
+ * the staged ops above (sampler, maskcache_lookup, grid_sample of the density and act_shift grids, raw2alpha with shift 0, the sequential
+ * transmittance product of alpha2weight incl. its T < 1e-3 stop):
+ *   steps2 [n_rays][n_samples] int16 : per ray, the steps of its alpha-passing samples, ascending (first cnt2[ray] entries)
+ *   keep3  [n_rays][n_samples] uint8 : per such sample, 1 when its weight passes too
+ *   cnt2, cnt3 [n_rays] int64        : the counts
+ * The caller forms the inclusive cumsums of cnt2 / cnt3, reads the two totals back (one synchronisation, to size the tensors), and
+ * k4_train_compact writes ray_id / step_id [total2] of the alpha-passing samples and idx3 [total3], the positions of the shaded ones in
+ * that list; k4_ndc_points_of recomputes their points (render_utils_kernel.cu:260 on listed samples).  The differentiable ops then run on
+ * those lists exactly as the reference runs them on its filtered tensors. */
+int k4_train_select_mpi(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max, int64_t n_rays, int32_t n_samples,
+                        const uint8_t* mask, const float* xyz2ijk_scale, const float* xyz2ijk_shift, int32_t mi, int32_t mj, int32_t mk,
+                        const float* density, int32_t x, int32_t y, int32_t z, const float* act_shift, int32_t act_depth,
+                        float interval, float fast_color_thres,
+                        int16_t* steps2, uint8_t* keep3, int64_t* cnt2, int64_t* cnt3, void* stream);
+int k4_train_compact(const int16_t* steps2, const uint8_t* keep3, const int64_t* cnt2, const int64_t* cumsum2, const int64_t* cumsum3,
+                     int64_t n_rays, int32_t n_samples, int64_t* ray_id, int64_t* step_id, int64_t* idx3, void* stream);
+int k4_ndc_points_of(const float* rays_o, const float* rays_d, const int64_t* ray_id, const int64_t* step_id, int64_t n, int32_t n_samples,
+                     float* pts, void* stream);
 /* infer_t_minmax (render_utils.cpp:50-58) */
 int k4_infer_t_minmax(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max,
                       float near, float far, int64_t n_rays, float* out_t_min, float* out_t_max, void* stream);

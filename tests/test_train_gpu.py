@@ -225,3 +225,44 @@ def test_occupancy_and_resolution_maintenance_vs_reference_classes(name):
         a = model(ro, rd, vd, **rk)
         b = model(ro, rd, vd, k4_staged=True, **rk)
     assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)
+
+
+@pytest.mark.parametrize('cfg,hw', [(dict(seed=71, num_voxels=64 * 64 * 48, mpi_depth=48), (64, 64)),
+                                    (dict(seed=72, num_voxels=56 * 56 * 64, mpi_depth=64, stepsize=0.5), (48, 52)),          # interval != 1: the powf form, 127 samples
+                                    (dict(seed=73, num_voxels=40 * 40 * 32, mpi_depth=32, mask_cache_world_size=[33, 29, 23]), (40, 40))])
+def test_preselected_training_forward_equals_the_filter_by_filter_form(cfg, hw):
+    """Round 5: the training forward of DirectMPIGO with its three sample filters decided up front by ONE launch
+    (k4_train_select_mpi + k4_train_compact + k4_ndc_points_of, one read-back) against the op-for-op mirror of lib/dmpigo.py:300-333
+    (four read-backs): every key of the returned dict bit for bit, the loss, and every gradient (the grids' up to the order of the atomic
+    scatter)."""
+    from nerf4k_amd import scene
+    from oracle import marcher
+    ck = scene.make_llff_checkpoint(**cfg)
+    H, W = hw
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    rays = [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[6], ndc=True)]
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    tgt = torch.rand([H * W, 3], generator=torch.Generator().manual_seed(3)).cuda()
+    outs, grads, losses = [], [], []
+    for presel in (False, True):
+        model = utils.model_from_checkpoint_dict(ck).cuda()
+        with torch.enable_grad():
+            out = model(*rays, global_step=0, k4_presel=presel, **rk)
+            loss = F.mse_loss(out['rgb_marched'], tgt) + 1e-2 * (out['weights'] * out['raw_rgb'].sum(-1)).sum() / (H * W)
+            loss.backward()
+        outs.append(out)
+        losses.append(float(loss.detach()))
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b = outs
+    assert set(a) == set(b)
+    assert a['ray_id'].numel() > 1000                                  # a non-trivial batch
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+    assert losses[0] == losses[1]
+    assert set(grads[0]) == set(grads[1]) and 'density.grid' in grads[0] and 'k0.grid' in grads[0]
+    for k in grads[0]:
+        _close(grads[1][k], grads[0][k].cpu(), k)
