@@ -746,8 +746,9 @@ __global__ void k_live_mask(const LiveParams P, const uint8_t* __restrict__ cell
 
 extern "C" int k4_sample_ndc_pts_on_rays(const float* o, const float* d, const float* mn, const float* mx,
                                          int64_t n_rays, int32_t n_samples, float* pts, uint8_t* mask, void* stream) {
-    REQ(o && d && mn && mx && pts && mask && n_rays >= 0 && n_samples >= 2);
-    if (n_rays == 0) return K4_OK;
+    REQ(n_rays >= 0 && n_samples >= 2);
+    if (n_rays == 0) return K4_OK;                          // (empty tensors carry NULL data pointers)
+    REQ(o && d && mn && mx && pts && mask);
     hipLaunchKernelGGL(k_sample_ndc, dim3(k4_blocks(n_rays * n_samples)), dim3(K4_THREADS), 0, ST, o, d, mn, mx, n_rays, n_samples, pts, mask);
     return k4_check_launch();
 }
@@ -816,8 +817,9 @@ extern "C" int k4_raw2alpha_backward(const float* ex, const float* gb, float int
 }
 extern "C" int k4_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int64_t n_rays,
                                float* weight, float* T, float* ainv, int64_t* i_start, int64_t* i_end, void* stream) {
-    REQ(n_pts >= 0 && n_rays >= 0 && ainv && i_start && i_end);
-    if (n_rays == 0) return K4_OK;
+    REQ(n_pts >= 0 && n_rays >= 0);
+    if (n_rays == 0) return K4_OK;                          // (empty tensors carry NULL data pointers)
+    REQ(ainv && i_start && i_end);
     // weight = zeros_like, T = ones_like, alphainv_last = ones, i_start/i_end = zeros (.cu:624-628)
     hipLaunchKernelGGL(k_fill2, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, ainv, 1.f, (float*)nullptr, 0.f, n_rays);
     hipLaunchKernelGGL(k_fill_i64, dim3(k4_blocks(n_rays)), dim3(K4_THREADS), 0, ST, i_start, i_end, n_rays);
@@ -848,7 +850,7 @@ extern "C" int k4_grid_sample_3d(const float* grid, int32_t C, int32_t X, int32_
 }
 extern "C" int k4_segment_sum(const float* src, const int64_t* index, int64_t n, int32_t C, int64_t n_seg, float* out,
                               void* stream) {
-    REQ(out && C > 0 && n >= 0 && n_seg >= 0);
+    REQ(C > 0 && n >= 0 && n_seg >= 0 && (out || n_seg == 0));
     if (n_seg > 0) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_seg * C, ST);
         if (e != hipSuccess) return (int)e;

@@ -276,13 +276,15 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
                                       N.ptr(steps2), N.ptr(keep3), N.ptr(cnt[0]), N.ptr(cnt[1]), st), 'k4_train_select_mpi')
         cum = cnt.cumsum(1)
         n2, n3 = (int(v) for v in cum[:, -1].tolist()) if Nr > 0 else (0, 0)            # the iteration's one device-to-host read in the marcher forward
-        ray_id = torch.empty([n2 + 1], dtype=torch.int64, device=dev)[:n2]            # (+1: a valid pointer for an empty list)
-        step_id = torch.empty([n2 + 1], dtype=torch.int64, device=dev)[:n2]
-        idx3 = torch.empty([n3 + 1], dtype=torch.int64, device=dev)[:n3]
+        # (+1: empty lists still hand the kernels a valid pointer; a zero-element view reports a NULL data pointer)
+        ray_id_b = torch.empty([n2 + 1], dtype=torch.int64, device=dev)
+        step_id_b = torch.empty([n2 + 1], dtype=torch.int64, device=dev)
+        idx3_b = torch.empty([n3 + 1], dtype=torch.int64, device=dev)
         N.check(L.k4_train_compact(N.ptr(steps2), N.ptr(keep3), N.ptr(cnt[0]), N.ptr(cum[0]), N.ptr(cum[1]), Nr, int(N_samples),
-                                   N.ptr(ray_id), N.ptr(step_id), N.ptr(idx3), st), 'k4_train_compact')
-        ray_pts = torch.empty([n2 + 1, 3], dtype=torch.float32, device=dev)[:n2]
-        N.check(L.k4_ndc_points_of(N.f32(rays_o), N.f32(rays_d), N.ptr(ray_id), N.ptr(step_id), n2, int(N_samples), N.f32(ray_pts), st), 'k4_ndc_points_of')
+                                   N.ptr(ray_id_b), N.ptr(step_id_b), N.ptr(idx3_b), st), 'k4_train_compact')
+        ray_pts_b = torch.empty([n2 + 1, 3], dtype=torch.float32, device=dev)
+        N.check(L.k4_ndc_points_of(N.f32(rays_o), N.f32(rays_d), N.ptr(ray_id_b), N.ptr(step_id_b), n2, int(N_samples), N.f32(ray_pts_b), st), 'k4_ndc_points_of')
+        ray_pts, ray_id, step_id, idx3 = ray_pts_b[:n2], ray_id_b[:n2], step_id_b[:n2], idx3_b[:n3]
         return ray_pts, ray_id, step_id, idx3
 
     def _forward_staged(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,

@@ -266,3 +266,35 @@ def test_preselected_training_forward_equals_the_filter_by_filter_form(cfg, hw):
     assert set(grads[0]) == set(grads[1]) and 'density.grid' in grads[0] and 'k0.grid' in grads[0]
     for k in grads[0]:
         _close(grads[1][k], grads[0][k].cpu(), k)
+
+
+def test_preselected_training_forward_on_an_empty_scene_and_on_zero_rays():
+    """Edge cases of the pre-selected training forward: a scene in which no sample passes the alpha threshold (empty lists end to end: the
+    loss is the background term alone and every gradient is zero or absent) and a batch of zero rays -- same results as the filter-by-filter
+    form, no crash."""
+    from nerf4k_amd import scene
+    from oracle import marcher
+    ck = scene.make_llff_checkpoint(seed=74, num_voxels=40 * 40 * 32, mpi_depth=32)
+    ck['model_state_dict']['density.grid'] = ck['model_state_dict']['density.grid'] - 60.0          # alpha ~ 0 everywhere
+    H, W = 24, 32
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    rays = [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[2], ndc=True)]
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    outs = []
+    for presel in (False, True):
+        model = utils.model_from_checkpoint_dict(ck).cuda()
+        with torch.enable_grad():
+            out = model(*rays, global_step=0, k4_presel=presel, **rk)
+            loss = out['rgb_marched'].sum() + out['alphainv_last'].sum()
+            if loss.requires_grad:
+                loss.backward()
+        outs.append(out)
+        empty = model(rays[0][:0], rays[1][:0], rays[2][:0], global_step=0, k4_presel=presel, **rk)
+        assert empty['rgb_marched'].shape == (0, 3) and empty['ray_id'].numel() == 0
+    a, b = outs
+    assert a['ray_id'].numel() == 0 and b['ray_id'].numel() == 0
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    assert torch.equal(b['alphainv_last'], torch.ones_like(b['alphainv_last']))
