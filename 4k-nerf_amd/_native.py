@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 10
+K4_ABI_VERSION = 11
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST, K0_BRICK4 = 0, 1, 2
@@ -46,7 +46,8 @@ class RdbTrain(C.Structure):         # k4_rdb_train
                 ('w_bwd', C.c_void_p * 5), ('b_bwd', C.c_void_p * 5), ('g5', C.c_void_p),
                 ('G', C.c_void_p), ('gx4', C.c_void_p), ('gx0', C.c_void_p), ('gc0', C.c_void_p), ('gc1', C.c_void_p),
                 ('dwdb', C.c_void_p * 5), ('gsft0', C.c_void_p * 8), ('gsft1', C.c_void_p * 8),
-                ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p)]
+                ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p),
+                ('gc_acc', C.c_void_p), ('gx0_add', C.c_void_p), ('dwdb_span', C.c_void_p), ('dwdb_span_floats', C.c_int64)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -157,6 +158,8 @@ _EXTRA_SIGS = {
     'k4_absmax_slice': ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_wgrad_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_conv2d_wgrad_dbias_bf16x6': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_conv2d_wgrad_dbias_bf16x6_acc': ([_P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_zero_f32': ([_P, _I64, _P], C.c_int),
     'k4_pack_conv_weight_bf16x6_multi': ([C.POINTER(PackJob), _I32, _P], C.c_int),
     'k4_rdb_train_fwd': ([C.POINTER(RdbTrain), _P], C.c_int),
     'k4_rdb_train_bwd': ([C.POINTER(RdbTrain), _P], C.c_int),
@@ -177,6 +180,8 @@ _EXTRA_SIGS = {
     'k4_sft_train_bwd_workspace_bytes': ([_I64, _I32], C.c_int64),
     'k4_sft_train_bwd': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                           _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    'k4_sft_train_bwd_ex': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
 }
 

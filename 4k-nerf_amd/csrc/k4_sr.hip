@@ -1010,7 +1010,9 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
         if ((int64_t)M.H[g] * M.W[g] * M.base.cin_stride > 0x7fffffffLL) return K4_ERR_UNSUPPORTED;
     int total = count(16);
     // Launches of at most two "rounds" of 16-row tiles (the 8-GPU job's windows; layers of small images): pick the tile height
-    // (8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead)
+    // (4 / 8 / 12 / 16 rows) that minimises rounds x serial work per workgroup (rows + halo / staging overhead).  4-row tiles: the 64x64
+    // training patch is 16 (32) tiles of 8 rows per 32 output channels on 256 CUs -- the launch lasts as long as ONE workgroup's chain
+    // of chunks x 9 taps x rows x 6 products; halving the rows per wave halves it (same accumulation order per pixel: bit-identical).
     int rpw = 4;
     // fp16 form: ALWAYS 8-row tiles.  Its activation scale is found per haloed workgroup tile, and elements 2^-16 below a chunk's maximum
     // round their low term as fp16 subnormals -- with a tile height picked from the launch size (below), the bits of a window would
@@ -1018,7 +1020,7 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     // window alone (tile_parallel's frame == the single-GPU frame, whatever the grouping).
     if (!(M.base.flags & K4_ARITH_F16X3) && total <= 2 * slots) {
         float best = 1e30f;
-        for (int cand = 4; cand >= 2; --cand) {
+        for (int cand = 4; cand >= 1; --cand) {
             const int c = count(4 * cand);
             const float cost = (float)((c + slots - 1) / slots) * ((float)cand + 0.6f);
             if (cost < best - 1e-3f) { best = cost; rpw = cand; }
@@ -1035,10 +1037,11 @@ static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     M.base.debug = k4_env().sr_debug;
     const dim3 grid((unsigned)total), block(256);
 #define K4_V2_LAUNCH(...) do { \
-        if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, __VA_ARGS__>), grid, block, 0, st, M); \
+        if (rpw == 1) hipLaunchKernelGGL((k4_conv_b6v2_kernel<1, __VA_ARGS__>), grid, block, 0, st, M); \
+        else if (rpw == 2) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, __VA_ARGS__>), grid, block, 0, st, M); \
         else if (rpw == 3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<3, __VA_ARGS__>), grid, block, 0, st, M); \
         else hipLaunchKernelGGL((k4_conv_b6v2_kernel<4, __VA_ARGS__>), grid, block, 0, st, M); } while (0)
-    if (M.base.flags & K4_ARITH_F16X3) K4_V2_LAUNCH(2, true, true);      // fp16 form: weight fragments through LDS
+    if (M.base.flags & K4_ARITH_F16X3) hipLaunchKernelGGL((k4_conv_b6v2_kernel<2, 2, true, true>), grid, block, 0, st, M);      // fp16 form: always 8-row tiles (above), weight fragments through LDS
     else if (M.base.flags & K4_ARITH_2TERM) K4_V2_LAUNCH(2, false);
     else K4_V2_LAUNCH(3, false);
 #undef K4_V2_LAUNCH

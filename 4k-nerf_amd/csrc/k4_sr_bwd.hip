@@ -162,7 +162,7 @@ static int wgrad_launch(const float* x, int32_t cin, int32_t x_stride, const flo
     P.ks = ksize; P.H = H; P.W = W; P.dw = dw; P.db = dbias;
     P.ci_blocks = (cin + 31) / 32; P.co_blocks = (cout + 31) / 32; P.bands = (H + K4_WG_BAND - 1) / K4_WG_BAND;
     const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
-    wg_zero(dw, zero_floats, (hipStream_t)stream);                                                                      // split-K partial sums are ADDED
+    if (zero_floats > 0) wg_zero(dw, zero_floats, (hipStream_t)stream);                                                 // split-K partial sums are ADDED
     hipLaunchKernelGGL(k4_conv_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
     return k4_check_launch();
 }
@@ -178,6 +178,20 @@ extern "C" int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t
     if (!dw_db) return K4_ERR_BAD_ARG;
     const int64_t nw = (int64_t)cout * cin * ksize * ksize;
     return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, nw + cout, stream);
+}
+
+// ... ADDED to dw_db (no zero-fill): the caller has zeroed it -- k4_rdb_train_bwd zeroes the five buffers of a dense block with one launch
+extern "C" int k4_conv2d_wgrad_dbias_bf16x6_acc(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                                                int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream) {
+    if (!dw_db) return K4_ERR_BAD_ARG;
+    const int64_t nw = (int64_t)cout * cin * ksize * ksize;
+    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, 0, stream);
+}
+extern "C" int k4_zero_f32(float* p, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && !p) || (n + 255) / 256 > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+    if (n == 0) return K4_OK;
+    wg_zero(p, n, (hipStream_t)stream);
+    return k4_check_launch();
 }
 
 extern "C" int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream) {

@@ -11,6 +11,8 @@
 // gfx950 only (wave64).  A training batch is ~10^5 points x (15..39 -> 64..128 -> 64..128 -> 3): ~1 GFLOP, far below the
 // matrix cores' interest; what matters is launch count and that nothing but x / h / grad streams through HBM once.
 #include "k4_common.h"
+#include <atomic>
+#include <mutex>
 
 #define TR_LS 68            // LDS row stride in floats: rows 16-byte aligned (ds_read_b128 along the sample axis), lane = sample reads conflict-free
 #define TR_MAX_DIM0 64
@@ -469,23 +471,29 @@ extern "C" int k4_distortion_loss(const float* w, const float* s, const int64_t*
 // glue each was ~13 launches forward and ~30 backward of 4-15 us apiece -- two thirds of the decoder's ~2500 launches.  Here:
 //   k_sft_train_fwd : one launch, nothing saved but the inputs (the backward recomputes the 64 hidden activations);
 //   k_sft_train_bwd : gx, gc (gradient of the 32-channel condition map) and the per-workgroup partial sums of the eight weight /
-//                     bias gradients (4x4 register blocks over the pixel axis as in k_rgbnet_bwd: no atomics, fixed order);
+//                     bias gradients (4x2 register blocks over the pixel axis, cf. k_rgbnet_bwd: no atomics, fixed order);
 //   k_sft_train_reduce : partials -> the eight gradient tensors.
-// Tile = 64 pixels, lane = pixel, wave = a quarter of the neurons / channels; weights are the nn.Conv2d tensors as stored
+// Tile = 64 pixels, lane = pixel, wave = a sixteenth of the neurons / channels; weights are the nn.Conv2d tensors as stored
 // ([out][in] row-major), read with wave-uniform indices (scalar loads).  Exact fp32 FMA chains.
 // --------------------------------------------------------------------------------------------------------------------
 #define SFT_G 32                          // condition channels = hidden width
 #define SFT_GB (SFT_G + 4)                // + ones row (bias gradient) + 3 zero rows: a multiple of 4
+// Workgroup = 16 waves (4 per SIMD) on one 64-pixel tile.  A 64x64 training patch is 64 tiles -> 64 workgroups on 256 CUs whatever the
+// workgroup size, so the time of a launch is the time of ONE tile: with 4 waves (one per SIMD, nothing to hide the LDS / scalar-load
+// latencies behind) the backward took 60 us and the forward 25 us per layer, 36 layers per joint iteration (profiles/
+// r05_joint_iteration_kernel_stats.csv).  16 waves split the same per-element FMA chains four times finer: same values, same order.
+#define SFT_T 1024
+#define SFT_NW (SFT_T / 64)
 
 // [n][stride] global rows (K channels from each) -> LDS [K][TR_LS]; samples >= nv read as 0
 __device__ __forceinline__ void sft_load_tile(const float* __restrict__ g, int64_t base, int stride, int K, int nv, float* lds, int t) {
-    for (int i = t; i < 64 * K; i += 256) {
+    for (int i = t; i < 64 * K; i += SFT_T) {
         const int s = i / K, k = i - s * K;
         lds[k * TR_LS + s] = s < nv ? g[(base + s) * stride + k] : 0.f;
     }
 }
 __device__ __forceinline__ void sft_store_tile(const float* lds, float* __restrict__ g, int64_t base, int stride, int K, int nv, int t) {
-    for (int i = t; i < 64 * K; i += 256) {
+    for (int i = t; i < 64 * K; i += SFT_T) {
         const int s = i / K, k = i - s * K;
         if (s < nv) g[(base + s) * stride + k] = lds[k * TR_LS + s];
     }
@@ -493,7 +501,7 @@ __device__ __forceinline__ void sft_store_tile(const float* lds, float* __restri
 // hidden activations of both branches: hs[j] = lrelu(b0[j] + sum_k w0[j][k] c[k]), j < 32 scale branch, j >= 32 shift branch
 __device__ __forceinline__ void sft_hidden(const float* cs, k4_cptr w0s, k4_cptr b0s, k4_cptr w0h, k4_cptr b0h, float slope,
                                            float* as, float* ah, int wv, int lane) {
-    for (int j0 = wv * 16; j0 < wv * 16 + 16; j0 += 4) {
+    for (int j0 = wv * (2 * SFT_G / SFT_NW); j0 < (wv + 1) * (2 * SFT_G / SFT_NW); j0 += 4) {
         const bool sh = j0 >= SFT_G;
         const k4_cptr w = (sh ? w0h : w0s) + (j0 & (SFT_G - 1)) * SFT_G, b = (sh ? b0h : b0s) + (j0 & (SFT_G - 1));
         float a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3];
@@ -508,7 +516,7 @@ __device__ __forceinline__ void sft_hidden(const float* cs, k4_cptr w0s, k4_cptr
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_sft_train_fwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride, int64_t n,
+__global__ __launch_bounds__(SFT_T) void k_sft_train_fwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride, int64_t n,
                                                        const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
                                                        const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h, const float* __restrict__ b1h,
                                                        float slope, float* __restrict__ y, int y_stride) {
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(256) void k_sft_train_fwd(const float* __restrict__
     sft_hidden(cs, k4_const(w0s), k4_const(b0s), k4_const(w0h), k4_const(b0h), slope, as, ah, wv, lane);
     __syncthreads();
     const k4_cptr w1sc = k4_const(w1s), w1hc = k4_const(w1h), b1sc = k4_const(b1s), b1hc = k4_const(b1h);
-    for (int co = wv * (C / 4); co < (wv + 1) * (C / 4); co += 2) {
+    for (int co = wv * (C / SFT_NW); co < (wv + 1) * (C / SFT_NW); co += 2) {
         float s0 = b1sc[co], s1 = b1sc[co + 1], h0 = b1hc[co], h1 = b1hc[co + 1];
         for (int k = 0; k < SFT_G; ++k) {
             const float a = as[k * TR_LS + lane], b = ah[k * TR_LS + lane];
@@ -547,16 +555,17 @@ struct SftBwdLayout {
     static constexpr int ROWS = 3 * SFT_GB + 2 * SFT_G + 3 * C + SFT_G;
     // partial sums: P1s [C][GB] | P1h [C][GB] | P0s [G][GB] | P0h [G][GB]   (column G = the bias gradient)
     static constexpr int N_PART = 2 * C * SFT_GB + 2 * SFT_G * SFT_GB;
-    static constexpr int N_BLK = N_PART / 16;
-    static constexpr int MAXB = (N_BLK + 255) / 256;
+    static constexpr int N_BLK = N_PART / 8;                  // 4 x 2 register blocks
+    static constexpr int MAXB = (N_BLK + SFT_T - 1) / SFT_T;
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride,
+__global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride,
                                                        const float* __restrict__ gyg, int gy_stride, int64_t n,
                                                        const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
                                                        const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h,
-                                                       float slope, float* __restrict__ gxg, float* __restrict__ gcg, float* __restrict__ part) {
+                                                       float slope, float* __restrict__ gxg, float* __restrict__ gcg, float* __restrict__ part,
+                                                       const float* __restrict__ gxa, int gxa_stride, int gc_acc) {
     typedef SftBwdLayout<C> L;
     constexpr int MAXB = L::MAXB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -571,31 +580,31 @@ __global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__
     float* const gc = gx + C * TR_LS;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    for (int i = t; i < L::ROWS * TR_LS; i += 256) smem[i] = 0.f;           // the zero padding rows stay zero for the whole kernel
+    for (int i = t; i < L::ROWS * TR_LS; i += SFT_T) smem[i] = 0.f;           // the zero padding rows stay zero for the whole kernel
 
     TrBlock blk[MAXB];
-    float acc[MAXB][16];
+    float acc[MAXB][8];
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
-        int b = t + 256 * q;
+        int b = t + SFT_T * q;
         blk[q].aoff = -1;
-        constexpr int NB1 = (C / 4) * (SFT_GB / 4), NB0 = (SFT_G / 4) * (SFT_GB / 4);
+        constexpr int NB1 = (C / 4) * (SFT_GB / 2), NB0 = (SFT_G / 4) * (SFT_GB / 2);
         if (b < 2 * NB1) {
             const bool sh = b >= NB1;
             b -= sh ? NB1 : 0;
-            const int ar = b / (SFT_GB / 4), bc = b - ar * (SFT_GB / 4);
-            blk[q] = {(int)((sh ? gy : gs) - smem) + 4 * ar * TR_LS, (int)((sh ? ah : as) - smem) + 4 * bc * TR_LS,
-                      (sh ? C * SFT_GB : 0) + 4 * ar * SFT_GB + 4 * bc, SFT_GB};
+            const int ar = b / (SFT_GB / 2), bc = b - ar * (SFT_GB / 2);
+            blk[q] = {(int)((sh ? gy : gs) - smem) + 4 * ar * TR_LS, (int)((sh ? ah : as) - smem) + 2 * bc * TR_LS,
+                      (sh ? C * SFT_GB : 0) + 4 * ar * SFT_GB + 2 * bc, SFT_GB};
         } else if (b < 2 * NB1 + 2 * NB0) {
             b -= 2 * NB1;
             const bool sh = b >= NB0;
             b -= sh ? NB0 : 0;
-            const int ar = b / (SFT_GB / 4), bc = b - ar * (SFT_GB / 4);
-            blk[q] = {(int)((sh ? gzh : gzs) - smem) + 4 * ar * TR_LS, (int)(cs - smem) + 4 * bc * TR_LS,
-                      2 * C * SFT_GB + (sh ? SFT_G * SFT_GB : 0) + 4 * ar * SFT_GB + 4 * bc, SFT_GB};
+            const int ar = b / (SFT_GB / 2), bc = b - ar * (SFT_GB / 2);
+            blk[q] = {(int)((sh ? gzh : gzs) - smem) + 4 * ar * TR_LS, (int)(cs - smem) + 2 * bc * TR_LS,
+                      2 * C * SFT_GB + (sh ? SFT_G * SFT_GB : 0) + 4 * ar * SFT_GB + 2 * bc, SFT_GB};
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+        for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
     }
     __syncthreads();
 
@@ -615,7 +624,7 @@ __global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__
         sft_hidden(cs, w0sc, k4_const(b0s), w0hc, k4_const(b0h), slope, as, ah, wv, lane);
         __syncthreads();
         // gx = gy * (scale + 1);  gs = gy * x   (the shift branch's output gradient is gy itself)
-        for (int co = wv * (C / 4); co < (wv + 1) * (C / 4); co += 2) {
+        for (int co = wv * (C / SFT_NW); co < (wv + 1) * (C / SFT_NW); co += 2) {
             float s0 = b1sc[co], s1 = b1sc[co + 1];
             for (int k = 0; k < SFT_G; ++k) {
                 const float a = as[k * TR_LS + lane];
@@ -626,35 +635,37 @@ __global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__
             gs[co * TR_LS + lane] *= g0; gs[(co + 1) * TR_LS + lane] *= g1;
         }
         __syncthreads();
-        // gz = lrelu'(z) * (W1^T g):  wave w -> hidden neurons 8w .. 8w+7 of both branches
-        for (int k0 = wv * 8; k0 < wv * 8 + 8; k0 += 4) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+        // gz = lrelu'(z) * (W1^T g):  wave w -> hidden neurons 4 (w & 7) .. +3 of the scale (w < 8) or shift (w >= 8) branch
+        {
+            static_assert(SFT_NW == 16, "wave -> (branch, 4 neurons)");
+            const bool sh = wv >= 8;
+            const int k0 = (wv & 7) * 4;
+            const float* const src = sh ? gy : gs;               // the shift branch's output gradient is gy itself
+            const k4_cptr w1 = sh ? w1hc : w1sc;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             for (int co = 0; co < C; ++co) {
-                const float a = gs[co * TR_LS + lane], b = gy[co * TR_LS + lane];
-                s0 = fmaf(a, w1sc[co * SFT_G + k0], s0); s1 = fmaf(a, w1sc[co * SFT_G + k0 + 1], s1);
-                s2 = fmaf(a, w1sc[co * SFT_G + k0 + 2], s2); s3 = fmaf(a, w1sc[co * SFT_G + k0 + 3], s3);
-                h0 = fmaf(b, w1hc[co * SFT_G + k0], h0); h1 = fmaf(b, w1hc[co * SFT_G + k0 + 1], h1);
-                h2 = fmaf(b, w1hc[co * SFT_G + k0 + 2], h2); h3 = fmaf(b, w1hc[co * SFT_G + k0 + 3], h3);
+                const float a = src[co * TR_LS + lane];
+                s0 = fmaf(a, w1[co * SFT_G + k0], s0); s1 = fmaf(a, w1[co * SFT_G + k0 + 1], s1);
+                s2 = fmaf(a, w1[co * SFT_G + k0 + 2], s2); s3 = fmaf(a, w1[co * SFT_G + k0 + 3], s3);
             }
-            const float sv[4] = {s0, s1, s2, s3}, hv[4] = {h0, h1, h2, h3};
+            const float sv[4] = {s0, s1, s2, s3};
+            const float* const act = sh ? ah : as;
+            float* const out = sh ? gzh : gzs;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {               // leaky_relu_backward: grad where the INPUT is > 0, slope * grad elsewhere (lrelu(z) > 0 <=> z > 0)
-                gzs[(k0 + e) * TR_LS + lane] = as[(k0 + e) * TR_LS + lane] > 0.f ? sv[e] : sv[e] * slope;
-                gzh[(k0 + e) * TR_LS + lane] = ah[(k0 + e) * TR_LS + lane] > 0.f ? hv[e] : hv[e] * slope;
-            }
+            for (int e = 0; e < 4; ++e)                          // leaky_relu_backward: grad where the INPUT is > 0, slope * grad elsewhere (lrelu(z) > 0 <=> z > 0)
+                out[(k0 + e) * TR_LS + lane] = act[(k0 + e) * TR_LS + lane] > 0.f ? sv[e] : sv[e] * slope;
         }
         __syncthreads();
-        // gc = W0s^T gz_s + W0h^T gz_h:  wave w -> condition channels 8w .. 8w+7
-        for (int k0 = wv * 8; k0 < wv * 8 + 8; k0 += 4) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // gc = W0s^T gz_s + W0h^T gz_h:  wave w -> condition channels 2w, 2w+1
+        {
+            const int k0 = wv * (SFT_G / SFT_NW);
+            float a0 = 0.f, a1 = 0.f;
             for (int j = 0; j < SFT_G; ++j) {
                 const float u = gzs[j * TR_LS + lane], v = gzh[j * TR_LS + lane];
                 a0 = fmaf(u, w0sc[j * SFT_G + k0], a0); a1 = fmaf(u, w0sc[j * SFT_G + k0 + 1], a1);
-                a2 = fmaf(u, w0sc[j * SFT_G + k0 + 2], a2); a3 = fmaf(u, w0sc[j * SFT_G + k0 + 3], a3);
                 a0 = fmaf(v, w0hc[j * SFT_G + k0], a0); a1 = fmaf(v, w0hc[j * SFT_G + k0 + 1], a1);
-                a2 = fmaf(v, w0hc[j * SFT_G + k0 + 2], a2); a3 = fmaf(v, w0hc[j * SFT_G + k0 + 3], a3);
             }
-            gc[k0 * TR_LS + lane] = a0; gc[(k0 + 1) * TR_LS + lane] = a1; gc[(k0 + 2) * TR_LS + lane] = a2; gc[(k0 + 3) * TR_LS + lane] = a3;
+            gc[k0 * TR_LS + lane] = a0; gc[(k0 + 1) * TR_LS + lane] = a1;
         }
         // weight-gradient blocks: acc[a][b] += sum_s A[a][s] * B[b][s]   (A, B rows were complete at the barrier above)
 #pragma unroll
@@ -663,22 +674,34 @@ __global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__
             const float4* const A = reinterpret_cast<const float4*>(smem + blk[q].aoff);
             const float4* const B = reinterpret_cast<const float4*>(smem + blk[q].boff);
             for (int s4 = 0; s4 < 16; ++s4) {
-                float4 av[4], bv[4];
+                float4 av[4], bv[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { av[r] = A[r * (TR_LS / 4) + s4]; bv[r] = B[r * (TR_LS / 4) + s4]; }
+                for (int r = 0; r < 4; ++r) av[r] = A[r * (TR_LS / 4) + s4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) bv[r] = B[r * (TR_LS / 4) + s4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        float v = acc[q][a * 4 + b];
+                    for (int b = 0; b < 2; ++b) {
+                        float v = acc[q][a * 2 + b];
                         v = fmaf(av[a].x, bv[b].x, v); v = fmaf(av[a].y, bv[b].y, v); v = fmaf(av[a].z, bv[b].z, v); v = fmaf(av[a].w, bv[b].w, v);
-                        acc[q][a * 4 + b] = v;
+                        acc[q][a * 2 + b] = v;
                     }
             }
         }
         __syncthreads();
-        sft_store_tile(gx, gxg, base, C, C, nv, t);
-        sft_store_tile(gc, gcg, base, SFT_G, SFT_G, nv, t);
+        if (gxa) {                                         // grad_x = this layer's gradient + gxa (the block's skip connection: one add kernel less per block)
+            for (int i = t; i < 64 * C; i += SFT_T) {
+                const int s = i / C, k = i - s * C;
+                if (s < nv) gxg[(base + s) * C + k] = gx[k * TR_LS + s] + gxa[(base + s) * gxa_stride + k];
+            }
+        } else sft_store_tile(gx, gxg, base, C, C, nv, t);
+        if (gc_acc) {                                      // grad_cond ACCUMULATES: every SFT layer of the decoder reads the same condition map
+            for (int i = t; i < 64 * SFT_G; i += SFT_T) {
+                const int s = i / SFT_G, k = i - s * SFT_G;
+                if (s < nv) gcg[(base + s) * SFT_G + k] += gc[k * TR_LS + s];
+            }
+        } else sft_store_tile(gc, gcg, base, SFT_G, SFT_G, nv, t);
         __syncthreads();
     }
     float* const mine = part + (size_t)blockIdx.x * L::N_PART;
@@ -688,7 +711,7 @@ __global__ __launch_bounds__(256) void k_sft_train_bwd(const float* __restrict__
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) mine[blk[q].ooff + a * blk[q].ostride + b] = acc[q][a * 4 + b];
+            for (int b = 0; b < 2; ++b) mine[blk[q].ooff + a * blk[q].ostride + b] = acc[q][a * 2 + b];
     }
 }
 
@@ -757,7 +780,7 @@ extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* c
     if (n_pix == 0) return K4_OK;
     if (!x || !cond || !y) return K4_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((n_pix + 63) / 64)), block(256);
+    const dim3 grid((unsigned)((n_pix + 63) / 64)), block(SFT_T);
     const size_t lds = (size_t)(3 * SFT_G + channels) * TR_LS * sizeof(float);
     if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
     else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
@@ -767,12 +790,12 @@ extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* c
 template <int C>
 static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                          float slope, float* gx, float* gc, float* ws, float* const* gout, hipStream_t st) {
+                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, hipStream_t st) {
     typedef SftBwdLayout<C> L;
     const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
     K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
     const int grid = sft_bwd_grid(n);
-    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(256), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws);
+    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc);
     int rc = k4_check_launch();
     if (rc) return rc;
     const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
@@ -781,21 +804,32 @@ static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, con
     return k4_check_launch();
 }
 
+extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                   int64_t n_pix, int32_t channels,
+                                   const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                   float slope, float* grad_x, float* grad_cond,
+                                   float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                                   float* workspace, int64_t workspace_bytes,
+                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, void* stream) {
+    if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
+    if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
+    if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
+    if (!gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < k4_sft_train_bwd_workspace_bytes(n_pix, channels)) return K4_ERR_BAD_ARG;
+    float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
+    hipStream_t st = (hipStream_t)stream;
+    const int acc = accumulate_grad_cond != 0;
+    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, st);
+    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, st);
+}
 extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                 int64_t n_pix, int32_t channels,
                                 const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
                                 float slope, float* grad_x, float* grad_cond,
                                 float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                                 float* workspace, int64_t workspace_bytes, void* stream) {
-    if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
-    if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G) return K4_ERR_BAD_ARG;
-    if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
-    if (!gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < k4_sft_train_bwd_workspace_bytes(n_pix, channels)) return K4_ERR_BAD_ARG;
-    float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
-    hipStream_t st = (hipStream_t)stream;
-    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
-    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, st);
+    return k4_sft_train_bwd_ex(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
+                               gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, nullptr, 0, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -829,22 +863,46 @@ extern "C" int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y,
 // A dense block of the training graph issued natively (include/k4nerf.h, k4_rdb_train): the launch sequences of lib/sr_train.py K4RDB.forward /
 // .backward, call for call -- the entry points below are the ones the host would call; what goes away is ~26 Python-to-C transitions per block.
 // ---------------------------------------------------------------------------------------------------------------------
+// Events come from a per-device ring created once (a dense block forks / joins the side stream six times: creating and destroying an event each
+// time was ~12 runtime calls per block on the host path that paces the joint iteration).  Re-recording an event does not disturb a wait already
+// queued on its previous record (hipStreamWaitEvent captures the record it was called after); the ring is far longer than a block's forks in flight.
+#define K4_EV_RING 256
+#define K4_EV_DEVS 16
+static hipEvent_t k4_ev_ring[K4_EV_DEVS][K4_EV_RING];
+static std::atomic<unsigned> k4_ev_next[K4_EV_DEVS];
+static std::once_flag k4_ev_once[K4_EV_DEVS];
+static bool k4_ev_ok[K4_EV_DEVS];
 static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // everything queued on `signaller` so far completes before what `waiter` gets next
     if (waiter == signaller) return 0;
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= K4_EV_DEVS) {                                     // beyond the ring table: an event of its own
+        hipEvent_t ev;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+        e = hipEventRecord(ev, signaller);
+        if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+        const hipError_t d = hipEventDestroy(ev);                          // (released by the runtime once the recorded work has completed)
+        return (int)(e != hipSuccess ? e : d);
+    }
+    std::call_once(k4_ev_once[dev], [dev]() {
+        bool ok = true;
+        for (int i = 0; i < K4_EV_RING; ++i) ok = ok && hipEventCreateWithFlags(&k4_ev_ring[dev][i], hipEventDisableTiming) == hipSuccess;
+        k4_ev_ok[dev] = ok;
+    });
+    if (!k4_ev_ok[dev]) return K4_ERR_BAD_ARG;
+    hipEvent_t ev = k4_ev_ring[dev][k4_ev_next[dev].fetch_add(1u) % K4_EV_RING];
     e = hipEventRecord(ev, signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
-    const hipError_t d = hipEventDestroy(ev);                              // (released by the runtime once the recorded work has completed)
-    return (int)(e != hipSuccess ? e : d);
+    return (int)e;
 }
 static bool k4_rdb_ok(const k4_rdb_train* p, bool bwd) {
     if (!p || p->H <= 0 || p->W <= 0 || p->g != 32 || (p->nf != 32 && p->nf != 64) || !p->t || !p->c || !p->buf || !p->x4) return false;
     for (int k = 0; k < 5; ++k) if (!p->w_fwd[k] && !bwd) return false;
     for (int k = 0; k < 8; ++k) if (!p->sft0[k] || !p->sft1[k]) return false;
     if (!bwd) return p->out != nullptr;
-    if (!p->g5 || !p->G || !p->gx4 || !p->gx0 || !p->gc0 || !p->gc1 || !p->ws0 || !p->ws1) return false;
+    if (!p->g5 || !p->G || !p->gx4 || !p->gx0 || !p->ws0 || !p->ws1 || (!p->gc_acc && (!p->gc0 || !p->gc1)) || p->dwdb_span_floats < 0) return false;
     for (int k = 0; k < 5; ++k) if (!p->w_bwd[k] || !p->b_bwd[k] || !p->dwdb[k]) return false;
     for (int k = 0; k < 8; ++k) if (!p->gsft0[k] || !p->gsft1[k]) return false;
     return true;
@@ -879,18 +937,26 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     // a weight gradient on the side stream: forked behind everything queued on the main stream so far (= the producer of the gradient slice it reads)
 #define K4_RDB_WGRAD(CIN, GY, COUT, GYS, K) do { \
         K4_RDB_TRY(k4_wait_stream(side, main_s)); \
-        K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); } while (0)
+        if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); \
+        else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); } while (0)
     // G[:, 0:COUT'] (+)= dgrad: the output is its own residual
 #define K4_RDB_DGRAD(K, SRC, SS, CIN_OF_LAYER, ACC) \
         K4_RDB_TRY(k4_conv2d_nhwc_bf16x6((SRC), (K) == 4 ? nf : g, (SS), p->w_bwd[K], p->b_bwd[K], 3, p->G, (CIN_OF_LAYER), bw, H, W, (ACC) ? K4_EPI_RES : 0u, 0.2f, \
                                          (ACC) ? p->G : nullptr, (ACC) ? bw : 0, 1.f, nullptr, 0, stream))
+    // dwdb_span_floats > 0: the five [dW | dbias] buffers are one span starting at dwdb_span: ONE zero-fill on the side stream (ordered before every
+    // weight gradient there) instead of one per layer
+    if (p->dwdb_span_floats > 0) {
+        if (!p->dwdb_span) return K4_ERR_BAD_ARG;
+        K4_RDB_TRY(k4_wait_stream(side, main_s));                                  // (the span may be memory the main stream's earlier work still reads)
+        K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
+    }
     // conv5: out = 0.2 conv5(buf) + t
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
     K4_RDB_DGRAD(4, p->g5, nf, bw, false);                                         // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
-    K4_RDB_TRY(k4_sft_train_bwd(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
-                                0.2f, p->gx4, p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
-                                p->ws1, p->ws1_bytes, stream));
+    K4_RDB_TRY(k4_sft_train_bwd_ex(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+                                   0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
+                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, stream));
     K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
     K4_RDB_WGRAD(nf + 3 * g, p->gx4, g, g, 3);
     K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true);                                  // G[:, 0:nf+3g] += dgrad
@@ -900,9 +966,10 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
         K4_RDB_WGRAD(off, p->G + off, g, bw, k - 1);
         K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true);
     }
-    K4_RDB_TRY(k4_sft_train_bwd(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
-                                0.2f, p->gx0, p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
-                                p->ws0, p->ws0_bytes, stream));
+    // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
+    K4_RDB_TRY(k4_sft_train_bwd_ex(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+                                   0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
+                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, stream));
 join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD

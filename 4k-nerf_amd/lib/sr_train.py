@@ -164,41 +164,68 @@ class K4Conv2d(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class _CondFan(torch.autograd.Function):
+    """The condition map on its way to the decoder's SFT layers (21 consumers in SFTNet: 15 dense blocks, 6 SFT layers).  Forward: the map
+    itself.  The consumers ADD their condition gradients into `acc` inside their backward kernels (k4_sft_train_bwd_ex) and return None;
+    this node, which the engine runs after all of them, returns the sum -- instead of 35 elementwise additions per backward pass (20 by the
+    autograd engine, 15 inside the dense blocks), each a launch on the host path that paces the joint training iteration.
+    `acc` must be zero when the backward pass starts (``forward_train`` allocates it zeroed, one per forward)."""
+
+    @staticmethod
+    def forward(ctx, c, acc):
+        ctx.acc = acc
+        ctx.set_materialize_grads(False)
+        return c.view_as(c)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        acc = ctx.acc
+        acc._k4_spent = True                              # a second backward pass over the same graph would add to a gradient already handed out
+        return (acc if g is None else acc + g), None      # g: consumers outside the fused Functions (none in SFTNet)
+
+
 class K4SFTLayer(torch.autograd.Function):
     """SFTLayer (lib/sr_esrnet.py:112-123) of an NHWC image: ``x * (scale(cond) + 1) + shift(cond)`` with both 1x1-convolution pairs,
     LeakyReLU and the modulation in ONE launch forward (k4_sft_train_fwd) and two backward (k4_sft_train_bwd: grad_x, grad_cond, the
-    eight weight / bias gradients).  As four K4Conv2d Functions + elementwise autograd a layer was ~45 launches per iteration."""
+    eight weight / bias gradients).  As four K4Conv2d Functions + elementwise autograd a layer was ~45 launches per iteration.
+    `acc` (None | [H, W, 32]): the layer's condition gradient is ADDED to it and None returned for `cond` (see _CondFan)."""
 
     @staticmethod
-    def forward(ctx, x, cond, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h):
+    def forward(ctx, x, cond, acc, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h):
         if not x.is_cuda:
             raise N.K4Error('K4SFTLayer: the MI355X-native decoder has no CPU path')
         x, cond = x.contiguous().float(), cond.contiguous().float()
         H, W, C = x.shape
         assert cond.shape == (H, W, 32) and w0s.shape[:2] == (32, 32) and w1s.shape[:2] == (C, 32)
+        assert acc is None or (acc.shape == cond.shape and acc.is_contiguous() and acc.dtype == torch.float32)
         ws = [t.detach().contiguous() for t in (w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h)]
         y = torch.empty_like(x)
         N.check(N.lib().k4_sft_train_fwd(N.f32(x), C, N.f32(cond), 32, H * W, C, *[N.f32(t) for t in ws], 0.2, N.f32(y), C, N.stream()),
                 'k4_sft_train_fwd')
         ctx.save_for_backward(x, cond, *ws)
+        ctx.acc = acc
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         x, cond, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h = ctx.saved_tensors
+        acc = ctx.acc
+        _check_acc(acc)
         gy = gy.contiguous().float()
         H, W, C = x.shape
         n = H * W
         L = N.lib()
-        gx, gc = torch.empty_like(x), torch.empty_like(cond)
+        gx = torch.empty_like(x)
+        gc = acc if acc is not None else torch.empty_like(cond)
         g = [torch.empty_like(t) for t in (w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h)]
         nbytes = int(L.k4_sft_train_bwd_workspace_bytes(n, C))
         ws = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
-        N.check(L.k4_sft_train_bwd(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
-                                   N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
-                                   N.f32(ws), nbytes, N.stream()), 'k4_sft_train_bwd')
-        return (gx, gc, *g)
+        N.check(L.k4_sft_train_bwd_ex(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
+                                      N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
+                                      N.f32(ws), nbytes, None, 0, int(acc is not None), N.stream()), 'k4_sft_train_bwd_ex')
+        return (gx, None if acc is not None else gc, None, *g)
 
 
 def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
@@ -218,6 +245,7 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
 
 _NATIVE_RDB = os.environ.get('K4_TRAIN_NATIVE_RDB', '1') != '0'      # 0: a dense block's launches issued one by one from Python (A/B)
 _WGRAD_STREAM = os.environ.get('K4_TRAIN_WGRAD_STREAM', '1') != '0'   # 0: the block's weight gradients on the chain's own stream (A/B)
+_COND_ACC = os.environ.get('K4_TRAIN_COND_ACC', '1') != '0'           # 0: every SFT consumer returns its condition gradient, autograd adds them (A/B)
 _SIDE_STREAMS = {}
 
 
@@ -232,6 +260,12 @@ def _side_stream(device):
     return st.cuda_stream
 
 
+def _check_acc(acc):
+    if acc is not None and getattr(acc, '_k4_spent', False):
+        raise N.K4Error('second backward pass through a decoder graph whose condition-gradient accumulator was already consumed '
+                        '(retain_graph use: K4_TRAIN_COND_ACC=0)')
+
+
 def _rdb_desc(t, c, buf, x4, P, H, W, nf, g):
     d = N.RdbTrain()
     d.H, d.W, d.nf, d.g = H, W, nf, g
@@ -242,6 +276,34 @@ def _rdb_desc(t, c, buf, x4, P, H, W, nf, g):
     return d
 
 
+_RDB_LAYOUTS = {}
+
+
+def _rdb_bwd_layout(P, n, nf, g, with_gc):
+    """Float offsets of a dense block's backward buffers inside TWO allocations (per (n_pix, nf, g): computed once).
+    param grads: [dW1 | db1 | ... | dW5 | db5] (the span one launch zeroes for the split-K weight gradients) | sft0's eight | sft1's eight;
+    scratch:     gx0 [n, nf] | G [n, bw] | gx4 [n, g] | sft0 workspace | sft1 workspace | (gc0 | gc1 [n, 32] without an accumulator).
+    As ~31 torch.empty calls + one zero-fill per layer this was a third of K4RDB.backward's host time, which paces the joint iteration."""
+    key = (n, nf, g, with_gc)
+    lay = _RDB_LAYOUTS.get(key)
+    if lay is None:
+        L = N.lib()
+        order = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17] + list(range(8)) + list(range(18, 26))        # indices into P, in buffer order
+        sizes = [P[i].numel() for i in order]
+        offs = [0]
+        for q in sizes:
+            offs.append(offs[-1] + q)
+        span = offs[10]
+        nb0, nb1 = int(L.k4_sft_train_bwd_workspace_bytes(n, nf)), int(L.k4_sft_train_bwd_workspace_bytes(n, g))
+        bw = nf + 4 * g
+        ssz = [n * nf, n * bw, n * g, nb0 // 4, nb1 // 4] + ([n * 32, n * 32] if with_gc else [])
+        soff = [0]
+        for q in ssz:
+            soff.append(soff[-1] + q)
+        lay = _RDB_LAYOUTS[key] = (order, sizes, offs, span, soff, nb0, nb1, [tuple(P[i].shape) if P[i].dim() > 1 else None for i in order])
+    return lay
+
+
 class K4RDB(torch.autograd.Function):
     """ResidualDenseBlock_5C with its two SFT layers (lib/sr_esrnet.py:126-158) as ONE autograd node.
 
@@ -250,10 +312,11 @@ class K4RDB(torch.autograd.Function):
     Backward: ONE gradient image of the same shape; the dgrad of conv_k ACCUMULATES into the channel prefix it read (residual epilogue
     with the output as its own residual), so the five-way sums of the concatenations need no kernels of their own.
     7 launches forward, 21 backward (+ the weight packers, batched by _WeightCache.prepack); as separate Functions a block was ~70.
+    `acc` (None | [H, W, 32]): the block's condition gradient is ADDED to it and None returned for `c` (see _CondFan).
     params: sft0 (w0s b0s w1s b1s w0h b0h w1h b1h), conv1..conv5 (weight, bias), sft1 (8)."""
 
     @staticmethod
-    def forward(ctx, t, c, cache, *P):
+    def forward(ctx, t, c, cache, acc, *P):
         if not t.is_cuda:
             raise N.K4Error('K4RDB: the MI355X-native decoder has no CPU path')
         L = N.lib()
@@ -262,10 +325,14 @@ class K4RDB(torch.autograd.Function):
         g = P[8].shape[0]
         bw, n = nf + 4 * g, H * W
         assert c.shape == (H, W, 32) and len(P) == 26 and g == 32 and nf in (32, 64)
-        P = [q.detach().contiguous() for q in P]
-        buf = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
-        x4 = torch.empty([H, W, g], dtype=torch.float32, device=t.device)
-        out = torch.empty([H, W, nf], dtype=torch.float32, device=t.device)
+        assert acc is None or (acc.shape == c.shape and acc.is_contiguous() and acc.dtype == torch.float32)
+        for q in P:
+            if not q.is_contiguous():
+                P = [q.contiguous() for q in P]
+                break
+        f32 = dict(dtype=torch.float32, device=t.device)
+        buf, x4, out = torch.empty([H, W, bw], **f32), torch.empty([H, W, g], **f32), torch.empty([H, W, nf], **f32)
+        ctx.acc = acc
         if _NATIVE_RDB:                                   # the seven launches below, issued by ONE native call (include/k4nerf.h, k4_rdb_train)
             d = _rdb_desc(t, c, buf, x4, P, H, W, nf, g)
             d.out = out.data_ptr()
@@ -275,7 +342,7 @@ class K4RDB(torch.autograd.Function):
                 d.w_fwd[k], d.b_fwd[k] = pk.w.data_ptr(), pk.b.data_ptr()
             N.check(L.k4_rdb_train_fwd(N.C.byref(d), N.stream()), 'k4_rdb_train_fwd')
             ctx.save_for_backward(t, c, buf, x4, *P)
-            ctx.cache = cache
+            ctx.cache, ctx.desc = cache, d                # the backward fills in its own fields of the same descriptor
             return out
         N.check(L.k4_sft_train_fwd(N.f32(t), nf, N.f32(c), 32, n, nf, *[N.f32(q) for q in P[0:8]], 0.2, N.f32(buf), bw, N.stream()), 'k4_sft_train_fwd')
         for k in (1, 2, 3):
@@ -293,41 +360,52 @@ class K4RDB(torch.autograd.Function):
     def backward(ctx, go):
         t, c, buf, x4 = ctx.saved_tensors[:4]
         P = ctx.saved_tensors[4:]
-        cache = ctx.cache
+        cache, acc = ctx.cache, ctx.acc
+        _check_acc(acc)
         H, W, nf = t.shape
         g = P[8].shape[0]
         bw, n = nf + 4 * g, H * W
         go = go.contiguous().float()
-        G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
         grads = [None] * 26
         if _NATIVE_RDB:                                   # the 19 launches of the host form below, issued by ONE native call; the weight gradients on a second stream
             L, dev = N.lib(), t.device
-            f32 = dict(dtype=torch.float32, device=dev)
-            d = _rdb_desc(t, c, buf, x4, P, H, W, nf, g)
+            d = ctx.desc
+            order, sizes, offs, span, soff, nb0, nb1, shapes = _rdb_bwd_layout(P, n, nf, g, acc is None)
+            pg = torch.empty([offs[-1]], dtype=torch.float32, device=dev)
+            scr = torch.empty([soff[-1]], dtype=torch.float32, device=dev)
+            pb, sb = pg.data_ptr(), scr.data_ptr()
+            for q, (i, piece, shape) in enumerate(zip(order, pg.split(sizes), shapes)):
+                grads[i] = piece if shape is None else piece.view(shape)
+                ptr = pb + 4 * offs[q]
+                if q < 10:
+                    if q % 2 == 0:
+                        d.dwdb[q // 2] = ptr                                          # [dW | dbias] of conv q/2 + 1
+                elif q < 18:
+                    d.gsft0[q - 10] = ptr
+                else:
+                    d.gsft1[q - 18] = ptr
+            d.dwdb_span, d.dwdb_span_floats = pb, span
             g5 = go * 0.2
-            gx4, gx0 = torch.empty([n, g], **f32), torch.empty([n, nf], **f32)
-            gc0, gc1 = torch.empty([n, 32], **f32), torch.empty([n, 32], **f32)
-            d.g5, d.G, d.gx4, d.gx0, d.gc0, d.gc1 = g5.data_ptr(), G.data_ptr(), gx4.data_ptr(), gx0.data_ptr(), gc0.data_ptr(), gc1.data_ptr()
+            d.g5, d.gx0_add = g5.data_ptr(), go.data_ptr()
+            d.gx0, d.G, d.gx4, d.ws0, d.ws1 = (sb + 4 * o for o in soff[:5])
+            d.ws0_bytes, d.ws1_bytes = nb0, nb1
+            if acc is None:
+                d.gc0, d.gc1, d.gc_acc = sb + 4 * soff[5], sb + 4 * soff[6], None
+            else:
+                d.gc_acc = acc.data_ptr()
             keep = []
             for k in range(5):
-                w = P[8 + 2 * k]
-                pk = cache.bwd(w)
+                pk = cache.bwd(P[8 + 2 * k])
                 assert pk.mode == 'bf16x6' and pk.k == 3 and pk.flags_extra == 0
                 d.w_bwd[k], d.b_bwd[k] = pk.w.data_ptr(), pk.b.data_ptr()
-                dwdb = torch.empty([w.numel() + w.shape[0]], **f32)                  # zeroed by the wgrad entry point
-                d.dwdb[k] = dwdb.data_ptr()
-                grads[8 + 2 * k], grads[9 + 2 * k] = dwdb[:w.numel()].view(w.shape), dwdb[w.numel():]
                 keep.append(pk)
-            for i in range(8):
-                g0, g1 = torch.empty_like(P[i]), torch.empty_like(P[18 + i])
-                d.gsft0[i], d.gsft1[i] = g0.data_ptr(), g1.data_ptr()
-                grads[i], grads[18 + i] = g0, g1
-            nb0, nb1 = int(L.k4_sft_train_bwd_workspace_bytes(n, nf)), int(L.k4_sft_train_bwd_workspace_bytes(n, g))
-            ws0, ws1 = torch.empty([nb0 // 4], **f32), torch.empty([nb1 // 4], **f32)
-            d.ws0, d.ws0_bytes, d.ws1, d.ws1_bytes = ws0.data_ptr(), nb0, ws1.data_ptr(), nb1
             d.side_stream = _side_stream(dev)
             N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
-            return (go + gx0.view(H, W, nf), (gc0 + gc1).view(H, W, 32), None, *grads)
+            gt = scr[:n * nf].view(H, W, nf)                                          # = go + the gradient through sft0 (added in the kernel's store)
+            gc = None if acc is not None else (scr[soff[5]:soff[6]] + scr[soff[6]:soff[7]]).view(H, W, 32)
+            return (gt, gc, None, None, *grads)
+
+        G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
 
         def accum(pk, src, s_off, s_stride, cout):                      # G[..., :cout] += dgrad: the output is its own residual
             SFTNet._conv(pk, src, s_off, s_stride, G, 0, bw, cout, H, W, flags=EPI_RES, res=(G, 0, bw, 1.0))
@@ -350,7 +428,10 @@ class K4RDB(torch.autograd.Function):
         gx0, gc0, grads[0:8] = _sft_bwd(t, nf, nf, c, G, 0, bw, n, P[0:8])                                            # xc0 = sft0(t)
         gt = go + gx0.view(H, W, nf)
         gc = (gc0 + gc1).view(H, W, 32)
-        return (gt, gc, None, *grads)
+        if acc is not None:
+            acc.add_(gc)
+            gc = None
+        return (gt, gc, None, None, *grads)
 
 
 _TAP = None        # tests/debug/sr_rdb_debug3.py: callback(block, input, cond, output) per dense block
@@ -385,6 +466,10 @@ def forward_train(net, x, cond):
     feat = conv(net.conv_first, xi)
     cn = net.CondNet
     c = conv(cn[6], conv(cn[4], conv(cn[2], conv(cn[0], ci, True), True), True))
+    # the fused SFT layers / dense blocks add their condition gradients into one buffer inside their kernels (see _CondFan)
+    acc = torch.zeros_like(c) if fused and _COND_ACC and c.requires_grad and c.shape[2] == 32 else None
+    if acc is not None:
+        c = _CondFan.apply(c, acc)
 
     def sft_params(layer):
         return (layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
@@ -392,7 +477,7 @@ def forward_train(net, x, cond):
 
     def sft(layer, t):                                                        # lib/sr_esrnet.py:120-123
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32:
-            return K4SFTLayer.apply(t, c, *sft_params(layer))
+            return K4SFTLayer.apply(t, c, acc, *sft_params(layer))
         scale = conv(layer.SFT_scale_conv1, lrelu(conv(layer.SFT_scale_conv0, c)))
         shift = conv(layer.SFT_shift_conv1, lrelu(conv(layer.SFT_shift_conv0, c)))
         return t * (scale + 1) + shift
@@ -400,7 +485,7 @@ def forward_train(net, x, cond):
     def rdb(blk, t):                                                          # lib/sr_esrnet.py:149-158
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32 and blk.conv1.weight.shape[0] == 32:
             convs = [q for m in (blk.conv1, blk.conv2, blk.conv3, blk.conv4, blk.conv5) for q in (m.weight, m.bias)]
-            return K4RDB.apply(t, c, cache, *sft_params(blk.sft0), *convs, *sft_params(blk.sft1))
+            return K4RDB.apply(t, c, cache, acc, *sft_params(blk.sft0), *convs, *sft_params(blk.sft1))
         xc0 = sft(blk.sft0, t)
         x1 = lrelu(conv(blk.conv1, xc0))
         x2 = lrelu(conv(blk.conv2, torch.cat((xc0, x1), 2)))

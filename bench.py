@@ -339,7 +339,7 @@ def main():
             from nerf4k_amd.lib import dvgo as _dv
             full_rays = [x.reshape(-1, 3).contiguous() for x in
                          _dv.get_rays_of_a_view(H, W, K, torch.from_numpy(poses[0]).to(dev), True, False, False, False)]
-        joint_dp = _side(joint_train_step, ck, full_rays, H, W, dev, 4, world, rank)
+        joint_dp = _side(joint_train_step, ck, full_rays, H, W, dev, 8, world, rank)
     if rank == 0:
         if joint_dp is not None:
             res['joint_train_step'] = joint_dp
@@ -733,7 +733,7 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
     return out
 
 
-def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
+def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     """BASELINE configs[4] on ONE GPU: iterations of the joint loop (run_sr.py:801-1061 -> 4k-nerf_amd/joint_train.JointTrainer.step) at
     the sizes of configs/llff/fern_lg_joint_l1.py -- a 64x64 ray patch of the 1008x756 view marched through the full 417x353x256
     scene under autograd, SFTNet(5 blocks) x4 to 256x256, L1 + L1 + entropy + distortion + per-point rgb, backward, dense
@@ -757,12 +757,14 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
         r0, c0 = (37 * i) % (H - pr), (101 * i) % (W - pc)
         rays = [x[r0:r0 + pr, c0:c0 + pc].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
         return rays + [torch.rand([pr * pc, 3], device=dev, generator=gen), torch.rand([16 * pr * pc, 3], device=dev, generator=gen), pr, pc]
-    first = float(tr.step(*batch(0), global_step=1)['total'])            # warm-up: packing, optimizer state, allocator
+    first = float(tr.step(*batch(0), global_step=1)['total'])            # warm-up: packing, optimizer state (the second step builds the optimizer's
+    for i in range(2):                                                   # fast-path plan), allocator
+        tr.step(*batch(1 + i), global_step=2 + i)
     torch.cuda.synchronize()
     t = time.perf_counter()
     n_samples = 0
     for i in range(iters):
-        tr.step(*batch(1 + i), global_step=2 + i)
+        tr.step(*batch(3 + i), global_step=4 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / iters
     if world > 1:
@@ -778,7 +780,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=4, world=1, rank=0):
                 'workload': f'configs[4] fern_lg_joint_l1, patch-parallel over {world} GPUs: one 64x64 patch per rank, decoder + small tensors in ONE '
                             'all-reduce bucket, voxel-grid gradients as (index, value) lists in ONE all-gather per grid (RCCL)'}
     # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
-    b = batch(9)
+    b = batch(19)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with torch.enable_grad():

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      10      /* 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, k4_rdb_train.gc_acc / gx0_add / dwdb_span; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -434,6 +434,10 @@ int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_
  * buffer [cout*cin*k*k floats of dW | cout floats of dbias], overwritten. */
 int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                                  int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream);
+/* ... ADDED to dw_db, which the caller has zeroed (k4_zero_f32): several layers' buffers zeroed by one launch */
+int k4_conv2d_wgrad_dbias_bf16x6_acc(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
+                                     int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream);
+int k4_zero_f32(float* p, int64_t n, void* stream);
 /* Device-side weight packing for the training loop (every optimizer step changes every weight: 2 x 260 packings per iteration).
  * Writes the `w_split` operand of k4_conv2d_nhwc_bf16x6 for the nn.Conv2d weight w [cout][cin][k][k], bit-identical to the host packer:
  *   form 0: the layer as stored (k4_conv_weight_bf16x6_bytes(cout, cin, k) bytes; bias_out [ceil(cout/32)*32] = bias, zero padded)
@@ -483,6 +487,11 @@ typedef struct k4_rdb_train {
     float* gsft0[8]; float* gsft1[8];
     float* ws0; int64_t ws0_bytes; float* ws1; int64_t ws1_bytes;
     void* side_stream;
+    /* optional (all NULL / 0 = the behaviour above): */
+    float* gc_acc;                  /* both SFT layers ADD their condition gradient into this [n_pix][32] buffer (gc0 / gc1 unused): every SFT layer of the
+                                       decoder reads the same condition map, the sum over layers needs no kernels of its own */
+    const float* gx0_add;           /* gx0 = gradient of t through sft0 + gx0_add [n_pix][nf] (the block's skip connection: grad_out) */
+    float* dwdb_span; int64_t dwdb_span_floats;   /* the five dwdb buffers lie in this one span: ONE zero-fill for all of them */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -570,6 +579,16 @@ int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_
                      float slope, float* grad_x, float* grad_cond,
                      float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                      float* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the two sums the training graph puts right behind it folded into the stores: grad_x = the layer's gradient + grad_x_add
+ * ([n_pix][gxa_stride] rows; NULL = none) and, with accumulate_grad_cond != 0, grad_cond += the layer's gradient (the caller zeroes it once per
+ * backward pass: every SFT layer of the decoder reads the same condition map). */
+int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                        int64_t n_pix, int32_t channels,
+                        const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                        float slope, float* grad_x, float* grad_cond,
+                        float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                        float* workspace, int64_t workspace_bytes,
+                        const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,11 +29,19 @@ def batch(i):
 for i in range(2):
     tr.step(*batch(i), global_step=1 + i)
 torch.cuda.synchronize()
+# K4_PROF_BWD=1: the backward pass on the calling thread (no engine worker threads), so that the Function.backward bodies show up below
+ctx = torch.autograd.set_multithreading_enabled(False) if os.environ.get('K4_PROF_BWD', '0') == '1' else contextlib.nullcontext()
 pr = cProfile.Profile()
-pr.enable()
-for i in range(3):
-    tr.step(*batch(2 + i), global_step=3 + i)
-torch.cuda.synchronize()
-pr.disable()
+with ctx:
+    for i in range(2):
+        tr.step(*batch(2 + i), global_step=3 + i)
+    torch.cuda.synchronize()
+    pr.enable()
+    for i in range(3):
+        tr.step(*batch(4 + i), global_step=5 + i)
+    torch.cuda.synchronize()
+    pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(int(os.environ.get('K4_PROF_ROWS', 28)))
+if os.environ.get('K4_PROF_BWD', '0') == '1':
+    st.sort_stats('cumulative').print_stats(40)

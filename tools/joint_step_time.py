@@ -25,13 +25,18 @@ for i in range(3):
     losses.append(float(tr.step(*batch(i), global_step=1 + i)['total']))
 torch.cuda.synchronize()
 n = int(os.environ.get('ITERS', '6'))
-t = time.perf_counter()
-for i in range(n):
-    tr.step(*batch(3 + i), global_step=4 + i)
-t_host = time.perf_counter() - t                  # the host has issued everything (a step that reads a loss back synchronises inside: then host == wall)
-torch.cuda.synchronize()
-print('joint iteration ms', round((time.perf_counter() - t) / n * 1e3, 2), '(host returned after', round(t_host / n * 1e3, 2), 'ms per iteration)',
-      'first losses', [round(v, 5) for v in losses])
+blocks = []
+for b in range(int(os.environ.get('BLOCKS', '5'))):                  # the iteration is paced by the host: one block of 6 iterations is noisy from box to box
+    t = time.perf_counter()
+    for i in range(n):
+        tr.step(*batch(3 + b * n + i), global_step=4 + b * n + i)
+    t_host = time.perf_counter() - t              # the host has issued everything (a step that reads a loss back synchronises inside: then host == wall)
+    torch.cuda.synchronize()
+    blocks.append(((time.perf_counter() - t) / n * 1e3, t_host / n * 1e3))
+blocks.sort()
+med = blocks[len(blocks) // 2]
+print('joint iteration ms', round(med[0], 2), '(host returned after', round(med[1], 2), 'ms per iteration; median of', len(blocks), 'blocks of', n,
+      'iterations, fastest', round(blocks[0][0], 2), 'slowest', round(blocks[-1][0], 2), ') first losses', [round(v, 5) for v in losses])
 if os.environ.get('PROFILE_HOST') == '1':
     import cProfile, pstats
     pr = cProfile.Profile()
