@@ -177,7 +177,10 @@ __device__ __forceinline__ float k4_clamp1(float x) { return fminf(fmaxf(x, -1.f
 
 // One thread = 4 consecutive k (needs sz_k % 4 == 0 and 16-byte aligned bases).  The +-1 neighbours along k are the
 // adjacent lanes' values except at the two ends of the 4-group, fetched as scalars (same cache lines).
-template <bool DENSE>
+// MODE 0: only where grad != 0 (sparse), 1: everywhere (dense), 2: dense and grad is OVERWRITTEN with the TV term (not read): the term
+// computed before the backward pass into the buffer the lookups' backward then accumulates into (lib/grid.py total_variation_seed_grad) --
+// 8 bytes per voxel instead of 4 (zero-fill) + 12, and off the tail of the training iteration.  0 + term == term: same values.
+template <int MODE>
 __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* __restrict__ param, float* __restrict__ grad,
                                                                    float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
                                                                    int64_t sz_k, int64_t n4) {
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* 
     const int64_t t = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
     if (t >= n4) return;
     const int64_t index = t * 4;
-    float4 g = *(const float4*)(grad + index);
+    constexpr bool DENSE = MODE != 0;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE != 2) g = *(const float4*)(grad + index);
     if (!DENSE && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
     const int64_t k = index % sz_k;
     const int64_t j = index / sz_k % sz_j;
@@ -232,14 +237,15 @@ __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* 
     *(float4*)(grad + index) = g;
 }
 
-template <bool DENSE>
+template <int MODE>
 __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_scalar_kernel(const float* __restrict__ param, float* __restrict__ grad,
                                                                       float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
                                                                       int64_t sz_k, int64_t n) {
     const int b = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int64_t index = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
     if (index >= n) return;
-    const float g = grad[index];
+    constexpr bool DENSE = MODE != 0;
+    const float g = MODE == 2 ? 0.f : grad[index];
     if (!DENSE && g == 0.f) return;
     const int64_t k = index % sz_k;
     const int64_t j = index / sz_k % sz_j;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_scalar_kernel(const floa
 
 extern "C" int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
                                            int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream) {
-    if (n < 0 || sz_i <= 0 || sz_j <= 0 || sz_k <= 0 || n % (sz_i * sz_j * sz_k) != 0) return K4_ERR_BAD_ARG;
+    if (n < 0 || sz_i <= 0 || sz_j <= 0 || sz_k <= 0 || n % (sz_i * sz_j * sz_k) != 0 || dense_mode < 0 || dense_mode > 2) return K4_ERR_BAD_ARG;
     if (n == 0) return 0;
     if (!param || !grad) return K4_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -267,16 +273,12 @@ extern "C" int k4_total_variation_add_grad(const float* param, float* grad, floa
     const int64_t units = vec ? n / 4 : n;
     const int64_t blocks = (units + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
     if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
-    if (vec) {
-        if (dense_mode)
-            hipLaunchKernelGGL(k4_tv_vec_kernel<true>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
-        else
-            hipLaunchKernelGGL(k4_tv_vec_kernel<false>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
-    } else {
-        if (dense_mode)
-            hipLaunchKernelGGL(k4_tv_scalar_kernel<true>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
-        else
-            hipLaunchKernelGGL(k4_tv_scalar_kernel<false>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units);
-    }
+#define K4_TV_LAUNCH(KERNEL) do { \
+        if (dense_mode == 2) hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
+        else if (dense_mode) hipLaunchKernelGGL(KERNEL<1>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
+        else hipLaunchKernelGGL(KERNEL<0>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); } while (0)
+    if (vec) K4_TV_LAUNCH(k4_tv_vec_kernel);
+    else K4_TV_LAUNCH(k4_tv_scalar_kernel);
+#undef K4_TV_LAUNCH
     return k4_check_launch();
 }

@@ -28,6 +28,9 @@ from . import _native as N
 from .lib import sr_train, train_ops, utils
 from .lib.masked_adam import MaskedAdam
 
+_ADAM_SIDE = os.environ.get('K4_TRAIN_ADAM_SIDE', '1') != '0'  # 0: the k0 grid's optimizer step on the current stream (A/B, tests)
+_TV_SEED = os.environ.get('K4_TRAIN_TV_SEED', '1') != '0'      # 0: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
+
 SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
 
 
@@ -134,6 +137,7 @@ class JointTrainer:
         self.render_kwargs = dict(render_kwargs)
         self.n_train_images, self.sr_ratio = n_train_images, sr_ratio
         self.optimizer = utils.create_optimizer_or_freeze_model(model, cfg_train, global_step=0)                  # run_sr.py:640
+        self._side_stream_updates()
         self.optimizer_sr = MaskedAdam([{'params': net_sr.parameters(), 'lr': cfg_train.lrate_srnet, 'kname': 'srnet',
                                          'skip_zero_grad': False}])                                               # run_sr.py:665-667
         self.last_exchange = None
@@ -145,7 +149,15 @@ class JointTrainer:
         """Re-create the marcher's optimizer after ``model.scale_volume_grid`` replaced the grid parameters (run_sr.py:812-818 does the
         same after every progressive-growing step): the old MaskedAdam would keep stepping the dead tensors."""
         self.optimizer = utils.create_optimizer_or_freeze_model(self.model, self.cfg, global_step=global_step)
+        self._side_stream_updates()
         return self.optimizer
+
+    def _side_stream_updates(self):
+        """The feature grid's optimizer step (1.9 ms of HBM time on the LLFF scene) on a second stream: the next iteration's sample selection
+        reads the density grid only and no longer queues behind it; DenseGrid makes every reader of k0 wait (lib/grid.DenseGrid.params_ready)."""
+        k0 = getattr(self.model, 'k0', None)
+        if _ADAM_SIDE and isinstance(self.optimizer, MaskedAdam) and hasattr(k0, 'note_pending_update') and k0.grid.is_cuda:
+            self.optimizer.update_on_side_stream(k0.grid, k0)
 
     def losses(self, rr, rgb_sr, target, target_4x, pr, pc, n_rays):
         """run_sr.py:877-995: the scalar terms of one iteration (dict of tensors; 'total' is what is back-propagated)."""
@@ -192,16 +204,33 @@ class JointTrainer:
     def step(self, rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step):
         """One iteration (run_sr.py:869-1014,1052-1061).  Returns the dict of loss tensors (detached)."""
         cfg = self.cfg
+        tv_now = cfg.tv_after < global_step < cfg.tv_before and global_step % cfg.tv_every == 0                 # run_sr.py:1005-1011
+        # DENSE total variation does not look at the gradient: its term is written ahead of the backward pass (side stream) into the buffer
+        # the grid lookups' backward accumulates into -- the same sum with a third of the memory traffic, and none of it at the end of the
+        # iteration where the next iteration's sample selection waits (lib/grid.py total_variation_seed_grad).  Not under data parallelism:
+        # the gradient exchange between backward and TV sends the TOUCHED voxels, which a dense seed would make all of them.
+        seed_tv = tv_now and _TV_SEED and self.group is None and global_step < cfg.tv_dense_before
+        seeded = []
+        if seed_tv:
+            for weight, grid, fn in ((cfg.weight_tv_density, getattr(self.model, 'density', None), self.model.density_total_variation_add_grad),
+                                     (cfg.weight_tv_k0, getattr(self.model, 'k0', None), self.model.k0_total_variation_add_grad)):
+                if weight > 0 and hasattr(grid, 'finish_grad_seed') and grid.grid.requires_grad:
+                    fn(weight / self.n_train_images, 'seed')
+                    seeded.append(grid)
         with torch.enable_grad():
             rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
+            if hasattr(self.model, '_k4_params_ready'):
+                self.model._k4_params_ready()                # (a forward that never read k0: its pending update still precedes what follows)
             self.optimizer.zero_grad(set_to_none=True)
             self.optimizer_sr.zero_grad(set_to_none=True)
             ls['total'].backward()
+        for grid in seeded:
+            grid.finish_grad_seed()
         self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
-        if cfg.tv_after < global_step < cfg.tv_before and global_step % cfg.tv_every == 0:                       # run_sr.py:1005-1011
-            if cfg.weight_tv_density > 0:
+        if tv_now:
+            if cfg.weight_tv_density > 0 and getattr(self.model, 'density', None) not in seeded:
                 self.model.density_total_variation_add_grad(cfg.weight_tv_density / self.n_train_images, global_step < cfg.tv_dense_before)
-            if cfg.weight_tv_k0 > 0:
+            if cfg.weight_tv_k0 > 0 and getattr(self.model, 'k0', None) not in seeded:
                 self.model.k0_total_variation_add_grad(cfg.weight_tv_k0 / self.n_train_images, global_step < cfg.tv_dense_before)
         self.optimizer.step()
         self.optimizer_sr.step()

@@ -221,6 +221,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         staged = render_kwargs.get('k4_staged', False) or torch.is_grad_enabled() or not self._k4_fusable()
         if staged:
             return self._forward_staged(rays_o, rays_d, viewdirs, global_step=global_step, **render_kwargs)
+        self._k4_params_ready()
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,
@@ -265,6 +266,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         Nr, dev = rays_o.shape[0], rays_o.device
         L = N.lib()
         mc, dg, ag = self.mask_cache, self.density.grid, self.act_shift.grid
+        self.density.params_ready()
         steps2 = torch.empty([Nr, N_samples], dtype=torch.int16, device=dev)
         keep3 = torch.empty([Nr, N_samples], dtype=torch.uint8, device=dev)
         cnt = torch.empty([2, Nr], dtype=torch.int64, device=dev)

@@ -181,10 +181,18 @@ class _FusedMarcher:
             c[('workspace', slot)] = ws
         return ws, need
 
+    def _k4_params_ready(self):
+        """A grid whose optimizer step runs on a second stream (MaskedAdam.update_on_side_stream): the current stream waits for it."""
+        for g in (self.density, self.k0):
+            ready = getattr(g, 'params_ready', None)
+            if ready is not None:
+                ready()
+
     def _k4_grid(self, act_shift_grid=None, live=None):
         """k4_grid_desc of this model.  live = (act_shift scalar, interval): look samples up in the live mask (_k4_live_mask)
         instead of mask_cache.mask -- the render path; None: the MaskGrid itself (sample counters, fast_color_thres == 0)."""
         gd = N.GridDesc()
+        self._k4_params_ready()
         dens = self.density.grid
         k0cl, cpad, k0_layout = self._k4_k0_channel_last()
         gd.density = dens.data_ptr()
@@ -509,6 +517,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
         staged = render_kwargs.get('k4_staged', False) or torch.is_grad_enabled() or not self._k4_fusable()
         if staged:
             return self._forward_staged(rays_o, rays_d, viewdirs, **render_kwargs)
+        self._k4_params_ready()
         return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
 
     def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False,

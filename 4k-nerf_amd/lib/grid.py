@@ -30,9 +30,10 @@ class GridSample3D(torch.autograd.Function):
     lib/grid.py:124 in the reference's training step).  No gradient w.r.t. the sample points (they come from rays)."""
 
     @staticmethod
-    def forward(ctx, grid, pts, xyz_min, xyz_max):
+    def forward(ctx, grid, pts, xyz_min, xyz_max, owner=None):
         ctx.save_for_backward(pts, xyz_min, xyz_max)
         ctx.grid_shape = tuple(grid.shape)
+        ctx.owner = owner                                  # the DenseGrid: its backward may find a pre-seeded gradient buffer there
         return _grid_sample_fwd(grid.detach().contiguous(), pts, xyz_min, xyz_max)
 
     @staticmethod
@@ -40,10 +41,12 @@ class GridSample3D(torch.autograd.Function):
     def backward(ctx, grad_out):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         _, C_, X, Y, Z = ctx.grid_shape
-        gg = torch.zeros(ctx.grid_shape, dtype=torch.float32, device=grad_out.device)
+        gg = ctx.owner._take_grad_seed(ctx.grid_shape, grad_out.device) if ctx.owner is not None else None
+        if gg is None:
+            gg = torch.zeros(ctx.grid_shape, dtype=torch.float32, device=grad_out.device)
         go = grad_out.float().contiguous()
         grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg)
-        return gg, None, None, None
+        return gg, None, None, None, None
 
 
 _GSB_WS = {}          # device -> [(C, X, Y, Z), all-zero workspace of k4_grid_sample_3d_backward_cl, event of its last use]; one grid shape per device
@@ -101,8 +104,18 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
             raise ValueError('total_variation_add_grad: tensors must be contiguous fp32 device tensors')
     N.check(N.lib().k4_total_variation_add_grad(N.ptr(param), N.ptr(grad), float(wx), float(wy), float(wz),
                                                 param.size(2), param.size(3), param.size(4), param.numel(),
-                                                1 if dense_mode else 0, N.stream()),
+                                                2 if dense_mode == 'write' else 1 if dense_mode else 0, N.stream()),
             'k4_total_variation_add_grad')
+
+
+_TV_STREAMS = {}
+
+
+def _tv_stream(device):
+    st = _TV_STREAMS.get(device)
+    if st is None:
+        st = _TV_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _vec3(v):
@@ -132,8 +145,9 @@ class DenseGrid(nn.Module):
         k4_grid_sample_3d; under autograd its backward is k4_grid_sample_3d_backward (gradient w.r.t. the grid)."""
         shape = xyz.shape[:-1]
         pts = xyz.reshape(-1, 3).contiguous()
+        self.params_ready()
         if torch.is_grad_enabled() and self.grid.requires_grad:
-            out = GridSample3D.apply(self.grid, pts.detach(), self.xyz_min, self.xyz_max)
+            out = GridSample3D.apply(self.grid, pts.detach(), self.xyz_min, self.xyz_max, self)
         else:
             out = _grid_sample_fwd(self.grid.detach(), pts, self.xyz_min, self.xyz_max)
         out = out.reshape(*shape, self.channels)
@@ -145,6 +159,7 @@ class DenseGrid(nn.Module):
         """Trilinear resample to a new resolution (progressive growing, lib/grid.py:130-135): F.interpolate(trilinear,
         align_corners=True) on the HIP kernel k4_resample_trilinear.  The new tensor replaces the parameter, as upstream."""
         size = tuple(int(v) for v in new_world_size)
+        self.params_ready()
         old = self.grid.data
         if self.channels == 0:
             data = torch.zeros([1, 0, *size], device=old.device)
@@ -161,10 +176,71 @@ class DenseGrid(nn.Module):
         self.world_size = new_world_size
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
-        '''Add gradients by total variation loss in-place (lib/grid.py:137-140).'''
+        '''Add gradients by total variation loss in-place (lib/grid.py:137-140).  dense_mode == 'seed' (no reference counterpart): the
+        dense term ahead of the backward pass, see total_variation_seed_grad.'''
+        if isinstance(dense_mode, str) and dense_mode == 'seed':
+            return self.total_variation_seed_grad(wx, wy, wz)
+        self.params_ready()
         total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
 
+    # ---- the dense TV term BEFORE the backward pass (no reference counterpart; joint_train.JointTrainer.step) ----
+    # The reference adds the term after backward (run_sr.py:1005-1011): zero-fill the gradient (4 B / voxel), scatter, then read grad + param
+    # and write grad (12 B) -- on the 339 M-float LLFF k0 that is 1.1 ms at the END of the iteration, where the next iteration's sample
+    # selection (a device-to-host read) waits for it.  Dense mode does not look at the gradient, so the term can be WRITTEN into a fresh
+    # buffer first (8 B / voxel, on a side stream under the iteration's host-paced phases) and the lookup's backward accumulates into
+    # that buffer instead of into zeros: grad = term + scatter, the same sum.
+    _k4_seed = None
+    # ---- an optimizer step of the grid running on a second stream (lib/masked_adam.MaskedAdam.update_on_side_stream) ----
+    _k4_pending = None
+
+    def note_pending_update(self, event):
+        self._k4_pending = event
+
+    def params_ready(self, stream=None, clear=True):
+        """Everything queued on `stream` (default: the current one) after this call sees the finished parameter update.  Called by every
+        reader of the parameter in this package (lookups, total variation, resampling, the fused marchers' descriptors, state_dict)."""
+        ev = self._k4_pending
+        if ev is not None:
+            (stream if stream is not None else torch.cuda.current_stream(self.grid.device)).wait_event(ev)
+            if clear:
+                self._k4_pending = None
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.params_ready()
+        return super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def total_variation_seed_grad(self, wx, wy, wz):
+        """Start computing the dense TV term of the CURRENT parameter values into a new buffer (side stream).  The next backward pass
+        through this grid accumulates into it; ``finish_grad_seed`` after the backward pass covers a pass that never reached the grid."""
+        cur = torch.cuda.current_stream(self.grid.device)
+        seed = torch.empty_like(self.grid.data, memory_format=torch.contiguous_format)
+        side = _tv_stream(self.grid.device)
+        side.wait_stream(cur)                              # the optimizer step that produced these parameter values (and the allocation point)
+        self.params_ready(side, clear=False)               # ... also when that step runs on a stream of its own (the current stream still has to wait)
+        with torch.cuda.stream(side):
+            total_variation_add_grad(self.grid.data, seed, wx, wy, wz, 'write')
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._k4_seed = (seed, ev)
+
+    def _take_grad_seed(self, shape, device):
+        hit, self._k4_seed = self._k4_seed, None
+        if hit is None:
+            return None
+        seed, ev = hit
+        torch.cuda.current_stream(device).wait_event(ev)
+        if tuple(seed.shape) != tuple(shape) or seed.device != device:        # the grid was replaced in between (scale_volume_grid)
+            raise N.K4Error('total_variation_seed_grad: the grid changed shape between the seed and the backward pass')
+        return seed
+
+    def finish_grad_seed(self):
+        """After the backward pass: a seed no lookup consumed becomes (or is added to) the gradient."""
+        if self._k4_seed is not None:
+            seed = self._take_grad_seed(self.grid.shape, self.grid.device)
+            self.grid.grad = seed if self.grid.grad is None else self.grid.grad.add_(seed)
+
     def get_dense_grid(self):
+        self.params_ready()
         return self.grid
 
     @torch.no_grad()

@@ -1,6 +1,8 @@
 """MaskedAdam -- the reference's grid optimizer (lib/masked_adam.py:18-71) over the gfx950 streaming kernels of
 csrc/k4_opt.hip.  Same constructor, param-group keys (`lr`, `betas`, `eps`, `skip_zero_grad`), state keys (`step`,
 `exp_avg`, `exp_avg_sq`), `set_pervoxel_lr` and kernel selection order as upstream; there is no CPU path."""
+import contextlib
+
 import torch
 
 from .. import _native as N
@@ -40,6 +42,16 @@ def masked_adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, ep
 def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
     """adam_upd_cuda.adam_upd_with_perlr (lib/cuda/adam_upd.cpp:58-69)."""
     _launch('k4_adam_upd_with_perlr', param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 _MULTI_BELOW = 1 << 20          # tensors smaller than this are updated through k4_adam_upd_multi (same arithmetic per element)
@@ -96,7 +108,16 @@ class MaskedAdam(torch.optim.Optimizer):
                 raise ValueError(msg)
         self.per_lr = None
         self._fast = {}             # id(param group) -> plan of the group's small tensors (see _fast_step)
+        self._side = {}             # id(param) -> owner (an object with ``note_pending_update(event)``): see update_on_side_stream
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def update_on_side_stream(self, param, owner):
+        """The update of `param` (a large voxel grid) runs on a second HIP stream, behind the gradient on the current stream; the event of
+        its completion is handed to ``owner.note_pending_update`` -- the owner (lib/grid.DenseGrid) makes every later reader of the
+        parameter wait for it.  The 339 M-float LLFF k0 takes 1.9 ms of HBM time per step (28 bytes per element): on the current stream
+        that is 1.9 ms between the end of one training iteration and the first kernel of the next, whose sample selection (a device-to-host
+        read of counts, density grid only) the host waits for.  No reference counterpart (one stream there); same values."""
+        self._side[id(param)] = owner
 
     def set_pervoxel_lr(self, count):
         assert self.param_groups[0]['params'][0].shape == count.shape
@@ -169,15 +190,29 @@ class MaskedAdam(torch.optim.Optimizer):
                 grad = param.grad.contiguous()
                 moments = (state['exp_avg'], state['exp_avg_sq'])
                 hyper = (state['step'], beta1, beta2, lr, eps)
-                # kernel selection order of lib/masked_adam.py:58-71: per-voxel lr first, then the masked update
-                if self.per_lr is not None and param.shape == self.per_lr.shape:
-                    adam_upd_with_perlr(param, grad, *moments, self.per_lr, *hyper)
-                elif param.numel() < _MULTI_BELOW:
-                    small.setdefault((bool(masked), state['step']), []).append((param, grad) + moments)
-                elif masked:
-                    masked_adam_upd(param, grad, *moments, *hyper)
+                owner = self._side.get(id(param)) if param.is_cuda and param.numel() >= _MULTI_BELOW else None
+                if owner is not None:
+                    cur, side = torch.cuda.current_stream(param.device), _side_stream(param.device)
+                    side.wait_stream(cur)                       # the gradient (and everything that read the old values) is done
+                    # (no grad.record_stream: the owner's readers -- and JointTrainer before zero_grad -- make the current stream wait for this
+                    # update, so the gradient's block returns to the allocator only after it; a recorded 1.4 GB block would sit in limbo)
+                    ctx = torch.cuda.stream(side)
                 else:
-                    adam_upd(param, grad, *moments, *hyper)
+                    ctx = contextlib.nullcontext()
+                with ctx:
+                    # kernel selection order of lib/masked_adam.py:58-71: per-voxel lr first, then the masked update
+                    if self.per_lr is not None and param.shape == self.per_lr.shape:
+                        adam_upd_with_perlr(param, grad, *moments, self.per_lr, *hyper)
+                    elif param.numel() < _MULTI_BELOW:
+                        small.setdefault((bool(masked), state['step']), []).append((param, grad) + moments)
+                    elif masked:
+                        masked_adam_upd(param, grad, *moments, *hyper)
+                    else:
+                        adam_upd(param, grad, *moments, *hyper)
+                    if owner is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        owner.note_pending_update(ev)
             # the group's small tensors (the decoder: 458 of them) share hyper-parameters: a handful of launches instead of one each
             for (msk, step), items in small.items():
                 adam_upd_multi(items, msk, step, beta1, beta2, lr, eps)

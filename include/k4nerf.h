@@ -523,7 +523,8 @@ int k4_adam_upd_multi(const k4_adam_job* jobs, int32_t n_jobs, int32_t masked, i
  * total_variation_kernel.cu:13-66), called by DenseGrid.total_variation_add_grad (lib/grid.py:137-140).
  * param/grad: [1, C, sz_i, sz_j, sz_k] contiguous fp32, n = C*sz_i*sz_j*sz_k; grad += sum over the 6 neighbours of
  * (w_axis/6)*clamp(param - param_nb, -1, 1) with wx on the k (fastest) axis, wy on j, wz on i -- the reference's
- * naming; dense_mode == 0 restricts the update to elements whose grad is non-zero. */
+ * naming; dense_mode == 0 restricts the update to elements whose grad is non-zero; dense_mode == 2 (no reference counterpart) WRITES the dense term:
+ * grad = term, grad not read -- the term computed before the backward pass into the buffer the lookups' backward then accumulates into. */
 int k4_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz, int64_t sz_i,
                                 int64_t sz_j, int64_t sz_k, int64_t n, int32_t dense_mode, void* stream);
 

@@ -220,6 +220,49 @@ def test_joint_trainer_steps_lower_the_loss():
     assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)
 
 
+def test_dense_tv_written_ahead_of_backward_and_side_stream_adam_equal_the_reference_order(monkeypatch):
+    """JointTrainer.step writes the DENSE total-variation term into the grid gradients' buffers before the backward pass (side stream;
+    the lookups' backward accumulates into them) instead of adding it after (run_sr.py:1005-1011): grad = term + scatter either way.
+    Three steps each way from the same state: same losses, same parameters (scatter atomics reorder sums: 1e-5 relative), and the
+    sparse-TV steps (global_step >= tv_dense_before) take the reference's order in both.  Likewise the k0 grid's optimizer step on a
+    second stream (MaskedAdam.update_on_side_stream): readers of the grid wait for it, results unchanged."""
+    from nerf4k_amd.lib import masked_adam
+    monkeypatch.setattr(masked_adam, '_MULTI_BELOW', 1000)      # the test scene's grids (19 440 / 2 160 floats) take the large-tensor path of the LLFF grids
+    res = []
+    for seed_on, adam_side in ((False, False), (True, False), (False, True), (True, True)):
+        z, model, net, rk, cfg, batch = _load_joint()
+        cfg = joint_train.JointCfg(dict(cfg, tv_before=100, tv_dense_before=3))          # steps 1, 2 dense; step 3 sparse
+        monkeypatch.setattr(joint_train, '_TV_SEED', seed_on)
+        monkeypatch.setattr(joint_train, '_ADAM_SIDE', adam_side)                       # the k0 grid's optimizer step on a second stream
+        tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+        hist = [float(tr.step(*batch, global_step=1 + i)['total']) for i in range(3)]
+        assert model.k0._k4_seed is None and model.density._k4_seed is None            # every seed was consumed (or folded in by finish_grad_seed)
+        assert (model.k0._k4_pending is not None) == adam_side                         # the last step's update may still be running ...
+        sd = model.state_dict()                                                         # ... every reader waits for it: state_dict,
+        assert model.k0._k4_pending is None
+        with torch.no_grad():                                                           # the fused marcher
+            img = model(*batch[:3], **{k: v for k, v in rk.items() if k != 'rand_bkgd'})['rgb_marched'].clone()
+        res.append((hist, {k: v.detach().clone() for k, v in sd.items() if v.is_floating_point()}, [p.detach().clone() for p in net.parameters()], img))
+    h0, m0, s0, i0 = res[0]
+    for h1, m1, s1, i1 in res[1:]:
+        assert np.allclose(h1, h0, rtol=1e-6, atol=0), (h1, h0)
+        for k in m1:
+            _close(m1[k], m0[k].cpu(), k, rel=1e-5, abs_=1e-8)
+        for a, b in zip(s1, s0):
+            _close(a, b.cpu(), 'decoder parameter', rel=1e-5, abs_=1e-8)
+        _close(i1, i0.cpu(), 'render after the steps', rel=1e-5, abs_=1e-7)
+    # a backward pass that never reaches the grid: the seed becomes the gradient
+    z, model, net, rk, cfg, batch = _load_joint()
+    g = model.k0
+    g.total_variation_add_grad(0.3, 0.3, 0.1, 'seed')
+    assert g.grid.grad is None and g._k4_seed is not None
+    g.finish_grad_seed()
+    want = torch.zeros_like(g.grid)
+    from nerf4k_amd.lib import grid as k4grid
+    k4grid.total_variation_add_grad(g.grid, want, 0.3, 0.3, 0.1, True)
+    assert g._k4_seed is None and torch.equal(g.grid.grad, want)
+
+
 def test_graphed_decoder_matches_eager_and_sees_weight_updates():
     """lib/sr_train.GraphedDecoder: SFTNet's training forward + backward captured as hipGraphs (the weight packers run inside them).
     Replays must equal the eager path (same kernels; wgrad / dbias sum with atomics: 2e-5 relative) -- also after the weights changed."""

@@ -33,6 +33,8 @@ for b in range(int(os.environ.get('BLOCKS', '5'))):                  # the itera
     t_host = time.perf_counter() - t              # the host has issued everything (a step that reads a loss back synchronises inside: then host == wall)
     torch.cuda.synchronize()
     blocks.append(((time.perf_counter() - t) / n * 1e3, t_host / n * 1e3))
+if os.environ.get('SHOW_BLOCKS') == '1':
+    print('blocks (wall, host) ms:', [(round(a, 2), round(b, 2)) for a, b in blocks])
 blocks.sort()
 med = blocks[len(blocks) // 2]
 print('joint iteration ms', round(med[0], 2), '(host returned after', round(med[1], 2), 'ms per iteration; median of', len(blocks), 'blocks of', n,
