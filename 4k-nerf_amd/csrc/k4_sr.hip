@@ -502,7 +502,7 @@ typedef unsigned k4s_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 typedef float k4_f4 __attribute__((ext_vector_type(4)));
 // per-tile scalars (workgroup-uniform)
-struct V2Tile { const float* x; float* y; const float* res; int H, W, srcW, x0, y0, nb; };
+struct V2Tile { const float* x; float* y; const float* res; const float* modx; int H, W, srcW, x0, y0, nb; };
 template <int TROWS>
 __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_count, bool ups) {
     int g = 0;
@@ -511,7 +511,7 @@ __device__ __forceinline__ V2Tile k4_v2_tile(const ConvMulti& M, int b, int nb_c
     const int tile = local / nb_count;
     V2Tile T;
     T.nb = local - tile * nb_count;
-    T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.H = M.H[g]; T.W = M.W[g];
+    T.x = M.x[g]; T.y = M.y[g]; T.res = M.res[g]; T.modx = M.modx[g]; T.H = M.H[g]; T.W = M.W[g];
     T.srcW = ups ? T.W / 2 : T.W;
     const int tiles_x = M.tiles_x[g];
     T.x0 = (tile % tiles_x) * TILE_W; T.y0 = (tile / tiles_x) * TROWS;
@@ -916,6 +916,9 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
             for (int j = 0; j < NBK; ++j) {
                 const int co = (T.nb * NBK + j) * 32 + l31;
                 const bool co_ok = co < P.cout;
+                // K4_EPI_LRELU_BWD: the LAST 32 output channels are the gradient slice of a LeakyReLU output that this accumulation completes --
+                // multiplied by (activation > 0 ? 1 : slope) here instead of by a k4_lrelu_bwd launch behind this one (workgroup-uniform)
+                const bool lbwd = (P.flags & K4_EPI_LRELU_BWD) && (T.nb * NBK + j) == nb_count - 1 && co_ok;
                 const float bias = P.bias[co_ok ? co : 0];
                 float unscale = 1.f;
                 if constexpr (F16) unscale = ldexpf(wtail[co_ok ? co : 0], -tcur);
@@ -933,6 +936,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                             float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
                             v = fmaxf(v, v * sl);
                             v = k4s_mul_add(v, P.res_scale, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, (int)roff, dp * P.res_stride * 4, 0)));
+                            if (lbwd) v = T.modx[(size_t)(pix0 + dp) * P.mod_stride + co] > 0.f ? v : v * P.slope;
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)yoff, dp * P.cout_stride * 4, 0);
                         }
                     } else {
@@ -941,6 +945,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                             const int dp = (e & 3) + 8 * (e >> 2);
                             float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
                             v = fmaxf(v, v * sl);
+                            if (lbwd) v = T.modx[(size_t)(pix0 + dp) * P.mod_stride + co] > 0.f ? v : v * P.slope;
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)yoff, dp * P.cout_stride * 4, 0);
                         }
                     }
@@ -967,6 +972,7 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
                         float v = F16 ? fmaf(acc[j][r][e], unscale, bias) : acc[j][r][e] + bias;
                         if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
                         if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, T.res[pix * P.res_stride + co]);
+                        if ((P.flags & K4_EPI_LRELU_BWD) && (T.nb * NBK + j) == nb_count - 1) v = T.modx[pix * P.mod_stride + co] > 0.f ? v : v * P.slope;
                         T.y[pix * P.cout_stride + co] = v;
                     }
                 }
@@ -1271,6 +1277,8 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
     const bool modulate = (flags & K4_EPI_MODULATE) != 0;
     if (modulate && (mod_stride <= 0 || cout % 32 != 0)) return K4_ERR_BAD_ARG;
     if ((flags & K4_EPI_RES) && res_stride <= 0) return K4_ERR_BAD_ARG;
+    const bool lbwd = (flags & K4_EPI_LRELU_BWD) != 0;
+    if (lbwd && (ksize != 3 || cout % 32 != 0 || mod_stride < cout || modulate || (flags & K4_W_TAPS_AS_COUT))) return K4_ERR_BAD_ARG;
     const int gemm_n = modulate ? 2 * cout : cout;
     const int nt = (gemm_n + 31) / 32;
     ConvMulti M{};
@@ -1283,7 +1291,7 @@ static int conv_b6_multi(const k4_conv_job* jobs, int32_t n_jobs, int32_t cin, i
         const k4_conv_job& j = jobs[g];
         if (!j.x || !j.y || j.H <= 0 || j.W <= 0) return K4_ERR_BAD_ARG;
         if ((flags & K4_EPI_RES) && !j.res) return K4_ERR_BAD_ARG;
-        if (modulate && !j.mod_x) return K4_ERR_BAD_ARG;
+        if ((modulate || lbwd) && !j.mod_x) return K4_ERR_BAD_ARG;
         if ((flags & K4_PRE_UPSAMPLE2X) && ((j.H & 1) || (j.W & 1))) return K4_ERR_BAD_ARG;
         M.x[g] = j.x; M.y[g] = j.y; M.res[g] = j.res; M.modx[g] = j.mod_x; M.H[g] = j.H; M.W[g] = j.W;
     }

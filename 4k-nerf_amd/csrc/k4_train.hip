@@ -565,7 +565,7 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
                                                        const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
                                                        const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h,
                                                        float slope, float* __restrict__ gxg, float* __restrict__ gcg, float* __restrict__ part,
-                                                       const float* __restrict__ gxa, int gxa_stride, int gc_acc) {
+                                                       const float* __restrict__ gxa, int gxa_stride, int gc_acc, int gx_lrelu) {
     typedef SftBwdLayout<C> L;
     constexpr int MAXB = L::MAXB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -631,8 +631,13 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
                 s0 = fmaf(a, w1sc[co * SFT_G + k], s0); s1 = fmaf(a, w1sc[(co + 1) * SFT_G + k], s1);
             }
             const float g0 = gy[co * TR_LS + lane], g1 = gy[(co + 1) * TR_LS + lane];
-            gx[co * TR_LS + lane] = g0 * (s0 + 1.f); gx[(co + 1) * TR_LS + lane] = g1 * (s1 + 1.f);
-            gs[co * TR_LS + lane] *= g0; gs[(co + 1) * TR_LS + lane] *= g1;
+            const float x0 = gs[co * TR_LS + lane], x1 = gs[(co + 1) * TR_LS + lane];
+            float o0 = g0 * (s0 + 1.f), o1 = g1 * (s1 + 1.f);
+            if (gx_lrelu) {                                 // x = lrelu(z): the gradient in front of the activation (k4_lrelu_bwd's arithmetic)
+                o0 = x0 > 0.f ? o0 : o0 * slope; o1 = x1 > 0.f ? o1 : o1 * slope;
+            }
+            gx[co * TR_LS + lane] = o0; gx[(co + 1) * TR_LS + lane] = o1;
+            gs[co * TR_LS + lane] = x0 * g0; gs[(co + 1) * TR_LS + lane] = x1 * g1;
         }
         __syncthreads();
         // gz = lrelu'(z) * (W1^T g):  wave w -> hidden neurons 4 (w & 7) .. +3 of the scale (w < 8) or shift (w >= 8) branch
@@ -790,12 +795,12 @@ extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* c
 template <int C>
 static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, hipStream_t st) {
+                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, hipStream_t st) {
     typedef SftBwdLayout<C> L;
     const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
     K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
     const int grid = sft_bwd_grid(n);
-    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc);
+    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc, gx_lrelu);
     int rc = k4_check_launch();
     if (rc) return rc;
     const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
@@ -810,7 +815,7 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
                                    float slope, float* grad_x, float* grad_cond,
                                    float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                                    float* workspace, int64_t workspace_bytes,
-                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, void* stream) {
+                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
     if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
@@ -819,8 +824,8 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
     float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
     hipStream_t st = (hipStream_t)stream;
     const int acc = accumulate_grad_cond != 0;
-    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, st);
-    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, st);
+    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, st);
+    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, st);
 }
 extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                 int64_t n_pix, int32_t channels,
@@ -829,7 +834,7 @@ extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* c
                                 float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                                 float* workspace, int64_t workspace_bytes, void* stream) {
     return k4_sft_train_bwd_ex(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
-                               gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, nullptr, 0, 0, stream);
+                               gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, nullptr, 0, 0, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -897,6 +902,15 @@ static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // e
     if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
     return (int)e;
 }
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_scale_f32(const float* __restrict__ in, float s, float* __restrict__ out, int64_t units) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= units) return;
+    if (VEC) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    } else out[i] = in[i] * s;
+}
 static bool k4_rdb_ok(const k4_rdb_train* p, bool bwd) {
     if (!p || p->H <= 0 || p->W <= 0 || p->g != 32 || (p->nf != 32 && p->nf != 64) || !p->t || !p->c || !p->buf || !p->x4) return false;
     for (int k = 0; k < 5; ++k) if (!p->w_fwd[k] && !bwd) return false;
@@ -932,6 +946,8 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     // every exit joins the side stream back into `stream`: after a failed launch the caller frees the gradient buffers on `stream` while weight
     // gradients already forked to the side stream may still be running on them
     int rc = 0;
+    const bool fl = p->fused_lrelu != 0;
+    if (p->g5_from_gx0_add && !p->gx0_add) return K4_ERR_BAD_ARG;
 #undef K4_RDB_TRY
 #define K4_RDB_TRY(CALL) do { rc = (CALL); if (rc != 0) goto join; } while (0)
     // a weight gradient on the side stream: forked behind everything queued on the main stream so far (= the producer of the gradient slice it reads)
@@ -940,9 +956,11 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
         if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); \
         else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); } while (0)
     // G[:, 0:COUT'] (+)= dgrad: the output is its own residual
-#define K4_RDB_DGRAD(K, SRC, SS, CIN_OF_LAYER, ACC) \
-        K4_RDB_TRY(k4_conv2d_nhwc_bf16x6((SRC), (K) == 4 ? nf : g, (SS), p->w_bwd[K], p->b_bwd[K], 3, p->G, (CIN_OF_LAYER), bw, H, W, (ACC) ? K4_EPI_RES : 0u, 0.2f, \
-                                         (ACC) ? p->G : nullptr, (ACC) ? bw : 0, 1.f, nullptr, 0, stream))
+    // MASK (fused_lrelu): the last 32 channels this launch completes are x_k's gradient slice -- LeakyReLU backward from buf's slice in the epilogue
+#define K4_RDB_DGRAD(K, SRC, SS, CIN_OF_LAYER, ACC, MASK) \
+        K4_RDB_TRY(k4_conv2d_nhwc_bf16x6((SRC), (K) == 4 ? nf : g, (SS), p->w_bwd[K], p->b_bwd[K], 3, p->G, (CIN_OF_LAYER), bw, H, W, \
+                                         ((ACC) ? K4_EPI_RES : 0u) | ((MASK) ? K4_EPI_LRELU_BWD : 0u), 0.2f, \
+                                         (ACC) ? p->G : nullptr, (ACC) ? bw : 0, 1.f, (MASK) ? p->buf : nullptr, (MASK) ? bw : 0, stream))
     // dwdb_span_floats > 0: the five [dW | dbias] buffers are one span starting at dwdb_span: ONE zero-fill on the side stream (ordered before every
     // weight gradient there) instead of one per layer
     if (p->dwdb_span_floats > 0) {
@@ -950,26 +968,33 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
         K4_RDB_TRY(k4_wait_stream(side, main_s));                                  // (the span may be memory the main stream's earlier work still reads)
         K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
     }
+    if (p->g5_from_gx0_add) {                                                       // g5 = 0.2 grad_out (conv5's output is scaled by 0.2 in the forward pass)
+        const bool vec = (((uintptr_t)p->gx0_add | (uintptr_t)p->g5) & 15u) == 0;
+        const int64_t units = vec ? n * nf / 4 : n * nf;
+        if (vec) hipLaunchKernelGGL(k_scale_f32<true>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, main_s, p->gx0_add, 0.2f, (float*)p->g5, units);
+        else hipLaunchKernelGGL(k_scale_f32<false>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, main_s, p->gx0_add, 0.2f, (float*)p->g5, units);
+        K4_RDB_TRY(k4_check_launch());
+    }
     // conv5: out = 0.2 conv5(buf) + t
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
-    K4_RDB_DGRAD(4, p->g5, nf, bw, false);                                         // G = dgrad (every channel)
+    K4_RDB_DGRAD(4, p->g5, nf, bw, false, false);                                  // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
     K4_RDB_TRY(k4_sft_train_bwd_ex(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                    0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
-                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, stream));
-    K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
+                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, stream));
+    if (!fl) K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
     K4_RDB_WGRAD(nf + 3 * g, p->gx4, g, g, 3);
-    K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true);                                  // G[:, 0:nf+3g] += dgrad
+    K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true, fl);                              // G[:, 0:nf+3g] += dgrad (+ the mask of x3's slice, its last 32 channels)
     for (int k = 3; k >= 1; --k) {                                                  // x_k = lrelu(conv_k(buf[:, 0:off]))
         const int off = nf + (k - 1) * g;
-        K4_RDB_TRY(k4_lrelu_bwd(p->G + off, bw, p->buf + off, bw, n, g, 0.2f, p->G + off, bw, stream));
+        if (!fl) K4_RDB_TRY(k4_lrelu_bwd(p->G + off, bw, p->buf + off, bw, n, g, 0.2f, p->G + off, bw, stream));
         K4_RDB_WGRAD(off, p->G + off, g, bw, k - 1);
-        K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true);
+        K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true, fl && k > 1);               // (k == 1 completes xc0's slice: sft0's output, no activation)
     }
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
     K4_RDB_TRY(k4_sft_train_bwd_ex(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                    0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
-                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, stream));
+                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, stream));
 join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD

@@ -224,7 +224,7 @@ class K4SFTLayer(torch.autograd.Function):
         ws = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
         N.check(L.k4_sft_train_bwd_ex(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
                                       N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
-                                      N.f32(ws), nbytes, None, 0, int(acc is not None), N.stream()), 'k4_sft_train_bwd_ex')
+                                      N.f32(ws), nbytes, None, 0, int(acc is not None), 0, N.stream()), 'k4_sft_train_bwd_ex')
         return (gx, None if acc is not None else gc, None, *g)
 
 
@@ -245,6 +245,7 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
 
 _NATIVE_RDB = os.environ.get('K4_TRAIN_NATIVE_RDB', '1') != '0'      # 0: a dense block's launches issued one by one from Python (A/B)
 _WGRAD_STREAM = os.environ.get('K4_TRAIN_WGRAD_STREAM', '1') != '0'   # 0: the block's weight gradients on the chain's own stream (A/B)
+_FUSED_LRELU = os.environ.get('K4_TRAIN_FUSED_LRELU', '1') != '0'    # 0: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _COND_ACC = os.environ.get('K4_TRAIN_COND_ACC', '1') != '0'           # 0: every SFT consumer returns its condition gradient, autograd adds them (A/B)
 _SIDE_STREAMS = {}
 
@@ -282,7 +283,7 @@ _RDB_LAYOUTS = {}
 def _rdb_bwd_layout(P, n, nf, g, with_gc):
     """Float offsets of a dense block's backward buffers inside TWO allocations (per (n_pix, nf, g): computed once).
     param grads: [dW1 | db1 | ... | dW5 | db5] (the span one launch zeroes for the split-K weight gradients) | sft0's eight | sft1's eight;
-    scratch:     gx0 [n, nf] | G [n, bw] | gx4 [n, g] | sft0 workspace | sft1 workspace | (gc0 | gc1 [n, 32] without an accumulator).
+    scratch:     gx0 [n, nf] | G [n, bw] | gx4 [n, g] | sft0 workspace | sft1 workspace | g5 [n, nf] | (gc0 | gc1 [n, 32] without an accumulator).
     As ~31 torch.empty calls + one zero-fill per layer this was a third of K4RDB.backward's host time, which paces the joint iteration."""
     key = (n, nf, g, with_gc)
     lay = _RDB_LAYOUTS.get(key)
@@ -296,7 +297,7 @@ def _rdb_bwd_layout(P, n, nf, g, with_gc):
         span = offs[10]
         nb0, nb1 = int(L.k4_sft_train_bwd_workspace_bytes(n, nf)), int(L.k4_sft_train_bwd_workspace_bytes(n, g))
         bw = nf + 4 * g
-        ssz = [n * nf, n * bw, n * g, nb0 // 4, nb1 // 4] + ([n * 32, n * 32] if with_gc else [])
+        ssz = [n * nf, n * bw, n * g, nb0 // 4, nb1 // 4, n * nf] + ([n * 32, n * 32] if with_gc else [])
         soff = [0]
         for q in ssz:
             soff.append(soff[-1] + q)
@@ -385,12 +386,12 @@ class K4RDB(torch.autograd.Function):
                 else:
                     d.gsft1[q - 18] = ptr
             d.dwdb_span, d.dwdb_span_floats = pb, span
-            g5 = go * 0.2
-            d.g5, d.gx0_add = g5.data_ptr(), go.data_ptr()
-            d.gx0, d.G, d.gx4, d.ws0, d.ws1 = (sb + 4 * o for o in soff[:5])
+            d.gx0_add = go.data_ptr()
+            d.gx0, d.G, d.gx4, d.ws0, d.ws1, d.g5 = (sb + 4 * o for o in soff[:6])
             d.ws0_bytes, d.ws1_bytes = nb0, nb1
+            d.g5_from_gx0_add, d.fused_lrelu = 1, int(_FUSED_LRELU)          # g5 = 0.2 grad_out inside the call; the four LeakyReLU backward passes in epilogues
             if acc is None:
-                d.gc0, d.gc1, d.gc_acc = sb + 4 * soff[5], sb + 4 * soff[6], None
+                d.gc0, d.gc1, d.gc_acc = sb + 4 * soff[6], sb + 4 * soff[7], None
             else:
                 d.gc_acc = acc.data_ptr()
             keep = []
@@ -402,7 +403,7 @@ class K4RDB(torch.autograd.Function):
             d.side_stream = _side_stream(dev)
             N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
             gt = scr[:n * nf].view(H, W, nf)                                          # = go + the gradient through sft0 (added in the kernel's store)
-            gc = None if acc is not None else (scr[soff[5]:soff[6]] + scr[soff[6]:soff[7]]).view(H, W, 32)
+            gc = None if acc is not None else (scr[soff[6]:soff[7]] + scr[soff[7]:soff[8]]).view(H, W, 32)
             return (gt, gc, None, None, *grads)
 
         G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)

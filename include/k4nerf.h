@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, k4_rdb_train.gc_acc / gx0_add / dwdb_span; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -295,6 +295,9 @@ int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, fl
 #define K4_EPI_RES         4u    /* y = y*res_scale + res[pix][co]                 (after the activation)      */
 #define K4_EPI_MODULATE    8u    /* SFTLayer tail: the GEMM yields 2*cout channels [scale | shift];
                                     y[co] = mod_x[pix][co]*(scale[co]+1) + shift[co]   (lib/sr_esrnet.py:123)   */
+#define K4_EPI_LRELU_BWD 256u    /* k4_conv2d_nhwc_bf16x6(_multi), 3x3 layers with cout % 32 == 0: after everything else the LAST 32 output channels are
+                                    multiplied by (mod_x[pix][co] > 0 ? 1 : slope), mod_x = [H][W][mod_stride] addressed with the OUTPUT's channel index:
+                                    LeakyReLU backward (k4_lrelu_bwd) of the gradient slice a dgrad accumulation has just completed, in its epilogue */
 #define K4_W_TAPS_AS_COUT 32u    /* k4_conv2d_nhwc_bf16x6 only, 3x3 with cout <= 3: w_split holds the 1x1 layer [9*cout -> 32][cin]
                                     (n = tap*cout + co) in the bf16x6 layout; the kernel sums the 9 taps from LDS        */
 #define K4_PRE_UPSAMPLE2X 16u    /* the input is read through a nearest x2 upsample (lib/sr_esrnet.py:461-463)  */
@@ -492,6 +495,9 @@ typedef struct k4_rdb_train {
                                        decoder reads the same condition map, the sum over layers needs no kernels of its own */
     const float* gx0_add;           /* gx0 = gradient of t through sft0 + gx0_add [n_pix][nf] (the block's skip connection: grad_out) */
     float* dwdb_span; int64_t dwdb_span_floats;   /* the five dwdb buffers lie in this one span: ONE zero-fill for all of them */
+    int32_t fused_lrelu;            /* != 0: the four k4_lrelu_bwd launches run inside the epilogues of the launches in front of them (K4_EPI_LRELU_BWD, grad_x_lrelu):
+                                       same values */
+    int32_t g5_from_gx0_add;        /* != 0: g5 (a caller's [n_pix][nf] buffer) is WRITTEN here as 0.2 * gx0_add (= grad_out) */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -582,14 +588,15 @@ int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_
                      float* workspace, int64_t workspace_bytes, void* stream);
 /* The same with the two sums the training graph puts right behind it folded into the stores: grad_x = the layer's gradient + grad_x_add
  * ([n_pix][gxa_stride] rows; NULL = none) and, with accumulate_grad_cond != 0, grad_cond += the layer's gradient (the caller zeroes it once per
- * backward pass: every SFT layer of the decoder reads the same condition map). */
+ * backward pass: every SFT layer of the decoder reads the same condition map).  grad_x_lrelu != 0: x is the OUTPUT of a LeakyReLU(slope) and
+ * grad_x is the gradient in front of it: grad_x *= (x > 0 ? 1 : slope) (k4_lrelu_bwd folded in; before grad_x_add). */
 int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                         int64_t n_pix, int32_t channels,
                         const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
                         float slope, float* grad_x, float* grad_cond,
                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                         float* workspace, int64_t workspace_bytes,
-                        const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, void* stream);
+                        const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, void* stream);
 
 #ifdef __cplusplus
 }

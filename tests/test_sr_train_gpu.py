@@ -118,6 +118,37 @@ def test_condition_gradient_accumulator_equals_the_autograd_sums_and_refuses_a_s
         loss.backward()
 
 
+def test_dense_block_backward_with_folded_leaky_relu_is_bit_identical(monkeypatch):
+    """k4_rdb_train_bwd with fused_lrelu: the block's four LeakyReLU backward passes run in the epilogues of the launches in front of them
+    (K4_EPI_LRELU_BWD in three dgrad accumulations, grad_x_lrelu in sft1's backward) instead of as k4_lrelu_bwd launches.  Same
+    arithmetic, same order: the gradients of the block's input and of the condition map (no atomics on that chain) must be bit-identical;
+    the weight gradients (split-K atomics) to rounding."""
+    g = torch.Generator().manual_seed(31)
+    blk = sr_esrnet.ResidualDenseBlock_SFT(64, 32)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if 'SFT' in n else 1.5 / max(1, p[0].numel()) ** 0.5))
+    blk = blk.cuda()
+    H, W = 37, 45                                                   # ragged tiles: the kernels' general epilogue path as well as the fast one
+    t0, c0 = torch.randn([H, W, 64], generator=g).cuda(), torch.randn([H, W, 32], generator=g).cuda()
+    go = torch.randn([H, W, 64], generator=g).cuda()
+
+    def sp(layer):
+        return (layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
+                layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias)
+    convs = [q for m in (blk.conv1, blk.conv2, blk.conv3, blk.conv4, blk.conv5) for q in (m.weight, m.bias)]
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(sr_train, '_FUSED_LRELU', fused)
+        blk.zero_grad(set_to_none=True)
+        t, c = t0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        sr_train.K4RDB.apply(t, c, sr_train._WeightCache(), None, *sp(blk.sft0), *convs, *sp(blk.sft1)).backward(go)
+        res.append((t.grad.clone(), c.grad.clone(), [p.grad.clone() for p in blk.parameters()]))
+    (ta, ca, pa), (tb, cb, pb) = res
+    assert torch.equal(ta, tb) and torch.equal(ca, cb)
+    assert max(_rel(a, b) for a, b in zip(pa, pb)) <= 2e-6
+
+
 def test_training_step_updates_inference_path():
     """One optimizer step on the HIP training graph, then the no-grad inference kernels must see the new weights (packed-weight
     caches are keyed on parameter versions)."""
