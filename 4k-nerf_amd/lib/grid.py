@@ -209,6 +209,22 @@ class DenseGrid(nn.Module):
         self.params_ready()
         return super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _apply(self, fn, *args, **kwargs):                 # .to() / .cpu() / .cuda() / .float(): copies of the parameter on the current stream
+        self.params_ready()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __deepcopy__(self, memo):                          # copy.deepcopy(model) clones the parameter on the current stream
+        self.params_ready()
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy
+        for k, v in self.__dict__.items():
+            if k in ('_k4_seed', '_k4_pending'):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def total_variation_seed_grad(self, wx, wy, wz):
         """Start computing the dense TV term of the CURRENT parameter values into a new buffer (side stream).  The next backward pass
         through this grid accumulates into it; ``finish_grad_seed`` after the backward pass covers a pass that never reached the grid."""

@@ -192,9 +192,13 @@ class K4SFTLayer(torch.autograd.Function):
     `acc` (None | [H, W, 32]): the layer's condition gradient is ADDED to it and None returned for `cond` (see _CondFan)."""
 
     @staticmethod
-    def forward(ctx, x, cond, acc, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h):
+    def forward(ctx, x, cond, acc, *params):
         if not x.is_cuda:
             raise N.K4Error('K4SFTLayer: the MI355X-native decoder has no CPU path')
+        ctx.direct = None
+        if len(params) == 1 and isinstance(params[0], (list, tuple)):      # direct mode, as K4RDB
+            ctx.direct = params = list(params[0])
+        w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h = params
         x, cond = x.contiguous().float(), cond.contiguous().float()
         H, W, C = x.shape
         assert cond.shape == (H, W, 32) and w0s.shape[:2] == (32, 32) and w1s.shape[:2] == (C, 32)
@@ -225,6 +229,9 @@ class K4SFTLayer(torch.autograd.Function):
         N.check(L.k4_sft_train_bwd_ex(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
                                       N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
                                       N.f32(ws), nbytes, None, 0, int(acc is not None), 0, N.stream()), 'k4_sft_train_bwd_ex')
+        if ctx.direct is not None:
+            _hand_over_grads(ctx.direct, g)
+            return gx, None if acc is not None else gc, None, None
         return (gx, None if acc is not None else gc, None, *g)
 
 
@@ -246,6 +253,7 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
 _NATIVE_RDB = os.environ.get('K4_TRAIN_NATIVE_RDB', '1') != '0'      # 0: a dense block's launches issued one by one from Python (A/B)
 _WGRAD_STREAM = os.environ.get('K4_TRAIN_WGRAD_STREAM', '1') != '0'   # 0: the block's weight gradients on the chain's own stream (A/B)
 _FUSED_LRELU = os.environ.get('K4_TRAIN_FUSED_LRELU', '1') != '0'    # 0: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
+_DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = os.environ.get('K4_TRAIN_COND_ACC', '1') != '0'           # 0: every SFT consumer returns its condition gradient, autograd adds them (A/B)
 _SIDE_STREAMS = {}
 
@@ -259,6 +267,18 @@ def _side_stream(device):
     if st is None:
         st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return st.cuda_stream
+
+
+def _hand_over_grads(params, grads):
+    """Direct mode of the fused Functions (K4_TRAIN_DIRECT_GRADS, see forward_train): the parameter gradients go to ``.grad`` here instead of
+    through 26 (8) AccumulateGrad nodes per Function -- what those do for a leaf: assign when there is no gradient yet, add otherwise."""
+    for prm, g in zip(params, grads):
+        if g is None or not prm.requires_grad:
+            continue
+        if prm.grad is None:
+            prm.grad = g
+        else:
+            prm.grad.add_(g)
 
 
 def _check_acc(acc):
@@ -321,6 +341,9 @@ class K4RDB(torch.autograd.Function):
         if not t.is_cuda:
             raise N.K4Error('K4RDB: the MI355X-native decoder has no CPU path')
         L = N.lib()
+        ctx.direct = None
+        if len(P) == 1 and isinstance(P[0], (list, tuple)):       # direct mode: the 26 parameters as ONE opaque argument (no autograd edges to them)
+            ctx.direct = P = list(P[0])
         t, c = t.contiguous(), c.contiguous()
         H, W, nf = t.shape
         g = P[8].shape[0]
@@ -342,7 +365,11 @@ class K4RDB(torch.autograd.Function):
                 assert pk.mode == 'bf16x6' and pk.k == 3 and pk.flags_extra == 0
                 d.w_fwd[k], d.b_fwd[k] = pk.w.data_ptr(), pk.b.data_ptr()
             N.check(L.k4_rdb_train_fwd(N.C.byref(d), N.stream()), 'k4_rdb_train_fwd')
-            ctx.save_for_backward(t, c, buf, x4, *P)
+            if ctx.direct is not None:
+                ctx.save_for_backward(t, c, buf, x4)
+                ctx.P = P
+            else:
+                ctx.save_for_backward(t, c, buf, x4, *P)
             ctx.cache, ctx.desc = cache, d                # the backward fills in its own fields of the same descriptor
             return out
         N.check(L.k4_sft_train_fwd(N.f32(t), nf, N.f32(c), 32, n, nf, *[N.f32(q) for q in P[0:8]], 0.2, N.f32(buf), bw, N.stream()), 'k4_sft_train_fwd')
@@ -352,7 +379,11 @@ class K4RDB(torch.autograd.Function):
         N.check(L.k4_sft_train_fwd(N.f32(x4), g, N.f32(c), 32, n, g, *[N.f32(q) for q in P[18:26]], 0.2,
                                    N.C.c_void_p(buf.data_ptr() + 4 * (nf + 3 * g)), bw, N.stream()), 'k4_sft_train_fwd')
         SFTNet._conv(cache.fwd(P[16], P[17]), buf, 0, bw, out, 0, nf, nf, H, W, flags=EPI_RES, res=(t, 0, nf, 0.2))
-        ctx.save_for_backward(t, c, buf, x4, *P)
+        if ctx.direct is not None:
+            ctx.save_for_backward(t, c, buf, x4)
+            ctx.P = P
+        else:
+            ctx.save_for_backward(t, c, buf, x4, *P)
         ctx.cache = cache
         return out
 
@@ -360,7 +391,7 @@ class K4RDB(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, go):
         t, c, buf, x4 = ctx.saved_tensors[:4]
-        P = ctx.saved_tensors[4:]
+        P = ctx.P if ctx.direct is not None else ctx.saved_tensors[4:]
         cache, acc = ctx.cache, ctx.acc
         _check_acc(acc)
         H, W, nf = t.shape
@@ -404,6 +435,9 @@ class K4RDB(torch.autograd.Function):
             N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
             gt = scr[:n * nf].view(H, W, nf)                                          # = go + the gradient through sft0 (added in the kernel's store)
             gc = None if acc is not None else (scr[soff[6]:soff[7]] + scr[soff[7]:soff[8]]).view(H, W, 32)
+            if ctx.direct is not None:
+                _hand_over_grads(ctx.direct, grads)
+                return gt, gc, None, None, None
             return (gt, gc, None, None, *grads)
 
         G = torch.empty([H, W, bw], dtype=torch.float32, device=t.device)
@@ -432,6 +466,9 @@ class K4RDB(torch.autograd.Function):
         if acc is not None:
             acc.add_(gc)
             gc = None
+        if ctx.direct is not None:
+            _hand_over_grads(ctx.direct, grads)
+            return gt, gc, None, None, None
         return (gt, gc, None, None, *grads)
 
 
@@ -469,6 +506,10 @@ def forward_train(net, x, cond):
     c = conv(cn[6], conv(cn[4], conv(cn[2], conv(cn[0], ci, True), True), True))
     # the fused SFT layers / dense blocks add their condition gradients into one buffer inside their kernels (see _CondFan)
     acc = torch.zeros_like(c) if fused and _COND_ACC and c.requires_grad and c.shape[2] == 32 else None
+    # direct mode: the fused Functions take their parameters as one opaque list and write ``.grad`` themselves (no autograd edges to 438 of
+    # the decoder's 458 parameter tensors: ~1.5 ms of host time per iteration in Function.apply and AccumulateGrad).  loss.backward() sees no
+    # difference; torch.autograd.grad(..., params), parameter hooks and graph capture need the edges: K4_TRAIN_DIRECT_GRADS=0 / automatic.
+    direct = fused and _DIRECT_GRADS and feat.requires_grad and not torch.cuda.is_current_stream_capturing()
     if acc is not None:
         c = _CondFan.apply(c, acc)
 
@@ -478,6 +519,8 @@ def forward_train(net, x, cond):
 
     def sft(layer, t):                                                        # lib/sr_esrnet.py:120-123
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32:
+            if direct and t.requires_grad:
+                return K4SFTLayer.apply(t, c, acc, list(sft_params(layer)))
             return K4SFTLayer.apply(t, c, acc, *sft_params(layer))
         scale = conv(layer.SFT_scale_conv1, lrelu(conv(layer.SFT_scale_conv0, c)))
         shift = conv(layer.SFT_shift_conv1, lrelu(conv(layer.SFT_shift_conv0, c)))
@@ -486,6 +529,8 @@ def forward_train(net, x, cond):
     def rdb(blk, t):                                                          # lib/sr_esrnet.py:149-158
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32 and blk.conv1.weight.shape[0] == 32:
             convs = [q for m in (blk.conv1, blk.conv2, blk.conv3, blk.conv4, blk.conv5) for q in (m.weight, m.bias)]
+            if direct and t.requires_grad:
+                return K4RDB.apply(t, c, cache, acc, [*sft_params(blk.sft0), *convs, *sft_params(blk.sft1)])
             return K4RDB.apply(t, c, cache, acc, *sft_params(blk.sft0), *convs, *sft_params(blk.sft1))
         xc0 = sft(blk.sft0, t)
         x1 = lrelu(conv(blk.conv1, xc0))

@@ -799,7 +799,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     n_samples = int(rr['weights'].numel())
-    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 23.7 ms against 16.8 eager (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 3)',
+    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 17.2 ms against 11.2-11.3 eager on the same box (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 5; 23.7 against 16.8 in round 3)',
             'rays_per_iteration': pr * pc,
             'shaded_samples': n_samples, 'first_loss': round(first, 5),
             'breakdown_ms': {'forward (march train + SFTNet + losses)': round((t1 - t0) * 1e3, 2), 'backward': round((t2 - t1) * 1e3, 2),

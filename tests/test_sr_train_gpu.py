@@ -118,6 +118,34 @@ def test_condition_gradient_accumulator_equals_the_autograd_sums_and_refuses_a_s
         loss.backward()
 
 
+def test_direct_parameter_gradients_equal_the_autograd_edges(monkeypatch):
+    """forward_train's direct mode: the fused Functions (dense blocks, SFT layers) take their parameters as one opaque list and write ``.grad``
+    themselves instead of returning 26 (8) gradients to as many AccumulateGrad nodes.  Against K4_TRAIN_DIRECT_GRADS=0 (every parameter an
+    autograd input): same gradients after one backward pass, after a SECOND pass accumulated on top (``.grad`` is added to, as a leaf's
+    accumulator does), and a frozen parameter gets none in either."""
+    sd = osr.make_state_dict(seed=13, num_block=1)
+    g = torch.Generator().manual_seed(6)
+    x0, c0 = torch.rand([1, 3, 16, 24], generator=g).cuda(), torch.rand([1, 1, 16, 24], generator=g).cuda()
+    tgt = torch.rand([1, 3, 64, 96], generator=g).cuda()
+
+    def run(direct):
+        monkeypatch.setattr(sr_train, '_DIRECT_GRADS', direct)
+        net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        frozen = net.body[0].rdb2.conv3.weight
+        frozen.requires_grad_(False)
+        x = x0.clone().requires_grad_(True)
+        for _ in range(2):                                          # no zero_grad in between: the second pass accumulates
+            F.l1_loss(net(x, c0), tgt).backward()
+        assert frozen.grad is None
+        return [x.grad] + [p.grad for p in net.parameters() if p.requires_grad]
+    on, off = run(True), run(False)
+    monkeypatch.setattr(sr_train, '_DIRECT_GRADS', True)
+    assert len(on) == len(off) and all(a is not None for a in on)
+    assert max(_rel(a, b) for a, b in zip(on, off)) <= 5e-6        # (weight gradients: split-K atomics)
+
+
 def test_dense_block_backward_with_folded_leaky_relu_is_bit_identical(monkeypatch):
     """k4_rdb_train_bwd with fused_lrelu: the block's four LeakyReLU backward passes run in the epilogues of the launches in front of them
     (K4_EPI_LRELU_BWD in three dgrad accumulations, grad_x_lrelu in sft1's backward) instead of as k4_lrelu_bwd launches.  Same
