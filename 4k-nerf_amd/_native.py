@@ -178,11 +178,12 @@ _EXTRA_SIGS = {
     'k4_rgbnet_bwd_workspace_bytes': ([_I64, _I32, _I32, _I32], C.c_int64),
     'k4_rgbnet_bwd': ([_P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'k4_sft_train_fwd': ([_P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I32, _P], C.c_int),
+    'k4_sft_train_fwd_ex': ([_P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I32, _P, _I32, _F, _P], C.c_int),
     'k4_sft_train_bwd_workspace_bytes': ([_I64, _I32], C.c_int64),
     'k4_sft_train_bwd': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                           _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     'k4_sft_train_bwd_ex': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
-                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _P], C.c_int),
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
 }
 

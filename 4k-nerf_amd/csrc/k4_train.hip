@@ -519,7 +519,8 @@ template <int C>
 __global__ __launch_bounds__(SFT_T) void k_sft_train_fwd(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride, int64_t n,
                                                        const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
                                                        const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h, const float* __restrict__ b1h,
-                                                       float slope, float* __restrict__ y, int y_stride) {
+                                                       float slope, float* __restrict__ y, int y_stride,
+                                                       const float* __restrict__ res, int res_stride, float res_scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const cs = smem;                       // [32][LS]
     float* const as = cs + SFT_G * TR_LS;         // [32][LS]
@@ -546,7 +547,12 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_fwd(const float* __restrict
         xs[(co + 1) * TR_LS + lane] = __fadd_rn(__fmul_rn(xs[(co + 1) * TR_LS + lane], s1 + 1.f), h1);   // two roundings, as the reference's ops
     }
     __syncthreads();
-    sft_store_tile(xs, y, base, y_stride, C, nv, t);
+    if (res) {                                             // y = sft(x) * res_scale + res: the RRDB's skip connection (lib/sr_esrnet.py:181), two roundings as the reference's two ops
+        for (int i = t; i < 64 * C; i += SFT_T) {
+            const int s = i / C, k = i - s * C;
+            if (s < nv) y[(base + s) * y_stride + k] = __fadd_rn(__fmul_rn(xs[k * TR_LS + s], res_scale), res[(base + s) * res_stride + k]);
+        }
+    } else sft_store_tile(xs, y, base, y_stride, C, nv, t);
 }
 
 template <int C>
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
                                                        const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
                                                        const float* __restrict__ w0h, const float* __restrict__ b0h, const float* __restrict__ w1h,
                                                        float slope, float* __restrict__ gxg, float* __restrict__ gcg, float* __restrict__ part,
-                                                       const float* __restrict__ gxa, int gxa_stride, int gc_acc, int gx_lrelu) {
+                                                       const float* __restrict__ gxa, int gxa_stride, int gc_acc, int gx_lrelu, float gy_scale) {
     typedef SftBwdLayout<C> L;
     constexpr int MAXB = L::MAXB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -615,7 +621,12 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
         const int nv = (n - base) < 64 ? (int)(n - base) : 64;
         sft_load_tile(cond, base, c_stride, SFT_G, nv, cs, t);
         sft_load_tile(x, base, x_stride, C, nv, gs, t);
-        sft_load_tile(gyg, base, gy_stride, C, nv, gy, t);
+        if (gy_scale != 1.f) {                             // the layer's output went through `* res_scale + res` (k4_sft_train_fwd_ex): gy = res_scale * incoming, one rounding
+            for (int i = t; i < 64 * C; i += SFT_T) {
+                const int s = i / C, k = i - s * C;
+                gy[k * TR_LS + s] = s < nv ? gyg[(base + s) * gy_stride + k] * gy_scale : 0.f;
+            }
+        } else sft_load_tile(gyg, base, gy_stride, C, nv, gy, t);
         if (t < 64) {
             const float one = t < nv ? 1.f : 0.f;
             cs[SFT_G * TR_LS + t] = one; as[SFT_G * TR_LS + t] = one; ah[SFT_G * TR_LS + t] = one;
@@ -775,32 +786,38 @@ extern "C" int64_t k4_sft_train_bwd_workspace_bytes(int64_t n_pix, int32_t chann
     return (int64_t)sft_bwd_grid(n_pix) * (channels == 64 ? SftBwdLayout<64>::N_PART : SftBwdLayout<32>::N_PART) * (int64_t)sizeof(float);
 }
 
-extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
-                                const float* w0s, const float* b0s, const float* w1s, const float* b1s,
-                                const float* w0h, const float* b0h, const float* w1h, const float* b1h,
-                                float slope, float* y, int32_t y_stride, void* stream) {
+extern "C" int k4_sft_train_fwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
+                                   const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                                   const float* w0h, const float* b0h, const float* w1h, const float* b1h,
+                                   float slope, float* y, int32_t y_stride, const float* res, int32_t res_stride, float res_scale, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
-    if (n_pix < 0 || x_stride < channels || y_stride < channels || cond_stride < SFT_G) return K4_ERR_BAD_ARG;
+    if (n_pix < 0 || x_stride < channels || y_stride < channels || cond_stride < SFT_G || (res && res_stride < channels)) return K4_ERR_BAD_ARG;
     if (!w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h || !b1h) return K4_ERR_BAD_ARG;
     if (n_pix == 0) return K4_OK;
     if (!x || !cond || !y) return K4_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((n_pix + 63) / 64)), block(SFT_T);
     const size_t lds = (size_t)(3 * SFT_G + channels) * TR_LS * sizeof(float);
-    if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
-    else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride);
+    if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
+    else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
     return k4_check_launch();
+}
+extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
+                                const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                                const float* w0h, const float* b0h, const float* w1h, const float* b1h,
+                                float slope, float* y, int32_t y_stride, void* stream) {
+    return k4_sft_train_fwd_ex(x, x_stride, cond, cond_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, nullptr, 0, 1.f, stream);
 }
 
 template <int C>
 static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, hipStream_t st) {
+                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, float gy_scale, hipStream_t st) {
     typedef SftBwdLayout<C> L;
     const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
     K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
     const int grid = sft_bwd_grid(n);
-    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc, gx_lrelu);
+    hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc, gx_lrelu, gy_scale);
     int rc = k4_check_launch();
     if (rc) return rc;
     const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
@@ -815,7 +832,7 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
                                    float slope, float* grad_x, float* grad_cond,
                                    float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                                    float* workspace, int64_t workspace_bytes,
-                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, void* stream) {
+                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
     if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
@@ -824,8 +841,8 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
     float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
     hipStream_t st = (hipStream_t)stream;
     const int acc = accumulate_grad_cond != 0;
-    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, st);
-    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, st);
+    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
+    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
 }
 extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                 int64_t n_pix, int32_t channels,
@@ -834,7 +851,7 @@ extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* c
                                 float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                                 float* workspace, int64_t workspace_bytes, void* stream) {
     return k4_sft_train_bwd_ex(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
-                               gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, nullptr, 0, 0, 0, stream);
+                               gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, nullptr, 0, 0, 0, 1.f, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -981,7 +998,7 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
     K4_RDB_TRY(k4_sft_train_bwd_ex(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                    0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
-                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, stream));
+                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, stream));
     if (!fl) K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
     K4_RDB_WGRAD(nf + 3 * g, p->gx4, g, g, 3);
     K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true, fl);                              // G[:, 0:nf+3g] += dgrad (+ the mask of x3's slice, its last 32 channels)
@@ -994,7 +1011,7 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
     K4_RDB_TRY(k4_sft_train_bwd_ex(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                    0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
-                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, stream));
+                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, stream));
 join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD

@@ -189,10 +189,12 @@ class K4SFTLayer(torch.autograd.Function):
     """SFTLayer (lib/sr_esrnet.py:112-123) of an NHWC image: ``x * (scale(cond) + 1) + shift(cond)`` with both 1x1-convolution pairs,
     LeakyReLU and the modulation in ONE launch forward (k4_sft_train_fwd) and two backward (k4_sft_train_bwd: grad_x, grad_cond, the
     eight weight / bias gradients).  As four K4Conv2d Functions + elementwise autograd a layer was ~45 launches per iteration.
-    `acc` (None | [H, W, 32]): the layer's condition gradient is ADDED to it and None returned for `cond` (see _CondFan)."""
+    `acc` (None | [H, W, 32]): the layer's condition gradient is ADDED to it and None returned for `cond` (see _CondFan).
+    `res` (None | [H, W, C]), `res_scale`: the layer's output goes through ``* res_scale + res`` in the forward kernel's store (the RRDB's
+    skip connection, lib/sr_esrnet.py:181: two elementwise launches less forward, one less backward; same roundings)."""
 
     @staticmethod
-    def forward(ctx, x, cond, acc, *params):
+    def forward(ctx, x, cond, acc, res, res_scale, *params):
         if not x.is_cuda:
             raise N.K4Error('K4SFTLayer: the MI355X-native decoder has no CPU path')
         ctx.direct = None
@@ -205,10 +207,15 @@ class K4SFTLayer(torch.autograd.Function):
         assert acc is None or (acc.shape == cond.shape and acc.is_contiguous() and acc.dtype == torch.float32)
         ws = [t.detach().contiguous() for t in (w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h)]
         y = torch.empty_like(x)
-        N.check(N.lib().k4_sft_train_fwd(N.f32(x), C, N.f32(cond), 32, H * W, C, *[N.f32(t) for t in ws], 0.2, N.f32(y), C, N.stream()),
-                'k4_sft_train_fwd')
+        if res is not None:
+            res = res.contiguous().float()
+            assert res.shape == x.shape
+        N.check(N.lib().k4_sft_train_fwd_ex(N.f32(x), C, N.f32(cond), 32, H * W, C, *[N.f32(t) for t in ws], 0.2, N.f32(y), C,
+                                            None if res is None else N.f32(res), C, float(res_scale), N.stream()), 'k4_sft_train_fwd_ex')
         ctx.save_for_backward(x, cond, *ws)
         ctx.acc = acc
+        ctx.gy_scale = float(res_scale) if res is not None else 1.0
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -228,11 +235,12 @@ class K4SFTLayer(torch.autograd.Function):
         ws = torch.empty([nbytes // 4], dtype=torch.float32, device=x.device)
         N.check(L.k4_sft_train_bwd_ex(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, N.f32(w0s), N.f32(b0s), N.f32(w1s), N.f32(b1s),
                                       N.f32(w0h), N.f32(b0h), N.f32(w1h), 0.2, N.f32(gx), N.f32(gc), *[N.f32(t) for t in g],
-                                      N.f32(ws), nbytes, None, 0, int(acc is not None), 0, N.stream()), 'k4_sft_train_bwd_ex')
+                                      N.f32(ws), nbytes, None, 0, int(acc is not None), 0, ctx.gy_scale, N.stream()), 'k4_sft_train_bwd_ex')
+        g_res = gy if ctx.has_res else None                # the skip connection's gradient is the incoming one itself
         if ctx.direct is not None:
             _hand_over_grads(ctx.direct, g)
-            return gx, None if acc is not None else gc, None, None
-        return (gx, None if acc is not None else gc, None, *g)
+            return gx, None if acc is not None else gc, None, g_res, None, None
+        return (gx, None if acc is not None else gc, None, g_res, None, *g)
 
 
 def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
@@ -517,14 +525,15 @@ def forward_train(net, x, cond):
         return (layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
                 layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias)
 
-    def sft(layer, t):                                                        # lib/sr_esrnet.py:120-123
+    def sft(layer, t, res=None, res_scale=1.0):                                # lib/sr_esrnet.py:120-123 (+ `* res_scale + res` when given)
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32:
             if direct and t.requires_grad:
-                return K4SFTLayer.apply(t, c, acc, list(sft_params(layer)))
-            return K4SFTLayer.apply(t, c, acc, *sft_params(layer))
+                return K4SFTLayer.apply(t, c, acc, res, res_scale, list(sft_params(layer)))
+            return K4SFTLayer.apply(t, c, acc, res, res_scale, *sft_params(layer))
         scale = conv(layer.SFT_scale_conv1, lrelu(conv(layer.SFT_scale_conv0, c)))
         shift = conv(layer.SFT_shift_conv1, lrelu(conv(layer.SFT_shift_conv0, c)))
-        return t * (scale + 1) + shift
+        y = t * (scale + 1) + shift
+        return y if res is None else y * res_scale + res
 
     def rdb(blk, t):                                                          # lib/sr_esrnet.py:149-158
         if fused and t.shape[2] in (32, 64) and c.shape[2] == 32 and blk.conv1.weight.shape[0] == 32:
@@ -551,7 +560,7 @@ def forward_train(net, x, cond):
             return o
     for rr in net.body:                                                       # lib/sr_esrnet.py:176-182
         out = rdb(rr.rdb3, rdb(rr.rdb2, rdb(rr.rdb1, body)))
-        body = sft(rr.sft0, out) * 0.2 + body
+        body = sft(rr.sft0, out, body, 0.2)                                   # lib/sr_esrnet.py:181: out * 0.2 + x
     body = conv(net.conv_body, sft(net.sftbody, body)) + feat
     if net.scale > 1:
         body = conv(net.conv_up1, _up2(body), True)

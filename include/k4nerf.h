@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -579,6 +579,12 @@ int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_
                      const float* w0s, const float* b0s, const float* w1s, const float* b1s,
                      const float* w0h, const float* b0h, const float* w1h, const float* b1h,
                      float slope, float* y, int32_t y_stride, void* stream);
+/* ... followed by the RRDB's skip connection in the store: y = sft(x) * res_scale + res ([n_pix][res_stride] rows; NULL = plain), two roundings as the
+ * reference's two ops (lib/sr_esrnet.py:181).  Its backward: k4_sft_train_bwd_ex with grad_y_scale = res_scale (the skip's own gradient is grad_y itself). */
+int k4_sft_train_fwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
+                        const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                        const float* w0h, const float* b0h, const float* w1h, const float* b1h,
+                        float slope, float* y, int32_t y_stride, const float* res, int32_t res_stride, float res_scale, void* stream);
 int64_t k4_sft_train_bwd_workspace_bytes(int64_t n_pix, int32_t channels);       /* < 0: unsupported channel count */
 int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                      int64_t n_pix, int32_t channels,
@@ -589,14 +595,15 @@ int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_
 /* The same with the two sums the training graph puts right behind it folded into the stores: grad_x = the layer's gradient + grad_x_add
  * ([n_pix][gxa_stride] rows; NULL = none) and, with accumulate_grad_cond != 0, grad_cond += the layer's gradient (the caller zeroes it once per
  * backward pass: every SFT layer of the decoder reads the same condition map).  grad_x_lrelu != 0: x is the OUTPUT of a LeakyReLU(slope) and
- * grad_x is the gradient in front of it: grad_x *= (x > 0 ? 1 : slope) (k4_lrelu_bwd folded in; before grad_x_add). */
+ * grad_x is the gradient in front of it: grad_x *= (x > 0 ? 1 : slope) (k4_lrelu_bwd folded in; before grad_x_add).  grad_y_scale: grad_y is multiplied by it as it is
+ * read (1 = as is). */
 int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                         int64_t n_pix, int32_t channels,
                         const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
                         float slope, float* grad_x, float* grad_cond,
                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                         float* workspace, int64_t workspace_bytes,
-                        const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, void* stream);
+                        const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -244,7 +244,7 @@ def test_fused_sft_layer_function_matches_torch_autograd(C, H, W, use_acc):
           layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias]
     acc0 = torch.randn([H, W, 32], generator=g).cuda() if use_acc else None
     acc = acc0.clone() if use_acc else None
-    y = sr_train.K4SFTLayer.apply(x, c, acc, *ps)
+    y = sr_train.K4SFTLayer.apply(x, c, acc, None, 1.0, *ps)
     y.backward(gy)
     if use_acc:
         assert c.grad is None                                       # handed to the accumulator instead
@@ -265,9 +265,35 @@ def test_fused_sft_layer_function_matches_torch_autograd(C, H, W, use_acc):
     for p in ps:
         p.grad = None
     x.grad = c.grad = None
-    sr_train.K4SFTLayer.apply(x, c, acc0.clone() if use_acc else None, *ps).backward(gy)
+    sr_train.K4SFTLayer.apply(x, c, acc0.clone() if use_acc else None, None, 1.0, *ps).backward(gy)
     for a, p in zip(got[3:], ps):
         assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize('C,H,W', [(64, 21, 30), (32, 64, 64)])
+def test_sft_layer_with_folded_skip_connection_is_bit_identical(C, H, W):
+    """K4SFTLayer(res, res_scale): the RRDB's ``sft(out) * 0.2 + x`` (lib/sr_esrnet.py:181) in the forward kernel's store and the 0.2 on the
+    incoming gradient as the backward kernel reads it, against the same layer followed by the two elementwise ops: every output and gradient
+    bit-identical (no atomics anywhere on this path)."""
+    g = torch.Generator().manual_seed(3 * C + H)
+    layer = sr_esrnet.SFTLayer(C, 32)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.4)
+    layer = layer.cuda()
+    ps = [layer.SFT_scale_conv0.weight, layer.SFT_scale_conv0.bias, layer.SFT_scale_conv1.weight, layer.SFT_scale_conv1.bias,
+          layer.SFT_shift_conv0.weight, layer.SFT_shift_conv0.bias, layer.SFT_shift_conv1.weight, layer.SFT_shift_conv1.bias]
+    x0, c0, r0 = (torch.randn([H, W, k], generator=g).cuda() for k in (C, 32, C))
+    gy = torch.randn([H, W, C], generator=g).cuda()
+    res = []
+    for folded in (False, True):
+        layer.zero_grad(set_to_none=True)
+        x, c, r = (t.clone().requires_grad_(True) for t in (x0, c0, r0))
+        y = sr_train.K4SFTLayer.apply(x, c, None, r, 0.2, *ps) if folded else sr_train.K4SFTLayer.apply(x, c, None, None, 1.0, *ps) * 0.2 + r
+        y.backward(gy)
+        res.append([y.detach(), x.grad, c.grad, r.grad] + [p.grad.clone() for p in ps])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('cin,cout,H,W', [(64, 64, 17, 23), (3, 64, 12, 9), (64, 32, 8, 40)])
