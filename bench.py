@@ -693,7 +693,9 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
             ('adam_upd', lambda: MA.adam_upd(p, g, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 28.0),
             ('masked_adam_upd_1pct', lambda: MA.masked_adam_upd(p, gs, m, v, 3, 0.9, 0.99, 1e-3, 1e-8), 4.0 + 24.0 * frac_touched),
             ('tv_add_grad_dense', lambda: G.total_variation_add_grad(p, g, 1e-3, 1e-3, 1e-3, True), 12.0),
-            ('tv_add_grad_sparse_1pct', lambda: G.total_variation_add_grad(p, gs, 1e-3, 1e-3, 1e-3, False), 4.0 + 8.0 * frac_touched)):
+            ('tv_add_grad_sparse_1pct', lambda: G.total_variation_add_grad(p, gs, 1e-3, 1e-3, 1e-3, False), 4.0 + 8.0 * frac_touched),
+            # the dense term WRITTEN (dense_mode 2: param read, grad written, no zero-fill in front): what the joint loop runs ahead of the backward pass
+            ('tv_term_written_dense', lambda: G.total_variation_add_grad(p, g, 1e-3, 1e-3, 1e-3, 'write'), 8.0)):
         ms = timed(fn)
         gbs = n * bpe / (ms * 1e-3) / 1e9
         out[name] = {'ms': round(ms, 3), 'B_per_voxel': round(bpe, 2), 'GBs': round(gbs, 1), 'frac_hbm': round(gbs / HBM_PEAK_GBS, 3)}
