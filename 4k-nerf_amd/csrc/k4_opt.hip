@@ -10,6 +10,7 @@
 // Arithmetic follows the reference op for op (same association; a*b+c written as fmaf where nvcc contracts it).
 #include "k4_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define K4_OPT_THREADS 256
 
@@ -177,25 +178,51 @@ __device__ __forceinline__ float k4_clamp1(float x) { return fminf(fmaxf(x, -1.f
 
 // One thread = 4 consecutive k (needs sz_k % 4 == 0 and 16-byte aligned bases).  The +-1 neighbours along k are the
 // adjacent lanes' values except at the two ends of the 4-group, fetched as scalars (same cache lines).
+// The gradient is streamed (read once, written once).  K4_TV_NT=1: non-temporal accesses for it (so that it does not evict the parameter planes the stencil
+// re-reads from L2) -- measured neutral on the dense sweeps (1.229 / 1.237 ms), -6 % on the sparse one; off.
+#ifndef K4_TV_NT
+#define K4_TV_NT 0
+#endif
+typedef float k4_tv_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 k4_tv_ld4(const float* p) {
+#if K4_TV_NT
+    const k4_tv_f4 v = __builtin_nontemporal_load(reinterpret_cast<const k4_tv_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void k4_tv_st4(float* p, const float4& g) {
+#if K4_TV_NT
+    const k4_tv_f4 v = {g.x, g.y, g.z, g.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<k4_tv_f4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = g;
+#endif
+}
 // MODE 0: only where grad != 0 (sparse), 1: everywhere (dense), 2: dense and grad is OVERWRITTEN with the TV term (not read): the term
 // computed before the backward pass into the buffer the lookups' backward then accumulates into (lib/grid.py total_variation_seed_grad) --
 // 8 bytes per voxel instead of 4 (zero-fill) + 12, and off the tail of the training iteration.  0 + term == term: same values.
-template <int MODE>
+// IDX = unsigned for tensors below 2^31 elements: the voxel coordinates cost three 32-bit divisions per thread instead of five 64-bit ones -- which, not
+// memory, bounded the first form (the LLFF k0 sweep: 1.23 ms at 12 B / voxel = 0.55 of HBM peak with ~600 integer instructions per thread in front of 8 memory
+// instructions).
+template <int MODE, typename IDX>
 __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* __restrict__ param, float* __restrict__ grad,
-                                                                   float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
-                                                                   int64_t sz_k, int64_t n4) {
+                                                                   float wx, float wy, float wz, int64_t sz_i_, int64_t sz_j_,
+                                                                   int64_t sz_k_, int64_t n4) {
     const int b = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int64_t t = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
-    if (t >= n4) return;
-    const int64_t index = t * 4;
+    const IDX t = (IDX)b * K4_OPT_THREADS + threadIdx.x;
+    if ((int64_t)t >= n4) return;
+    const IDX index = t * 4;
     constexpr bool DENSE = MODE != 0;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE != 2) g = *(const float4*)(grad + index);
+    if (MODE != 2) g = k4_tv_ld4(grad + index);
     if (!DENSE && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
-    const int64_t k = index % sz_k;
-    const int64_t j = index / sz_k % sz_j;
-    const int64_t i = index / sz_k / sz_j % sz_i;
-    const int64_t sj = sz_k, si = sz_k * sz_j;
+    const IDX sz_i = (IDX)sz_i_, sz_j = (IDX)sz_j_, sz_k = (IDX)sz_k_;
+    const IDX row = index / sz_k, k = index - row * sz_k;      // row = (c * sz_i + i) * sz_j + j
+    const IDX pl = row / sz_j, j = row - pl * sz_j;
+    const IDX i = pl % sz_i;
+    const IDX sj = sz_k, si = sz_k * sz_j;
     const float4 c = *(const float4*)(param + index);
     const float cv[4] = {c.x, c.y, c.z, c.w};
     float add[4] = {0.f, 0.f, 0.f, 0.f};
@@ -234,23 +261,24 @@ __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_vec_kernel(const float* 
     if (DENSE || g.y != 0.f) g.y += add[1];
     if (DENSE || g.z != 0.f) g.z += add[2];
     if (DENSE || g.w != 0.f) g.w += add[3];
-    *(float4*)(grad + index) = g;
+    k4_tv_st4(grad + index, g);
 }
 
-template <int MODE>
+template <int MODE, typename IDX>
 __global__ __launch_bounds__(K4_OPT_THREADS) void k4_tv_scalar_kernel(const float* __restrict__ param, float* __restrict__ grad,
-                                                                      float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
-                                                                      int64_t sz_k, int64_t n) {
+                                                                      float wx, float wy, float wz, int64_t sz_i_, int64_t sz_j_,
+                                                                      int64_t sz_k_, int64_t n) {
     const int b = k4_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int64_t index = (int64_t)b * K4_OPT_THREADS + threadIdx.x;
-    if (index >= n) return;
+    const IDX index = (IDX)b * K4_OPT_THREADS + threadIdx.x;
+    if ((int64_t)index >= n) return;
     constexpr bool DENSE = MODE != 0;
     const float g = MODE == 2 ? 0.f : grad[index];
     if (!DENSE && g == 0.f) return;
-    const int64_t k = index % sz_k;
-    const int64_t j = index / sz_k % sz_j;
-    const int64_t i = index / sz_k / sz_j % sz_i;
-    const int64_t sj = sz_k, si = sz_k * sz_j;
+    const IDX sz_i = (IDX)sz_i_, sz_j = (IDX)sz_j_, sz_k = (IDX)sz_k_;
+    const IDX row = index / sz_k, k = index - row * sz_k;
+    const IDX pl = row / sz_j, j = row - pl * sz_j;
+    const IDX i = pl % sz_i;
+    const IDX sj = sz_k, si = sz_k * sz_j;
     const float c = param[index];
     float add = 0.f;
     if (k != 0) add = fmaf(wx, k4_clamp1(c - param[index - 1]), add);
@@ -273,12 +301,15 @@ extern "C" int k4_total_variation_add_grad(const float* param, float* grad, floa
     const int64_t units = vec ? n / 4 : n;
     const int64_t blocks = (units + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
     if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
-#define K4_TV_LAUNCH(KERNEL) do { \
-        if (dense_mode == 2) hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
-        else if (dense_mode) hipLaunchKernelGGL(KERNEL<1>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
-        else hipLaunchKernelGGL(KERNEL<0>, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); } while (0)
+    const bool small = n + 4 * K4_OPT_THREADS < 0x7fffffffLL;            // every index the kernel forms (incl. the last block's overhang) fits 31 bits
+#define K4_TV_LAUNCH_I(KERNEL, IDX) do { \
+        if (dense_mode == 2) hipLaunchKernelGGL((KERNEL<2, IDX>), dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
+        else if (dense_mode) hipLaunchKernelGGL((KERNEL<1, IDX>), dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); \
+        else hipLaunchKernelGGL((KERNEL<0, IDX>), dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, st, param, grad, wx, wy, wz, sz_i, sz_j, sz_k, units); } while (0)
+#define K4_TV_LAUNCH(KERNEL) do { if (small) K4_TV_LAUNCH_I(KERNEL, unsigned); else K4_TV_LAUNCH_I(KERNEL, int64_t); } while (0)
     if (vec) K4_TV_LAUNCH(k4_tv_vec_kernel);
     else K4_TV_LAUNCH(k4_tv_scalar_kernel);
 #undef K4_TV_LAUNCH
+#undef K4_TV_LAUNCH_I
     return k4_check_launch();
 }

@@ -3,6 +3,7 @@
 Tolerance: the kernels follow the reference's fp32 op order; the oracle emulates FMA through float64, which can differ
 from a true FMA by one rounding, and a parameter update p - num/den adds an ulp of p.  rtol 2e-6 / atol 1e-7 on
 moments, atol 2e-7 on parameters of magnitude ~1 (written at each check)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -110,7 +111,7 @@ def test_masked_adam_optimizer_trajectory_matches_oracle():
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 5, 6, 8), (1, 3, 4, 7, 5), (1, 2, 1, 3, 4), (1, 2, 9, 1, 12), (1, 1, 1, 1, 1),
-                                   (1, 12, 10, 11, 256)])
+                                   (1, 12, 10, 11, 256), (1, 3, 8, 5, 20), (1, 2, 9, 13, 128), (1, 2, 17, 9, 260)])
 @pytest.mark.parametrize('dense', [True, False])
 def test_total_variation_matches_oracle(shape, dense):
     rng = np.random.default_rng(sum(shape))
@@ -127,6 +128,19 @@ def test_total_variation_matches_oracle(shape, dense):
         z = g == 0
         assert np.array_equal(tg.cpu().numpy()[z], g[z])
     assert torch.equal(tp.cpu(), torch.from_numpy(p))
+
+
+@pytest.mark.parametrize('shape', [(1, 2, 9, 13, 128), (1, 3, 4, 7, 5), (1, 1, 8, 300, 260)])
+def test_written_dense_tv_term_is_the_added_one(shape):
+    """dense_mode 2 ('write': the term computed ahead of the backward pass, lib/grid.py total_variation_seed_grad) must produce exactly what
+    adding the term to zeros produces, whatever the buffer held before."""
+    g = torch.Generator().manual_seed(sum(shape))
+    p = (torch.randn(shape, generator=g) * 1.5).cuda()
+    w = torch.full(shape, 7.0, device='cuda')
+    G.total_variation_add_grad(p, w, 0.7, 1.3, 2.1, 'write')
+    z = torch.zeros(shape, device='cuda')
+    G.total_variation_add_grad(p, z, 0.7, 1.3, 2.1, True)
+    assert torch.equal(w, z)
 
 
 def test_dense_grid_and_model_tv_entry_points():
