@@ -763,12 +763,17 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     for i in range(2):                                                   # fast-path plan), allocator
         tr.step(*batch(1 + i), global_step=2 + i)
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    n_samples = 0
-    for i in range(iters):
-        tr.step(*batch(3 + i), global_step=4 + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / iters
+    # the iteration is paced by the host as much as by the GPU: blocks of iterations, the MEDIAN block is the figure, all of them are reported
+    n_samples, blocks, it = 0, [], 3
+    per_block = max(1, iters // 2)
+    for b in range(5):
+        t = time.perf_counter()
+        for i in range(per_block):
+            tr.step(*batch(it), global_step=it + 1)
+            it += 1
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t) / per_block)
+    dt = float(np.median(blocks))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -782,7 +787,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
                 'workload': f'configs[4] fern_lg_joint_l1, patch-parallel over {world} GPUs: one 64x64 patch per rank, decoder + small tensors in ONE '
                             'all-reduce bucket, voxel-grid gradients as (index, value) lists in ONE all-gather per grid (RCCL)'}
     # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
-    b = batch(19)
+    b = batch(it + 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with torch.enable_grad():
@@ -801,7 +806,9 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     n_samples = int(rr['weights'].numel())
-    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2), 'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 17.2 ms against 11.2-11.3 eager on the same box (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 5; 23.7 against 16.8 in round 3)',
+    return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2),
+            'ms_per_iteration_blocks': [round(v * 1e3, 2) for v in blocks], 'statistic': f'median of 5 blocks of {per_block} iterations after 3 warm-up iterations',
+            'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 17.2 ms against 11.2-11.3 eager on the same box (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 5; 23.7 against 16.8 in round 3)',
             'rays_per_iteration': pr * pc,
             'shaded_samples': n_samples, 'first_loss': round(first, 5),
             'breakdown_ms': {'forward (march train + SFTNet + losses)': round((t1 - t0) * 1e3, 2), 'backward': round((t2 - t1) * 1e3, 2),

@@ -25,6 +25,9 @@ for i in range(3):
     losses.append(float(tr.step(*batch(i), global_step=1 + i)['total']))
 torch.cuda.synchronize()
 n = int(os.environ.get('ITERS', '6'))
+if os.environ.get('K4_TOOL_NOGC') == '1':                               # diagnosis: are the slow blocks Python's cyclic garbage collector?
+    import gc
+    gc.collect(); gc.disable()
 blocks = []
 for b in range(int(os.environ.get('BLOCKS', '5'))):                  # the iteration is paced by the host: one block of 6 iterations is noisy from box to box
     t = time.perf_counter()
