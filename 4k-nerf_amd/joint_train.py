@@ -152,6 +152,12 @@ class JointTrainer:
         self._side_stream_updates()
         return self.optimizer
 
+    def _dense_tv_ahead(self, global_step):
+        """Write the dense TV term ahead of the backward pass?  Only while TV is dense, and only in a single-process job: under data parallelism (a group of
+        its own OR the default process group -- ``self.group`` is None for both that and no job at all) the exchange between backward and TV sends the
+        touched voxels, which a dense seed would make all of them (3.6 GB per rank instead of a few MB)."""
+        return _TV_SEED and _world(self.group) == 1 and global_step < self.cfg.tv_dense_before
+
     def _side_stream_updates(self):
         """The feature grid's optimizer step (1.9 ms of HBM time on the LLFF scene) on a second stream: the next iteration's sample selection
         reads the density grid only and no longer queues behind it; DenseGrid makes every reader of k0 wait (lib/grid.DenseGrid.params_ready)."""
@@ -209,7 +215,7 @@ class JointTrainer:
         # the grid lookups' backward accumulates into -- the same sum with a third of the memory traffic, and none of it at the end of the
         # iteration where the next iteration's sample selection waits (lib/grid.py total_variation_seed_grad).  Not under data parallelism:
         # the gradient exchange between backward and TV sends the TOUCHED voxels, which a dense seed would make all of them.
-        seed_tv = tv_now and _TV_SEED and self.group is None and global_step < cfg.tv_dense_before
+        seed_tv = tv_now and self._dense_tv_ahead(global_step)
         seeded = []
         if seed_tv:
             for weight, grid, fn in ((cfg.weight_tv_density, getattr(self.model, 'density', None), self.model.density_total_variation_add_grad),

@@ -258,3 +258,18 @@ def test_joint_loss_terms_equal_the_oracle_restatement():
     import pytest
     with pytest.raises(NotImplementedError):
         joint_train.JointTrainer(None, None, joint_train.JointCfg.fern_lg_joint_l1(weight_gan=0.1), {}, 1)
+
+
+def test_dense_tv_is_written_ahead_only_in_a_single_process_job(monkeypatch):
+    """JointTrainer._dense_tv_ahead: the dense TV term goes in front of the backward pass (lib/grid.py total_variation_seed_grad) only while TV is dense
+    and only without data parallelism -- also when the job runs on the DEFAULT process group (trainer.group is None): a seeded gradient touches every
+    voxel, and the touched-voxel exchange between backward and TV would then gather the whole grid."""
+    from nerf4k_amd import joint_train
+    tr = joint_train.JointTrainer.__new__(joint_train.JointTrainer)
+    tr.cfg, tr.group = joint_train.JointCfg.fern_lg_joint_l1(tv_dense_before=100), None
+    assert tr._dense_tv_ahead(5) and not tr._dense_tv_ahead(100)
+    monkeypatch.setattr(joint_train, '_world', lambda group: 2)
+    assert not tr._dense_tv_ahead(5)
+    monkeypatch.setattr(joint_train, '_world', lambda group: 1)
+    monkeypatch.setattr(joint_train, '_TV_SEED', False)
+    assert not tr._dense_tv_ahead(5)
