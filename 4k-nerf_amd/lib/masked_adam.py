@@ -119,6 +119,12 @@ class MaskedAdam(torch.optim.Optimizer):
         read of counts, density grid only) the host waits for.  No reference counterpart (one stream there); same values."""
         self._side[id(param)] = owner
 
+    def zero_grad(self, set_to_none=True):
+        # a gradient an update on the side stream may still be reading goes back to the current stream's allocator here: wait for that update first
+        for owner in self._side.values():
+            owner.params_ready()
+        return super().zero_grad(set_to_none=set_to_none)
+
     def set_pervoxel_lr(self, count):
         assert self.param_groups[0]['params'][0].shape == count.shape
         self.per_lr = (count.float() / count.max()).contiguous()
@@ -196,6 +202,8 @@ class MaskedAdam(torch.optim.Optimizer):
                     side.wait_stream(cur)                       # the gradient (and everything that read the old values) is done
                     # (no grad.record_stream: the owner's readers -- and JointTrainer before zero_grad -- make the current stream wait for this
                     # update, so the gradient's block returns to the allocator only after it; a recorded 1.4 GB block would sit in limbo)
+                    if grad is not param.grad:
+                        grad.record_stream(side)                # a contiguous COPY made above: a temporary the current stream's allocator would recycle
                     ctx = torch.cuda.stream(side)
                 else:
                     ctx = contextlib.nullcontext()
