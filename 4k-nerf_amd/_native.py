@@ -12,10 +12,10 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 11
+K4_ABI_VERSION = 12
 K4_ERR_UNSUPPORTED = 10002
 
-K0_CHANNEL_MAJOR, K0_CHANNEL_LAST, K0_BRICK4 = 0, 1, 2
+K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
 
 
 class GridDesc(C.Structure):
@@ -141,10 +141,6 @@ _EXTRA_SIGS = {
     'k4_conv2d_nhwc_bf16x6': ([_P, _I32, _I32, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, C.c_uint32, _F,
                                _P, _I32, _F, _P, _I32, _P], C.c_int),
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
-    'k4_march_workspace_bytes_pre': ([_I64, _I32, _I32], C.c_int64),
-    'k4_march_pre_supported': ([C.POINTER(GridDesc), C.POINTER(MlpDesc), _I32], C.c_int),
-    'k4_k0_brick4_floats': ([_I32, _I32, _I32, _I32], C.c_int64),
-    'k4_repack_k0_brick4': ([_P, _I32, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_grid_sample_3d_backward_workspace_bytes': ([_I32, _I32, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),

@@ -121,16 +121,12 @@ static inline int k4_check_launch() {
 // for kernel F") are cached in fixed arrays indexed by the HIP device ordinal; concurrent first calls write the same values.
 struct K4Env {
     int geom_skip;       // K4_GEOM_SKIP    (1) 0: do not use the coarse occupancy summary (A/B of the empty-space skipping)
-    int shade_grid_wg;   // K4_SHADE_GRID_WG    persistent shading workgroups per CU
     int debug;           // K4_DEBUG        (0) ablation bits of the marcher kernels, profiling only
     int sr_debug;        // K4_SR_DEBUG     (0) profiling bits of the decoder kernels (1: input channel stride 0 = no memory traffic, WRONG results; 2..16: phases of the 3x3 kernel off; 32: SFT layers on the unpipelined kernel)
-    int feat_minw;       // K4_FEAT_MINW    (4) register bound of the feature kernel (split shading path): 4 / 6 / 8 waves per SIMD
-    int shade_pre_grid_wg;   // K4_SHADE_PRE_GRID_WG  persistent workgroups per CU of the split path's shading kernel
-    int part_batches;    // K4_PART_BATCHES (0) > 0: bundles of more 64-record batches are shaded in parts of at most this many (measured neutral for the default shading kernel, +10 % for the split path: profiles/r05_marcher_split_path.md)
 };
 // Settled by measurement and no longer switchable (the evidence is in profiles/ and DESIGN.md): geometry kernel bounded for 5 waves per
-// SIMD (6 spilled), serpentine ray order inside an 8x8 tile, one row of workgroup tiles per XCD band, persistent shading grid sized in
-// whole workgroups per CU, small-launch tile rule of the 3x3 convolution on, 16-row tiles for the 3-term kernel and 8-row tiles for the
+// SIMD (6 spilled), serpentine ray order inside an 8x8 tile, one row of workgroup tiles per XCD band, persistent shading grid of 2 workgroups
+// per CU (K4_SHADE_WG_PER_CU, a compile-time constant), small-launch tile rule of the 3x3 convolution on, 16-row tiles for the 3-term kernel and 8-row tiles for the
 // 2-term (f16x3) kernel beyond it (8-row 37.1 ms per 4K frame, 12-row 39.3, 16-row 38.5-38.8).
 const K4Env& k4_env();
 #define K4_MAX_DEVICES 64

@@ -58,20 +58,12 @@ struct MarchParams {
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
-    int2* jobs;                                    // workspace: the shading queue, most batches first (k4_order_kernel): {bundle, part | parts << 16}
-    int* arrive;                                   // workspace: [n_bundles] parts of a split bundle that have published their sums (zeroed by k4_order_kernel)
-    int* slot_of;                                  // workspace: [n_bundles] first part-sum slot of a split bundle, -1: shaded by one wave (k4_order_kernel)
-    double* part_sums;                             // workspace: [part_slots][64][4] per-ray fp64 sums, one slot per part of a split bundle
-    int part_slots;
-    int part_batches;                              // bundles of more 64-record batches than this are shaded in parts (0: never)
+    int* jobs;                                     // workspace: the shading queue = bundle ids, most batches first (k4_order_kernel)
     int n_bundles;
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     int serp;               // 1: serpentine ray order inside a tile (default)
     int band_blocks;        // geometry kernel: blocks per XCD band (0: one contiguous band per XCD)
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
-    float* feat;            // feature area of the split shading path (k4_feat_kernel -> k4_shade_pre_kernel) or NULL: [bundle][batch][tile][half][32][8]
-    int feat_minw;          // K4_FEAT_MINW: register bound (waves per SIMD) of the feature kernel instantiation
-    unsigned bsx, bsy;      // K4_K0_BRICK4: voxel-index strides of a brick step along x / y (64 * bricks along y * along z, 64 * bricks along z)
 };
 
 template <int MODE>
@@ -666,13 +658,10 @@ typedef __bf16 k4_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float k4_f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Corner voxel indices and trilinear weights of a shaded sample, shared by the shading kernel and the feature kernel (one
-// expression tree -> identical bits).  The geometry kernel only records samples inside the bounding box (mask_outbbox,
+// Corner voxel indices and trilinear weights of a shaded sample, The geometry kernel only records samples inside the bounding box (mask_outbbox,
 // lib/dvgo.py:306-316), so the lower corner is a voxel and an upper corner leaves the grid only at the far faces: its axis
 // factor is zeroed there (grid_sample's zero padding; the same weights as testing the 8 corners one by one: zl*yl*0 == 0)
 // and its address offset dropped.  ~15 VALU instead of ~100 for the eight bounds tests.
-// K4_K0_BRICK4: voxel (x,y,z) lives at brick (x>>2,y>>2,z>>2), slot (x&3)*16 + (y&3)*4 + (z&3): the index is a sum of one
-// term per axis, so the 8 corners are 6 terms + 8 sums.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void k4_corner_setup(const MarchParams& P, float nx, float ny, float nz, unsigned (&cidx)[8], float (&cw)[8]) {
     const float ux = k4_unnorm(nx, P.X), uy = k4_unnorm(ny, P.Y), uz = k4_unnorm(nz, P.Z);
@@ -685,44 +674,11 @@ __device__ __forceinline__ void k4_corner_setup(const MarchParams& P, float nx, 
     cw[0] = zl * yl * xl; cw[1] = zh * yl * xl; cw[2] = zl * yh * xl; cw[3] = zh * yh * xl;
     cw[4] = zl * yl * xh; cw[5] = zh * yl * xh; cw[6] = zl * yh * xh; cw[7] = zh * yh * xh;
     const int xc = min(max(x0, 0), P.X - 1), yc = min(max(y0, 0), P.Y - 1), zc = min(max(z0, 0), P.Z - 1);   // never an out-of-range address
-    if (P.k0_layout == K4_K0_BRICK4) {
-        const int xd = hx ? xc + 1 : xc, yd = hy ? yc + 1 : yc, zd = hz ? zc + 1 : zc;
-        const unsigned ax0 = (unsigned)(xc >> 2) * P.bsx + (unsigned)(xc & 3) * 16u, ax1 = (unsigned)(xd >> 2) * P.bsx + (unsigned)(xd & 3) * 16u;
-        const unsigned ay0 = (unsigned)(yc >> 2) * P.bsy + (unsigned)(yc & 3) * 4u, ay1 = (unsigned)(yd >> 2) * P.bsy + (unsigned)(yd & 3) * 4u;
-        const unsigned az0 = (unsigned)(zc >> 2) * 64u + (unsigned)(zc & 3), az1 = (unsigned)(zd >> 2) * 64u + (unsigned)(zd & 3);
+    const unsigned base = (unsigned)(xc * P.Y + yc) * (unsigned)P.Z + (unsigned)zc;
+    const unsigned ox = hx ? (unsigned)(P.Y * P.Z) : 0u, oy = hy ? (unsigned)P.Z : 0u, oz = hz ? 1u : 0u;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) cidx[c] = (K4_CX(c) ? ax1 : ax0) + (K4_CY(c) ? ay1 : ay0) + (K4_CZ(c) ? az1 : az0);
-    } else {
-        const unsigned base = (unsigned)(xc * P.Y + yc) * (unsigned)P.Z + (unsigned)zc;
-        const unsigned ox = hx ? (unsigned)(P.Y * P.Z) : 0u, oy = hy ? (unsigned)P.Z : 0u, oz = hz ? 1u : 0u;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) cidx[c] = base + (K4_CX(c) ? ox : 0u) + (K4_CY(c) ? oy : 0u) + (K4_CZ(c) ? oz : 0u);
-    }
+    for (int c = 0; c < 8; ++c) cidx[c] = base + (K4_CX(c) ? ox : 0u) + (K4_CY(c) ? oy : 0u) + (K4_CZ(c) ? oz : 0u);
 }
-// 12 padded channels (rgbnet_dim 9..12), voxel-major k0: the 8 corners x 48 B are 24 independent 16-byte fetches, issued together
-// (one memory round trip); accumulation order per channel = corner order (v_pk_fma_f32: two channels per instruction)
-__device__ __forceinline__ void k4_gather12(const float* __restrict__ k0, const unsigned (&cidx)[8], const float (&cw)[8], float (&vv)[12]) {
-    float4 q[3][8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4* const src = reinterpret_cast<const float4*>(k0 + (size_t)cidx[c] * 12);
-        q[0][c] = src[0]; q[1][c] = src[1]; q[2][c] = src[2];
-    }
-#pragma unroll
-    for (int g4 = 0; g4 < 3; ++g4) {
-        k4_f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const k4_f32x2 ww = {cw[c], cw[c]};
-            const k4_f32x2 qa = {q[g4][c].x, q[g4][c].y}, qb = {q[g4][c].z, q[g4][c].w};
-            va = __builtin_elementwise_fma(qa, ww, va);
-            vb = __builtin_elementwise_fma(qb, ww, vb);
-        }
-        vv[g4 * 4 + 0] = va.x; vv[g4 * 4 + 1] = va.y; vv[g4 * 4 + 2] = vb.x; vv[g4 * 4 + 3] = vb.y;
-    }
-}
-
-
 __device__ __forceinline__ unsigned k4_pk_bf16(float lo, float hi) {               // v_cvt_pk_bf16_f32 (RNE)
     const k4_f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, k4_bf16x2));
@@ -802,8 +758,7 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
 // with a clear sign bit stays NaN as in torch.relu (fmaxf turned it into 0).  Not inline asm: the compiler must see the instruction
 // to insert the wait states between an MFMA writing a register and a vector instruction reading it.
 __device__ __forceinline__ float k4_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-// Where a tile's layer-1 input comes from: LdsFeat = the shading kernel's feat[K1P][64] image in LDS; GlobalFeat = the feature
-// area written by k4_feat_kernel in B-operand order (the split shading path), one tile requested ahead.
+// A tile's layer-1 input: the shading kernel's feat[K1P][64] image in LDS.
 struct LdsFeat {
     const float* feat; int k1p, l31, half;
     __device__ __forceinline__ void load(int kb, int t, float (&v)[8]) {
@@ -812,24 +767,6 @@ struct LdsFeat {
             const int k = kb * 16 + 8 * half + e;
             v[e] = k < k1p ? feat[k * 64 + t * 32 + l31] : 0.f;
         }
-    }
-};
-typedef float k4_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 k4_ld4_nt(const float4* p) {          // global_load_dwordx4 ... nt: read once, do not keep
-    const k4_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const k4_f32x4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-struct GlobalFeat {
-    const float4* p;        // this lane's two 16-byte units of the tile requested last
-    const float4* pend;     // ... of the bundle's last tile (requests past it re-read it)
-    float4 a, b;            // the tile requested last (in flight until load() consumes it)
-    int nofetch;            // K4_DEBUG & 256 (profiling): every tile computes on the bundle's first tile, no further fetches
-    __device__ __forceinline__ void load(int kb, int t, float (&v)[8]) {
-        (void)kb; (void)t;
-        asm volatile("" ::: "memory");     // the weight fragments stay in LDS: without a clobber LICM hoists the loop-invariant ds_reads of all three layers into registers
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        p = (p + 128 < pend) ? p + 128 : pend;             // 512 floats per 32-sample tile
-        if (!nofetch) { a = k4_ld4_nt(p); b = k4_ld4_nt(p + 1); }
     }
 };
 // LOWREG (the split path's 128-register shading kernel): layer 2 one 32-neuron output block at a time (16 accumulators live instead
@@ -1090,27 +1027,18 @@ __device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane,
 // of 64-record batches, descending -- the tail of the queue is then made of the lightest bundles.  One workgroup; the
 // shading results do not depend on the order (exact per-ray sums, independent bundles).
 // ------------------------------------------------------------------------------------------------------------------
-// Round 5: a bundle of more than `part_batches` batches is queued as several PARTS (equal runs of batches), each shaded by its own wave:
-// with one wave per bundle the heaviest bundles (30+ batches on the LLFF frames, against ~50 per wave on average) kept their waves busy
-// long after the queue was dry (mean wave lifetime 0.83 of the longest at 2 waves per SIMD, 0.61 at 4).  Per-ray sums are exact, so the
-// parts of a bundle can add theirs in any order (k4_finish_bundle).  Queue entry = {bundle, part | parts << 16}, sorted by the batches
-// of a part, descending.
-#define K4_ORDER_CLASSES 256     // parts of >= 255 batches share the first class
+#define K4_ORDER_CLASSES 256     // bundles of >= 255 batches share the first class
 #define K4_ORDER_SUB 16          // sub-bins per class (bundle id & 15): 16x fewer same-address LDS atomics -- most bundles fall in a few classes
-#define K4_PART_MIN 4            // smallest part_batches the workspace is sized for
 #define K4_QLEN 32               // qhead[K4_QLEN] = queue length: its own 128-byte line (the head word's line is busy with the queue's atomics)
 __device__ __forceinline__ int k4_batches_of(int count) { return (int)(((unsigned)max(count, 0) + 63u) >> 6); }
-template <bool PARTS>        // PARTS = false (part_batches == 0, the default): one job per bundle, the round-4 kernel's instruction stream
-__global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int2* __restrict__ jobs, int n_bundles, int* qhead, int part_batches,
-                                                        int* __restrict__ slot_of, int* __restrict__ arrive, int part_slots) {
+__global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int* __restrict__ jobs, int n_bundles, int* qhead) {
     constexpr int NBIN = K4_ORDER_CLASSES * K4_ORDER_SUB;            // 4096 = 4 per thread
     __shared__ int hist[NBIN];
     __shared__ int wsum[16];
-    __shared__ int slot_head;
     const int tid = (int)threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) hist[tid * 4 + i] = 0;
-    if (tid == 0) { qhead[0] = 0; slot_head = 0; }
+    if (tid == 0) qhead[0] = 0;
     __syncthreads();
     // class 0 = the most batches; any int is a valid key (the workspace may hold anything before its first use)
     // (16 counts per thread are fetched together: one memory round trip per 16384 bundles instead of one per 1024)
@@ -1122,20 +1050,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
             const int nbat = k4_batches_of(v[i]);
-            if constexpr (!PARTS) {
-                if (b < n_bundles) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
-                continue;
-            }
-            if (b >= n_bundles) continue;
-            int np = nbat > part_batches ? min((nbat + part_batches - 1) / part_batches, 32767) : 1;
-            int slot = -1;
-            if (np > 1) {                                            // a run of part-sum slots, while they last
-                slot = atomicAdd(&slot_head, np);
-                if (slot + np > part_slots) { slot = -1; np = 1; }
-            }
-            slot_of[b] = slot; arrive[b] = 0;
-            const int q = (nbat + np - 1) / np;                       // batches per part (the last part may hold fewer)
-            atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(q, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], np);
+            if (b < n_bundles) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
         }
     }
     __syncthreads();
@@ -1166,60 +1081,26 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
             const int nbat = k4_batches_of(v[i]);
-            if constexpr (!PARTS) {
-                if (b < n_bundles) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = make_int2(b, 1 << 16);
-                continue;
-            }
-            if (b >= n_bundles) continue;
-            const int np = slot_of[b] < 0 ? 1 : min((nbat + part_batches - 1) / part_batches, 32767);     // this thread's own decision of the first pass
-            const int q = (nbat + np - 1) / np;
-            const int pos = atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(q, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], np);
-            for (int pp = 0; pp < np; ++pp) jobs[pos + pp] = make_int2(b, pp | (np << 16));
+            if (b < n_bundles) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = b;
         }
     }
 }
 
-// A shading job: the records [rec0, rec1) of bundle `B` = part `part` of `nparts`.
-struct ShadeJob { Bundle B; int total, rec0, rec1, part, nparts; };
+// A shading job: every record of one bundle, taken from the queue k4_order_kernel wrote.
+struct ShadeJob { Bundle B; int total; };
 __device__ __forceinline__ bool k4_next_job(const MarchParams& P, int lane, ShadeJob& J) {
     int bid = 0;
     if (lane == 0) bid = atomicAdd(P.qhead, 1);
     bid = __builtin_amdgcn_readfirstlane(bid);
     if (bid >= __builtin_amdgcn_readfirstlane(P.qhead[K4_QLEN])) return false;
-    const int2 jb = P.jobs[bid];
-    const int bundle = __builtin_amdgcn_readfirstlane(jb.x), pw = __builtin_amdgcn_readfirstlane(jb.y);
+    const int bundle = __builtin_amdgcn_readfirstlane(P.jobs[bid]);
     J.B = bundle_from_id(P, bundle);
     J.total = __builtin_amdgcn_readfirstlane(P.counts[bundle]);
-    J.nparts = pw >> 16; J.part = pw & 0xffff;
-    const int nbat = k4_batches_of(J.total), q = (nbat + J.nparts - 1) / J.nparts;
-    J.rec0 = min(J.part * q * 64, J.total);
-    J.rec1 = J.nparts > 1 ? min(J.rec0 + q * 64, J.total) : J.total;
     return true;
 }
-// Per-ray outputs of a finished job: rgb_marched = sum + alphainv_last*bg (lib/dmpigo.py:397), depth.  A bundle shaded in parts: every
-// part publishes its fp64 sums in its own slot (system-scope stores: written through to memory, the per-XCD L2s are not coherent with
-// each other) and counts itself in with a device-scope atomic; the part that arrives last adds the slots up (system-scope loads) and
-// writes the outputs.  Every term was rounded to a multiple of 2^-40 and the sums stay below 2^12, so every addition is exact and the
-// total does not depend on how the bundle was cut: the same bits as one wave summing the whole bundle.
+// Per-ray outputs of a finished bundle: rgb_marched = sum + alphainv_last*bg (lib/dmpigo.py:397), depth.
 __device__ __forceinline__ void k4_finish_bundle(const MarchParams& P, const ShadeJob& J, const double* acc, int lane) {
-    double s0 = acc[lane * 4 + 0], s1 = acc[lane * 4 + 1], s2 = acc[lane * 4 + 2], s3 = acc[lane * 4 + 3];
-    if (J.nparts > 1) {
-        double* const base = P.part_sums + (size_t)__builtin_amdgcn_readfirstlane(P.slot_of[J.B.id]) * 256 + lane * 4;
-        double* const mine = base + (size_t)J.part * 256;
-        __hip_atomic_store(mine + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(mine + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(mine + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(mine + 3, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every lane's stores are acknowledged before this wave counts itself in
-        int prev = 0;
-        if (lane == 0) prev = __hip_atomic_fetch_add(P.arrive + J.B.id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        if (prev != J.nparts - 1) return;                              // not the last part
-        s0 = s1 = s2 = s3 = 0.;
-        for (int pp = 0; pp < J.nparts; ++pp) {
-            const double* const q = base + (size_t)pp * 256;
-            s0 += __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); s1 += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s2 += __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); s3 += __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    const double s0 = acc[lane * 4 + 0], s1 = acc[lane * 4 + 1], s2 = acc[lane * 4 + 2], s3 = acc[lane * 4 + 3];
     const int ray = ray_index(P, J.B, lane);
     if (ray >= 0) {
         const float ab = P.out_ainv[ray] * P.bg;
@@ -1265,7 +1146,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     const Bundle B = J.B;
     acc[lane * 4 + 0] = 0.; acc[lane * 4 + 1] = 0.; acc[lane * 4 + 2] = 0.; acc[lane * 4 + 3] = 0.;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-    const int total = J.rec1;                                            // this job's records: [J.rec0, J.rec1)
+    const int total = J.total;
     // the bundle's 64 rays live in registers, lane = ray slot; a record reads its ray's with ds_bpermute (__shfl).
     // One fetch round per bundle instead of a dependent one per 64-record batch (the batch loop was 59 % s_waitcnt:
     // record -> ray -> 3 rounds of corner fetches were five serial round trips; now the corner fetches are the only one)
@@ -1278,9 +1159,9 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
                         P.rays_d[ms * 3 + 0], P.rays_d[ms * 3 + 1], P.rays_d[ms * 3 + 2], my_sx, my_sy, my_sz, my_dx, my_dy, my_dz, nsteps_unused);
         my_vx = P.viewdirs[ms * 3 + 0]; my_vy = P.viewdirs[ms * 3 + 1]; my_vz = P.viewdirs[ms * 3 + 2];
     }
-    uint2 en_next = ent[J.rec0 + lane < total ? J.rec0 + lane : 0];
+    uint2 en_next = ent[lane < total ? lane : 0];
 
-    for (int base = J.rec0; base < total; base += 64) {
+    for (int base = 0; base < total; base += 64) {
         K4_TSTAMP(7);                                    // between batches: queue ticket, ray setup, per-ray outputs
         const int nproc = (total - base) < 64 ? (total - base) : 64;
         const bool lact = lane < nproc;
@@ -1477,181 +1358,6 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
 }
 
 
-// =====================================================================================================
-// Split shading path (round 5): K1.5 k4_feat_kernel + K2' k4_shade_pre_kernel
-// =====================================================================================================
-// k4_shade_kernel holds 24 16-byte corner fetches (96 registers), the corner arithmetic AND the MLP's accumulators in one wave:
-// 256 VGPRs, 2 waves per SIMD, and the L1 miss path of the gather is waited for by the waves that also own the matrix pipe
-// (profiles/r04_marcher_ta_tcp_pmc.md: L1 stalled on pending misses 45 % of the kernel).  Here the gather + trilinear blend runs in
-// its own launch at 4-8 waves per SIMD (lane = record) and writes every shaded record's COMPLETE layer-1 input -- k0 features,
-// position embedding, view direction, the constant 1 that carries the bias, zero padding: 16 floats -- into the feature area in
-// the MLP's B-operand order: per 64-record batch two 32-sample tiles of [half][32][8] floats, i.e. lane l of the shading wave reads
-// its 8 inputs of a tile as two consecutive 16-byte units at (tile*64 + l) * 32 B: fully coalesced, no LDS staging, no shuffles,
-// requested one tile ahead.  The shading kernel is then records + features -> MLP -> exact fp64 blend: no address arithmetic, no
-// ray table, ~128 VGPRs -> 4 waves per SIMD.  Same expression trees as k4_shade_kernel (k4_corner_setup, k4_gather12, mlp_mfma_b3)
-// -> bit-identical pixels (tests: torch.equal between the two paths).
-// Covered shapes: voxel-major k0 with 12 padded channels, no positional-encoding frequencies, no k0_skip, dim0 + 1 <= 16, rgbnet
-// width 32 / 64 on the split-bf16 arithmetic -- the LLFF configurations (BASELINE configs[1..4]); everything else keeps
-// k4_shade_kernel.  The feature area is worst-case sized like the record workspace (64 B per record slot) and sparsely touched;
-// the caller opts in by handing k4_march_*_fwd a workspace of k4_march_workspace_bytes_pre() bytes.
-// -----------------------------------------------------------------------------------------------------
-template <int MODE, int MINW>
-__global__ __launch_bounds__(256, MINW) void k4_feat_kernel(const MarchParams P) {
-    const int lane = k4_lane();
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bid = (int)blockIdx.x;
-    if (bid >= P.n_bundles) return;
-    const Bundle B = bundle_from_id(P, bid);
-    const int total = __builtin_amdgcn_readfirstlane(P.counts[B.id]);
-    const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-    float* const fb = P.feat + (size_t)B.id * ((size_t)(P.ent_stride >> 6) * 1024);
-    for (int base = wv * 64; base < total; base += 256) {
-        const int nproc = (total - base) < 64 ? (total - base) : 64;
-        const bool lact = lane < nproc;
-        const uint2 en = ent[base + (lact ? lane : 0)];
-        const int rl = (int)(en.x >> 24);
-        const int k = (int)(en.x & 0xffffffu);
-        const int ray = ray_index(P, B, rl);                            // a record's ray exists
-        const int rs = ray < 0 ? 0 : ray;
-        float sx, sy, sz, dx, dy, dz;
-        int nsteps_unused;
-        ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
-                        P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps_unused);
-        const float vd0 = P.viewdirs[rs * 3 + 0], vd1 = P.viewdirs[rs * 3 + 1], vd2 = P.viewdirs[rs * 3 + 2];
-        const float tk = step_t<MODE>(P, k);
-        const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
-        const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
-        const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
-        const float nz = k4_norm_coord_r(pz, P.minz, P.lenz, P.rlenz);
-        unsigned cidx[8];
-        float cw[8];
-        k4_corner_setup(P, nx, ny, nz, cidx, cw);
-        float vv[12];
-        if (P.debug & 1) {                                              // ablation: no corner fetches
-#pragma unroll
-            for (int i = 0; i < 12; ++i) vv[i] = cw[i & 7];
-        } else k4_gather12(P.k0, cidx, cw, vv);
-        // layer-1 input in the order of W1ext's columns.  MPI (C = 9): k0[0..9) | pe_spa = (nz, ny, nx) (lib/dmpigo.py:338) | viewdirs | 1;
-        // DVGO (C = 12): k0[0..12) | viewdirs | 1  (lib/dvgo.py:387-392)
-        float f[16];
-        if (MODE == MODE_MPI) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) f[i] = vv[i];
-            f[9] = nz; f[10] = ny; f[11] = nx;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) f[i] = vv[i];
-        }
-        f[12] = vd0; f[13] = vd1; f[14] = vd2; f[15] = 1.f;
-        if (!lact) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) f[i] = 0.f;                      // lanes past the bundle's last record: the tile's unused columns
-        }
-        if ((lane & 32) < nproc) {                                        // the second tile of a bundle's last batch may hold no record at all
-            float4* const dst = reinterpret_cast<float4*>(fb + (size_t)(base >> 6) * 1024 + (size_t)(lane >> 5) * 512 + (size_t)(lane & 31) * 8);
-            dst[0] = make_float4(f[0], f[1], f[2], f[3]); dst[1] = make_float4(f[4], f[5], f[6], f[7]);
-            dst[64] = make_float4(f[8], f[9], f[10], f[11]); dst[65] = make_float4(f[12], f[13], f[14], f[15]);
-        }
-    }
-}
-
-#ifndef K4_SHADEP_MINW
-#define K4_SHADEP_MINW 4
-#endif
-#ifndef K4_SHADEP_LOWREG
-#define K4_SHADEP_LOWREG 1
-#endif
-template <int MODE, int WIDTH, int NHID>
-__global__ __launch_bounds__(256, K4_SHADEP_MINW) void k4_shade_pre_kernel(const MarchParams P) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = k4_lane();
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef K4_SHADE_TIMING
-    const unsigned long long twave0 = __builtin_amdgcn_s_memtime(), rwave0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // LDS carve: [split-bf16 section of the packed rgbnet][per wave: acc 64 x 4 fp64]
-    const int mlp_floats = P.mlp_floats_b3;
-    const int mlp_pad = (mlp_floats + 3) & ~3;
-    float* const wl = smem;
-    double* const acc = reinterpret_cast<double*>(smem + mlp_pad + wv * 512);
-    {
-        const float* const src = P.mlp + P.mlp_floats;
-        for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = src[i];
-    }
-    __syncthreads();
-    const int half = lane >> 5;
-#ifdef K4_SHADE_TIMING
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tlast;
-#endif
-    for (;;) {
-    ShadeJob J;
-    if (!k4_next_job(P, lane, J)) break;
-    const Bundle B = J.B;
-    acc[lane * 4 + 0] = 0.; acc[lane * 4 + 1] = 0.; acc[lane * 4 + 2] = 0.; acc[lane * 4 + 3] = 0.;
-    const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-    const int total = J.rec1;                                            // this job's records: [J.rec0, J.rec1), rec0 a multiple of 64
-    GlobalFeat fs;
-    fs.nofetch = P.debug & 256;
-    const float4* const f0 = reinterpret_cast<const float4*>(P.feat + (size_t)B.id * ((size_t)(P.ent_stride >> 6) * 1024) + (size_t)lane * 8);
-    fs.p = f0 + (size_t)(J.rec0 >> 5) * 128;
-    fs.pend = f0 + (size_t)(total > J.rec0 ? ((total + 31) >> 5) - 1 : (J.rec0 >> 5)) * 128;
-    if (total > J.rec0) { fs.a = k4_ld4_nt(fs.p); fs.b = k4_ld4_nt(fs.p + 1); }
-    else { fs.a = make_float4(0.f, 0.f, 0.f, 0.f); fs.b = fs.a; }
-    uint2 en_next = ent[J.rec0 + lane < total ? J.rec0 + lane : 0];
-    for (int base = J.rec0; base < total; base += 64) {
-        K4_TSTAMP(7);
-        const int nproc = (total - base) < 64 ? (total - base) : 64;
-        const bool lact = lane < nproc;
-        const uint2 en = en_next;
-        en_next = ent[(base + 64 + lane < total) ? base + 64 + lane : 0];
-        const float w = lact ? __uint_as_float(en.y) : 0.f;
-        const int rl = lact ? (int)(en.x >> 24) : 0;
-        const int k = (int)(en.x & 0xffffffu);
-        float o0, o1, o2;
-        mlp_mfma_b3<WIDTH, NHID, GlobalFeat, K4_SHADEP_LOWREG != 0>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
-        // sigmoid + exact fp64 blend: k4_shade_kernel's expressions
-        const double QC = 4096.0;
-        double v0 = ((double)(w * (1.f / (1.f + expf(-o0)))) + QC) - QC;
-        double v1 = ((double)(w * (1.f / (1.f + expf(-o1)))) + QC) - QC;
-        double v2 = ((double)(w * (1.f / (1.f + expf(-o2)))) + QC) - QC;
-        double v3 = ((double)(w * (((float)k + 0.5f) / (float)P.depth_n)) + QC) - QC;
-        if (lact && !(P.debug & 512)) {                                  // (512: ablation, no per-ray sums)
-            k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
-        }
-        __builtin_amdgcn_wave_barrier();
-        K4_TSTAMP(6);
-    }
-    k4_finish_bundle(P, J, acc, lane);
-    __builtin_amdgcn_wave_barrier();
-    }   // job
-#ifdef K4_SHADE_TIMING
-    if (P.counters && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&P.counters[8 + i], tacc[i]);
-        const unsigned long long life = __builtin_amdgcn_s_memtime() - tstart;
-        atomicAdd(&P.counters[16], life); atomicMax(&P.counters[17], life); atomicAdd(&P.counters[18], 1ull);
-        atomicAdd(&P.counters[19], tstart - twave0);                                  // weight staging (s_memtime ticks)
-        const unsigned long long rnow = __builtin_amdgcn_s_memrealtime();
-        atomicMin(&P.counters[20], rwave0); atomicMax(&P.counters[21], rnow);          // kernel span (100 MHz ticks)
-        atomicAdd(&P.counters[22], rwave0); atomicAdd(&P.counters[23], rnow);          // mean start / exit
-    }
-#endif
-}
-
-// shapes the split shading path covers (see above); mode = MODE_MPI / MODE_DVGO
-static bool pre_supported(const k4_grid_desc* g, const k4_mlp_desc* m, int mode) {
-    if (!g || !m) return false;
-    if (g->k0_layout == K4_K0_CHANNEL_MAJOR || g->k0_cpad != 12) return false;
-    if ((m->width != 32 && m->width != 64) || m->n_hidden < 0 || m->n_hidden > 1 || m->arith == K4_MLP_ARITH_FP32) return false;
-    if (m->viewbase_pe != 0 || m->spatial_pe != 0 || m->k0_skip != 0) return false;
-    if (g->k0_ch != (mode == MODE_MPI ? 9 : 12)) return false;          // 15 inputs + the bias input = one 16-wide k block
-    return m->dim0 == 15;
-}
-extern "C" int k4_march_pre_supported(const k4_grid_desc* grid, const k4_mlp_desc* mlp, int32_t dvgo) {
-    return pre_supported(grid, mlp, dvgo ? MODE_DVGO : MODE_MPI) ? 1 : 0;
-}
-
 static int n_workgroups(int64_t n_rays, int img_w) {
     if (img_w > 0) return (int)(((img_w + 15) / 16) * (((n_rays / img_w) + 15) / 16));
     return (int)((n_rays + 255) / 256);
@@ -1689,34 +1395,15 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     }
     int rc = k4_check_launch();
     if (rc) return rc;
-    if (P.part_batches > 0) hipLaunchKernelGGL(k4_order_kernel<true>, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead, P.part_batches, P.slot_of, P.arrive, P.part_slots);
-    else hipLaunchKernelGGL(k4_order_kernel<false>, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead, 0, P.slot_of, P.arrive, P.part_slots);
+    hipLaunchKernelGGL(k4_order_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.jobs, P.n_bundles, P.qhead);
     rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
-    if (P.feat != nullptr) {
-        // split shading path: features of every shaded record (one workgroup per bundle, four batches at a time), then records +
-        // features -> MLP -> blend on persistent workgroups, 4 per CU
-#define K4_LAUNCH_FEAT(MW) hipLaunchKernelGGL((k4_feat_kernel<MODE, MW>), dim3((unsigned)P.n_bundles), block, 0, st, P)
-        if (P.feat_minw >= 8) K4_LAUNCH_FEAT(8); else if (P.feat_minw >= 6) K4_LAUNCH_FEAT(6); else K4_LAUNCH_FEAT(4);
-#undef K4_LAUNCH_FEAT
-        rc = k4_check_launch();
-        if (rc) return rc;
-        const size_t lds_pre = sizeof(float) * (((size_t)P.mlp_floats_b3 + 3) / 4 * 4 + 4 * 512);
-        const dim3 pgrid((unsigned)min(P.n_bundles, n_cu * k4_env().shade_pre_grid_wg));
-#define K4_LAUNCH_PRE(WD, NH) hipLaunchKernelGGL((k4_shade_pre_kernel<MODE, WD, NH>), pgrid, block, lds_pre, st, P)
-        if (width == 32 && nh == 0) K4_LAUNCH_PRE(32, 0);
-        else if (width == 32) K4_LAUNCH_PRE(32, 1);
-        else if (nh == 0) K4_LAUNCH_PRE(64, 0);
-        else K4_LAUNCH_PRE(64, 1);
-#undef K4_LAUNCH_PRE
-        return k4_check_launch();
-    }
     // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; k4_mlp_desc.arith =
     // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
     const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
     const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 8 + (width ? (size_t)P.k1p * 64 : 0)));
-    const dim3 sgrid((unsigned)min(nwg, n_cu * k4_env().shade_grid_wg));
+    const dim3 sgrid((unsigned)min(nwg, n_cu * K4_SHADE_WG_PER_CU));
     const size_t lds = lds_base;
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
@@ -1742,35 +1429,21 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
 // records per bundle: 64 rays x max_steps rounded up to a whole number of 64-sample blocks per depth quarter
 static inline int64_t ent_stride_of(int32_t max_steps) { return 64 * (((int64_t)max_steps + 255) / 256 * 256); }
 
-// workspace: [records nb x ent_stride x 8 B][counts nb] | [queue head .. queue length: 64 ints] | [arrive nb][slot_of nb] |
-// [jobs: nb x (1 + ent_stride / 64 / K4_PART_MIN) x 8 B] | [part sums: K4_PART_SLOTS_PER_BUNDLE x nb slots x 2 KB], each 256-aligned
-#define K4_PART_SLOTS_PER_BUNDLE 4           // part-sum slots per bundle ON AVERAGE; when a frame needs more, the rest of its bundles are shaded whole
-struct WsLayout { int64_t counts, qhead, arrive, slot_of, jobs, part_sums, part_slots, total; };
+// workspace: [records nb x ent_stride x 8 B][counts nb] | [queue head .. queue length: 64 ints] | [jobs: nb x 4 B], each 256-aligned
+struct WsLayout { int64_t counts, qhead, jobs, total; };
 static WsLayout ws_layout(int64_t nb, int64_t ent_stride) {
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
     WsLayout L;
     L.counts = nb * ent_stride * (int64_t)sizeof(uint2);
     L.qhead = up(L.counts + nb * 4);
-    L.arrive = L.qhead + 64 * 4;
-    L.slot_of = L.arrive + nb * 4;
-    L.jobs = up(L.slot_of + nb * 4);
-    L.part_sums = up(L.jobs + nb * (1 + ent_stride / 64 / K4_PART_MIN) * 8);
-    L.part_slots = k4_env().part_batches > 0 ? nb * K4_PART_SLOTS_PER_BUNDLE : 0;     // (the default never splits a bundle: no slots, 2 KB each)
-    L.total = up(L.part_sums + L.part_slots * 256 * 8);
+    L.jobs = up(L.qhead + 64 * 4);
+    L.total = up(L.jobs + nb * 4);
     return L;
 }
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
     if (n_rays < 0 || img_w < 0 || max_steps <= 0 || (img_w > 0 && n_rays % img_w != 0)) return -1;
     const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
     return ws_layout(nb, ent_stride_of(max_steps)).total;
-}
-
-// base workspace + the feature area of the split shading path: 16 floats per record slot
-extern "C" int64_t k4_march_workspace_bytes_pre(int64_t n_rays, int32_t img_w, int32_t max_steps) {
-    const int64_t base = k4_march_workspace_bytes(n_rays, img_w, max_steps);
-    if (base < 0) return -1;
-    const int64_t nb = (int64_t)n_workgroups(n_rays, img_w) * 4;
-    return base + nb * ent_stride_of(max_steps) * 64;
 }
 
 static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -1782,7 +1455,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     if (!g->density || !g->k0 || !g->mask) return K4_ERR_BAD_ARG;
     if (img_w < 0 || (img_w > 0 && n_rays % img_w != 0)) return K4_ERR_BAD_ARG;
     if (g->k0_layout != K4_K0_CHANNEL_MAJOR && (g->k0_cpad % 4 != 0 || g->k0_cpad < g->k0_ch)) return K4_ERR_BAD_ARG;
-    if (g->k0_layout < 0 || g->k0_layout > K4_K0_BRICK4) return K4_ERR_BAD_ARG;
+    if (g->k0_layout != K4_K0_CHANNEL_MAJOR && g->k0_layout != K4_K0_CHANNEL_LAST) return K4_ERR_BAD_ARG;
     if (m->width == 0 && g->k0_ch != 3) return K4_ERR_BAD_ARG;
     if (m->width != 0 && !m->packed) return K4_ERR_BAD_ARG;
     if (m->k0_skip != 0 && m->k0_skip != 3) return K4_ERR_BAD_ARG;
@@ -1813,24 +1486,8 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + L.counts);
     P.qhead = (int*)((char*)workspace + L.qhead);
-    P.arrive = (int*)((char*)workspace + L.arrive);
-    P.slot_of = (int*)((char*)workspace + L.slot_of);
-    P.jobs = (int2*)((char*)workspace + L.jobs);
-    P.part_sums = (double*)((char*)workspace + L.part_sums);
-    P.part_slots = (int)(L.part_slots > 0x7fffffff ? 0x7fffffff : L.part_slots);
-    P.part_batches = k4_env().part_batches <= 0 ? 0 : (k4_env().part_batches < K4_PART_MIN ? K4_PART_MIN : k4_env().part_batches);
+    P.jobs = (int*)((char*)workspace + L.jobs);
     P.n_bundles = (int)nb;
-    // the caller opts into the split shading path with the larger workspace; shapes it does not cover keep k4_shade_kernel
-    P.feat = nullptr;
-    if (n_rays > 0 && workspace_bytes >= k4_march_workspace_bytes_pre(n_rays, img_w, max_steps) && pre_supported(g, m, mode))
-        P.feat = (float*)((char*)workspace + k4_march_workspace_bytes(n_rays, img_w, max_steps));
-    P.feat_minw = k4_env().feat_minw;
-    if (g->k0_layout == K4_K0_BRICK4) {
-        if (g->k0_cpad % 4 != 0 || g->k0_cpad < g->k0_ch) return K4_ERR_BAD_ARG;
-        const unsigned nby = (unsigned)(g->dims[1] + 3) >> 2, nbz = (unsigned)(g->dims[2] + 3) >> 2;
-        P.bsx = 64u * nby * nbz; P.bsy = 64u * nbz;
-        if ((int64_t)((g->dims[0] + 3) >> 2) * nby * nbz * 64 > 0x7fffffffLL) return K4_ERR_UNSUPPORTED;
-    }
     P.debug = k4_env().debug; P.serp = 1;
     // XCD bands of the geometry kernel: ONE row of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to
     // the 8 XCDs.  One contiguous band per XCD (0) left the XCDs 0.61..1.31 of the mean work on the LLFF frames -- the kernel ran at
@@ -1846,8 +1503,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
-    env_int("K4_GEOM_SKIP", 1), env_int("K4_SHADE_GRID_WG", K4_SHADE_WG_PER_CU), env_int("K4_DEBUG", 0), env_int("K4_SR_DEBUG", 0),
-    env_int("K4_FEAT_MINW", 4), env_int("K4_SHADE_PRE_GRID_WG", K4_SHADEP_MINW), env_int("K4_PART_BATCHES", 0)};
+    env_int("K4_GEOM_SKIP", 1), env_int("K4_DEBUG", 0), env_int("K4_SR_DEBUG", 0)};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

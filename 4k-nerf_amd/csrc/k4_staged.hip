@@ -571,20 +571,6 @@ __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t
     out[t] = ch < C ? in[(size_t)ch * nvox + v] : 0.f;
 }
 
-// K4_K0_BRICK4: [bx][by][bz][x&3][y&3][z&3][CP]; one thread per output float, padded voxels / channels are zero
-__global__ void k_repack_k0_brick4(const float* __restrict__ in, int C, int CP, int X, int Y, int Z, float* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nby = (Y + 3) >> 2, nbz = (Z + 3) >> 2, nbx = (X + 3) >> 2;
-    if (t >= (int64_t)nbx * nby * nbz * 64 * CP) return;
-    const int ch = (int)(t % CP);
-    const int64_t v = t / CP;
-    const int slot = (int)(v & 63);
-    const int64_t brick = v >> 6;
-    const int bz = (int)(brick % nbz), by = (int)((brick / nbz) % nby), bx = (int)(brick / ((int64_t)nbz * nby));
-    const int x = bx * 4 + (slot >> 4), y = by * 4 + ((slot >> 2) & 3), z = bz * 4 + (slot & 3);
-    out[t] = (ch < C && x < X && y < Y && z < Z) ? in[(size_t)ch * X * Y * Z + ((size_t)x * Y + y) * Z + z] : 0.f;
-}
-
 // DenseGrid.scale_volume_grid (lib/grid.py:130-135): F.interpolate(mode='trilinear', align_corners=True) of a [C][X][Y][Z] grid.
 // One thread per output voxel and channel; source index = dst * (in-1)/(out-1) (PyTorch's area_pixel_compute_scale / _source_index
 // with align_corners), upper neighbour clamped, weights (1-l, l) per axis, products accumulated as upsample_trilinear3d does.
@@ -989,16 +975,6 @@ extern "C" int k4_ndc_points_of(const float* rays_o, const float* rays_d, const 
     if (n == 0) return K4_OK;
     REQ(rays_o && rays_d && ray_id && step_id && pts);
     hipLaunchKernelGGL(k_ndc_points_of, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, rays_o, rays_d, ray_id, step_id, n, n_samples, pts);
-    return k4_check_launch();
-}
-extern "C" int64_t k4_k0_brick4_floats(int32_t x, int32_t y, int32_t z, int32_t cpad) {
-    if (x <= 0 || y <= 0 || z <= 0 || cpad <= 0) return -1;
-    return (int64_t)((x + 3) >> 2) * ((y + 3) >> 2) * ((z + 3) >> 2) * 64 * cpad;
-}
-extern "C" int k4_repack_k0_brick4(const float* in, int32_t C, int32_t CP, int32_t X, int32_t Y, int32_t Z, float* out, void* stream) {
-    const int64_t n = k4_k0_brick4_floats(X, Y, Z, CP);
-    if (!in || !out || C <= 0 || CP < C || n < 0) return K4_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k_repack_k0_brick4, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, (hipStream_t)stream, in, C, CP, X, Y, Z, out);
     return k4_check_launch();
 }
 extern "C" int k4_repack_k0(const float* in, int32_t C, int32_t CP, int64_t nvox, float* out, void* stream) {

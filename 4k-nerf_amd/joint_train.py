@@ -28,8 +28,8 @@ from . import _native as N
 from .lib import sr_train, train_ops, utils
 from .lib.masked_adam import MaskedAdam
 
-_ADAM_SIDE = os.environ.get('K4_TRAIN_ADAM_SIDE', '1') != '0'  # 0: the k0 grid's optimizer step on the current stream (A/B, tests)
-_TV_SEED = os.environ.get('K4_TRAIN_TV_SEED', '1') != '0'      # 0: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
+_ADAM_SIDE = True   # False: the k0 grid's optimizer step on the current stream (A/B, tests)
+_TV_SEED = True     # False: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
 
 SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
 

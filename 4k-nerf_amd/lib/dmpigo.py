@@ -12,7 +12,6 @@ Reference quirks honoured: ``act_type`` / ``mode_type`` a
 (lib/dmpigo.py:392-397); ``mode_type`` 'TRANS'/'adain' reference undefined modules upstream and are
 rejected here.
 """
-import os
 
 import numpy as np
 import torch
@@ -22,7 +21,7 @@ from .. import _native as N
 from . import grid
 from . import dvgo as _dvgo
 
-_TRAIN_PRESEL = os.environ.get('K4_TRAIN_PRESEL', '1') != '0'      # training forward: the three sample filters decided by one launch (same values)
+_TRAIN_PRESEL = True      # training forward: the three sample filters decided by one launch (same values)
 from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid, _take
 
 
@@ -247,7 +246,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             return (md, gd, n_samples, itv), keep
         md, gd, N_samples, interval = self._k4_plan('mpi', (float(stepsize), use_live, float(self.fast_color_thres)), build)
         if Nr > 0:
-            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot, pre=(gd, md, 0) if _dvgo._MARCH_PRE else None)
+            ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot)
             N.check(N.lib().k4_march_mpi_fwd(
                 N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
                 N_samples, interval, float(self.fast_color_thres), float(bg), N.ptr(ws), ws_bytes,
@@ -294,7 +293,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         """The reference's op sequence (lib/dmpigo.py:300-427) on the staged gfx950 kernels.  With a mask cache and fast_color_thres > 0 (every
         BASELINE configuration) the three sample filters are decided up front by ``_select_samples``: the differentiable ops then run on the
         same lists the op-for-op sequence ends with (same values, same gradients), with one host synchronisation instead of four.
-        ``K4_TRAIN_PRESEL=0`` / ``k4_presel=False`` keeps the filter-by-filter form (A/B, tests)."""
+        ``k4_presel=False`` keeps the filter-by-filter form (A/B, tests)."""
         ret_dict = {}
         Nr = len(rays_o)
         interval = stepsize * self.voxel_size_ratio

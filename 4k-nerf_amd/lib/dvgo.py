@@ -29,9 +29,6 @@ from . import train_ops
 
 _FUSED_WIDTHS = (32, 64, 128)
 _LIVE_MASK = os.environ.get('K4_LIVE_MASK', '1') != '0'      # A/B switch of the density-derived live mask (identical results)
-_MARCH_PRE = os.environ.get('K4_MARCH_PRE', '0') == '1'      # split shading path (k4_feat_kernel + k4_shade_pre_kernel; identical results, measured SLOWER: opt-in)
-_PRE_MAX_BYTES = int(float(os.environ.get('K4_PRE_MAX_GB', '24')) * 2 ** 30)     # largest workspace the split path may ask for
-_K0_BRICK = os.environ.get('K4_K0_BRICK', '0') == '1'        # k0 repacked in 4x4x4-voxel bricks (experiment; identical results)
 
 
 class _FusedMarcher:
@@ -60,11 +57,10 @@ class _FusedMarcher:
 
     def _k4_k0_channel_last(self):
         """Load-time repack of k0.grid [1,C,X,Y,Z] -> [X,Y,Z,CP] (CP = C rounded up to 4): the 8 corners of a
-        shaded sample become 4 runs of 2*CP contiguous floats instead of 8*C scattered dwords.  ``K4_K0_BRICK=1`` (experiment,
-        DESIGN.md 6.1): 4x4x4-voxel bricks of 64*CP contiguous floats instead (K4_K0_BRICK4), same results.
+        shaded sample become 4 runs of 2*CP contiguous floats instead of 8*C scattered dwords.
         Returns (repacked grid, CP, k4_grid_desc.k0_layout)."""
         g = self.k0.grid
-        key = ('k0', g.data_ptr(), g._version, str(g.device), _K0_BRICK)
+        key = ('k0', g.data_ptr(), g._version, str(g.device))
         c = self._k4_cache()
         if c.get('k0_key') != key:
             C = g.shape[1]
@@ -72,14 +68,10 @@ class _FusedMarcher:
             X, Y, Z = (int(v) for v in g.shape[2:])
             nvox = X * Y * Z
             src = g.detach().contiguous()
-            if _K0_BRICK:
-                out = torch.empty([int(N.lib().k4_k0_brick4_floats(X, Y, Z, CP))], dtype=torch.float32, device=g.device)
-                N.check(N.lib().k4_repack_k0_brick4(N.f32(src), C, CP, X, Y, Z, N.f32(out), N.stream()), 'repack_k0_brick4')
-            else:
-                out = torch.empty([nvox * CP], dtype=torch.float32, device=g.device)
-                N.check(N.lib().k4_repack_k0(N.f32(src), C, CP, nvox, N.f32(out), N.stream()), 'repack_k0')
+            out = torch.empty([nvox * CP], dtype=torch.float32, device=g.device)
+            N.check(N.lib().k4_repack_k0(N.f32(src), C, CP, nvox, N.f32(out), N.stream()), 'repack_k0')
             c['k0_key'], c['k0_cl'], c['k0_cpad'] = key, out, CP
-        return c['k0_cl'], c['k0_cpad'], (N.K0_BRICK4 if _K0_BRICK else N.K0_CHANNEL_LAST)
+        return c['k0_cl'], c['k0_cpad'], N.K0_CHANNEL_LAST
 
     def _k4_occ_summary(self, m=None, slot='occ'):
         """Load-time coarse occupancy summary of a mask (k4_build_occupancy_summary), cached per mask version: lets the
@@ -151,27 +143,17 @@ class _FusedMarcher:
             return train_ops.rgbnet_sigmoid(self.rgbnet, feat, add)
         return train_ops.rgbnet_sigmoid_layers(self.rgbnet, feat, add)
 
-    def _k4_workspace(self, n_rays, img_w, max_steps, device, slot=0, pre=None):
+    def _k4_workspace(self, n_rays, img_w, max_steps, device, slot=0):
         """Scratch between the geometry and the shading kernel: worst-case sized (every sample of every ray
         shaded), sparsely touched, cached and grown on demand.  One per ``slot``: calls that may be in flight
-        concurrently (different HIP streams) must use different slots (render_kwargs['k4_ws_slot']).
-        ``pre = (grid desc, mlp desc, dvgo)``: with ``K4_MARCH_PRE=1`` (an experiment of round 5, bit-identical and measured slower:
-        DESIGN.md 6.1), when the split shading path covers this model (k4_march_pre_supported) and its feature area fits
-        ``K4_PRE_MAX_GB`` (default 24), the workspace carries it -- that is how a caller opts in (include/k4nerf.h)."""
+        concurrently (different HIP streams) must use different slots (render_kwargs['k4_ws_slot'])."""
         c = self._k4_cache()
         nkey = ('ws_need', int(n_rays), int(img_w), int(max_steps))
-        if pre is not None and _MARCH_PRE:
-            gd, md, dvgo_mode = pre
-            nkey += (gd.k0_layout, gd.k0_cpad, gd.k0_ch, md.dim0, md.width, md.n_hidden, md.viewbase_pe, md.spatial_pe, md.k0_skip, md.arith, dvgo_mode)
         need = c.get(nkey)
         if need is None:
             need = int(N.lib().k4_march_workspace_bytes(int(n_rays), int(img_w), int(max_steps)))
             if need < 0:
                 raise N.K4Error('k4_march_workspace_bytes: bad arguments')
-            if pre is not None and _MARCH_PRE and N.lib().k4_march_pre_supported(N.C.byref(pre[0]), N.C.byref(pre[1]), int(pre[2])):
-                need_pre = int(N.lib().k4_march_workspace_bytes_pre(int(n_rays), int(img_w), int(max_steps)))
-                if 0 < need_pre <= _PRE_MAX_BYTES:
-                    need = need_pre
             c[nkey] = need
         ws = c.get(('workspace', slot))
         if ws is None or ws.numel() < need or ws.device != device:
@@ -241,7 +223,7 @@ class _FusedMarcher:
             for l in lins[1]:
                 ts.append(l.weight)
                 ts.append(l.bias)
-        key = (tag, extra_key, _MARCH_PRE, _K0_BRICK, _LIVE_MASK, os.environ.get('K4_MLP')) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+        key = (tag, extra_key, _LIVE_MASK, os.environ.get('K4_MLP')) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
         c = self._k4_cache()
         plan = c.get(('plan', tag))
         st = N.stream().value
@@ -550,7 +532,7 @@ class DirectVoxGO(torch.nn.Module, _FusedMarcher):
             if render_depth:
                 ret['depth'] = depth
             return ret
-        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot, pre=(gd, md, 1) if _MARCH_PRE else None)
+        ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, max_steps, dev, k4_ws_slot)
         N.check(N.lib().k4_march_dvgo_fwd(
             N.f32(rays_o), N.f32(rays_d), N.f32(viewdirs), Nr, int(k4_img_w), N.C.byref(gd), N.C.byref(md),
             float(near), 1e9, stepdist, max_steps, depth_n, act_shift, interval,

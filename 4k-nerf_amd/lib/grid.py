@@ -6,7 +6,6 @@ arguments, parameter / buffer names (``grid``, ``xyz_min``, ``xyz_max``, ``mask`
 ``TensoRFGrid`` / ``VQGrid`` are not selected by any BASELINE configuration
 (configs/default.py:85-86) and are out of the hot-path scope.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -58,15 +57,18 @@ def release_grid_sample_workspace(device=None):
         _GSB_WS.pop(d, None)
 
 
+GSB_CHANNEL_LAST = True
+
+
 def grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg):
     """gg [1|-, C, X, Y, Z] += d(trilinear lookup)/d(grid) for grad_out `go` [n, C] at `pts` [n, 3].  More than one channel: through the
     channel-last scratch image (k4_grid_sample_3d_backward_cl; the workspace, as large as the gradient, is allocated and cleared once
-    per device and grid shape and kept -- K4_GSB_CL=0 or an allocation failure selects the channel-major atomic scatter).
+    per device and grid shape and kept -- GSB_CHANNEL_LAST = False (module attribute: bench A/B) or an allocation failure selects the channel-major atomic scatter).
     The workspace must be all-zero on entry and is left all-zero by the sweep; it is ONE buffer per device, so a use on another HIP
     stream waits for the previous use (event), and a failed launch drops it (the next call allocates a cleared one)."""
     L = N.lib()
     n = pts.shape[0]
-    nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if os.environ.get('K4_GSB_CL', '1') != '0' else -1
+    nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if GSB_CHANNEL_LAST else -1
     hit = None
     if nbytes > 0 and n > 0:
         hit = _GSB_WS.get(go.device)

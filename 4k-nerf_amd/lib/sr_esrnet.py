@@ -31,6 +31,7 @@ from .. import _native as N
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
 DEFAULT_MODE = 'f16x3p'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
+SR_GROUP = None                 # windows of tile_process decoded per grouped launch (None: as many as the ABI takes, K4_MAX_JOBS); results do not depend on it (tests)
 P16_TARGET_EXP = 9              # calibration maps a tensor's largest magnitude into [2^9, 2^10): 64-128x head room below fp16's 65504
 
 
@@ -57,9 +58,9 @@ class SFTLayer(nn.Module):
         self.SFT_shift_conv1 = nn.Conv2d(num_grow_ch, num_feat, 1)
 
     def forward(self, x, cond):
-        scale = self.SFT_scale_conv1(F.leaky_relu(self.SFT_scale_conv0(cond), 0.2))
-        shift = self.SFT_shift_conv1(F.leaky_relu(self.SFT_shift_conv0(cond), 0.2))
-        return x * (scale + 1) + shift
+        """lib/sr_esrnet.py:120-123.  A parameter container here: the layer runs inside SFTNet.forward (k4_sft_nhwc_p16_multi / the 3x3
+        epilogue) and sr_train.forward_train (k4_sft_train_fwd); there is no PyTorch evaluation of it in the product."""
+        raise N.K4Error('SFTLayer is evaluated by SFTNet.forward / sr_train.forward_train on the HIP kernels; it has no stand-alone forward')
 
 
 class ResidualDenseBlock_SFT(nn.Module):
@@ -76,14 +77,8 @@ class ResidualDenseBlock_SFT(nn.Module):
         default_init_weights([self.conv1, self.conv2, self.conv3, self.conv4, self.conv5], 0.1)
 
     def forward(self, x):
-        xc0 = self.sft0(x[0], x[1])
-        x1 = self.lrelu(self.conv1(xc0))
-        x2 = self.lrelu(self.conv2(torch.cat((xc0, x1), 1)))
-        x3 = self.lrelu(self.conv3(torch.cat((xc0, x1, x2), 1)))
-        x4 = self.lrelu(self.conv4(torch.cat((xc0, x1, x2, x3), 1)))
-        xc1 = self.sft1(x4, x[1])
-        x5 = self.conv5(torch.cat((xc0, x1, x2, x3, xc1), 1))
-        return (x5 * 0.2 + x[0], x[1])
+        """lib/sr_esrnet.py:149-158.  A parameter container here (see SFTLayer.forward)."""
+        raise N.K4Error('ResidualDenseBlock_SFT is evaluated by SFTNet.forward / sr_train.forward_train on the HIP kernels; it has no stand-alone forward')
 
 
 class RRDB_SFT(nn.Module):
@@ -95,11 +90,8 @@ class RRDB_SFT(nn.Module):
         self.sft0 = SFTLayer(num_feat, num_grow_ch)
 
     def forward(self, x):
-        out = self.rdb1(x)
-        out = self.rdb2(out)
-        out = self.rdb3(out)
-        out = self.sft0(out[0], x[1])
-        return (out * 0.2 + x[0], x[1])
+        """lib/sr_esrnet.py:176-182.  A parameter container here (see SFTLayer.forward)."""
+        raise N.K4Error('RRDB_SFT is evaluated by SFTNet.forward / sr_train.forward_train on the HIP kernels; it has no stand-alone forward')
 
 
 class RRDBNet_bps(nn.Module):
@@ -957,8 +949,8 @@ class SFTNet(nn.Module):
         tiles = tiles if tiles is not None else self.tile_geometry(height, width, tile_size, tile_pad)
         # tiles are independent images that share every weight: up to K4_MAX_JOBS of them go through the decoder TOGETHER, one
         # grouped launch per layer (a 520x520 window alone launches 561 workgroups on 256 CUs = 73 % tail efficiency; the four
-        # windows of a 1008x756 frame together 1649 = 92 %).  K4_SR_GROUP=1 processes them one by one.
-        grp = max(1, min(N.K4_MAX_JOBS, int(os.environ.get('K4_SR_GROUP', str(N.K4_MAX_JOBS)))))
+        # windows of a 1008x756 frame together 1649 = 92 %).  SR_GROUP = 1 (module attribute) processes them one by one.
+        grp = max(1, min(N.K4_MAX_JOBS, int(SR_GROUP or N.K4_MAX_JOBS)))
         for t0 in range(0, len(tiles), grp):
             part = tiles[t0:t0 + grp]
             outs = self._forward_hip_multi([img[:, :, yp0:yp1, xp0:xp1] for (_, _, _, _, yp0, yp1, xp0, xp1) in part],

@@ -258,11 +258,11 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
     return gx, gc, g
 
 
-_NATIVE_RDB = os.environ.get('K4_TRAIN_NATIVE_RDB', '1') != '0'      # 0: a dense block's launches issued one by one from Python (A/B)
-_WGRAD_STREAM = os.environ.get('K4_TRAIN_WGRAD_STREAM', '1') != '0'   # 0: the block's weight gradients on the chain's own stream (A/B)
-_FUSED_LRELU = os.environ.get('K4_TRAIN_FUSED_LRELU', '1') != '0'    # 0: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
+_NATIVE_RDB = True      # False: a dense block's launches issued one by one from Python (A/B)
+_WGRAD_STREAM = True    # False: the block's weight gradients on the chain's own stream (A/B)
+_FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
-_COND_ACC = os.environ.get('K4_TRAIN_COND_ACC', '1') != '0'           # 0: every SFT consumer returns its condition gradient, autograd adds them (A/B)
+_COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
 _SIDE_STREAMS = {}
 
 
@@ -292,7 +292,7 @@ def _hand_over_grads(params, grads):
 def _check_acc(acc):
     if acc is not None and getattr(acc, '_k4_spent', False):
         raise N.K4Error('second backward pass through a decoder graph whose condition-gradient accumulator was already consumed '
-                        '(retain_graph use: K4_TRAIN_COND_ACC=0)')
+                        '(retain_graph use: sr_train._COND_ACC = False)')
 
 
 def _rdb_desc(t, c, buf, x4, P, H, W, nf, g):

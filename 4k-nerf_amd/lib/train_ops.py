@@ -14,7 +14,6 @@
 There is no CPU path and no PyTorch path: CPU tensors raise ``K4Error``; so do these out-of-shape stacks under autograd, and anything that is
 not a biased Linear-ReLU stack ending in 3 outputs (another activation, a bias-free Linear, a layer wider than 128 / more than 192 inputs).
 """
-import os
 
 import torch
 from torch import nn
@@ -101,6 +100,7 @@ def rgbnet_sigmoid(rgbnet, x, add=None):
 
 
 _GENERIC_PACKS = {}
+CHECK_DISTLOSS = False      # True: check the two preconditions of the distortion loss' fast path on every call (costs a host sync; debugging)
 
 
 def rgbnet_sigmoid_layers(rgbnet, x, add=None):
@@ -175,7 +175,7 @@ class FlattenEffDistLoss(torch.autograd.Function):
         # the launch bound must be a host integer: any bound > max(ray_id) is correct (rays without samples contribute 0).  Without one
         # from the caller it costs a host synchronisation per step.
         n_rays = int(n_rays_bound) if n_rays_bound is not None else int(idx[-1]) + 1
-        if os.environ.get('K4_CHECK_DISTLOSS') == '1':              # debug check of the two preconditions of the fast path (costs a host sync)
+        if CHECK_DISTLOSS:              # debug check of the two preconditions of the fast path (costs a host sync)
             if n > 1 and bool((idx[1:] < idx[:-1]).any()):
                 raise ValueError('flatten_eff_distloss: ray_id is not ascending')
             if int(idx[-1]) >= n_rays:

@@ -16,7 +16,6 @@ One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL on ROCm); the 
 """
 import contextlib
 import math
-import os
 
 import torch
 import torch.distributed as dist
@@ -182,6 +181,9 @@ def _to8b(x):
 _POOLS = {}
 
 
+TILE_STREAMS = 4        # HIP streams a rank deals its tiles to (1: sequential; same pixels either way, tests)
+
+
 def _stream_pool(dev, n):
     pool = _POOLS.setdefault(str(dev), [])
     while len(pool) < n:
@@ -190,10 +192,10 @@ def _stream_pool(dev, n):
 
 
 def _n_streams(dev, n_tiles, march_fn, sr_fn):
-    """Streams for this rank's tiles: only for the HIP-backed functions (they take a `slot`), K4_TILE_STREAMS (default 4)."""
+    """Streams for this rank's tiles: only for the HIP-backed functions (they take a `slot`); TILE_STREAMS (module attribute, 4)."""
     if dev.type != 'cuda' or not (getattr(march_fn, 'k4_slots', False) and getattr(sr_fn, 'k4_slots', False)):
         return 1
-    return max(1, min(n_tiles, int(os.environ.get('K4_TILE_STREAMS', '4'))))
+    return max(1, min(n_tiles, int(TILE_STREAMS)))
 
 
 def hip_march_fn(model, render_kwargs):

@@ -708,13 +708,13 @@ def training_step_kernels(dev, frame_rays=None, model=None, reps=5):
 
     def scatter(pts, mn, mx):
         # the product path (lib/grid.grid_sample_3d_backward: channel-last scratch + sweep, workspace kept across calls) and the
-        # channel-major atomic scatter it replaced (K4_GSB_CL=0)
+        # channel-major atomic scatter it replaced (grid.GSB_CHANNEL_LAST = False)
         res = {}
-        for name, env in (('', '1'), ('_channel_major_atomics', '0')):
-            os.environ['K4_GSB_CL'] = env
+        for name, env in (('', True), ('_channel_major_atomics', False)):
+            G.GSB_CHANNEL_LAST = env
             g.zero_()
             res[name] = timed(lambda: G.grid_sample_3d_backward(gout, 12, 417, 353, 256, pts, mn, mx, g))
-        os.environ.pop('K4_GSB_CL', None)
+        G.GSB_CHANNEL_LAST = True
         G._GSB_WS.clear()                                                   # 1.8 GB of workspace: not needed by the rest of the bench
         return res
 

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      11      /* 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      12      /* 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -44,9 +44,6 @@ int k4_abi_version(void);
  * ------------------------------------------------------------------------------------------- */
 #define K4_K0_CHANNEL_MAJOR 0   /* k0 = [C][X][Y][Z]   (checkpoint layout, `k0.grid` [1,C,X,Y,Z]) */
 #define K4_K0_CHANNEL_LAST  1   /* k0 = [X][Y][Z][CP]  (load-time repack, CP = C rounded up to 4)  */
-#define K4_K0_BRICK4        2   /* k0 = [ceil(X/4)][ceil(Y/4)][ceil(Z/4)][4][4][4][CP]: 4x4x4-voxel bricks of 64*CP contiguous floats
-                                   (k4_repack_k0_brick4; voxels past the grid are zero).  An experiment in cache locality of the corner
-                                   gather (round 5): same results, see DESIGN.md */
 
 typedef struct k4_grid_desc {
     const float*   density;          /* [X][Y][Z] fp32, Z fastest (`density.grid` [1,1,X,Y,Z], lib/grid.py:115) */
@@ -139,16 +136,6 @@ int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden);   /
  *                  (caller zeroes) -- the counts SURVEY 8(d)'s algorithmic-bytes formula needs.
  * ------------------------------------------------------------------------------------------- */
 int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps);
-/* Split shading path (round 5): a workspace of k4_march_workspace_bytes_pre() bytes (the above + a feature area of 64 bytes per
- * record slot, worst-case sized and sparsely touched like the records) lets k4_march_*_fwd run the corner gather + trilinear blend
- * of the shaded samples as its own high-occupancy launch (k4_feat_kernel) that hands the colour MLP its complete layer-1 input in
- * matrix-operand order; the shading launch (k4_shade_pre_kernel) then holds no gather registers and runs at twice the waves per
- * SIMD.  Same expression trees -> results bit-identical to the two-launch form.  Shapes: k4_march_pre_supported() (voxel-major k0
- * with 12 padded channels, rgbnet width 32 / 64 on the default arithmetic, 15 inputs, no positional-encoding frequencies -- the
- * LLFF configurations); other shapes ignore the extra bytes.  Replaces nothing further in the reference: it is a re-cut of
- * lib/dmpigo.py:336-398 between launches. */
-int64_t k4_march_workspace_bytes_pre(int64_t n_rays, int32_t img_w, int32_t max_steps);
-int k4_march_pre_supported(const k4_grid_desc* grid, const k4_mlp_desc* mlp, int32_t dvgo);
 
 int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,
                      int64_t n_rays, int32_t img_w,
@@ -273,9 +260,6 @@ int k4_get_rays_of_a_view(int32_t H, int32_t W, const float* K_dev, const float*
 int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream);
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
-/* same, into K4_K0_BRICK4 order; out holds k4_k0_brick4_floats(x, y, z, cpad) floats */
-int64_t k4_k0_brick4_floats(int32_t x, int32_t y, int32_t z, int32_t cpad);
-int k4_repack_k0_brick4(const float* k0_cmajor, int32_t channels, int32_t cpad, int32_t x, int32_t y, int32_t z, float* out, void* stream);
 
 /* Occupancy / resolution maintenance of the training loop (lib/dmpigo.py:189-226, lib/dvgo.py:200-233):
  *   k4_resample_trilinear : DenseGrid.scale_volume_grid (lib/grid.py:130-135) = F.interpolate(trilinear, align_corners=True) of a

@@ -24,4 +24,4 @@ bad = []
 for i in range(6):
     d = (run() - ref).abs().amax(-1)
     bad.append((int((d > 0).sum()), float(d.max())))
-print(f'{root} K4_LIB={os.environ.get("K4_LIB", "-")} K4_MARCH_PRE={os.environ.get("K4_MARCH_PRE", "-")}: 6 repeats vs the first run: (rays differing, max abs) = {bad}')
+print(f'{root} K4_LIB={os.environ.get("K4_LIB", "-")}: 6 repeats vs the first run: (rays differing, max abs) = {bad}')

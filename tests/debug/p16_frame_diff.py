@@ -22,7 +22,7 @@ if kind == 'smooth':
     c = (0.5 + 0.4 * torch.sin(5 * u - 2 * v)).unsqueeze(0).cuda()
 with torch.no_grad():
     for grp in ('8', '1'):
-        os.environ['K4_SR_GROUP'] = grp
+        sr_esrnet.SR_GROUP = int(grp)
         net.k4_mode = 'f16x3'
         a = net.tile_process_device(x, c, 510, 10).clone()
         net.k4_mode = 'f16x3p'

@@ -79,6 +79,13 @@ def test_no_cpu_fallback():
     net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
     with pytest.raises(N.K4Error):
         net(torch.zeros(1, 3, 8, 8), torch.zeros(1, 1, 8, 8))
+    # the decoder's sub-blocks are parameter containers: calling one directly must not evaluate it with PyTorch
+    blk = net.body[0]
+    for call in (lambda: blk.sft0(torch.zeros(1, 64, 4, 4), torch.zeros(1, 32, 4, 4)),
+                 lambda: blk.rdb1((torch.zeros(1, 64, 4, 4), torch.zeros(1, 32, 4, 4))),
+                 lambda: blk((torch.zeros(1, 64, 4, 4), torch.zeros(1, 32, 4, 4)))):
+        with pytest.raises(N.K4Error):
+            call()
 
 
 def test_no_pytorch_fallback_in_the_product_source():
@@ -94,6 +101,31 @@ def test_no_pytorch_fallback_in_the_product_source():
                 assert node.name != '_forward_torch', (rel, node.lineno)
             if isinstance(node, ast.Constant) and isinstance(node.value, str):
                 assert node.value not in ('K4_SR_TRAIN', 'K4_RGBNET'), (rel, node.lineno)
+            # an nn.Module.forward that evaluates layers with PyTorch: F.<op>(...) or self.<sub-module>(...) inside a method named forward
+            if isinstance(node, ast.FunctionDef) and node.name == 'forward' and node.args.args and node.args.args[0].arg == 'self':
+                for sub in ast.walk(node):
+                    if not (isinstance(sub, ast.Call) and isinstance(sub.func, ast.Attribute) and isinstance(sub.func.value, ast.Name)):
+                        continue
+                    assert sub.func.value.id != 'F', (rel, sub.lineno, 'torch.nn.functional call inside a Module.forward')
+                    if sub.func.value.id == 'self':
+                        assert not re.match(r'(conv|sft|rdb|lrelu|SFT_|rgbnet|body|CondNet)', sub.func.attr), \
+                            (rel, sub.lineno, f'self.{sub.func.attr}(...) evaluates a PyTorch sub-module inside a Module.forward')
+
+
+def test_at_most_fifteen_environment_switches():
+    """Experiment knobs are module attributes (tests monkeypatch them); what the package and the library read from the environment
+    stays a short, documented list (README.md)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, '4k-nerf_amd', '**', '*.py'), recursive=True):
+        names |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'(K4_[A-Z0-9_]+)'", open(f).read()))
+    for f in glob.glob(os.path.join(root, '4k-nerf_amd', 'csrc', '*')):
+        names |= set(re.findall(r'env_int\("(K4_[A-Z0-9_]+)"', open(f).read())) | set(re.findall(r'getenv\("(K4_[A-Z0-9_]+)"', open(f).read()))
+    assert 0 < len(names) <= 15, sorted(names)
+    readme = open(os.path.join(root, 'README.md')).read()
+    for n in names:
+        assert n in readme, f'{n} is read from the environment but not documented in README.md'
 
 
 def test_oracle_and_reference_stay_behind_the_test_boundary():

@@ -75,10 +75,10 @@ def test_tile_parallel_hip_path_vs_oracle(tile, n_tiles, monkeypatch):
     net = net.cuda().eval()
     rays = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(pose).cuda(), True, False, False, False)
     march_fn, sr_fn = tp.hip_march_fn(model, ck['render_kwargs']), tp.hip_sr_fn(net)
-    monkeypatch.setenv('K4_TILE_STREAMS', '4')
+    monkeypatch.setattr(tp, 'TILE_STREAMS', 4)
     got = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile).clone()
     got2 = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile).clone()          # warm caches, reused slots
-    monkeypatch.setenv('K4_TILE_STREAMS', '1')
+    monkeypatch.setattr(tp, 'TILE_STREAMS', 1)
     seq = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile)
     assert torch.equal(got, seq) and torch.equal(got2, seq)
     want, _ = _oracle_frame(ck, H, W, K, pose, sd, tile)

@@ -560,87 +560,31 @@ def test_dvgo_config0_at_baseline_size():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Split shading path (round 5: k4_feat_kernel + k4_shade_pre_kernel) and the brick order of k0.  Contract: every
-# output of the fused marcher is BIT-IDENTICAL to the two-launch form on the voxel-major grid -- same expression trees, exact
-# per-ray sums -- on every shape the split path covers, and shapes it does not cover keep the two-launch form.
+# A ray's outputs do not depend on the rays marched with it (exact, order-independent per-ray sums): the unit of the tile-parallel
+# renderer.  (Round 5's split shading path / brick order / part batches were measured slower or neutral and live in
+# profiles/r05_split_path_brick_parts_removed.patch.)
 # ---------------------------------------------------------------------------------------------------------------------
-SPLIT = [
-    ('mpi', dict(seed=51, num_voxels=64 * 64 * 48, mpi_depth=48), (90, 120), True),
-    ('mpi', dict(seed=52, num_voxels=56 * 56 * 64, mpi_depth=64, stepsize=0.5, rgbnet_width=32), (75, 101), True),     # ragged image, width 32
-    ('mpi', dict(seed=53, num_voxels=40 * 40 * 32, mpi_depth=32, rgbnet_depth=2), (48, 64), True),                      # no hidden layer
-    ('mpi', dict(seed=54, num_voxels=40 * 40 * 32, mpi_depth=32, spatial_pe=2), (48, 64), False),                       # PE frequencies: not covered
-    ('dvgo', dict(seed=55, num_voxels=48 ** 3, rgbnet_dim=12, rgbnet_width=64, viewbase_pe=0), (64, 64), True),
-    ('dvgo', dict(seed=56, num_voxels=40 ** 3), (64, 64), False),                                                       # configs[0] shape: not covered
-]
-
-
-def _march_variant(monkeypatch, model, rays, W, rk, pre, brick, img=True):
-    monkeypatch.setattr(dvgo, '_MARCH_PRE', pre)
-    monkeypatch.setattr(dvgo, '_K0_BRICK', brick)
+def _march_once(model, rays, W, rk, img=True):
     out = model(*rays, k4_img_w=W if img else 0, **rk)
     torch.cuda.synchronize()
     return {k: out[k].clone() for k in ('rgb_marched', 'depth', 'alphainv_last')}
 
 
-@pytest.mark.parametrize('kind,cfg,hw,covered', SPLIT)
-def test_split_shading_path_and_brick_order_are_bit_identical(kind, cfg, hw, covered, monkeypatch):
-    from nerf4k_amd import _native as N
-    ck = scene.make_llff_checkpoint(**cfg) if kind == 'mpi' else scene.make_lego_checkpoint(**cfg)
-    model = _model(ck)
-    rk = dict(ck['render_kwargs'], render_depth=True)
-    H, W = hw
-    rays = _llff_rays(H, W) if kind == 'mpi' else _lego_rays(H, W)
-    base = _march_variant(monkeypatch, model, rays, W, rk, pre=False, brick=False)
-    ws_base = model._k4_cache()[('workspace', 0)].numel()
-    assert float(base['rgb_marched'].abs().sum()) > 0
-    base_lin = _march_variant(monkeypatch, model, rays, W, rk, pre=False, brick=False, img=False)      # 64 consecutive rays per bundle
-    for pre, brick, img in ((True, False, True), (False, True, True), (True, True, True), (True, False, False)):
-        got = _march_variant(monkeypatch, model, rays, W, rk, pre=pre, brick=brick, img=img)
-        ref = base if img else base_lin
-        for k in ref:
-            assert torch.equal(got[k], ref[k]), (pre, brick, img, k, float((got[k] - ref[k]).abs().max()))
-    # the split path really ran where it is covered (the caller opts in through the workspace size) and only there
-    ws_pre = model._k4_cache()[('workspace', 0)].numel()
-    if covered:
-        assert ws_pre > ws_base, (ws_pre, ws_base)
-    else:
-        assert ws_pre == ws_base, (ws_pre, ws_base)
-    # against the oracle as well (the shared helper's tolerances)
-    want = marcher.forward(ck['model_class'], ck['model_kwargs'], ck['model_state_dict'], *[r.cpu() for r in rays], **ck['render_kwargs'])
-    got = _march_variant(monkeypatch, model, rays, W, rk, pre=True, brick=True)
-    _cmp(got['rgb_marched'].cpu(), want['rgb_marched'], 'rgb_marched')
-
-
-def test_split_shading_path_full_frame_and_tile_windows(monkeypatch):
-    """BASELINE-size frame (1008 x 756, the bench scene): split path == two-launch form bit for bit, for the whole frame and for a
-    ragged window marched as its own call (the tile-parallel unit)."""
+def test_full_frame_tile_window_and_linear_bundles_bit_identical():
+    """BASELINE-size frame (1008 x 756, the bench scene): a ragged window marched as its own call (the tile-parallel unit) and the
+    same rays bundled 64 in a row instead of 8 x 8 tiles give the frame's bits."""
     ck = scene.make_llff_checkpoint()
     model = _model(ck)
     rk = dict(ck['render_kwargs'], render_depth=True)
     H, W = scene.LLFF_HW
     rays = _llff_rays(H, W, frame=3)
-    a = _march_variant(monkeypatch, model, rays, W, rk, pre=False, brick=False)
-    b = _march_variant(monkeypatch, model, rays, W, rk, pre=True, brick=False)
+    a = _march_once(model, rays, W, rk)
+    assert float(a['rgb_marched'].abs().sum()) > 0
+    b = _march_once(model, rays, W, rk, img=False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
     idx = (torch.arange(100, 289, device='cuda')[:, None] * W + torch.arange(37, 226, device='cuda')[None, :]).reshape(-1)
     win = [r[idx].contiguous() for r in rays]
-    c = _march_variant(monkeypatch, model, win, 189, rk, pre=True, brick=False)
+    c = _march_once(model, win, 189, rk)
     for k in a:
         assert torch.equal(c[k], a[k][idx]), k
-
-
-def test_marcher_env_variants_bit_identical():
-    """The load-time knobs of round 5 -- split shading path, bundles shaded in parts (exact cross-wave sums through system-scope slots),
-    brick order of k0, register bound of the feature kernel -- in their own processes: one hash."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    def run(**env):
-        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
-        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'march_hash.py')], env=e, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        return [l for l in out.stdout.splitlines() if l.startswith('MARCH_HASH')][-1]
-    base = run(K4_MARCH_PRE=0, K4_PART_BATCHES=0, K4_K0_BRICK=0)
-    assert run(K4_MARCH_PRE=0, K4_PART_BATCHES=4) == base
-    assert run(K4_MARCH_PRE=1, K4_PART_BATCHES=0, K4_FEAT_MINW=8) == base
-    assert run(K4_MARCH_PRE=1, K4_PART_BATCHES=5, K4_K0_BRICK=1, K4_SHADE_PRE_GRID_WG=2) == base

@@ -354,14 +354,14 @@ def test_full_size_tile_process_is_grouping_invariant_and_fp32_equivalent(monkey
     frames = {}
     for mode in ('bf16x6', 'f16x3', 'f16x3p'):           # per-tile (f16x3) / per-tensor (f16x3p, the default) scales must not depend on the launch
         net.k4_mode = mode
-        monkeypatch.setenv('K4_SR_GROUP', '8')
+        monkeypatch.setattr(sr_esrnet, 'SR_GROUP', 8)
         a = net.tile_process_device(x, c, 510, 10).clone()
-        monkeypatch.setenv('K4_SR_GROUP', '1')
+        monkeypatch.setattr(sr_esrnet, 'SR_GROUP', 1)
         b = net.tile_process_device(x, c, 510, 10).clone()
-        monkeypatch.setenv('K4_SR_GROUP', '3')           # ragged grouping: 3 + 1 windows
+        monkeypatch.setattr(sr_esrnet, 'SR_GROUP', 3)           # ragged grouping: 3 + 1 windows
         b3 = net.tile_process_device(x, c, 510, 10)
         assert torch.equal(a, b3), mode
-        monkeypatch.delenv('K4_SR_GROUP')
+        monkeypatch.setattr(sr_esrnet, 'SR_GROUP', None)
         assert a.shape == (1, 3, 3024, 4032) and torch.equal(a, b), mode
         frames[mode] = a
     a = frames['bf16x6']

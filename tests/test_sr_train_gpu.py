@@ -89,7 +89,7 @@ def test_sftnet_gradients_match_reference_module():
 
 def test_condition_gradient_accumulator_equals_the_autograd_sums_and_refuses_a_second_backward(monkeypatch):
     """forward_train hands every fused SFT consumer ONE buffer to add its condition gradient into (sr_train._CondFan: 35 elementwise
-    additions less per backward pass); K4_TRAIN_COND_ACC=0 lets autograd add the consumers' gradients instead.  Same gradients (the order
+    additions less per backward pass); sr_train._COND_ACC = False lets autograd add the consumers' gradients instead.  Same gradients (the order
     of the 21 addends differs: rounding only); a second backward pass over the same graph would add into a gradient already handed out
     and must raise."""
     from nerf4k_amd import _native as N

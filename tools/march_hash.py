@@ -1,5 +1,5 @@
 """sha1 of the fused marcher's outputs on a mid-size synthetic LLFF frame, under the CURRENT environment (the library reads its K4_* knobs
-once while it loads, so variants are compared across processes: tests/test_march_gpu.py::test_marcher_env_variants_bit_identical)."""
+once while it loads, so variants -- K4_MLP, K4_GEOM_SKIP, K4_LIB builds -- are compared across processes)."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
