@@ -13,6 +13,9 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
 K4_ABI_VERSION = 12
+# True: the data-path collectives (tile all-gather, gradient exchange) are issued even on a process group of ONE rank -- the RCCL smoke test
+# on a single GPU (tests/test_rccl_gpu.py: communicator + the production collective calls on device buffers); never set in production
+FORCE_COLLECTIVES = False
 K4_ERR_UNSUPPORTED = 10002
 
 K0_CHANNEL_MAJOR, K0_CHANNEL_LAST = 0, 1
@@ -143,6 +146,7 @@ _EXTRA_SIGS = {
     'k4_march_workspace_bytes': ([_I64, _I32, _I32], C.c_int64),
     'k4_grid_sample_3d_backward_workspace_bytes': ([_I32, _I32, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
+    'k4_mlp_b2_layer1_terms': ([], C.c_int),
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv_weight_p16_bytes': ([_I32, _I32], C.c_int64),

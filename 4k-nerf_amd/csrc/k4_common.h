@@ -28,7 +28,10 @@ __device__ __forceinline__ int k4_run_id(int key, int lane) {
     return __popcll(heads & (~0ull >> (63 - lane)));
 }
 
-// LDS accumulate (ds_add_f32 / ds_add_f64, no return value)
+// LDS accumulate (ds_add_f32 / ds_add_f64 / ds_add_u64, no return value)
+__device__ __forceinline__ void k4_lds_add(unsigned long long* p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void k4_lds_add(float* p, float v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -50,13 +50,14 @@ struct MarchParams {
     float minx, miny, minz, maxx, maxy, maxz;
     float msx, msy, msz, mtx, mty, mtz;
     float lenx, leny, lenz, rlenx, rleny, rlenz;     // xyz_max - xyz_min and its correctly rounded reciprocal
-    const float* mlp; int mlp_floats; int mlp_floats_b3; int dim0; int k1p; int vpe; int spe; int k0_skip;
+    const float* mlp; int mlp_floats; int mlp_floats_b3; int mlp_floats_b2; int dim0; int k1p; int vpe; int spe; int k0_skip;
     int n_samples;          // MPI: samples per ray
     int max_steps;          // capacity per ray in the workspace
     int ent_stride;         // records per bundle in the workspace: 64 * max_steps rounded up to 256 (4 depth quarters)
     int depth_n;            // denominator of s = (k+0.5)/depth_n
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
+    float depth_fx, depth_fx_inv;   // fixed-point scale of the per-ray depth sums (a power of two: 2^30 / the largest s a record can carry) and its reciprocal
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
     int* jobs;                                     // workspace: the shading queue = bundle ids, most batches first (k4_order_kernel)
     int n_bundles;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     __syncthreads();
     const bool unit_interval = P.interval == 1.f;
     const bool use_thres = P.thres > 0.f;
-    unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0, n_shade = 0;
+    unsigned long long n_inb = 0, n_mask = 0, n_alpha = 0, n_shade = 0, n_behind = 0;
 
     // static, XCD-banded bundle map, one bundle per workgroup: per-XCD or global work queues measured 6-25 % slower -- the
     // hardware's in-order dispatch already keeps neighbouring tiles on one XCD's L2.  (Heaviest-first by the previous frame's record
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
             for (int u = 0; u < 4; ++u) a[u] = (j0 + u < c) ? __uint_as_float(run[seg + j0 + u].y) : 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (COUNT) n_behind += __popcll(__ballot(j0 + u < c && stopped));      // density was evaluated for a sample the scan then drops
                 if (j0 + u < c) {
                     float wgt = -1.f;                                  // behind the early stop: never shaded
                     if (!stopped) {
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     }   // bundle
     if (COUNT && P.counters && lane == 0) {
         atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
-        atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade);
+        atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade); atomicAdd(&P.counters[4], n_behind);
     }
 }
 
@@ -727,13 +729,48 @@ __device__ __forceinline__ void k4_split3(const float (&v)[8], uint4& t0, uint4&
     ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
     ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); } while (0)
 
-template <int W, int NHID>
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6, the DEFAULT arithmetic ("b2"): layer 1 keeps the exact 3-term form; the HIDDEN activations and the layer-2 weights are split
+// into TWO bf16 terms (a ~ a0 + a1, 16 significant bits) and a product is a1 w0 + a0 w1 + a0 w0: half the matrix instructions of layer 2
+// and 24 instead of 44 vector instructions per 8 activations.  Dropped: a1 w1, a0 w2, a2 w0 -- each <= 2^-16 |a w|; measured on the
+// LLFF frame against the CPU oracle: tests/test_march_gpu.py (>= 100 dB), bench.py parity_vs_oracle.  K4_MLP_ARITH_B3 keeps rounds 2-5's
+// exact form.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void k4_split2(const float (&v)[8], uint4& t0, uint4& t1) {
+    unsigned p0[4], p1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const k4_f32x2 x = {v[2 * i], v[2 * i + 1]};
+        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, k4_bf16x2));
+        const k4_f32x2 h0 = {__uint_as_float(p0[i] << 16), __uint_as_float(p0[i] & 0xffff0000u)};
+        const k4_f32x2 r = x - h0;
+        p1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, k4_bf16x2));
+    }
+    t0 = make_uint4(p0[0], p0[1], p0[2], p0[3]); t1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+}
+#define K4_MFMA_B2(ACC, A0, A1, B0, B1) do { \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B1), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACC, 0, 0, 0); } while (0)
+#define K4_MFMA_B2_X2(ACCA, ACCB, A0, A1, C0, C1, B0, B1) do { \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A1), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C1), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B1), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B1), ACCB, 0, 0, 0); \
+    ACCA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, A0), __builtin_bit_cast(k4_bf16x8, B0), ACCA, 0, 0, 0); \
+    ACCB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k4_bf16x8, C0), __builtin_bit_cast(k4_bf16x8, B0), ACCB, 0, 0, 0); } while (0)
+
+// NT1 / NT2 = bf16 terms of the layer-1 / layer-2 operands (weights AND activations of that layer): 3 (exact, "b3") or 2 ("b2")
+#ifndef K4_B2_L1_TERMS
+#define K4_B2_L1_TERMS 2                  // layer-1 terms of the default arithmetic (3: layer 1 exact, only layer 2 on 2-term splits -- A/B builds)
+#endif
+template <int W, int NHID, int NT1 = 3, int NT2 = 3>
 struct MlpLayoutB3 {                      // offsets in floats from the start of the split section
     static constexpr int NB = W / 32;
     __host__ __device__ static int kb1(int k1p) { return (k1p + 15) >> 4; }
     __host__ __device__ static int w1s(int k1p) { (void)k1p; return 0; }
-    __host__ __device__ static int w2s(int k1p) { return NB * kb1(k1p) * 3 * 64 * 4; }
-    __host__ __device__ static int b2s(int k1p) { return w2s(k1p) + (NHID ? NB * (W / 16) * 3 * 64 * 4 : 0); }
+    __host__ __device__ static int w2s(int k1p) { return NB * kb1(k1p) * NT1 * 64 * 4; }
+    __host__ __device__ static int b2s(int k1p) { return w2s(k1p) + (NHID ? NB * (W / 16) * NT2 * 64 * 4 : 0); }
     __host__ __device__ static int wot(int k1p) { return b2s(k1p) + (NHID ? NB * 2 * 16 : 0); }
     __host__ __device__ static int bo(int k1p) { return wot(k1p) + NB * 16 * 2 * 4; }
     __host__ __device__ static int total(int k1p) { return bo(k1p) + 4; }
@@ -769,137 +806,126 @@ struct LdsFeat {
         }
     }
 };
-// LOWREG (the split path's 128-register shading kernel): layer 2 one 32-neuron output block at a time (16 accumulators live instead
-// of 32, the output layer's share of a block right behind it); every accumulator and every output sum still receives its terms in
-// the same order -> the same bits.
-template <int W, int NHID, class FS, bool LOWREG = false>
-__device__ __forceinline__ void mlp_mfma_b3(const float* ws, FS& fs, int k1p, int lane, int half, int debug, int nproc,
+// The general form (any covered width / depth / input size), one 32-sample tile at a time.  NT2 = 3: the exact form of rounds 2-5 (every
+// accumulator receives its products in the order of K4_MFMA_B3); NT2 = 2: the round-6 default (see k4_split2).  The 32-neuron output
+// blocks of a layer are taken two at a time, side by side (independent accumulators: consecutive MFMAs never depend on each other);
+// width 128 = two such passes per layer, so that at most 2 x 16 accumulators are live beside the split hidden activations.
+template <int W, int NHID, int NT1, int NT2, class FS>
+__device__ __forceinline__ void mlp_mfma_bx(const float* ws, FS& fs, int k1p, int lane, int half, int debug, int nproc,
                                             float& out0, float& out1, float& out2 K4_TARGS) {
     constexpr int NB = W / 32;
     constexpr int KB2 = W / 16;
-    typedef MlpLayoutB3<W, NHID> ML;
-    const int l31 = lane & 31;
-    const int kb1 = (debug & 2) ? 0 : ML::kb1(k1p);
+    constexpr int NP = NB >= 2 ? NB / 2 : 1;              // passes of (up to) two output blocks
+    constexpr int PB = NB >= 2 ? 2 : 1;                   // blocks per pass
+    typedef MlpLayoutB3<W, NHID, NT1, NT2> ML;
+    const int kb1n = ML::kb1(k1p);
+    const int kb1 = (debug & 2) ? 0 : kb1n;
     const uint4* const w1s = reinterpret_cast<const uint4*>(ws + ML::w1s(k1p));
     const uint4* const w2s = reinterpret_cast<const uint4*>(ws + ML::w2s(k1p));
     const float* const b2s = ws + ML::b2s(k1p);
     const float* const wot = ws + ML::wot(k1p);
     const float* const bo = ws + ML::bo(k1p);
     out0 = out1 = out2 = 0.f;
-    // one 32-sample tile at a time, NOT unrolled: the live set is one tile's accumulators + split operands (~110 VGPRs),
-    // the second tile reuses the code and the registers
+    // one 32-sample tile at a time, NOT unrolled: the second tile reuses the code and the registers
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
         if (t * 32 >= nproc) break;                  // a bundle's last batch: no record in the second tile (wave-uniform)
-        // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s] ----------------
+        // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s], exact 3-term products ----------------
         f32x16 h1[NB];
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) h1[mb] = (f32x16)(0.f);
         for (int kb = 0; kb < kb1; ++kb) {
             float v[8];
             fs.load(kb, t, v);
-            uint4 x0, x1, x2;
-            k4_split3(v, x0, x1, x2);
-            if constexpr (NB == 2 && K4_MLP_X2) {
-                const uint4* const wp = w1s + (kb * 3) * 64 + lane;
-                const uint4* const wq = w1s + ((ML::kb1(k1p) + kb) * 3) * 64 + lane;
-                const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
-                K4_MFMA_B3_X2(h1[0], h1[1], a0, a1, a2, c0, c1, c2, x0, x1, x2);
-            } else {
+            uint4 x[NT1];
+            if constexpr (NT1 == 3) k4_split3(v, x[0], x[1], x[2]);
+            else k4_split2(v, x[0], x[1]);
 #pragma unroll
-                for (int mb = 0; mb < NB; ++mb) {
-                    const uint4* const wp = w1s + ((mb * ML::kb1(k1p) + kb) * 3) * 64 + lane;
+            for (int pp = 0; pp < NP; ++pp) {
+                const uint4* const wp = w1s + (((pp * PB) * kb1n + kb) * NT1) * 64 + lane;
+                const uint4* const wq = w1s + (((pp * PB + PB - 1) * kb1n + kb) * NT1) * 64 + lane;
+                if constexpr (NT1 == 3) {
                     const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
-                    K4_MFMA_B3(h1[mb], a0, a1, a2, x0, x1, x2);
+                    if constexpr (PB == 2) {
+                        const uint4 c0 = wq[0], c1 = wq[64], c2 = wq[128];
+                        K4_MFMA_B3_X2(h1[pp * 2], h1[pp * 2 + 1], a0, a1, a2, c0, c1, c2, x[0], x[1], x[NT1 - 1]);
+                    } else {
+                        K4_MFMA_B3(h1[0], a0, a1, a2, x[0], x[1], x[NT1 - 1]);
+                    }
+                } else {
+                    const uint4 a0 = wp[0], a1 = wp[64];
+                    if constexpr (PB == 2) {
+                        const uint4 c0 = wq[0], c1 = wq[64];
+                        K4_MFMA_B2_X2(h1[pp * 2], h1[pp * 2 + 1], a0, a1, c0, c1, x[0], x[1]);
+                    } else {
+                        K4_MFMA_B2(h1[0], a0, a1, x[0], x[1]);
+                    }
                 }
             }
         }
         K4_TSTAMP(3);                                    // layer 1
         k4_f32x2 pt01 = {0.f, 0.f};
         float pt2 = 0.f;
+        auto out_block = [&](const f32x16& cc, int mb) {   // this lane's share of the output layer for one 32-neuron block
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
+                const float a0 = k4_relu(cc[r]);
+                const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
+                pt01 = __builtin_elementwise_fma(w01, aa, pt01);                  // v_pk_fma_f32: channels 0 and 1 in one instruction
+                pt2 = fmaf(wo.z, a0, pt2);
+            }
+        };
         if (NHID == 1 && !(debug & 2)) {
-            // relu + split of this tile's hidden activations once; the NB output blocks accumulate side by side
-            uint4 hs[KB2][3];
+            // relu + split of this tile's hidden activations once
+            uint4 hs[KB2][NT2];
 #pragma unroll
             for (int kb = 0; kb < KB2; ++kb) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = k4_relu(h1[kb >> 1][8 * (kb & 1) + e]);
-                k4_split3(v, hs[kb][0], hs[kb][1], hs[kb][2]);
+                if constexpr (NT2 == 3) k4_split3(v, hs[kb][0], hs[kb][1], hs[kb][NT2 - 1]);
+                else k4_split2(v, hs[kb][0], hs[kb][1]);
             }
-            if constexpr (LOWREG) {
 #pragma unroll
-                for (int mb2 = 0; mb2 < NB; ++mb2) {
-                    f32x16 c1;
+            for (int pp = 0; pp < NP; ++pp) {
+                f32x16 c[PB];
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const float4 bv = *reinterpret_cast<const float4*>(b2s + (mb2 * 2 + half) * 16 + r4 * 4);
-                        c1[r4 * 4 + 0] = bv.x; c1[r4 * 4 + 1] = bv.y; c1[r4 * 4 + 2] = bv.z; c1[r4 * 4 + 3] = bv.w;
+                        const float4 bv = *reinterpret_cast<const float4*>(b2s + ((pp * PB + q) * 2 + half) * 16 + r4 * 4);
+                        c[q][r4 * 4 + 0] = bv.x; c[q][r4 * 4 + 1] = bv.y; c[q][r4 * 4 + 2] = bv.z; c[q][r4 * 4 + 3] = bv.w;
                     }
 #pragma unroll
-                    for (int kb = 0; kb < KB2; ++kb) {
-                        const uint4* const wp = w2s + ((mb2 * KB2 + kb) * 3) * 64 + lane;
-                        const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
-                        K4_MFMA_B3(c1, a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][2]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
-                        const float a0 = k4_relu(c1[r]);
-                        const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
-                        pt01 = __builtin_elementwise_fma(w01, aa, pt01);
-                        pt2 = fmaf(wo.z, a0, pt2);
-                    }
-                }
-                K4_TSTAMP(4);
-            } else {
-            f32x16 c[NB];
-#pragma unroll
-            for (int mb2 = 0; mb2 < NB; ++mb2)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 bv = *reinterpret_cast<const float4*>(b2s + (mb2 * 2 + half) * 16 + r4 * 4);
-                    c[mb2][r4 * 4 + 0] = bv.x; c[mb2][r4 * 4 + 1] = bv.y; c[mb2][r4 * 4 + 2] = bv.z; c[mb2][r4 * 4 + 3] = bv.w;
-                }
-#pragma unroll
-            for (int kb = 0; kb < KB2; ++kb) {
-                if constexpr (NB == 2 && K4_MLP_X2) {
-                    const uint4* const wp = w2s + (kb * 3) * 64 + lane;
-                    const uint4* const wq = w2s + ((KB2 + kb) * 3) * 64 + lane;
-                    const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
-                    K4_MFMA_B3_X2(c[0], c[1], a0, a1, a2, c0, c1, c2, hs[kb][0], hs[kb][1], hs[kb][2]);
-                } else {
-#pragma unroll
-                    for (int mb2 = 0; mb2 < NB; ++mb2) {
-                        const uint4* const wp = w2s + ((mb2 * KB2 + kb) * 3) * 64 + lane;
-                        const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
-                        K4_MFMA_B3(c[mb2], a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][2]);
+                for (int kb = 0; kb < KB2; ++kb) {
+                    const uint4* const wp = w2s + (((pp * PB) * KB2 + kb) * NT2) * 64 + lane;
+                    if constexpr (PB == 2) {
+                        const uint4* const wq = w2s + (((pp * PB + 1) * KB2 + kb) * NT2) * 64 + lane;
+                        if constexpr (NT2 == 3) {
+                            const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128], c0 = wq[0], c1 = wq[64], c2 = wq[128];
+                            K4_MFMA_B3_X2(c[0], c[1], a0, a1, a2, c0, c1, c2, hs[kb][0], hs[kb][1], hs[kb][NT2 - 1]);
+                        } else {
+                            const uint4 a0 = wp[0], a1 = wp[64], c0 = wq[0], c1 = wq[64];
+                            K4_MFMA_B2_X2(c[0], c[1], a0, a1, c0, c1, hs[kb][0], hs[kb][1]);
+                        }
+                    } else {
+                        if constexpr (NT2 == 3) {
+                            const uint4 a0 = wp[0], a1 = wp[64], a2 = wp[128];
+                            K4_MFMA_B3(c[0], a0, a1, a2, hs[kb][0], hs[kb][1], hs[kb][NT2 - 1]);
+                        } else {
+                            const uint4 a0 = wp[0], a1 = wp[64];
+                            K4_MFMA_B2(c[0], a0, a1, hs[kb][0], hs[kb][1]);
+                        }
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < PB; ++q) out_block(c[q], pp * PB + q);
             }
-            K4_TSTAMP(4);                                // split of the hidden activations + layer 2
-#pragma unroll
-            for (int mb2 = 0; mb2 < NB; ++mb2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb2 * 16 + r) * 2 + half) * 4);
-                    const float a0 = k4_relu(c[mb2][r]);
-                    const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
-                    pt01 = __builtin_elementwise_fma(w01, aa, pt01);                  // v_pk_fma_f32: channels 0 and 1 in one instruction
-                    pt2 = fmaf(wo.z, a0, pt2);
-                }
-            }
+            K4_TSTAMP(4);                                // split of the hidden activations + layer 2 + output layer
         } else {
 #pragma unroll
-            for (int mb = 0; mb < NB; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float4 wo = *reinterpret_cast<const float4*>(wot + ((mb * 16 + r) * 2 + half) * 4);
-                    const float a0 = k4_relu(h1[mb][r]);
-                    const k4_f32x2 w01 = {wo.x, wo.y}, aa = {a0, a0};
-                    pt01 = __builtin_elementwise_fma(w01, aa, pt01);
-                    pt2 = fmaf(wo.z, a0, pt2);
-                }
+            for (int mb = 0; mb < NB; ++mb) out_block(h1[mb], mb);
         }
         // lanes l and l^32 hold the two halves of the neurons of sample (l&31) of this tile; sample 32*t + (l&31) belongs to
         // lane 32*t + (l&31)
@@ -931,16 +957,22 @@ __device__ __forceinline__ void mlp_mfma_b3(const float* ws, FS& fs, int k1p, in
 // one stage: NM MFMAs, each followed by NV vector instructions (the scheduler takes them from the stage's region in dependency order)
 #define K4_STAGE_SCHED(NM, NV) do { _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) { \
         __builtin_amdgcn_sched_group_barrier(K4_SGB_MFMA, 1, 0); __builtin_amdgcn_sched_group_barrier(K4_SGB_VALU, (NV), 0); } } while (0)
-__device__ __forceinline__ void k4_relu_split8(const f32x16& h, int hi, uint4& t0, uint4& t1, uint4& t2) {
+template <int NT2>
+__device__ __forceinline__ void k4_relu_split8(const f32x16& h, int hi, uint4 (&t)[NT2]) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = k4_relu(h[8 * hi + e]);
-    k4_split3(v, t0, t1, t2);
+    if constexpr (NT2 == 3) k4_split3(v, t[0], t[1], t[2]);
+    else k4_split2(v, t[0], t[1]);
 }
-template <class FS>
-__device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane, int half,
-                                              float& out0, float& out1, float& out2 K4_TARGS) {
-    typedef MlpLayoutB3<64, 1> ML;
+// NT2 = 3: rounds 2-5's exact arithmetic (same bits as mlp_mfma_bx<64, 1, 3>); NT2 = 2: the round-6 default -- a layer-2 stage is 6
+// MFMAs and ~32 vector instructions (8 ReLUs + a 2-term split) instead of 12 and ~52.
+template <int NT1, int NT2, class FS>
+__device__ __forceinline__ void mlp_pair64(const float* ws, FS& fs, int lane, int half,
+                                           float& out0, float& out1, float& out2 K4_TARGS) {
+    typedef MlpLayoutB3<64, 1, NT1, NT2> ML;
+    constexpr int NM1 = 2 * (NT1 == 3 ? 6 : 3);          // MFMAs of a layer-1 stage
+    constexpr int NM2 = 2 * (NT2 == 3 ? 6 : 3);          // ... of a layer-2 stage
     const uint4* const w1s = reinterpret_cast<const uint4*>(ws + ML::w1s(16));
     const uint4* const w2s = reinterpret_cast<const uint4*>(ws + ML::w2s(16));
     const float* const b2s = ws + ML::b2s(16);
@@ -950,22 +982,24 @@ __device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane,
     fs.load(0, 0, vA);
     fs.load(0, 1, vB);
     // layer-1 weight fragments (both 32-neuron blocks), shared by the two tiles
-    const uint4 a0 = w1s[lane], a1 = w1s[64 + lane], a2 = w1s[128 + lane];
-    const uint4 c0 = w1s[192 + lane], c1 = w1s[256 + lane], c2 = w1s[320 + lane];
-    uint4 xA0, xA1, xA2, xB0, xB1, xB2;
-    k4_split3(vA, xA0, xA1, xA2);
+    uint4 a[NT1], c[NT1], xA[NT1], xB[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) { a[t] = w1s[t * 64 + lane]; c[t] = w1s[(NT1 + t) * 64 + lane]; }
+    if constexpr (NT1 == 3) k4_split3(vA, xA[0], xA[1], xA[NT1 - 1]); else k4_split2(vA, xA[0], xA[1]);
     __builtin_amdgcn_sched_barrier(0);
     // ---- S1: layer 1 of tile A  ||  input split of tile B ----
     f32x16 hA0 = (f32x16)(0.f), hA1 = (f32x16)(0.f), hB0 = (f32x16)(0.f), hB1 = (f32x16)(0.f);
-    K4_MFMA_B3_X2(hA0, hA1, a0, a1, a2, c0, c1, c2, xA0, xA1, xA2);
-    k4_split3(vB, xB0, xB1, xB2);
-    K4_STAGE_SCHED(12, 3);
+    if constexpr (NT1 == 3) { K4_MFMA_B3_X2(hA0, hA1, a[0], a[1], a[NT1 - 1], c[0], c[1], c[NT1 - 1], xA[0], xA[1], xA[NT1 - 1]); }
+    else { K4_MFMA_B2_X2(hA0, hA1, a[0], a[1], c[0], c[1], xA[0], xA[1]); }
+    if constexpr (NT1 == 3) k4_split3(vB, xB[0], xB[1], xB[NT1 - 1]); else k4_split2(vB, xB[0], xB[1]);
+    K4_STAGE_SCHED(NM1, NT1 == 3 ? 3 : 4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- S2: layer 1 of tile B  ||  ReLU + split of tile A's hidden block 0 ----
-    uint4 hsA[4][3], hsB[4][3];
-    K4_MFMA_B3_X2(hB0, hB1, a0, a1, a2, c0, c1, c2, xB0, xB1, xB2);
-    k4_relu_split8(hA0, 0, hsA[0][0], hsA[0][1], hsA[0][2]);
-    K4_STAGE_SCHED(12, 4);
+    uint4 hsA[4][NT2], hsB[4][NT2];
+    if constexpr (NT1 == 3) { K4_MFMA_B3_X2(hB0, hB1, a[0], a[1], a[NT1 - 1], c[0], c[1], c[NT1 - 1], xB[0], xB[1], xB[NT1 - 1]); }
+    else { K4_MFMA_B2_X2(hB0, hB1, a[0], a[1], c[0], c[1], xB[0], xB[1]); }
+    k4_relu_split8<NT2>(hA0, 0, hsA[0]);
+    K4_STAGE_SCHED(NM1, (NT2 == 3 ? 52 : 32) / NM1 + 1);
     __builtin_amdgcn_sched_barrier(0);
     // layer-2 accumulators start from the bias
     f32x16 cA0, cA1, cB0, cB1;
@@ -979,18 +1013,24 @@ __device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane,
     cB0 = cA0; cB1 = cA1;
     // ---- S3..S6: layer 2 of tile A, hidden block kb  ||  ReLU + split of the next hidden block (of A, then B's first) ----
 #define K4_L2_STAGE(C0, C1, HS, KB, NEXT_STMT, NV) do { \
-        const uint4* const wp_ = w2s + ((KB) * 3) * 64 + lane; \
-        const uint4* const wq_ = w2s + ((4 + (KB)) * 3) * 64 + lane; \
-        const uint4 p0_ = wp_[0], p1_ = wp_[64], p2_ = wp_[128], q0_ = wq_[0], q1_ = wq_[64], q2_ = wq_[128]; \
-        K4_MFMA_B3_X2(C0, C1, p0_, p1_, p2_, q0_, q1_, q2_, HS[KB][0], HS[KB][1], HS[KB][2]); \
+        const uint4* const wp_ = w2s + ((KB) * NT2) * 64 + lane; \
+        const uint4* const wq_ = w2s + ((4 + (KB)) * NT2) * 64 + lane; \
+        if constexpr (NT2 == 3) { \
+            const uint4 p0_ = wp_[0], p1_ = wp_[64], p2_ = wp_[128], q0_ = wq_[0], q1_ = wq_[64], q2_ = wq_[128]; \
+            K4_MFMA_B3_X2(C0, C1, p0_, p1_, p2_, q0_, q1_, q2_, HS[KB][0], HS[KB][1], HS[KB][NT2 - 1]); \
+        } else { \
+            const uint4 p0_ = wp_[0], p1_ = wp_[64], q0_ = wq_[0], q1_ = wq_[64]; \
+            K4_MFMA_B2_X2(C0, C1, p0_, p1_, q0_, q1_, HS[KB][0], HS[KB][1]); \
+        } \
         NEXT_STMT; \
-        K4_STAGE_SCHED(12, NV); \
+        K4_STAGE_SCHED(NM2, NV); \
         __builtin_amdgcn_sched_barrier(0); } while (0)
     K4_TSTAMP(3);                                        // (timing builds) input splits + layer 1 of both tiles + first hidden block's split
-    K4_L2_STAGE(cA0, cA1, hsA, 0, k4_relu_split8(hA0, 1, hsA[1][0], hsA[1][1], hsA[1][2]), 4);
-    K4_L2_STAGE(cA0, cA1, hsA, 1, k4_relu_split8(hA1, 0, hsA[2][0], hsA[2][1], hsA[2][2]), 4);
-    K4_L2_STAGE(cA0, cA1, hsA, 2, k4_relu_split8(hA1, 1, hsA[3][0], hsA[3][1], hsA[3][2]), 4);
-    K4_L2_STAGE(cA0, cA1, hsA, 3, k4_relu_split8(hB0, 0, hsB[0][0], hsB[0][1], hsB[0][2]), 4);
+    constexpr int NVS = NT2 == 3 ? 4 : 5;                // vector instructions per MFMA of a ReLU + split stage (~52 / 12, ~32 / 6)
+    K4_L2_STAGE(cA0, cA1, hsA, 0, k4_relu_split8<NT2>(hA0, 1, hsA[1]), NVS);
+    K4_L2_STAGE(cA0, cA1, hsA, 1, k4_relu_split8<NT2>(hA1, 0, hsA[2]), NVS);
+    K4_L2_STAGE(cA0, cA1, hsA, 2, k4_relu_split8<NT2>(hA1, 1, hsA[3]), NVS);
+    K4_L2_STAGE(cA0, cA1, hsA, 3, k4_relu_split8<NT2>(hB0, 0, hsB[0]), NVS);
     // ---- S7..S10: layer 2 of tile B  ||  the next hidden block of B + tile A's output layer (its accumulators are complete) ----
     k4_f32x2 ptA01 = {0.f, 0.f}, ptB01 = {0.f, 0.f};
     float ptA2 = 0.f, ptB2 = 0.f;
@@ -1002,10 +1042,11 @@ __device__ __forceinline__ void mlp_pair64_b3(const float* ws, FS& fs, int lane,
             PT01 = __builtin_elementwise_fma(w01_, aa_, PT01); \
             PT2 = fmaf(wo_.z, a_, PT2); } } while (0)
     K4_TSTAMP(4);                                        // layer 2 of tile A (+ splits)
-    K4_L2_STAGE(cB0, cB1, hsB, 0, k4_relu_split8(hB0, 1, hsB[1][0], hsB[1][1], hsB[1][2]); K4_OUT_HALF(cA0, 0, 0, ptA01, ptA2), 5);
-    K4_L2_STAGE(cB0, cB1, hsB, 1, k4_relu_split8(hB1, 0, hsB[2][0], hsB[2][1], hsB[2][2]); K4_OUT_HALF(cA0, 0, 8, ptA01, ptA2), 5);
-    K4_L2_STAGE(cB0, cB1, hsB, 2, k4_relu_split8(hB1, 1, hsB[3][0], hsB[3][1], hsB[3][2]); K4_OUT_HALF(cA1, 1, 0, ptA01, ptA2), 5);
-    K4_L2_STAGE(cB0, cB1, hsB, 3, K4_OUT_HALF(cA1, 1, 8, ptA01, ptA2), 2);
+    constexpr int NVO = NT2 == 3 ? 5 : 8;                // ... of a ReLU + split + half-block output stage (~76 / 12, ~56 / 6: what does not fit runs behind the stage)
+    K4_L2_STAGE(cB0, cB1, hsB, 0, k4_relu_split8<NT2>(hB0, 1, hsB[1]); K4_OUT_HALF(cA0, 0, 0, ptA01, ptA2), NVO);
+    K4_L2_STAGE(cB0, cB1, hsB, 1, k4_relu_split8<NT2>(hB1, 0, hsB[2]); K4_OUT_HALF(cA0, 0, 8, ptA01, ptA2), NVO);
+    K4_L2_STAGE(cB0, cB1, hsB, 2, k4_relu_split8<NT2>(hB1, 1, hsB[3]); K4_OUT_HALF(cA1, 1, 0, ptA01, ptA2), NVO);
+    K4_L2_STAGE(cB0, cB1, hsB, 3, K4_OUT_HALF(cA1, 1, 8, ptA01, ptA2), NT2 == 3 ? 2 : 4);
 #undef K4_L2_STAGE
     K4_TSTAMP(5);                                        // layer 2 of tile B (+ splits, tile A's output layer)
     // ---- S11: tile B's output layer ----
@@ -1098,37 +1139,52 @@ __device__ __forceinline__ bool k4_next_job(const MarchParams& P, int lane, Shad
     J.total = __builtin_amdgcn_readfirstlane(P.counts[bundle]);
     return true;
 }
+// ---- per-ray sums (segment_coo, lib/dmpigo.py:382-386,418-424) in FIXED POINT (round 6; rounds 2-5: fp64 with terms rounded to 2^-40) ----
+// A record's four terms -- w rgb (each <= 1, and sum_w <= 1 per ray) and w s -- are rounded to multiples of 2^-30 (depth: of 1 / depth_fx,
+// depth_fx = 2^30 / the largest s a record can carry rounded up to a power of two) and added as INTEGERS with two ds_add_u64 per record:
+// word 0 = red | green << 32, word 1 = blue | depth << 32; a field stays below 2^31, so nothing carries between fields.  Integer sums are
+// exact and commute: a ray's sums do not depend on how its records fall into batches or on the order the LDS unit serialises same-address
+// lanes in -- whole frame, tile window and row band give bit-identical pixels, as with the fp64 form -- at 8 fp32-rate vector
+// instructions + 2 LDS atomics per record instead of 12 fp64-rate + 4.  The 2^-31 rounding per term (a few hundred terms per ray) is the
+// size of one fp32 rounding of the result.  A NaN term (NaN weights / features) cannot be carried by an integer: it sets bit 31 of its
+// field, which no finite sum reaches, and the ray's output is NaN as in the reference.
+#define K4_FX_ONE 1073741824.f                     // 2^30
+__device__ __forceinline__ unsigned k4_fx(float x, float scale) { return (unsigned)fmaf(x, scale, 0.5f); }      // x >= 0; NaN -> 0
+__device__ __forceinline__ float k4_unfx(unsigned f, float inv) { return (f & 0x80000000u) ? __uint_as_float(0x7fc00000u) : (float)f * inv; }
 // Per-ray outputs of a finished bundle: rgb_marched = sum + alphainv_last*bg (lib/dmpigo.py:397), depth.
-__device__ __forceinline__ void k4_finish_bundle(const MarchParams& P, const ShadeJob& J, const double* acc, int lane) {
-    const double s0 = acc[lane * 4 + 0], s1 = acc[lane * 4 + 1], s2 = acc[lane * 4 + 2], s3 = acc[lane * 4 + 3];
+__device__ __forceinline__ void k4_finish_bundle(const MarchParams& P, const ShadeJob& J, const unsigned long long* acc, int lane) {
+    const unsigned long long a0 = acc[lane * 2 + 0], a1 = acc[lane * 2 + 1];
     const int ray = ray_index(P, J.B, lane);
     if (ray >= 0) {
         const float ab = P.out_ainv[ray] * P.bg;
-        P.out_rgb[(size_t)ray * 3 + 0] = (float)s0 + ab;
-        P.out_rgb[(size_t)ray * 3 + 1] = (float)s1 + ab;
-        P.out_rgb[(size_t)ray * 3 + 2] = (float)s2 + ab;
-        P.out_depth[ray] = (float)s3;
+        P.out_rgb[(size_t)ray * 3 + 0] = k4_unfx((unsigned)a0, 1.f / K4_FX_ONE) + ab;
+        P.out_rgb[(size_t)ray * 3 + 1] = k4_unfx((unsigned)(a0 >> 32), 1.f / K4_FX_ONE) + ab;
+        P.out_rgb[(size_t)ray * 3 + 2] = k4_unfx((unsigned)a1, 1.f / K4_FX_ONE) + ab;
+        P.out_depth[ray] = k4_unfx((unsigned)(a1 >> 32), P.depth_fx_inv);
     }
 }
 
-template <int MODE, int WIDTH, int NHID, bool B3>
-__global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const MarchParams P) {
+// ARITH: 0 = fp32-input MFMA (mlp_mfma), 3 = exact 3-term bf16 splits, 2 = layer 2 on 2-term splits (the default; see k4_split2).
+// WG = workgroups per CU the register allocation is bounded for (width 128 holds ~150 KB of LDS: one).
+template <int MODE, int WIDTH, int NHID, int ARITH, int WG = K4_SHADE_WG_PER_CU>
+__global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) {
+    constexpr bool B3 = ARITH != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int W = WIDTH > 0 ? WIDTH : 32;
     constexpr int NB = W / 32;
     typedef MlpLayout<W, NHID> ML;
     const int lane = k4_lane();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // LDS carve: [mlp weights][per wave: acc 64x4 | feat K1P x 64]
-    // B3: only the split-bf16 section of the packed buffer is staged (it carries its own copy of the fp32 tail)
-    const int mlp_floats = WIDTH > 0 ? (B3 ? P.mlp_floats_b3 : P.mlp_floats) : 0;
+    // LDS carve: [mlp weights][per wave: acc 64 x 2 u64 | feat K1P x 64]
+    // packed buffer = [fp32 section][b3 section][b2 section]; only the section of this arithmetic is staged (each carries its own fp32 tail)
+    const int mlp_floats = WIDTH > 0 ? (ARITH == 3 ? P.mlp_floats_b3 : ARITH == 2 ? P.mlp_floats_b2 : P.mlp_floats) : 0;
     const int mlp_pad = (mlp_floats + 3) & ~3;
     float* const wl = smem;
-    const int per_wave = 64 * 8 + (WIDTH > 0 ? P.k1p * 64 : 0);
-    double* const acc = reinterpret_cast<double*>(smem + mlp_pad + wv * per_wave);     // [64][4]  r,g,b,depth  (fp64, see the blend below)
-    float* const feat = reinterpret_cast<float*>(acc + 64 * 4);                        // [K1P][64]
+    const int per_wave = 64 * 4 + (WIDTH > 0 ? P.k1p * 64 : 0);
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(smem + mlp_pad + wv * per_wave);     // [64][2]  red | green, blue | depth (fixed point)
+    float* const feat = reinterpret_cast<float*>(acc + 64 * 2);                        // [K1P][64]
     if (WIDTH > 0) {
-        const float* const src = P.mlp + (B3 ? P.mlp_floats : 0);
+        const float* const src = P.mlp + (ARITH == 3 ? P.mlp_floats : ARITH == 2 ? P.mlp_floats + P.mlp_floats_b3 : 0);
         for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = src[i];
     }
     __syncthreads();
@@ -1144,7 +1200,7 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
     ShadeJob J;
     if (!k4_next_job(P, lane, J)) break;
     const Bundle B = J.B;
-    acc[lane * 4 + 0] = 0.; acc[lane * 4 + 1] = 0.; acc[lane * 4 + 2] = 0.; acc[lane * 4 + 3] = 0.;
+    acc[lane * 2 + 0] = 0ull; acc[lane * 2 + 1] = 0ull;
     const uint2* __restrict__ ent = P.entries + (size_t)B.id * (size_t)P.ent_stride;
     const int total = J.total;
     // the bundle's 64 rays live in registers, lane = ray slot; a record reads its ray's with ds_bpermute (__shfl).
@@ -1296,49 +1352,37 @@ __global__ __launch_bounds__(256, K4_SHADE_WG_PER_CU) void k4_shade_kernel(const
             float l0, l1, l2;
             if (B3) {
                 LdsFeat fs = {feat, P.k1p, lane & 31, half};
+                constexpr int NT2 = ARITH == 3 ? 3 : 2, NT1 = ARITH == 3 ? 3 : K4_B2_L1_TERMS;
                 if constexpr (K4_MLP_PAIR && W == 64 && NHID == 1) {
                     // a full batch of the LLFF shape: both tiles through one software pipeline (same bits); anything else one tile at a time
-                    if (P.k1p == 16 && nproc > 32 && !(P.debug & 2)) mlp_pair64_b3(wl, fs, lane, half, l0, l1, l2 K4_TPASS);
-                    else mlp_mfma_b3<W, NHID>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
-                } else mlp_mfma_b3<W, NHID>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
+                    if (P.k1p == 16 && nproc > 32 && !(P.debug & 2)) mlp_pair64<NT1, NT2>(wl, fs, lane, half, l0, l1, l2 K4_TPASS);
+                    else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
+                } else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, P.k1p, lane, half, P.debug, nproc, l0, l1, l2 K4_TPASS);
             }
             else mlp_mfma<W, NHID>(wl, feat, P.k1p, lane, half, P.debug, l0, l1, l2);
             o0 = l0 + dif0; o1 = l1 + dif1; o2 = l2 + dif2;            // rgb_logit + k0_diffuse (lib/dvgo.py:412)
             __builtin_amdgcn_wave_barrier();
         }
-        // sigmoid, blend.  The per-ray sums (segment_coo, lib/dmpigo.py:382-386,418-424) are carried in fp64 with every fp32 term first
-        // rounded to a multiple of 2^-40 (the (x + 2^12) - 2^12 pair): terms <= 1, at most a few hundred per ray -> every fp64 addition is
-        // EXACT, so the sum does not depend on how records fall into batches, scan trees or LDS-atomic order.  A ray's colour is therefore
-        // independent of which other rays were marched with it (whole frame vs tile window vs row band: bit-identical pixels); the
-        // 2^-41 quantisation is 5 orders below an fp32 ulp of the result.
-        const double QC = 4096.0;
-        double v0 = ((double)(w * (1.f / (1.f + expf(-o0)))) + QC) - QC;
-        double v1 = ((double)(w * (1.f / (1.f + expf(-o1)))) + QC) - QC;
-        double v2 = ((double)(w * (1.f / (1.f + expf(-o2)))) + QC) - QC;
-        double v3 = ((double)(w * (((float)k + 0.5f) / (float)P.depth_n)) + QC) - QC;       // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
-#if K4_SHADE_SCAN
-        // segmented inclusive scan over RUNS of equal ray (a ray's records are contiguous within a depth quarter, so
-        // one batch can hold two runs of the same ray: key = index of the run, not the ray)
-        const int keyr = k4_run_id(lact ? rl : (256 + lane), lane);
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int ok_ = __shfl_up(keyr, off);
-            const double u0 = __shfl_up(v0, off), u1 = __shfl_up(v1, off), u2 = __shfl_up(v2, off), u3 = __shfl_up(v3, off);
-            if (lane >= off && ok_ == keyr) { v0 += u0; v1 += u1; v2 += u2; v3 += u3; }
+        // sigmoid, blend, per-ray sums in fixed point (see k4_fx above)
+        const float r0 = w * (1.f / (1.f + expf(-o0))), r1 = w * (1.f / (1.f + expf(-o1))), r2 = w * (1.f / (1.f + expf(-o2)));
+        const float r3 = w * (((float)k + 0.5f) / (float)P.depth_n);                        // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
+        unsigned f0 = k4_fx(r0, K4_FX_ONE), f1 = k4_fx(r1, K4_FX_ONE), f2 = k4_fx(r2, K4_FX_ONE);
+        const unsigned f3 = k4_fx(r3, P.depth_fx);
+        const float rs = r0 + r1 + r2;
+        if (__builtin_expect(rs != rs, 0)) {                                              // some colour term is NaN (rare path): its field gets the poison bit
+            if (r0 != r0) f0 = 0x80000000u;
+            if (r1 != r1) f1 = 0x80000000u;
+            if (r2 != r2) f2 = 0x80000000u;
+            if (lact) {                                                                   // OR, not add: two NaN records must not carry out of the field
+                atomicOr(&acc[rl * 2 + 0], (unsigned long long)(f0 & 0x80000000u) | ((unsigned long long)(f1 & 0x80000000u) << 32));
+                atomicOr(&acc[rl * 2 + 1], (unsigned long long)(f2 & 0x80000000u));
+            }
+            f0 &= 0x7fffffffu; f1 &= 0x7fffffffu; f2 &= 0x7fffffffu;
         }
-        const int nextk = __shfl_down(keyr, 1);
-        if (lact && (lane == 63 || nextk != keyr)) {
-            // ds_add_f64: two runs of one ray can end in the same batch (sparse bundles), a plain read-modify-write would lose one
-            k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
-        }
-#else
-        // every record adds its four terms to its ray's fp64 sums with ds_add_f64: exact additions commute, so the LDS unit's own
-        // serialisation of same-address lanes replaces the ~180 VALU + 54 ds_bpermute of a segmented wave scan (the LDS pipe is
-        // otherwise nearly idle in this kernel, the VALU is what bounds it)
         if (lact && !(P.debug & 512)) {                                  // (512: ablation, no per-ray sums)
-            k4_lds_add(&acc[rl * 4 + 0], v0); k4_lds_add(&acc[rl * 4 + 1], v1); k4_lds_add(&acc[rl * 4 + 2], v2); k4_lds_add(&acc[rl * 4 + 3], v3);
+            k4_lds_add(&acc[rl * 2 + 0], (unsigned long long)f0 | ((unsigned long long)f1 << 32));
+            k4_lds_add(&acc[rl * 2 + 1], (unsigned long long)f2 | ((unsigned long long)f3 << 32));
         }
-#endif
         __builtin_amdgcn_wave_barrier();
         K4_TSTAMP(6);                                    // sigmoid, blend, per-ray sums
     }
@@ -1363,11 +1407,11 @@ static int n_workgroups(int64_t n_rays, int img_w) {
     return (int)((n_rays + 255) / 256);
 }
 
-static size_t mlp_floats_b3_of(const k4_mlp_desc* m, int k1p) {       // split-bf16 section (MlpLayoutB3)
+static size_t mlp_floats_b3_of(const k4_mlp_desc* m, int k1p, int nt1 = 3, int nt2 = 3) {       // split-bf16 section (MlpLayoutB3<W, NHID, nt1, nt2>)
     if (m->width == 0) return 0;
     const size_t nb = m->width / 32, kb1 = (size_t)(k1p + 15) / 16;
-    size_t n = nb * kb1 * 3 * 64 * 4;
-    if (m->n_hidden) n += nb * (m->width / 16) * 3 * 64 * 4 + nb * 2 * 16;
+    size_t n = nb * kb1 * (size_t)nt1 * 64 * 4;
+    if (m->n_hidden) n += nb * (m->width / 16) * (size_t)nt2 * 64 * 4 + nb * 2 * 16;
     n += nb * 16 * 2 * 4 + 4;
     return n;
 }
@@ -1399,21 +1443,25 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     rc = k4_check_launch();
     if (rc) return rc;
     const int width = mlp->width, nh = mlp->n_hidden;
-    // rgbnet arithmetic: split-bf16 matrix pipe (fp32-equivalent, see mlp_mfma_b3) for width <= 64; k4_mlp_desc.arith =
-    // K4_MLP_ARITH_FP32 selects the fp32-input MFMA form (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time)
-    const bool b3 = width != 0 && width <= 64 && mlp->arith != K4_MLP_ARITH_FP32;
-    const size_t lds_base = sizeof(float) * (((size_t)(b3 ? P.mlp_floats_b3 : P.mlp_floats) + 3) / 4 * 4 + 4 * (64 * 8 + (width ? (size_t)P.k1p * 64 : 0)));
-    const dim3 sgrid((unsigned)min(nwg, n_cu * K4_SHADE_WG_PER_CU));
-    const size_t lds = lds_base;
+    // rgbnet arithmetic (k4_mlp_desc.arith): default = layer 1 exact, layer 2 on 2-term bf16 splits (mlp_mfma_bx<.., 2>, every width);
+    // K4_MLP_ARITH_B3 = the exact 3-term form of rounds 2-5 (width <= 64: the width-128 operand does not fit the LDS);
+    // K4_MLP_ARITH_FP32 = fp32-input MFMA (bit-exact fp32 FMA chains, 2.7x the matrix-pipe time of B3)
+    const int arith = width == 0 ? 0 : mlp->arith == K4_MLP_ARITH_FP32 ? 0 : mlp->arith == K4_MLP_ARITH_B3 ? 3 : 2;
+    if (arith == 3 && width > 64) return K4_ERR_UNSUPPORTED;
+    const int wg_per_cu = width == 128 ? 1 : K4_SHADE_WG_PER_CU;
+    const size_t mlp_fl = arith == 3 ? P.mlp_floats_b3 : arith == 2 ? P.mlp_floats_b2 : P.mlp_floats;
+    const size_t lds = sizeof(float) * ((mlp_fl + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
         if (lds > 64 * 1024) { \
             hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
         hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)      /* lds varies with the MLP shape: set per launch */
-#define K4_LAUNCH(WD, NH) do { if (b3 && WD > 0 && WD <= 64) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD > 0 && WD <= 64 ? WD : 32), NH, true>)); \
-                               else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, false>)); } while (0)
-    if (width == 0) K4_LAUNCH(0, 0);
+#define K4_LAUNCH(WD, NH) do { if (arith == 2) K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, 2, (WD == 128 ? 1 : K4_SHADE_WG_PER_CU)>)); \
+                               else if (arith == 3) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD <= 64 ? WD : 32), NH, 3>)); \
+                               else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, 0, (WD == 128 ? 1 : K4_SHADE_WG_PER_CU)>)); } while (0)
+    if (width == 0) K4_LAUNCH_K((k4_shade_kernel<MODE, 0, 0, 0>));
     else if (width == 32 && nh == 0) K4_LAUNCH(32, 0);
     else if (width == 32 && nh == 1) K4_LAUNCH(32, 1);
     else if (width == 64 && nh == 0) K4_LAUNCH(64, 0);
@@ -1477,6 +1525,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.mlp = m->packed; P.dim0 = m->dim0; P.k1p = (m->dim0 + 2) & ~1;
     P.mlp_floats = (int)mlp_floats_of(m, P.k1p);
     P.mlp_floats_b3 = (int)mlp_floats_b3_of(m, P.k1p);
+    P.mlp_floats_b2 = (int)mlp_floats_b3_of(m, P.k1p, K4_B2_L1_TERMS, 2);
     P.vpe = m->viewbase_pe; P.spe = m->spatial_pe; P.k0_skip = m->k0_skip;
     P.max_steps = max_steps;
     if (ent_stride_of(max_steps) > 0x7fffffff) return K4_ERR_BAD_ARG;
@@ -1497,6 +1546,16 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.out_rgb = out_rgb; P.out_depth = out_depth; P.out_ainv = out_ainv;
     P.counters = (unsigned long long*)counters;
     return K4_OK;
+}
+
+// fixed-point scale of the per-ray depth sums: sum_w s <= the largest s = (max_steps + 0.5) / depth_n a record can carry (sum_w <= 1);
+// rounded up to a power of two so that 2^30 / it is one (exact scaling both ways)
+static void set_depth_fx(MarchParams& P, int max_steps) {
+    const double smax = ((double)max_steps + 0.5) / (double)(P.depth_n > 0 ? P.depth_n : 1);
+    int e = 0;
+    while (e < 60 && ldexp(1.0, e) < smax) ++e;
+    P.depth_fx = (float)ldexp(1.0, 30 - e);
+    P.depth_fx_inv = (float)ldexp(1.0, e - 30);
 }
 
 extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
@@ -1521,7 +1580,9 @@ extern "C" int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_h
     if ((width != 32 && width != 64 && width != 128) || n_hidden < 0 || n_hidden > 1 || dim0 <= 0) return -1;
     k4_mlp_desc m{};
     m.width = width; m.n_hidden = n_hidden; m.dim0 = dim0;
-    return (int64_t)(mlp_floats_of(&m, (dim0 + 2) & ~1) + mlp_floats_b3_of(&m, (dim0 + 2) & ~1));
+    return (int64_t)(mlp_floats_of(&m, (dim0 + 2) & ~1) + mlp_floats_b3_of(&m, (dim0 + 2) & ~1) + mlp_floats_b3_of(&m, (dim0 + 2) & ~1, K4_B2_L1_TERMS, 2));
+}
+extern "C" int k4_mlp_b2_layer1_terms(void) { return K4_B2_L1_TERMS;
 }
 
 extern "C" int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -1541,6 +1602,7 @@ extern "C" int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const 
         if (mlp->dim0 != want || mlp->k0_skip != 0) return K4_ERR_BAD_ARG;
     }
     P.n_samples = n_samples; P.depth_n = n_samples; P.nsm1 = (float)(n_samples - 1);
+    set_depth_fx(P, n_samples);
     P.shift = 0.f;                                                                            // lib/dmpigo.py:261
     P.interval = interval; P.thres = fast_color_thres; P.bg = bg;
     return launch_march<MODE_MPI>(P, mlp, (hipStream_t)stream);
@@ -1564,6 +1626,7 @@ extern "C" int k4_march_dvgo_fwd(const float* rays_o, const float* rays_d, const
         if (mlp->dim0 != want) return K4_ERR_BAD_ARG;
     }
     P.depth_n = depth_n_samples; P.stepdist = stepdist; P.near_ = near; P.far_ = far;
+    set_depth_fx(P, max_steps);
     P.shift = act_shift; P.interval = interval; P.thres = fast_color_thres; P.bg = bg;
     return launch_march<MODE_DVGO>(P, mlp, (hipStream_t)stream);
 }

@@ -62,7 +62,7 @@ def sparse_grad_allreduce(params, group=None, average=True):
     world = _world(group)
     stats = {'world': world, 'bytes_gathered': 0, 'touched': []}
     params = [p for p in params if p.requires_grad]
-    if world == 1:
+    if world == 1 and not (N.FORCE_COLLECTIVES and dist.is_initialized()):
         return stats
     for p in params:
         C = p.shape[1] if p.dim() == 5 else 1
@@ -96,7 +96,7 @@ def sparse_grad_allreduce(params, group=None, average=True):
 
 def exchange_gradients(model, net_sr, group=None):
     """Data-parallel gradient exchange of the joint step: big grids sparse, everything else in one dense bucket."""
-    if _world(group) == 1:
+    if _world(group) == 1 and not (N.FORCE_COLLECTIVES and dist.is_initialized()):
         return {'world': 1}
     everything = [p for p in list(model.parameters()) + list(net_sr.parameters()) if p.requires_grad]
     big = [p for p in everything if p.numel() >= SPARSE_MIN_NUMEL and p.dim() == 5]

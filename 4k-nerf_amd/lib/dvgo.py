@@ -117,7 +117,7 @@ class _FusedMarcher:
         md.viewbase_pe = int(len(self.viewfreq)) if self.rgbnet is not None else 0
         md.spatial_pe = int(spatial_pe)
         md.k0_skip = int(k0_skip)
-        md.arith = 1 if os.environ.get('K4_MLP') == 'fp32' else 0      # K4_MLP_ARITH_FP32: exact-fp32 MFMA form (tests, A/B runs)
+        md.arith = {'fp32': 1, 'b3': 2}.get(os.environ.get('K4_MLP', ''), 0)      # K4_MLP_ARITH_*: default 'b2' (2-term hidden activations); 'b3' exact 3-term; 'fp32' fp32-input MFMA (tests, A/B runs)
         if self.rgbnet is None:
             md.packed, md.dim0, md.width, md.n_hidden = None, 0, 0, 0
             return md, None
@@ -624,7 +624,8 @@ def pack_mlp_mfma(lins):
     bo = torch.zeros([4], dtype=torch.float32, device=dev)
     bo[:3] = lins[-1].bias.detach().float()
     parts.append(bo)
-    parts += _pack_mlp_split_bf16(w1, lins, wot, bo)
+    parts += _pack_mlp_split_bf16(w1, lins, wot, bo, 3, 3)                                    # K4_MLP_ARITH_B3 section: exact
+    parts += _pack_mlp_split_bf16(w1, lins, wot, bo, int(N.lib().k4_mlp_b2_layer1_terms()), 2)   # default (b2) section: the two leading terms
     out = torch.cat(parts).contiguous()
     want = N.lib().k4_mlp_packed_floats(dim0, W, len(lins) - 2)
     assert out.numel() == want, (out.numel(), want)
@@ -640,7 +641,7 @@ def _split3_bf16(x):
     return t0, t1, t2
 
 
-def _pack_mlp_split_bf16(w1ext, lins, wot, bo):
+def _pack_mlp_split_bf16(w1ext, lins, wot, bo, nt1=3, nt2=3):
     """Split-bf16 section of the packed rgbnet buffer (layout: csrc/k4_march.hip, MlpLayoutB3), returned as fp32-typed
     views of the raw bytes.  v_mfma_f32_32x32x16_bf16 operand order: lane l holds 8 bf16 = row (l&31), k = 8*(l>>5)+e."""
     dev = w1ext.device
@@ -651,7 +652,7 @@ def _pack_mlp_split_bf16(w1ext, lins, wot, bo):
     mb = torch.arange(NB, device=dev)
 
     def as_f32(terms, index_fn):
-        # [..., 3 terms, 64 lanes, 8] bf16 -> flat fp32 view
+        # [..., terms, 64 lanes, 8] bf16 -> flat fp32 view
         g = torch.stack([index_fn(t) for t in terms], dim=-3)
         return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
@@ -660,7 +661,7 @@ def _pack_mlp_split_bf16(w1ext, lins, wot, bo):
     kb = torch.arange(KB1, device=dev)
     j = (mb[:, None, None, None] * 32 + (lane & 31)[None, None, :, None]).expand(NB, KB1, 64, 8)
     k = (kb[None, :, None, None] * 16 + 8 * (lane >> 5)[None, None, :, None] + e[None, None, None, :]).expand(NB, KB1, 64, 8)
-    parts = [as_f32(_split3_bf16(w1p), lambda t: t[j, k])]
+    parts = [as_f32(_split3_bf16(w1p)[:nt1], lambda t: t[j, k])]
     if len(lins) == 3:
         w2 = lins[1].weight.detach().float()
         kb = torch.arange(KB2, device=dev)
@@ -668,7 +669,7 @@ def _pack_mlp_split_bf16(w1ext, lins, wot, bo):
         n = ((kb >> 1)[None, :, None, None] * 32 + (e & 3)[None, None, None, :]
              + 8 * (2 * (kb & 1)[None, :, None, None] + (e >> 2)[None, None, None, :]) + 4 * h).expand(NB, KB2, 64, 8)
         j2 = (mb[:, None, None, None] * 32 + (lane & 31)[None, None, :, None]).expand(NB, KB2, 64, 8)
-        parts.append(as_f32(_split3_bf16(w2), lambda t: t[j2, n]))
+        parts.append(as_f32(_split3_bf16(w2)[:nt2], lambda t: t[j2, n]))
         b2 = lins[1].bias.detach().float()
         r = torch.arange(16, device=dev)
         hh = torch.arange(2, device=dev)

@@ -631,7 +631,7 @@ def allreduce_gradients(params, group=None, average=True):
             flat[off:off + n].copy_(p.grad.reshape(-1))
         off += n
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
+    if world > 1 or (N.FORCE_COLLECTIVES and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)          # backend "nccl" = RCCL on the GPUs, gloo in the CPU tests
         if average:
             flat /= world

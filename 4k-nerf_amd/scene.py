@@ -31,8 +31,9 @@ def _axis(lo, hi, n):
     return torch.linspace(float(lo), float(hi), int(n))
 
 
-def _blob_field(xyz_min, xyz_max, world_size, g, n_blobs, amp, sigma_range, sheet=True):
-    """Sum of anisotropic Gaussian blobs (+ one slanted thin sheet) evaluated on the voxel grid.
+def _blob_field(xyz_min, xyz_max, world_size, g, n_blobs, amp, sigma_range, sheet=True, sheet_z=0.72, sheet_amp=None, sheet_vox=1.5):
+    """Sum of anisotropic Gaussian blobs (+ one slanted sheet: thin and translucent by default; ``sheet_amp`` / ``sheet_vox`` / ``sheet_z``
+    make it an opaque wall somewhere else in depth) evaluated on the voxel grid.
     Separable per blob, so the full-size LLFF grid (37.7 M voxels) takes a few seconds on CPU."""
     X, Y, Z = [int(v) for v in world_size]
     ax = [_axis(xyz_min[i], xyz_max[i], world_size[i]) for i in range(3)]
@@ -49,11 +50,11 @@ def _blob_field(xyz_min, xyz_max, world_size, g, n_blobs, amp, sigma_range, shee
         field += a * gx[:, None, None] * gy[None, :, None] * gz[None, None, :]
     if sheet:
         # slanted plane  z = z0 + sx*x + sy*y, thickness ~1.5 voxels in z
-        z0 = float(xyz_min[2] + ext[2] * 0.72)
+        z0 = float(xyz_min[2] + ext[2] * sheet_z)
         sx, sy = 0.11, -0.07
-        th = 1.5 * ext[2] / Z
+        th = sheet_vox * ext[2] / Z
         zc = z0 + sx * ax[0][:, None] + sy * ax[1][None, :]
-        field += amp * torch.exp(-0.5 * ((ax[2][None, None, :] - zc[:, :, None]) / th) ** 2)
+        field += (amp if sheet_amp is None else sheet_amp) * torch.exp(-0.5 * ((ax[2][None, None, :] - zc[:, :, None]) / th) ** 2)
     return field
 
 
@@ -104,9 +105,12 @@ def _raw2alpha(density, shift, interval):
 def make_llff_checkpoint(seed=777, num_voxels=384 * 384 * 256, mpi_depth=256, rgbnet_dim=9,
                          rgbnet_width=64, rgbnet_depth=3, viewbase_pe=0, spatial_pe=0,
                          stepsize=1.0, bbox=LLFF_BBOX, n_blobs=24, mask_margin=5.5,
-                         mask_cache_world_size=None):
+                         mask_cache_world_size=None, opaque=False):
     """DirectMPIGO checkpoint with the LLFF configuration of configs/llff/llff_default_lg.py:33-44
-    (defaults) or a scaled-down version of it (smaller ``num_voxels`` / ``mpi_depth``)."""
+    (defaults) or a scaled-down version of it (smaller ``num_voxels`` / ``mpi_depth``).
+    ``opaque=True``: the statistics of a TRAINED forward-facing scene instead of translucent blobs -- an opaque slanted wall around 0.4
+    of the depth range (density +22 over three planes: alpha = 1 to fp32) behind the front blobs, so that every ray reaches the
+    T < 1e-3 stop of Alphas2Weights (render_utils_kernel.cu:597-600) by mid-depth and the blobs behind the wall are never seen."""
     g = _gen(seed)
     xyz_min = torch.tensor(bbox[0], dtype=torch.float32)
     xyz_max = torch.tensor(bbox[1], dtype=torch.float32)
@@ -119,7 +123,8 @@ def make_llff_checkpoint(seed=777, num_voxels=384 * 384 * 256, mpi_depth=256, rg
     fast_color_thres = stepsize / mpi_depth / 5                       # llff_default_lg.py:43
     ws = world_size.tolist()
 
-    field = _blob_field(xyz_min, xyz_max, ws, g, n_blobs, amp=16.0, sigma_range=(0.028, 0.075))
+    field = _blob_field(xyz_min, xyz_max, ws, g, n_blobs, amp=16.0, sigma_range=(0.028, 0.075),
+                        **(dict(sheet_z=0.4, sheet_amp=32.0, sheet_vox=3.0) if opaque else {}))
     density = (field - 10.0)[None, None].contiguous()                 # background -10
     act_shift = mpi_act_shift(mpi_depth, voxel_size_ratio)
 

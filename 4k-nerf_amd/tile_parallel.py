@@ -20,6 +20,8 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import _native as _N
+
 
 def tile_geometry(height, width, tile_size, tile_pad=10):
     """The reference's tile loop as data (lib/sr_esrnet.py:478-497):
@@ -151,7 +153,7 @@ def decode_frame_tiles(state, out=None, out_dtype=None):
         send = _to8b(send)
     elif odt != torch.float32:
         raise ValueError('render_frame_tiles: out_dtype must be torch.float32 or torch.uint8')
-    if ws > 1:
+    if ws > 1 or (_N.FORCE_COLLECTIVES and dist.is_initialized()):
         recv = torch.empty([ws, 3, slot], dtype=odt, device=dev)
         dist.all_gather_into_tensor(recv.view(ws * 3, slot), send, group=group)      # final pixels only
     else:

@@ -156,7 +156,7 @@ class MarcherRun:
     def isolated(self, n):
         """ISOLATED launch duration (one stream, HIP events around each call on the launch stream) and the device sample
         counters -- the duration the rocprofv3 --stats summary of `bench.py --streams 1` must agree with."""
-        cnt = torch.zeros(4, dtype=torch.int64, device=self.dev)
+        cnt = torch.zeros(8, dtype=torch.int64, device=self.dev)
         st0 = self.streams[0]
         iso = []
         with torch.no_grad():
@@ -852,7 +852,7 @@ def scene_sweep(dev, H, W, K, poses):
         model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
         rk = ck['render_kwargs']
         views = scene.llff_spiral_poses()[::max(1, 20 // n_views)][:n_views]
-        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(8, dtype=torch.int64, device=dev)
         ms = []
         with torch.no_grad():
             for i, p in enumerate(views):
@@ -865,7 +865,7 @@ def scene_sweep(dev, H, W, K, poses):
                     a.record(); model(ro, rd, vd, k4_img_w=W, **rk); b.record()
                     torch.cuda.synchronize()
                     ms.append(a.elapsed_time(b))
-        inb, msk, alp, shd = [c / len(views) for c in cnt.cpu().tolist()]
+        inb, msk, alp, shd = [c / len(views) for c in cnt.cpu().tolist()[:4]]
         m = float(np.median(ms))
         b_alg = H * W * 56 + inb + msk * 32 + shd * 8 * model.k0_dim * 4
         out[name] = {'views': len(views), 'ms_per_call_median': round(m, 4), 'mrays_isolated': round(H * W / (m * 1e-3) / 1e6, 1),
@@ -926,7 +926,7 @@ def dvgo_config0(dev, with_oracle=True):
             K = scene.lego_K(H, H)
             ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in
                           dvgo.get_rays_of_a_view(H, H, K, torch.from_numpy(pose[:3, :4].astype(np.float32)).to(dev), False, False, False, False)]
-            cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+            cnt = torch.zeros(8, dtype=torch.int64, device=dev)
             model(ro, rd, vd, k4_img_w=H, k4_counters=cnt, **rk)
             got = model(ro, rd, vd, k4_img_w=H, **rk)
             torch.cuda.synchronize()
@@ -937,7 +937,7 @@ def dvgo_config0(dev, with_oracle=True):
                 ev.append((a, b))
             torch.cuda.synchronize()
             ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
-            inb, msk, alp, shd = cnt.cpu().tolist()
+            inb, msk, alp, shd = cnt.cpu().tolist()[:4]
             b_alg = H * H * 56 + inb + msk * 32 + shd * 8 * model.k0_dim * 4
             out[f'{H}x{H}'] = {'ms': round(ms, 4), 'mrays_per_s': round(H * H / (ms * 1e-3) / 1e6, 2),
                                'samples': {'in_bbox': inb, 'mask': msk, 'alpha': alp, 'shaded': shd},

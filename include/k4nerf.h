@@ -96,10 +96,11 @@ int k4_build_live_mask(const k4_grid_desc* grid, float act_shift_scalar, float i
  *     n_hidden==1:  W2A [NB][NB][16][64] = W2[mb2*32+(l&31)][mb*32+row(r,l>>5)] ;  B2A [NB][64] = l<32 ? b2[mb2*32+l] : 0
  *     WOT [NB][16][2][4]         = Wout[c][mb*32+row(r,h)]  (c = 0..2, 3rd padded with 0)
  *     BO  [4]
- * followed by the SPLIT section the default arithmetic uses (exact 3-term bf16 split w = t0 + t1 + t2, each term RNE of the
- * running remainder; v_mfma_f32_32x32x16_bf16 operand order, 16-byte units = 8 bf16; KB1 = ceil(K1P/16)):
- *     W1S [NB][KB1][3 terms][64]   = W1ext[mb*32+(l&31)][kb*16 + 8*(l>>5) + e]                      e = 0..7
- *     n_hidden==1:  W2S [NB][width/16][3][64] = W2[mb2*32+(l&31)][(kb>>1)*32 + (e&3) + 8*(2*(kb&1)+(e>>2)) + 4*(l>>5)]
+ * followed by TWO split sections (bf16 split w = t0 + t1 + t2, each term RNE of the running remainder: exact with 3 terms, 16
+ * significant bits with the 2 leading ones; v_mfma_f32_32x32x16_bf16 operand order, 16-byte units = 8 bf16; KB1 = ceil(K1P/16)),
+ * first with (NT1, NT2) = (3, 3) for K4_MLP_ARITH_B3, then with (NT1, NT2) = (k4_mlp_b2_layer1_terms(), 2) for the default arithmetic:
+ *     W1S [NB][KB1][NT1 terms][64] = W1ext[mb*32+(l&31)][kb*16 + 8*(l>>5) + e]                      e = 0..7
+ *     n_hidden==1:  W2S [NB][width/16][NT2][64] = W2[mb2*32+(l&31)][(kb>>1)*32 + (e&3) + 8*(2*(kb&1)+(e>>2)) + 4*(l>>5)]
  *                   B2S [NB][2][16] fp32      = b2[mb2*32 + row(r,h)]
  *     WOT, BO as above
  * width == 0 means "no rgbnet": rgb = sigmoid(k0) with k0_ch == 3 (lib/dvgo.py:377-379). */
@@ -113,9 +114,14 @@ typedef struct k4_mlp_desc {
     int32_t k0_skip;                 /* DVGO rgbnet_direct=False: 3 (first 3 k0 channels are added to the logits, lib/dvgo.py:385-386,412), else 0 */
     int32_t arith;                   /* K4_MLP_ARITH_*: matrix-pipe arithmetic of the rgbnet                */
 } k4_mlp_desc;
-#define K4_MLP_ARITH_DEFAULT 0      /* width <= 64: exact 3-term bf16 splits on v_mfma_f32_32x32x16_bf16 (fp32-equivalent); else fp32 */
-#define K4_MLP_ARITH_FP32    1      /* v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains (2.7x the matrix-pipe time)                  */
+#define K4_MLP_ARITH_DEFAULT 0      /* "b2" (round 6): activations and weights of both rgbnet layers on 2-term bf16 splits (16 significant bits,
+                                       3 products a1 w0 + a0 w1 + a0 w0 on v_mfma_f32_32x32x16_bf16, fp32 accumulation); every width incl. 128.
+                                       ~130 dB per sample against fp64 (fp32 itself: ~150); >= 100 dB per frame against the fp32 oracle is
+                                       asserted (tests/test_march_gpu.py, bench.py parity_vs_oracle)                                        */
+#define K4_MLP_ARITH_FP32    1      /* v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chains (2.7x the matrix-pipe time of B3)                        */
+#define K4_MLP_ARITH_B3      2      /* exact 3-term bf16 splits, 6 products (fp32-equivalent; the default of rounds 2-5); width <= 64            */
 int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden);   /* <0: unsupported shape */
+int k4_mlp_b2_layer1_terms(void);    /* NT1 of the default section: 2 (3 in A/B builds with -DK4_B2_L1_TERMS=3: layer 1 exact) */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused marchers: two launches (geometry + shading, csrc/k4_march.hip) replace everything inside
@@ -131,8 +137,9 @@ int64_t k4_mlp_packed_floats(int32_t dim0, int32_t width, int32_t n_hidden);   /
  *             {ray,step,weight} records between the two kernels; worst-case sized, sparsely touched);
  *             max_steps = n_samples for MPI.  Owned by the caller, reusable across calls on one stream.
  *   out_rgb [n_rays][3], out_depth [n_rays], out_alphainv [n_rays]
- *   out_counters : NULL or uint64[4] = {in-bbox samples, mask-pass samples, alpha-pass samples,
- *                  shaded samples} the kernels VISITED (they stop at the T<1e-3 early stop), ACCUMULATED
+ *   out_counters : NULL or uint64[8] (ABI 12; [4] before) = {in-bbox samples, mask-pass samples, alpha-pass samples,
+ *                  shaded samples, alpha-pass samples BEHIND their ray's T<1e-3 stop (density evaluated, then dropped by the
+ *                  transmittance scan: what a depth-ordered geometry stage could skip), 0, 0, 0}, ACCUMULATED
  *                  (caller zeroes) -- the counts SURVEY 8(d)'s algorithmic-bytes formula needs.
  * ------------------------------------------------------------------------------------------- */
 int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps);

@@ -123,15 +123,40 @@ def check_native(got, G, what):
         assert (err <= bound).all(), (what, key, float(err.max()), float((err - bound).max()))
 
 
-def sftnet_forward_torch(net, x, cond):
-    """The reference's op sequence (lib/sr_esrnet.py:446-465, fea=None) on the module's nn.Conv2d layers with PyTorch-ROCm ops: a
-    CHECKER for the HIP graphs (the product has no PyTorch path: SFTNet.forward raises where the HIP kernels do not apply)."""
+def sft_layer_torch(l, t, c):
+    """SFTLayer.forward (lib/sr_esrnet.py:120-123) with PyTorch ops on the module's parameters: test-side checker."""
     import torch.nn.functional as F
+    scale = l.SFT_scale_conv1(F.leaky_relu(l.SFT_scale_conv0(c), 0.2))
+    shift = l.SFT_shift_conv1(F.leaky_relu(l.SFT_shift_conv0(c), 0.2))
+    return t * (scale + 1) + shift
+
+
+def rdb_torch(b, t, c):
+    """ResidualDenseBlock_SFT.forward (lib/sr_esrnet.py:149-158) with PyTorch ops: test-side checker."""
+    import torch.nn.functional as F
+    lr = lambda v: F.leaky_relu(v, 0.2)
+    xc0 = sft_layer_torch(b.sft0, t, c)
+    x1 = lr(b.conv1(xc0))
+    x2 = lr(b.conv2(torch.cat((xc0, x1), 1)))
+    x3 = lr(b.conv3(torch.cat((xc0, x1, x2), 1)))
+    x4 = lr(b.conv4(torch.cat((xc0, x1, x2, x3), 1)))
+    xc1 = sft_layer_torch(b.sft1, x4, c)
+    return b.conv5(torch.cat((xc0, x1, x2, x3, xc1), 1)) * 0.2 + t
+
+
+def sftnet_forward_torch(net, x, cond):
+    """The reference's op sequence (lib/sr_esrnet.py:112-182,446-465, fea=None) on the module's nn.Conv2d PARAMETERS with PyTorch-ROCm
+    ops: a CHECKER for the HIP graphs.  The product has no PyTorch path: SFTNet.forward raises where the HIP kernels do not apply and the
+    sub-blocks (SFTLayer, ResidualDenseBlock_SFT, RRDB_SFT) are parameter containers whose forward raises -- so the block bodies live here."""
+    import torch.nn.functional as F
+    sft, rdb = sft_layer_torch, rdb_torch
     feat = net.conv_first(x)
     c = net.CondNet(cond)
-    body_feat = net.body((feat, c))
-    body_feat = net.sftbody(body_feat[0], body_feat[1])
-    body_feat = net.conv_body(body_feat) + feat
+    body = feat
+    for rr in net.body:                                                       # lib/sr_esrnet.py:176-182
+        out = rdb(rr.rdb3, rdb(rr.rdb2, rdb(rr.rdb1, body, c), c), c)
+        body = sft(rr.sft0, out, c) * 0.2 + body
+    body_feat = net.conv_body(sft(net.sftbody, body, c)) + feat
     if net.scale > 1:
         body_feat = net.lrelu(net.conv_up1(F.interpolate(body_feat, scale_factor=2, mode='nearest')))
         if net.scale == 4:

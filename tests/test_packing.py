@@ -58,40 +58,52 @@ def test_pack_mlp_sections_reproduce_the_weights(dim0, W, depth):
                         assert w2a[mb2, mb, r, l] == w2[mb2 * 32 + (l & 31), mb * 32 + _row(r, l >> 5)]
         off += NB * 64
     off += NB * 16 * 2 * 4 + 4
-    # ---- split-bf16 section (v_mfma_f32_32x32x16_bf16 order): terms must sum back to the weights exactly
+    # ---- split-bf16 sections (v_mfma_f32_32x32x16_bf16 order): first the exact one (K4_MLP_ARITH_B3: 3 terms everywhere, the terms sum back to
+    # the weights exactly), then the default one (layer 1 exact, the layer-2 weights' two LEADING terms: within 2^-16 relative)
     KB1, KB2 = (k1p + 15) // 16, W // 16
-    n1 = NB * KB1 * 3 * 64 * 4
-    w1s = _bf16_terms(buf[off:off + n1], [NB, KB1, 3, 64, 8]).sum(2); off += n1
-    for mb in range(NB):
-        for kb in range(KB1):
-            for l in (0, 9, 31, 32, 50, 63):
-                for e in range(8):
-                    k = kb * 16 + 8 * (l >> 5) + e
-                    want = w1ext[mb * 32 + (l & 31), k] if k < k1p else 0.0
-                    assert w1s[mb, kb, l, e] == want
-    if nh:
-        n2 = NB * KB2 * 3 * 64 * 4
-        w2s = _bf16_terms(buf[off:off + n2], [NB, KB2, 3, 64, 8]).sum(2); off += n2
-        for mb2 in range(NB):
-            for kb in range(KB2):
-                for l in (0, 31, 32, 63):
-                    for e in range(8):
-                        h = l >> 5
-                        n = (kb >> 1) * 32 + (e & 3) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * h
-                        assert w2s[mb2, kb, l, e] == w2[mb2 * 32 + (l & 31), n]
-        b2s = buf[off:off + NB * 2 * 16].reshape(NB, 2, 16); off += b2s.numel()
-        b2 = lins[1].bias.detach()
-        for mb2 in range(NB):
-            for h in range(2):
-                for r in range(16):
-                    assert b2s[mb2, h, r] == b2[mb2 * 32 + _row(r, h)]
-    wot = buf[off:off + NB * 16 * 2 * 4].reshape(NB, 16, 2, 4); off += wot.numel()
     wo = lins[-1].weight.detach()
-    for mb in range(NB):
-        for r in (0, 7, 15):
-            for h in range(2):
-                assert torch.equal(wot[mb, r, h, :3], wo[:, mb * 32 + _row(r, h)]) and wot[mb, r, h, 3] == 0
-    assert torch.equal(buf[off:off + 3], lins[-1].bias.detach()) and off + 4 == buf.numel()
+    for nt2 in (3, 2):
+        nt1 = 3 if nt2 == 3 else int(N.lib().k4_mlp_b2_layer1_terms())
+        n1 = NB * KB1 * nt1 * 64 * 4
+        w1s = _bf16_terms(buf[off:off + n1], [NB, KB1, nt1, 64, 8]).sum(2); off += n1
+        for mb in range(NB):
+            for kb in range(KB1):
+                for l in (0, 9, 31, 32, 50, 63):
+                    for e in range(8):
+                        k = kb * 16 + 8 * (l >> 5) + e
+                        want = w1ext[mb * 32 + (l & 31), k] if k < k1p else 0.0
+                        assert w1s[mb, kb, l, e] == want if nt1 == 3 else abs(float(w1s[mb, kb, l, e] - want)) <= 2.0 ** -16 * abs(float(want))
+        if nh:
+            n2 = NB * KB2 * nt2 * 64 * 4
+            terms = _bf16_terms(buf[off:off + n2], [NB, KB2, nt2, 64, 8]); off += n2
+            w2s = terms.sum(2)
+            t0, t1, _ = dvgo._split3_bf16(w2)
+            for mb2 in range(NB):
+                for kb in range(KB2):
+                    for l in (0, 31, 32, 63):
+                        for e in range(8):
+                            h = l >> 5
+                            n = (kb >> 1) * 32 + (e & 3) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * h
+                            j = mb2 * 32 + (l & 31)
+                            if nt2 == 3:
+                                assert w2s[mb2, kb, l, e] == w2[j, n]
+                            else:
+                                assert terms[mb2, kb, 0, l, e] == t0[j, n].float() and terms[mb2, kb, 1, l, e] == t1[j, n].float()
+                                assert abs(float(w2s[mb2, kb, l, e] - w2[j, n])) <= 2.0 ** -16 * abs(float(w2[j, n]))
+            b2s = buf[off:off + NB * 2 * 16].reshape(NB, 2, 16); off += b2s.numel()
+            b2 = lins[1].bias.detach()
+            for mb2 in range(NB):
+                for h in range(2):
+                    for r in range(16):
+                        assert b2s[mb2, h, r] == b2[mb2 * 32 + _row(r, h)]
+        wot = buf[off:off + NB * 16 * 2 * 4].reshape(NB, 16, 2, 4); off += wot.numel()
+        for mb in range(NB):
+            for r in (0, 7, 15):
+                for h in range(2):
+                    assert torch.equal(wot[mb, r, h, :3], wo[:, mb * 32 + _row(r, h)]) and wot[mb, r, h, 3] == 0
+        assert torch.equal(buf[off:off + 3], lins[-1].bias.detach())
+        off += 4
+    assert off == buf.numel()
 
 
 @pytest.mark.parametrize('cout,cin,k', [(32, 160, 3), (64, 192, 3), (64, 3, 3), (3, 64, 3), (128, 64, 1), (64, 1, 3)])

@@ -200,7 +200,7 @@ def test_fused_sft_layer(C, arith):
     res = torch.randn([H, W, C]).cuda()
     x = buf[:, :, 16:16 + C].clone()
     with torch.no_grad():
-        want = layer(x.permute(2, 0, 1).unsqueeze(0), cond.permute(2, 0, 1).unsqueeze(0))[0].permute(1, 2, 0) * 0.2 + res
+        want = helpers.sft_layer_torch(layer, x.permute(2, 0, 1).unsqueeze(0), cond.permute(2, 0, 1).unsqueeze(0))[0].permute(1, 2, 0) * 0.2 + res
     wp = sr_esrnet.pack_sft(layer)
     keep = buf.clone()
     if arith == 0:
@@ -248,7 +248,7 @@ def test_sft_layer_pipelined_and_general_kernels_agree(C, with_res):
         for (cond, buf, res, keep), n in zip(keep_refs, sizes):
             x = keep[:n, off:off + C]
             with torch.no_grad():
-                want = layer(x.t().reshape(1, C, 1, n), cond.t().reshape(1, 32, 1, n))[0, :, 0].t()
+                want = helpers.sft_layer_torch(layer, x.t().reshape(1, C, 1, n), cond.t().reshape(1, 32, 1, n))[0, :, 0].t()
                 if with_res:
                     want = want * 0.2 + res
             y = buf[:n, off:off + C]

@@ -366,8 +366,7 @@ def test_dense_block_function_matches_module_autograd(H, W, use_acc):
         c.grad = acc
     tr = t.detach().cpu().double().permute(2, 0, 1).unsqueeze(0).requires_grad_(True)
     cr = c.detach().cpu().double().permute(2, 0, 1).unsqueeze(0).requires_grad_(True)
-    outr = ref((tr, cr))
-    outr = outr[0] if isinstance(outr, (tuple, list)) else outr
+    outr = helpers.rdb_torch(ref, tr, cr)
     outr.backward(go.cpu().double().permute(2, 0, 1).unsqueeze(0))
     assert _rel(out.permute(2, 0, 1), outr[0]) <= 5e-6
     assert _rel(t.grad.permute(2, 0, 1), tr.grad[0]) <= 1e-5 and _rel(c.grad.permute(2, 0, 1), cr.grad[0]) <= 1e-5
