@@ -658,6 +658,7 @@ __device__ __forceinline__ void mlp_mfma(const float* wl, const float* feat, int
 typedef __bf16 k4_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 k4_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float k4_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned k4_u32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Corner voxel indices and trilinear weights of a shaded sample, The geometry kernel only records samples inside the bounding box (mask_outbbox,
@@ -804,6 +805,16 @@ struct LdsFeat {
             const int k = kb * 16 + 8 * half + e;
             v[e] = k < k1p ? feat[k * 64 + t * 32 + l31] : 0.f;
         }
+    }
+};
+// FAST shading path (round 6): the 16 layer-1 inputs of a record are built in ITS lane's registers and reach the B-operand layout
+// (lane l: sample l & 31 of tile t, inputs 8 (l >> 5) .. + 7) by 8 v_permlane32_swap -- no LDS image, no ds_write / ds_read round trip.
+struct RegFeat {
+    float x[8], y[8];                                     // tile 0's / tile 1's operand of this lane
+    __device__ __forceinline__ void load(int kb, int t, float (&v)[8]) {
+        (void)kb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t ? y[e] : x[e];
     }
 };
 // The general form (any covered width / depth / input size), one 32-sample tile at a time.  NT2 = 3: the exact form of rounds 2-5 (every
@@ -1166,9 +1177,15 @@ __device__ __forceinline__ void k4_finish_bundle(const MarchParams& P, const Sha
 
 // ARITH: 0 = fp32-input MFMA (mlp_mfma), 3 = exact 3-term bf16 splits, 2 = layer 2 on 2-term splits (the default; see k4_split2).
 // WG = workgroups per CU the register allocation is bounded for (width 128 holds ~150 KB of LDS: one).
-template <int MODE, int WIDTH, int NHID, int ARITH, int WG = K4_SHADE_WG_PER_CU>
+// FAST: the LLFF / plain-DVGO input shape fixed at compile time -- voxel-major k0 with 12 padded channels (9 used for MPI, 12 for DVGO),
+// no positional-encoding frequencies, no k0_skip, 15 inputs + the bias input = ONE 16-wide k block, split-bf16 arithmetic: no per-channel
+// branches in the batch loop, features through registers (RegFeat), MPI step positions from a table.  Same expression trees as the general
+// path -> the same bits (tests/test_march_gpu.py::test_fast_shading_path_bit_identical).
+template <int MODE, int WIDTH, int NHID, int ARITH, int WG = K4_SHADE_WG_PER_CU, bool FAST = false>
 __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) {
     constexpr bool B3 = ARITH != 0;
+    static_assert(!FAST || (B3 && WIDTH > 0 && WIDTH <= 64), "FAST needs the split-bf16 arithmetic");
+    __shared__ float tktab[FAST && MODE == MODE_MPI ? K4_TKTAB : 1];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int W = WIDTH > 0 ? WIDTH : 32;
     constexpr int NB = W / 32;
@@ -1180,12 +1197,15 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
     const int mlp_floats = WIDTH > 0 ? (ARITH == 3 ? P.mlp_floats_b3 : ARITH == 2 ? P.mlp_floats_b2 : P.mlp_floats) : 0;
     const int mlp_pad = (mlp_floats + 3) & ~3;
     float* const wl = smem;
-    const int per_wave = 64 * 4 + (WIDTH > 0 ? P.k1p * 64 : 0);
+    const int per_wave = 64 * 4 + (WIDTH > 0 && !FAST ? P.k1p * 64 : 0);
     unsigned long long* const acc = reinterpret_cast<unsigned long long*>(smem + mlp_pad + wv * per_wave);     // [64][2]  red | green, blue | depth (fixed point)
     float* const feat = reinterpret_cast<float*>(acc + 64 * 2);                        // [K1P][64]
     if (WIDTH > 0) {
         const float* const src = P.mlp + (ARITH == 3 ? P.mlp_floats : ARITH == 2 ? P.mlp_floats + P.mlp_floats_b3 : 0);
         for (int i = threadIdx.x; i < mlp_floats; i += 256) wl[i] = src[i];
+    }
+    if (FAST && MODE == MODE_MPI) {
+        for (int i = (int)threadIdx.x; i < K4_TKTAB; i += 256) tktab[i] = (float)i / P.nsm1;      // == step_t<MPI>: the same IEEE division, once per workgroup
     }
     __syncthreads();
     const int half = lane >> 5;
@@ -1228,7 +1248,7 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
         const int k = (int)(en.x & 0xffffffu);
         const float sx = __shfl(my_sx, rl), sy = __shfl(my_sy, rl), sz = __shfl(my_sz, rl);
         const float dx = __shfl(my_dx, rl), dy = __shfl(my_dy, rl), dz = __shfl(my_dz, rl);
-        const float tk = step_t<MODE>(P, k);
+        const float tk = FAST ? tk_of<MODE>(P, tktab, k) : step_t<MODE>(P, k);
         const float px = fmaf(dx, tk, sx), py = fmaf(dy, tk, sy), pz = fmaf(dz, tk, sz);
         const float nx = k4_norm_coord_r(px, P.minx, P.lenx, P.rlenx);
         const float ny = k4_norm_coord_r(py, P.miny, P.leny, P.rleny);
@@ -1238,7 +1258,46 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
         k4_corner_setup(P, nx, ny, nz, cidx, cw);
         K4_TSTAMP(0);                                    // record unpack, sample point, corner indices / weights
         float o0, o1, o2;
-        if (WIDTH == 0) {
+        if constexpr (FAST) {
+            // 8 corners x 48 B = 24 independent 16-byte fetches, one memory round trip; per channel the corners accumulate in corner order
+            // (the general path's expression: v_pk_fma_f32 pairs)
+            float4 q[3][8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4* const src = reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * 12);
+                q[0][c] = src[0]; q[1][c] = src[1]; q[2][c] = src[2];
+            }
+            float f[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 3; ++g4) {
+                k4_f32x2 va = {0.f, 0.f}, vb = {0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const k4_f32x2 ww = {cw[c], cw[c]};
+                    const k4_f32x2 qa = {q[g4][c].x, q[g4][c].y}, qb = {q[g4][c].z, q[g4][c].w};
+                    va = __builtin_elementwise_fma(qa, ww, va);
+                    vb = __builtin_elementwise_fma(qb, ww, vb);
+                }
+                f[g4 * 4 + 0] = va.x; f[g4 * 4 + 1] = va.y; f[g4 * 4 + 2] = vb.x; f[g4 * 4 + 3] = vb.y;
+            }
+            K4_TSTAMP(1);                                // 24 corner fetches + interpolation
+            // layer-1 input in the order of W1ext's columns.  MPI (C = 9): k0[0..9) | pe_spa = (nz, ny, nx) (lib/dmpigo.py:338) | viewdirs | 1;
+            // DVGO (C = 12): k0[0..12) | viewdirs | 1  (lib/dvgo.py:387-392)
+            if (MODE == MODE_MPI) { f[9] = nz; f[10] = ny; f[11] = nx; }
+            f[12] = __shfl(my_vx, rl); f[13] = __shfl(my_vy, rl); f[14] = __shfl(my_vz, rl); f[15] = 1.f;
+            RegFeat fs;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const k4_u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[e]), __float_as_uint(f[8 + e]), false, false);
+                fs.x[e] = __uint_as_float(sw.x); fs.y[e] = __uint_as_float(sw.y);
+            }
+            K4_TSTAMP(2);                                // remaining features, half-wave exchange
+            constexpr int NT2 = ARITH == 3 ? 3 : 2, NT1 = ARITH == 3 ? 3 : K4_B2_L1_TERMS;
+            if constexpr (K4_MLP_PAIR && W == 64 && NHID == 1) {
+                if (nproc > 32 && !(P.debug & 2)) mlp_pair64<NT1, NT2>(wl, fs, lane, half, o0, o1, o2 K4_TPASS);
+                else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
+            } else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
+        } else if (WIDTH == 0) {
             // rgbnet is None: rgb = sigmoid(k0)   (lib/dvgo.py:377-379)
             float v[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1450,7 +1509,10 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     if (arith == 3 && width > 64) return K4_ERR_UNSUPPORTED;
     const int wg_per_cu = width == 128 ? 1 : K4_SHADE_WG_PER_CU;
     const size_t mlp_fl = arith == 3 ? P.mlp_floats_b3 : arith == 2 ? P.mlp_floats_b2 : P.mlp_floats;
-    const size_t lds = sizeof(float) * ((mlp_fl + 3) / 4 * 4 + 4 * (64 * 4 + (width ? (size_t)P.k1p * 64 : 0)));
+    // FAST: the LLFF / plain-DVGO input shape (see k4_shade_kernel)
+    const bool fast = arith >= 2 && width <= 64 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && P.k0_skip == 0 && P.spe == 0 && P.vpe == 0 &&
+                      P.dim0 == 15 && P.C == (MODE == MODE_MPI ? 9 : 12) && !k4_env().no_fast_shade;
+    const size_t lds = sizeof(float) * ((mlp_fl + 3) / 4 * 4 + 4 * (64 * 4 + (width && !fast ? (size_t)P.k1p * 64 : 0)));
     const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
 #define K4_LAUNCH_K(KERN) do { \
@@ -1458,7 +1520,9 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
             hipError_t e_ = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e_ != hipSuccess) return (int)e_; } \
         hipLaunchKernelGGL(KERN, sgrid, block, lds, st, P); } while (0)      /* lds varies with the MLP shape: set per launch */
-#define K4_LAUNCH(WD, NH) do { if (arith == 2) K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, 2, (WD == 128 ? 1 : K4_SHADE_WG_PER_CU)>)); \
+#define K4_LAUNCH(WD, NH) do { if (fast && arith == 2) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD <= 64 ? WD : 32), NH, 2, K4_SHADE_WG_PER_CU, true>)); \
+                               else if (fast) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD <= 64 ? WD : 32), NH, 3, K4_SHADE_WG_PER_CU, true>)); \
+                               else if (arith == 2) K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, 2, (WD == 128 ? 1 : K4_SHADE_WG_PER_CU)>)); \
                                else if (arith == 3) K4_LAUNCH_K((k4_shade_kernel<MODE, (WD <= 64 ? WD : 32), NH, 3>)); \
                                else K4_LAUNCH_K((k4_shade_kernel<MODE, WD, NH, 0, (WD == 128 ? 1 : K4_SHADE_WG_PER_CU)>)); } while (0)
     if (width == 0) K4_LAUNCH_K((k4_shade_kernel<MODE, 0, 0, 0>));
@@ -1562,7 +1626,7 @@ extern "C" int k4_abi_version(void) { return K4_ABI_VERSION; }
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static const K4Env g_k4_env = {        // namespace-scope constant: initialised while the library is loaded, immutable afterwards
-    env_int("K4_GEOM_SKIP", 1), env_int("K4_DEBUG", 0), env_int("K4_SR_DEBUG", 0)};
+    env_int("K4_GEOM_SKIP", 1), env_int("K4_DEBUG", 0), env_int("K4_SR_DEBUG", 0), (env_int("K4_DEBUG", 0) & 1024) != 0};
 const K4Env& k4_env() { return g_k4_env; }
 int k4_num_cus() {
     static int n_cu[K4_MAX_DEVICES];

@@ -633,3 +633,21 @@ def test_full_frame_tile_window_and_linear_bundles_bit_identical():
     c = _march_once(model, win, 189, rk)
     for k in a:
         assert torch.equal(c[k], a[k][idx]), k
+
+
+def test_fast_shading_path_bit_identical():
+    """The shading kernel's FAST instantiation (LLFF input shape fixed at compile time, features through registers and v_permlane32_swap,
+    step positions from a table) against its general path (K4_DEBUG=1024, read when the library loads: own processes) -- one hash, for the
+    default arithmetic and for the exact one."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(**env):
+        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'march_hash.py')], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith('MARCH_HASH')][-1]
+    base = run(K4_DEBUG=1024)
+    assert run(K4_DEBUG=0) == base
+    b3 = run(K4_DEBUG=1024, K4_MLP='b3')
+    assert run(K4_DEBUG=0, K4_MLP='b3') == b3 and b3 != base
