@@ -26,7 +26,7 @@ class GridDesc(C.Structure):
                 ('dims', C.c_int32 * 3), ('k0_ch', C.c_int32), ('k0_cpad', C.c_int32), ('k0_layout', C.c_int32),
                 ('act_depth', C.c_int32), ('mask_dims', C.c_int32 * 3),
                 ('xyz_min', C.c_float * 3), ('xyz_max', C.c_float * 3),
-                ('xyz2ijk_scale', C.c_float * 3), ('xyz2ijk_shift', C.c_float * 3), ('occ_summary', C.c_void_p)]
+                ('xyz2ijk_scale', C.c_float * 3), ('xyz2ijk_shift', C.c_float * 3), ('occ_summary', C.c_void_p), ('depth_split', C.c_int32)]
 
 
 class MlpDesc(C.Structure):
@@ -147,6 +147,7 @@ _EXTRA_SIGS = {
     'k4_grid_sample_3d_backward_workspace_bytes': ([_I32, _I32, _I32, _I32], C.c_int64),
     'k4_mlp_packed_floats': ([_I32, _I32, _I32], C.c_int64),
     'k4_mlp_b2_layer1_terms': ([], C.c_int),
+    'k4_mpi_depth_split_stats': ([C.POINTER(GridDesc), C.c_float, C.c_float, _P, _P], C.c_int),
     'k4_conv2d_nhwc_bf16x6_multi': ([C.POINTER(ConvJob), _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, C.c_uint32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_sft_nhwc_multi': ([C.POINTER(SftJob), _I32, _I32, _P, _I32, _I32, _I32, _F, _I32, _F, _I32, _P], C.c_int),
     'k4_conv_weight_p16_bytes': ([_I32, _I32], C.c_int64),

@@ -61,6 +61,9 @@ struct MarchParams {
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
     int* jobs;                                     // workspace: the shading queue = bundle ids, most batches first (k4_order_kernel)
     int n_bundles;
+    int split_k;            // MPI: > 0 = depth-ordered geometry stage -- samples [0, split_k) in a first launch, [split_k, n_samples) in a second one that
+                            // drops every ray the first launch's transmittance scan stopped (k4_grid_desc.depth_split; a multiple of 64)
+    int slab;               // 0: the whole depth range in one launch; 1 / 2: first / second launch of the split form
     int debug;              // K4_DEBUG ablation bits (profiling only; 0 in production)
     int serp;               // 1: serpentine ray order inside a tile (default)
     int band_blocks;        // geometry kernel: blocks per XCD band (0: one contiguous band per XCD)
@@ -213,8 +216,13 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     if (bid >= P.n_bundles) break;
     const Bundle B = bundle_from_id(P, bid);
     uint2* const ent_base = P.entries + (size_t)B.id * (size_t)P.ent_stride;
-    const int quarter = P.ent_stride >> 2;
-    uint2* const ent = ent_base + (size_t)wv * quarter;                          // this wave's run of records
+    // the four runs of records of this launch (one per wave, depth-ascending): quarters of the bundle's slice, or -- split form -- runs of
+    // span0 (first launch) / span1 (second launch) samples per ray laid out one behind the other: 4 (span0 + span1) <= max_steps rounded up
+    const int slab = (MODE == MODE_MPI && !COUNT) ? P.slab : 0;
+    const int span0 = P.split_k >> 2, span1 = (((P.n_samples - P.split_k) + 63) >> 6) << 4;      // samples per ray and wave of the two launches
+    const int quarter = slab == 0 ? (P.ent_stride >> 2) : (slab == 1 ? span0 : span1) * 64;
+    const int run0 = slab == 2 ? 4 * span0 * 64 : 0;                              // records in front of this launch's first run
+    uint2* const ent = ent_base + run0 + (size_t)wv * quarter;                   // this wave's run of records
 
     // ---- ray setup, lane = ray of the bundle ----
     const int myray = ray_index(P, B, lane);
@@ -226,8 +234,18 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         ray_setup<MODE>(P, P.rays_o[rs * 3 + 0], P.rays_o[rs * 3 + 1], P.rays_o[rs * 3 + 2],
                         P.rays_d[rs * 3 + 0], P.rays_d[rs * 3 + 1], P.rays_d[rs * 3 + 2], sx, sy, sz, dx, dy, dz, nsteps);
         if (myray < 0) nsteps = 0;
-        const int nb4 = (((nsteps + 63) >> 6) + 3) >> 2;                         // 64-sample blocks per depth quarter of this ray
-        const int kq0 = wv * nb4 * 64, kq1 = min((wv + 1) * nb4 * 64, nsteps);
+        int kq0, kq1;
+        if (slab == 0) {
+            const int nb4 = (((nsteps + 63) >> 6) + 3) >> 2;                     // 64-sample blocks per depth quarter of this ray
+            kq0 = wv * nb4 * 64; kq1 = min((wv + 1) * nb4 * 64, nsteps);
+        } else if (slab == 1) {
+            kq0 = wv * span0; kq1 = min(kq0 + span0, nsteps);
+        } else {
+            // second launch: a ray whose transmittance fell below 1e-3 in the first launch takes no further sample (Alphas2Weights stops
+            // there, render_utils_kernel.cu:597-600): nothing of it is probed, looked up or recorded
+            const bool alive = myray >= 0 && !(P.out_ainv[rs] < 1e-3f);
+            kq0 = P.split_k + wv * span1; kq1 = alive ? min(kq0 + span1, nsteps) : kq0;
+        }
         ngrp = kq1 > kq0 ? (kq1 - kq0 + K4_GRP - 1) / K4_GRP : 0;
         *reinterpret_cast<float4*>(&L.raytab[lane][0]) = make_float4(sx, sy, sz, __int_as_float(kq0));
         *reinterpret_cast<float4*>(&L.raytab[lane][4]) = make_float4(dx, dy, dz, __int_as_float(kq1));
@@ -469,9 +487,10 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     // 4 runs (one per depth quarter), visited in depth order ----
     float T = 1.f;
     bool stopped = false;
+    if (slab == 2) { T = myray >= 0 ? P.out_ainv[myray] : 1.f; stopped = T < 1e-3f; }      // where the first launch's scan left this ray
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        uint2* const run = ent_base + (size_t)w * quarter;
+        uint2* const run = ent_base + run0 + (size_t)w * quarter;
         const int c = lds_all[w].acnt[lane];
         int incl = c;
 #pragma unroll
@@ -508,10 +527,10 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- stage D: keep w > thres, compacted to the front of the bundle's slice, run order preserved ----
-    int cnt = 0, na_all = 0;
+    int cnt = slab == 2 ? __builtin_amdgcn_readfirstlane(P.counts[B.id]) : 0, na_all = 0;      // second launch: append behind the first launch's survivors
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const uint2* const run = ent_base + (size_t)w * quarter;
+        const uint2* const run = ent_base + run0 + (size_t)w * quarter;
         int naw = na_sh[w];
         na_all += naw;
         if (P.debug & 128) naw = 0;                                    // ablation: no survivor compaction (nothing shaded)
@@ -1494,6 +1513,14 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
         // one workgroup (4 waves = 4 depth quarters) per bundle
         // MINW = waves per SIMD the register allocation is bounded for: 5 (85 VGPRs, no spills); 6 (80 VGPRs, 6 spilled) measured slower
         if (P.counters) hipLaunchKernelGGL((k4_geom3_kernel<MODE, true, 5>), dim3((unsigned)nwg * 4), block, 0, st, P);
+        else if (MODE == MODE_MPI && P.split_k > 0) {
+            // depth-ordered: front slab, then the back slab for the rays that are still alive (see MarchParams.split_k)
+            MarchParams Q = P;
+            Q.slab = 1;
+            hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, 0, st, Q);
+            Q.slab = 2;
+            hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, 0, st, Q);
+        }
         else hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, 0, st, P);
     }
     int rc = k4_check_launch();
@@ -1666,6 +1693,8 @@ extern "C" int k4_march_mpi_fwd(const float* rays_o, const float* rays_d, const 
         if (mlp->dim0 != want || mlp->k0_skip != 0) return K4_ERR_BAD_ARG;
     }
     P.n_samples = n_samples; P.depth_n = n_samples; P.nsm1 = (float)(n_samples - 1);
+    if (grid->depth_split < 0 || grid->depth_split % 64 != 0 || grid->depth_split >= n_samples) return K4_ERR_BAD_ARG;
+    P.split_k = k4_env().debug & 2048 ? 0 : grid->depth_split;                               // (K4_DEBUG & 2048: single launch whatever the descriptor says, A/B)
     set_depth_fx(P, n_samples);
     P.shift = 0.f;                                                                            // lib/dmpigo.py:261
     P.interval = interval; P.thres = fast_color_thres; P.bg = bg;

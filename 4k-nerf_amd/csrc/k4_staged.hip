@@ -947,6 +947,52 @@ extern "C" int k4_build_live_mask(const k4_grid_desc* g, float act_shift_scalar,
     hipLaunchKernelGGL(k_live_mask, dim3(k4_blocks((int64_t)P.MX * P.MY * P.MZ)), dim3(K4_THREADS), 0, ST, P, workspace, out_mask);
     return k4_check_launch();
 }
+// One thread per (x, y) column, z ascending: stop plane of a ray along the column + the column's alpha-passing voxels per eighth of the depth.
+__global__ void k_mpi_depth_split_stats(const float* __restrict__ density, const float* __restrict__ act_shift, int X, int Y, int Z, int D,
+                                        float interval, float thres, float* __restrict__ acc) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= X * Y) return;
+    const float* col = density + (size_t)t * Z;
+    float T = 1.f;
+    int zs = Z;                                                   // first plane BEHIND the stop (Z: the column never stops)
+    float cnt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < Z; ++z) {
+        // act_shift grid [D] sampled at the plane's normalised depth (align_corners): D == Z in every configuration, else nearest
+        const float sh = act_shift ? act_shift[D == Z ? z : min(D - 1, (int)((float)z * (float)(D - 1) / (float)max(Z - 1, 1) + 0.5f))] : 0.f;
+        float e_unused, a;
+        k4s_raw2alpha(col[z] + sh, 0.f, interval, e_unused, a);
+        if (a > thres) cnt[min(7, z * 8 / Z)] += 1.f;
+        if (zs == Z) { T = fmaf(-T, a, T); if (T < 1e-3f) zs = z + 1; }
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tot += cnt[e];
+    if (tot == 0.f) return;
+    atomicAdd(&acc[8], tot); atomicAdd(&acc[9], 1.f);
+    if (zs < Z) atomicAdd(&acc[0], 1.f);
+    float behind = 0.f;
+#pragma unroll
+    for (int b = 7; b >= 1; --b) {
+        behind += cnt[b];                                          // voxels at or behind plane b * Z / 8
+        if (zs <= b * Z / 8) atomicAdd(&acc[b], behind);
+    }
+}
+__global__ void k_mpi_depth_split_norm(float* acc) {
+    const int b = (int)threadIdx.x;
+    if (b >= 1 && b < 8) acc[b] = acc[8] > 0.f ? acc[b] / acc[8] : 0.f;
+    __syncthreads();
+    if (b == 0) acc[0] = acc[9] > 0.f ? acc[0] / acc[9] : 0.f;
+}
+extern "C" int k4_mpi_depth_split_stats(const k4_grid_desc* g, float interval, float fast_color_thres, float* out16, void* stream) {
+    REQ(g && g->density && g->act_shift && g->act_depth > 0 && out16 && interval > 0.f);
+    REQ(g->dims[0] > 0 && g->dims[1] > 0 && g->dims[2] > 0 && (int64_t)g->dims[0] * g->dims[1] < 0x7fffffff);
+    if (hipMemsetAsync(out16, 0, 16 * sizeof(float), ST) != hipSuccess) return K4_ERR_BAD_ARG;
+    const int n = g->dims[0] * g->dims[1];
+    hipLaunchKernelGGL(k_mpi_depth_split_stats, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ST, g->density, g->act_shift, g->dims[0], g->dims[1], g->dims[2],
+                       g->act_depth, interval, fast_color_thres, out16);
+    hipLaunchKernelGGL(k_mpi_depth_split_norm, dim3(1), dim3(64), 0, ST, out16);
+    return k4_check_launch();
+}
 extern "C" int k4_train_select_mpi(const float* rays_o, const float* rays_d, const float* xyz_min, const float* xyz_max, int64_t n_rays, int32_t n_samples,
                                    const uint8_t* mask, const float* xyz2ijk_scale, const float* xyz2ijk_shift, int32_t mi, int32_t mj, int32_t mk,
                                    const float* density, int32_t X, int32_t Y, int32_t Z, const float* act_shift, int32_t act_depth,

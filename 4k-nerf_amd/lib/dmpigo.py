@@ -21,7 +21,11 @@ from .. import _native as N
 from . import grid
 from . import dvgo as _dvgo
 
-_TRAIN_PRESEL = True      # training forward: the three sample filters decided by one launch (same values)
+_TRAIN_PRESEL = True
+DEPTH_SPLIT = True              # fused marcher: depth-ordered geometry stage where the scene's density says it pays (_k4_depth_split); False: always one launch
+DEPTH_SPLIT_MIN_GAIN = 0.05     # smallest share of alpha-passing voxels behind the split in stopped columns for which the geometry stage is cut in two launches
+                                # (measured, profiles/r06_depth_split.md: the cut itself costs 0-2 % of the call at 128 / 192 of 256 samples, +4 % at 64; the opaque scene gains 10 %)
+DEPTH_SPLIT_MIN_OPAQUE = 0.5    # ... and smallest share of occupied z columns along which a ray reaches the T < 1e-3 stop (bench scene: 0.16 -> one launch; opaque wall: 1.0)      # training forward: the three sample filters decided by one launch (same values)
 from .dvgo import Raw2Alpha, Alphas2Weights, render_utils_cuda, _FusedMarcher, segment_sum, coarse_mask_on_grid, _take
 
 
@@ -243,8 +247,9 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             itv = float(stepsize * self.voxel_size_ratio)                 # lib/dmpigo.py:306
             # sample counters are the ALGORITHM's counts: the counting pass looks samples up in mask_cache itself
             gd = self._k4_grid(act_shift_grid=self.act_shift.grid, live=(0.0, itv) if use_live else None)
+            gd.depth_split = self._k4_depth_split(gd, n_samples, itv) if (use_live and DEPTH_SPLIT) else 0
             return (md, gd, n_samples, itv), keep
-        md, gd, N_samples, interval = self._k4_plan('mpi', (float(stepsize), use_live, float(self.fast_color_thres)), build)
+        md, gd, N_samples, interval = self._k4_plan('mpi', (float(stepsize), use_live, float(self.fast_color_thres), DEPTH_SPLIT, DEPTH_SPLIT_MIN_GAIN, DEPTH_SPLIT_MIN_OPAQUE), build)
         if Nr > 0:
             ws, ws_bytes = self._k4_workspace(Nr, k4_img_w, N_samples, dev, k4_ws_slot)
             N.check(N.lib().k4_march_mpi_fwd(
@@ -256,6 +261,32 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         if render_depth:
             ret['depth'] = depth
         return ret
+
+    def _k4_depth_split(self, gd, n_samples, interval):
+        """k4_grid_desc.depth_split of this scene (include/k4nerf.h): the sample index at which the fused marcher's geometry stage is cut in a
+        front and a back launch, the back one skipping every ray the front one's transmittance scan stopped -- Alphas2Weights' early stop
+        (render_utils_kernel.cu:597-600) exploited in the density stage instead of after it, as the reference does (lib/dmpigo.py:316-333
+        evaluates density for every mask-passing sample and drops the ones behind the stop afterwards).  Chosen from the density grid at load
+        time (k4_mpi_depth_split_stats: per z column the plane where a ray along the column stops; ONE 16-float read-back per density
+        version): the multiple of 64 samples behind which the largest share of alpha-passing voxels sits in columns already stopped, if that
+        share is at least DEPTH_SPLIT_MIN_GAIN and at least DEPTH_SPLIT_MIN_OPAQUE of the occupied columns stop a ray at all (a scene of opaque
+        surfaces, as a trained LLFF scene is) -- translucent scenes keep the single launch (0).  Identical outputs either way (tests)."""
+        dens, act = self.density.grid, self.act_shift.grid
+        key = ('dsplit', dens.data_ptr(), dens._version, act.data_ptr(), act._version, float(interval), float(self.fast_color_thres), int(n_samples))
+        c = self._k4_cache()
+        if c.get('dsplit_key') != key:
+            out = torch.empty([16], dtype=torch.float32, device=dens.device)
+            N.check(N.lib().k4_mpi_depth_split_stats(N.C.byref(gd), float(interval), float(self.fast_color_thres), N.f32(out), N.stream()),
+                    'k4_mpi_depth_split_stats')
+            st = out.cpu().tolist()
+            best, gain = 0, 0.0
+            for k in range(64, int(n_samples), 64):
+                b = min(7, (k * 8) // int(n_samples))
+                if b >= 1 and st[b] > gain:
+                    best, gain = k, st[b]
+            use = gain >= DEPTH_SPLIT_MIN_GAIN and st[0] >= DEPTH_SPLIT_MIN_OPAQUE
+            c['dsplit_key'], c['dsplit'], c['dsplit_stats'] = key, (best if use else 0), st[:8]
+        return int(c['dsplit'])
 
     def _select_samples(self, rays_o, rays_d, N_samples, interval):
         """The three sample filters of lib/dmpigo.py:300-333 (bounding box + mask cache, alpha > thres, weight > thres) decided for the whole

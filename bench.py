@@ -940,7 +940,7 @@ def dvgo_config0(dev, with_oracle=True):
     model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
     rk = ck['render_kwargs']
     out = {'workload': 'configs[0]: nerf_synthetic-lego-like DirectVoxGO ' + 'x'.join(str(int(v)) for v in model.world_size.tolist())
-                       + ', rgbnet 39->128->128->3 (fp32-input MFMA), stepsize 0.5'}
+                       + ', rgbnet 39->128->128->3 (2-term bf16 splits, width-128 kernel at one workgroup per CU), stepsize 0.5'}
     pose = scene.lego_pose()
     with torch.no_grad():
         for H in (64, 800):

@@ -61,7 +61,19 @@ typedef struct k4_grid_desc {
     const uint32_t* occ_summary;     /* optional (NULL = none): coarse occupancy summary of `mask` built by
                                         k4_build_occupancy_summary(); lets the geometry kernel skip 16-sample groups of a ray
                                         that cannot touch an occupied voxel.  Results are identical with and without it. */
+    int32_t depth_split;             /* MPI, ABI 12: 0, or a multiple of 64 below n_samples: the geometry stage runs DEPTH-ORDERED -- samples
+                                        [0, depth_split) in a first launch, then [depth_split, n_samples) only for the rays whose transmittance is
+                                        still >= 1e-3 (Alphas2Weights' early stop, render_utils_kernel.cu:597-600: the reference evaluates density
+                                        behind the stop and throws it away).  Results are identical with and without it; it pays on scenes of opaque
+                                        surfaces (k4_mpi_depth_split_stats proposes a value from the density grid).  Ignored by k4_march_dvgo_fwd. */
 } k4_grid_desc;
+
+/* Where would a depth split pay?  Per (x, y) column of an MPI density grid the transmittance of a ray running along z (alpha from
+ * density + act_shift, `interval`, as lib/dmpigo.py:316-317) is followed to the plane where it falls below 1e-3; out[b] (b = 1..7) = the share of
+ * the grid's alpha > fast_color_thres voxels that lie at or behind plane b * Z / 8 in a column that stopped in front of that plane (what a
+ * split at sample b * n_samples / 8 lets the second launch skip, to first order), out[0] = the share of such columns among the columns that
+ * hold any such voxel, out[8..15] unused.  Load-time, one launch; the caller reads 16 floats back once per density version. */
+int k4_mpi_depth_split_stats(const k4_grid_desc* grid, float interval, float fast_color_thres, float* out16, void* stream);
 
 /* Coarse occupancy summary of a MaskGrid (load-time, like the k0 repack): [ceil(MX/8)][ceil(MY/8)][ceil(MZ/32)] dwords, bit z of
  * cell (cx,cy) = OR of mask[x][y][z] over the 8x8 (x,y) voxels of the cell (K4_OCC_CELL).  A group of consecutive samples of a ray touches only

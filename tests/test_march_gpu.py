@@ -16,7 +16,7 @@ import torch
 
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import scene, render
-from nerf4k_amd.lib import utils, dvgo, render_utils_cuda as ruc, grid as kgrid
+from nerf4k_amd.lib import utils, dvgo, dmpigo, render_utils_cuda as ruc, grid as kgrid
 from oracle import marcher, native_cpu as nat
 from helpers import GOLDEN, load_march_golden, psnr
 
@@ -651,3 +651,42 @@ def test_fast_shading_path_bit_identical():
     assert run(K4_DEBUG=0) == base
     b3 = run(K4_DEBUG=1024, K4_MLP='b3')
     assert run(K4_DEBUG=0, K4_MLP='b3') == b3 and b3 != base
+
+
+@pytest.mark.parametrize('cfg,expect_split', [
+    (dict(seed=781, num_voxels=96 * 96 * 128, mpi_depth=128, opaque=True), True),          # opaque wall at 0.4 of the depth: the back launch skips what it hides
+    (dict(seed=31, num_voxels=96 * 96 * 128, mpi_depth=128, n_blobs=6), None),             # translucent blobs: whatever the statistic says, outputs must not move
+])
+def test_depth_ordered_geometry_stage_is_bit_identical(cfg, expect_split, monkeypatch):
+    """k4_grid_desc.depth_split (round 6): front slab, then the back slab only for rays whose transmittance is still >= 1e-3.  Early
+    termination exploited in the density stage (the reference evaluates density behind the stop and drops it: render_utils_kernel.cu:577-651).
+    Every output equals the single-launch form bit for bit -- with the split the load-time statistic proposes and with a forced one."""
+    ck = scene.make_llff_checkpoint(**cfg)
+    model = _model(ck)
+    H, W = 96, 128
+    K = scene.LLFF_K.copy()
+    K[:2] *= W / scene.LLFF_HW[1]
+    rays = [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[5], ndc=True)]
+    rk = dict(ck['render_kwargs'], render_depth=True)
+    keys = ('rgb_marched', 'depth', 'alphainv_last')
+
+    def run():
+        o = model(*rays, k4_img_w=W, **rk)
+        torch.cuda.synchronize()
+        return {k: o[k].clone() for k in keys}
+    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT', False)
+    base = run()
+    assert float(base['rgb_marched'].abs().sum()) > 0
+    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT', True)
+    auto = run()
+    chosen = model._k4_cache()['dsplit']
+    if expect_split:
+        assert chosen > 0 and chosen % 64 == 0, (chosen, model._k4_cache()['dsplit_stats'])
+        assert float((base['alphainv_last'] < 1e-3).float().mean()) > 0.9
+    monkeypatch.setattr(dmpigo.DirectMPIGO, '_k4_depth_split', lambda self, gd, n, itv: 64)       # a forced split, whatever the statistic says
+    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT_MIN_GAIN', 0.0499)                                   # (part of the plan key: a new plan)
+    forced = run()
+    for k in keys:
+        assert torch.equal(auto[k], base[k]) and torch.equal(forced[k], base[k]), k
+    want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], *[r.cpu() for r in rays], **ck['render_kwargs'])
+    _cmp(forced['rgb_marched'].cpu(), want['rgb_marched'], 'rgb_marched', min_psnr=100.0)
