@@ -57,6 +57,7 @@ struct MarchParams {
     int depth_n;            // denominator of s = (k+0.5)/depth_n
     float nsm1;             // MPI: (float)(n_samples-1)
     float stepdist, near_, far_, shift, interval, thres, bg;
+    float depth_n_inv;              // 1 / depth_n, correctly rounded
     float depth_fx, depth_fx_inv;   // fixed-point scale of the per-ray depth sums (a power of two: 2^30 / the largest s a record can carry) and its reciprocal
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
     int* jobs;                                     // workspace: the shading queue = bundle ids, most batches first (k4_order_kernel)
@@ -678,6 +679,7 @@ typedef __bf16 k4_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 k4_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float k4_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned k4_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned k4_u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Corner voxel indices and trilinear weights of a shaded sample, The geometry kernel only records samples inside the bounding box (mask_outbbox,
@@ -1064,12 +1066,15 @@ __device__ __forceinline__ void mlp_pair64(const float* ws, FS& fs, int lane, in
     // ---- S7..S10: layer 2 of tile B  ||  the next hidden block of B + tile A's output layer (its accumulators are complete) ----
     k4_f32x2 ptA01 = {0.f, 0.f}, ptB01 = {0.f, 0.f};
     float ptA2 = 0.f, ptB2 = 0.f;
+#ifndef K4_OUT_SCALAR_FMA
+#define K4_OUT_SCALAR_FMA 1      // the output layer's channel pair as two v_fma_f32 instead of one v_pk_fma_f32: packed fp32 beside MFMAs is an anti-lever (K2 377 -> 372 us, same bits; 0 = the packed form)
+#endif
 #define K4_OUT_HALF(C, MB2, R0, PT01, PT2) do { \
         _Pragma("unroll") for (int r_ = (R0); r_ < (R0) + 8; ++r_) { \
             const float4 wo_ = *reinterpret_cast<const float4*>(wot + (((MB2) * 16 + r_) * 2 + half) * 4); \
             const float a_ = k4_relu(C[r_]); \
-            const k4_f32x2 w01_ = {wo_.x, wo_.y}, aa_ = {a_, a_}; \
-            PT01 = __builtin_elementwise_fma(w01_, aa_, PT01); \
+            if (K4_OUT_SCALAR_FMA) { PT01.x = fmaf(wo_.x, a_, PT01.x); PT01.y = fmaf(wo_.y, a_, PT01.y); } \
+            else { const k4_f32x2 w01_ = {wo_.x, wo_.y}, aa_ = {a_, a_}; PT01 = __builtin_elementwise_fma(w01_, aa_, PT01); } \
             PT2 = fmaf(wo_.z, a_, PT2); } } while (0)
     K4_TSTAMP(4);                                        // layer 2 of tile A (+ splits)
     constexpr int NVO = NT2 == 3 ? 5 : 8;                // ... of a ReLU + split + half-block output stage (~76 / 12, ~56 / 6: what does not fit runs behind the stage)
@@ -1178,6 +1183,9 @@ __device__ __forceinline__ bool k4_next_job(const MarchParams& P, int lane, Shad
 // instructions + 2 LDS atomics per record instead of 12 fp64-rate + 4.  The 2^-31 rounding per term (a few hundred terms per ray) is the
 // size of one fp32 rounding of the result.  A NaN term (NaN weights / features) cannot be carried by an integer: it sets bit 31 of its
 // field, which no finite sum reaches, and the ray's output is NaN as in the reference.
+__device__ __forceinline__ float k4_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 #define K4_FX_ONE 1073741824.f                     // 2^30
 __device__ __forceinline__ unsigned k4_fx(float x, float scale) { return (unsigned)fmaf(x, scale, 0.5f); }      // x >= 0; NaN -> 0
 __device__ __forceinline__ float k4_unfx(unsigned f, float inv) { return (f & 0x80000000u) ? __uint_as_float(0x7fc00000u) : (float)f * inv; }
@@ -1228,6 +1236,8 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
     }
     __syncthreads();
     const int half = lane >> 5;
+    __amdgpu_buffer_rsrc_t k0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.k0), 0, FAST ? (int)((unsigned)P.X * (unsigned)P.Y * (unsigned)P.Z * 48u) : 0, 0x00020000);
+    (void)k0rs;
 #ifdef K4_SHADE_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tlast;
@@ -1280,11 +1290,16 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
         if constexpr (FAST) {
             // 8 corners x 48 B = 24 independent 16-byte fetches, one memory round trip; per channel the corners accumulate in corner order
             // (the general path's expression: v_pk_fma_f32 pairs)
+            // (buffer loads: one 32-bit multiply per corner instead of 64-bit address arithmetic; FAST requires the repacked grid < 4 GB)
             float4 q[3][8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float4* const src = reinterpret_cast<const float4*>(P.k0 + (size_t)cidx[c] * 12);
-                q[0][c] = src[0]; q[1][c] = src[1]; q[2][c] = src[2];
+                const unsigned off = cidx[c] * 48u;
+#pragma unroll
+                for (int g4 = 0; g4 < 3; ++g4) {
+                    const k4_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(k0rs, (int)off, g4 * 16, 0);
+                    q[g4][c] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
             }
             float f[16];
 #pragma unroll
@@ -1442,8 +1457,10 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
             __builtin_amdgcn_wave_barrier();
         }
         // sigmoid, blend, per-ray sums in fixed point (see k4_fx above)
-        const float r0 = w * (1.f / (1.f + expf(-o0))), r1 = w * (1.f / (1.f + expf(-o1))), r2 = w * (1.f / (1.f + expf(-o2)));
-        const float r3 = w * (((float)k + 0.5f) / (float)P.depth_n);                        // s = (step_id+0.5)/N_samples (lib/dmpigo.py:398)
+        // sigmoid = rcp(1 + exp2(-x log2 e)) on v_exp_f32 / v_rcp_f32 (1 ulp each; ~4 instructions instead of ~20 for expf + an IEEE division: the
+        // result moves by <= 2e-7, the rgbnet's own arithmetic by 2e-6); s = (step_id+0.5)/N_samples (lib/dmpigo.py:398) by the rounded reciprocal
+        const float r0 = w * k4_sigmoid_fast(o0), r1 = w * k4_sigmoid_fast(o1), r2 = w * k4_sigmoid_fast(o2);
+        const float r3 = w * (((float)k + 0.5f) * P.depth_n_inv);
         unsigned f0 = k4_fx(r0, K4_FX_ONE), f1 = k4_fx(r1, K4_FX_ONE), f2 = k4_fx(r2, K4_FX_ONE);
         const unsigned f3 = k4_fx(r3, P.depth_fx);
         const float rs = r0 + r1 + r2;
@@ -1538,7 +1555,8 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     const size_t mlp_fl = arith == 3 ? P.mlp_floats_b3 : arith == 2 ? P.mlp_floats_b2 : P.mlp_floats;
     // FAST: the LLFF / plain-DVGO input shape (see k4_shade_kernel)
     const bool fast = arith >= 2 && width <= 64 && P.k0_layout == K4_K0_CHANNEL_LAST && P.CP == 12 && P.k0_skip == 0 && P.spe == 0 && P.vpe == 0 &&
-                      P.dim0 == 15 && P.C == (MODE == MODE_MPI ? 9 : 12) && !k4_env().no_fast_shade;
+                      P.dim0 == 15 && P.C == (MODE == MODE_MPI ? 9 : 12) && !k4_env().no_fast_shade &&
+                      (uint64_t)P.X * (uint64_t)P.Y * (uint64_t)P.Z * 48ull < 0xffffffffull;
     const size_t lds = sizeof(float) * ((mlp_fl + 3) / 4 * 4 + 4 * (64 * 4 + (width && !fast ? (size_t)P.k1p * 64 : 0)));
     const dim3 sgrid((unsigned)min(nwg, n_cu * wg_per_cu));
     if (lds > 160 * 1024) return K4_ERR_UNSUPPORTED;
@@ -1645,6 +1663,7 @@ static void set_depth_fx(MarchParams& P, int max_steps) {
     const double smax = ((double)max_steps + 0.5) / (double)(P.depth_n > 0 ? P.depth_n : 1);
     int e = 0;
     while (e < 60 && ldexp(1.0, e) < smax) ++e;
+    P.depth_n_inv = (float)(1.0 / (double)(P.depth_n > 0 ? P.depth_n : 1));
     P.depth_fx = (float)ldexp(1.0, 30 - e);
     P.depth_fx_inv = (float)ldexp(1.0, e - 30);
 }
