@@ -44,7 +44,7 @@ struct MarchParams {
     const float* rays_o; const float* rays_d; const float* viewdirs;
     int n_rays; int img_w; int img_h;
     const float* density; const float* k0; const float* act_shift; const uint8_t* mask;
-    const uint32_t* occ;      // coarse occupancy summary (k4_build_occupancy_summary) or NULL
+    const unsigned long long* occ;      // coarse occupancy summary (k4_build_occupancy_summary: four tables of 64-bit z windows) or NULL
     int X, Y, Z; int C; int CP; int k0_layout; int act_d;
     int MX, MY, MZ;
     float minx, miny, minz, maxx, maxy, maxz;
@@ -69,6 +69,7 @@ struct MarchParams {
     int serp;               // 1: serpentine ray order inside a tile (default)
     int band_blocks;        // geometry kernel: blocks per XCD band (0: one contiguous band per XCD)
     float* out_rgb; float* out_depth; float* out_ainv; unsigned long long* counters;
+    unsigned long long* timing;     // K4_GEOM_TIMING builds: [9] stage ticks + wave count (the kernel runs WITHOUT the counting instantiation)
 };
 
 template <int MODE>
@@ -188,8 +189,19 @@ __device__ __forceinline__ float tk_of(const MarchParams& P, const float* tktab,
 // COUNT: the sample counters of bench.py / the tests (k4_march_*_fwd `counters`) are a separate instantiation that visits EVERY
 // sample (no skipping), so that the counters are the algorithm's sample counts and the render path carries no
 // counting code.
+// K4_GEOM_TIMING (profiling builds only, tools/geom_timing.py): s_memtime stamps at the stage boundaries of the geometry kernel, summed per wave and
+// added to out_counters[8..15] by the COUNT-free instantiation when a counter buffer of >= 24 words is passed.  Not compiled into the product library.
+#ifdef K4_GEOM_TIMING
+#define K4_GSTAMP(SLOT) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                             gacc[SLOT] += now_ - glast; glast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define K4_GSTAMP(SLOT) do { } while (0)
+#endif
 template <int MODE, bool COUNT, int MINW>
 __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P) {
+#ifdef K4_GEOM_TIMING
+    unsigned long long gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ Geom2Lds lds_all[4];
     __shared__ int na_sh[4];
     __shared__ int arrived;                                            // waves of this workgroup that have finished their depth quarter
@@ -252,6 +264,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         *reinterpret_cast<float4*>(&L.raytab[lane][4]) = make_float4(dx, dy, dz, __int_as_float(kq1));
         L.acnt[lane] = 0;
     }
+    K4_GSTAMP(0);                                                                // workgroup prologue + ray setup
     int gq = ngrp;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gq = max(gq, __shfl_xor(gq, off));
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         const float4 rb = *reinterpret_cast<const float4*>(&L.raytab[lane][4]);
         const int kq0 = __float_as_int(ra.w), kq1 = __float_as_int(rb.w);
         const int ncy = (P.MY + K4_OCC_CELL - 1) >> K4_OCC_SHIFT, zw = (P.MZ + 31) >> 5;
+        const int ntab = ((P.MX + K4_OCC_CELL - 1) >> K4_OCC_SHIFT) * ncy * zw;                // entries per table
 #pragma unroll 4
         for (int j = 0; j < gq; ++j) {                                            // (unrolled: the summary fetches of 4 groups fly together)
             const int ka = kq0 + K4_GRP * j, kb = min(ka + K4_GRP - 1, kq1 - 1);
@@ -279,23 +293,21 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
             const int z0 = max(min(iaz, ibz), 0), z1 = min(max(iaz, ibz), P.MZ - 1);
             const bool empty = (x0 > x1) | (y0 > y1) | (z0 > z1);                // every sample's index is out of range on some axis
             const int cx0 = x0 >> K4_OCC_SHIFT, cy0 = y0 >> K4_OCC_SHIFT;
-            const int cx1 = min(x1 >> K4_OCC_SHIFT, cx0 + 1), cy1 = min(y1 >> K4_OCC_SHIFT, cy0 + 1);
-            const bool wide = ((x1 >> K4_OCC_SHIFT) - cx0 > 1) | ((y1 >> K4_OCC_SHIFT) - cy0 > 1) | (z1 - z0 >= 32);     // box beyond 2x2 cells / one 64-bit window: keep unseen
-            const int w0 = z0 >> 5, w1 = min(z1 >> 5, zw - 1);
-            unsigned lo = 0u, hi = 0u;
+            const int sx = (x1 >> K4_OCC_SHIFT) - cx0, sy = (y1 >> K4_OCC_SHIFT) - cy0;
+            const bool wide = (sx > 1) | (sy > 1) | (z1 - z0 >= 32);              // box beyond 2x2 cells / one 64-bit window: keep unseen
+            // ONE 8-byte fetch: the window of table (x span, y span) at the box's first cell and z word (k4nerf.h)
+            unsigned long long win = 0ull;
             if (!empty) {
-                const unsigned b00 = (unsigned)(cx0 * ncy + cy0) * (unsigned)zw, b01 = (unsigned)(cx0 * ncy + cy1) * (unsigned)zw;
-                const unsigned b10 = (unsigned)(cx1 * ncy + cy0) * (unsigned)zw, b11 = (unsigned)(cx1 * ncy + cy1) * (unsigned)zw;
-                lo = P.occ[b00 + w0] | P.occ[b01 + w0] | P.occ[b10 + w0] | P.occ[b11 + w0];
-                hi = P.occ[b00 + w1] | P.occ[b01 + w1] | P.occ[b10 + w1] | P.occ[b11 + w1];
+                const unsigned tab = (unsigned)((sx > 0) + 2 * (sy > 0));
+                win = P.occ[(size_t)tab * (size_t)ntab + (size_t)(cx0 * ncy + cy0) * (size_t)zw + (size_t)(z0 >> 5)];
             }
-            const unsigned long long win = w1 != w0 ? ((unsigned long long)hi << 32) | lo : (unsigned long long)lo;
             const int len = z1 - z0 + 1;
             const unsigned long long bits = (len >= 64 ? ~0ull : ((1ull << (len & 63)) - 1ull)) << (z0 & 31);
             const bool hit = !empty && (wide || (win & bits) != 0ull);
             if (j < ngrp && hit) keep |= 1ull << j;
         }
     }
+    K4_GSTAMP(1);                                                                // stage P: probe
     int qn = 0, qh = 0;          // ring fill / head (wave-uniform)
     int na = 0;                  // alpha-passing records written so far (wave-uniform)
 
@@ -429,6 +441,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
                     if ((m >> j) & 1ull) L.elist[o++] = (unsigned short)((lane << 10) | j);
             }
         }
+        K4_GSTAMP(2);                                                            // entry list
         // groups of 4 items: the 4 occupancy bytes are fetched together (one memory round trip per 256 samples), branch-free
         // (clamped index, validity folded into the predicate); all 4 are consumed (ballots) before any density batch is
         // issued, so the only fetches in flight across the next group's wait are that batch's
@@ -458,6 +471,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
                 inbv[j] = inb;
                 ikey[j] = ((unsigned)r_ << 24) | (unsigned)k;
             }
+            K4_GSTAMP(3);                                                        // stage A: index arithmetic + issue of the 4 byte fetches
             uint64_t mball[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -469,11 +483,14 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
                 if (mbyte[j] != 0) L.qk[(qh + qn + k4_prefix(mball[j])) & (K4_RING - 1)] = ikey[j];
                 qn += __popcll(mball[j]);
             }
+            K4_GSTAMP(4);                                                        // stage A: wait for the bytes, ballots, ring
             pump_b();
+            K4_GSTAMP(5);                                                        // stage B: retire the density batch in flight, issue the next
         }
     }
     if (pend_n) finish_b();
     while (qn > 0) { issue_b(min(qn, 128)); finish_b(); }
+    K4_GSTAMP(6);                                                                // drain
 
     // No barrier: a wave whose quarter is done leaves at once (depth quarters are very unequal -- waves parked at a barrier held 1/3
     // of the wave slots); the LAST wave to arrive finishes the bundle.  It re-reads records the other waves stored: every wave drains
@@ -505,10 +522,19 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
         maxc = __builtin_amdgcn_readfirstlane(maxc);
         if (P.debug & 32) maxc = 0;                                    // ablation: no transmittance scan
+        // (the NEXT four alphas are requested before the current four are folded into T: the loop is a load -> dependent chain -> store
+        //  sequence per iteration, 25 % of the kernel's wave time in round 5's form)
+        float an[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) an[u] = (u < c && maxc > 0) ? __uint_as_float(run[seg + u].y) : 0.f;
         for (int j0 = 0; j0 < maxc; j0 += 4) {
             float a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = (j0 + u < c) ? __uint_as_float(run[seg + j0 + u].y) : 0.f;
+            for (int u = 0; u < 4; ++u) a[u] = an[u];
+            if (j0 + 4 < maxc) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) an[u] = (j0 + 4 + u < c) ? __uint_as_float(run[seg + j0 + 4 + u].y) : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (COUNT) n_behind += __popcll(__ballot(j0 + u < c && stopped));      // density was evaluated for a sample the scan then drops
@@ -551,6 +577,14 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }   // bundle
+#ifdef K4_GEOM_TIMING
+    K4_GSTAMP(7);                                                                // arrival, stages C / D (last wave only)
+    if (P.timing && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&P.timing[i], gacc[i]);
+        atomicAdd(&P.timing[8], 1ull);
+    }
+#endif
     if (COUNT && P.counters && lane == 0) {
         atomicAdd(&P.counters[0], n_inb); atomicAdd(&P.counters[1], n_mask);
         atomicAdd(&P.counters[2], n_alpha); atomicAdd(&P.counters[3], n_shade); atomicAdd(&P.counters[4], n_behind);
@@ -1529,6 +1563,10 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
     {
         // one workgroup (4 waves = 4 depth quarters) per bundle
         // MINW = waves per SIMD the register allocation is bounded for: 5 (85 VGPRs, no spills); 6 (80 VGPRs, 6 spilled) measured slower
+#ifdef K4_GEOM_TIMING
+        if (P.counters) { MarchParams Q = P; Q.timing = P.counters + 8; Q.counters = nullptr;
+                          hipLaunchKernelGGL((k4_geom3_kernel<MODE, false, 5>), dim3((unsigned)nwg * 4), block, 0, st, Q); } else
+#endif
         if (P.counters) hipLaunchKernelGGL((k4_geom3_kernel<MODE, true, 5>), dim3((unsigned)nwg * 4), block, 0, st, P);
         else if (MODE == MODE_MPI && P.split_k > 0) {
             // depth-ordered: front slab, then the back slab for the rays that are still alive (see MarchParams.split_k)
@@ -1621,7 +1659,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.rays_o = rays_o; P.rays_d = rays_d; P.viewdirs = viewdirs;
     P.n_rays = (int)n_rays; P.img_w = img_w; P.img_h = img_w > 0 ? (int)(n_rays / img_w) : 0;
     P.density = g->density; P.k0 = g->k0; P.act_shift = g->act_shift; P.mask = g->mask;
-    P.occ = k4_env().geom_skip ? g->occ_summary : nullptr;
+    P.occ = k4_env().geom_skip ? reinterpret_cast<const unsigned long long*>(g->occ_summary) : nullptr;
     P.X = g->dims[0]; P.Y = g->dims[1]; P.Z = g->dims[2];
     P.C = g->k0_ch; P.CP = g->k0_cpad; P.k0_layout = g->k0_layout; P.act_d = g->act_depth;
     P.MX = g->mask_dims[0]; P.MY = g->mask_dims[1]; P.MZ = g->mask_dims[2];

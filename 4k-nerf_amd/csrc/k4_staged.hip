@@ -910,14 +910,36 @@ extern "C" int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, in
     hipLaunchKernelGGL(k_alpha_pool3_gt, dim3(k4_blocks((int64_t)x * y * z)), dim3(K4_THREADS), 0, ST, alpha, x, y, z, thres, out);
     return k4_check_launch();
 }
+// the four tables of 64-bit windows (k4nerf.h) from the base words (kept behind the tables in the same buffer)
+__global__ void k_occ_windows(const uint32_t* __restrict__ base, int ncx, int ncy, int zw, unsigned long long* __restrict__ out) {
+    const int64_t n = (int64_t)ncx * ncy * zw;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * n) return;
+    const int tab = (int)(t / n);
+    const int64_t e = t - (int64_t)tab * n;
+    const int w = (int)(e % zw), cy = (int)((e / zw) % ncy), cx = (int)(e / ((int64_t)zw * ncy));
+    unsigned long long v = 0ull;
+    for (int dx = 0; dx <= (tab & 1); ++dx)
+        for (int dy = 0; dy <= (tab >> 1); ++dy) {
+            const int x = cx + dx, y = cy + dy;
+            if (x >= ncx || y >= ncy) continue;
+            const uint32_t* p = base + ((size_t)x * ncy + y) * zw;
+            v |= (unsigned long long)p[w] | (w + 1 < zw ? (unsigned long long)p[w + 1] << 32 : 0ull);
+        }
+    out[t] = v;
+}
 extern "C" int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz) {
     if (mx <= 0 || my <= 0 || mz <= 0) return -1;
-    return (int64_t)((mx + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((my + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((mz + 31) / 32) * 4;
+    // 4 tables of 8-byte windows + the base words (build scratch, kept behind the tables)
+    return (int64_t)((mx + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((my + K4_OCC_CELL - 1) / K4_OCC_CELL) * ((mz + 31) / 32) * (4 * 8 + 4);
 }
 extern "C" int k4_build_occupancy_summary(const uint8_t* mask, int32_t mx, int32_t my, int32_t mz, uint32_t* out, void* stream) {
     REQ(mask && out && mx > 0 && my > 0 && mz > 0);
     const int ncx = (mx + K4_OCC_CELL - 1) / K4_OCC_CELL, ncy = (my + K4_OCC_CELL - 1) / K4_OCC_CELL, zw = (mz + 31) / 32;
-    hipLaunchKernelGGL(k_occ_summary, dim3(k4_blocks((int64_t)ncx * ncy * zw)), dim3(K4_THREADS), 0, ST, mask, mx, my, mz, ncx, ncy, zw, out);
+    const int64_t n = (int64_t)ncx * ncy * zw;
+    uint32_t* const base = out + 8 * n;                                   // behind the four tables
+    hipLaunchKernelGGL(k_occ_summary, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, mask, mx, my, mz, ncx, ncy, zw, base);
+    hipLaunchKernelGGL(k_occ_windows, dim3(k4_blocks(4 * n)), dim3(K4_THREADS), 0, ST, base, ncx, ncy, zw, reinterpret_cast<unsigned long long*>(out));
     return k4_check_launch();
 }
 extern "C" int64_t k4_live_mask_workspace_bytes(int32_t x, int32_t y, int32_t z) {

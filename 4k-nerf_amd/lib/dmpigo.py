@@ -239,7 +239,7 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
             rgb = torch.empty([Nr, 3], dtype=torch.float32, device=dev)
             depth = torch.empty([Nr], dtype=torch.float32, device=dev)
             ainv = torch.empty([Nr], dtype=torch.float32, device=dev)
-        use_live = bool(k4_live_mask and k4_counters is None)
+        use_live = bool(k4_live_mask and (k4_counters is None or k4_live_mask == 'force'))      # ('force': profiling builds that stamp the render instantiation)
 
         def build():
             md, keep = self._k4_mlp(k0_skip=0, spatial_pe=len(self.posfreq) if self.rgbnet is not None else 0)

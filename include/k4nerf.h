@@ -75,10 +75,13 @@ typedef struct k4_grid_desc {
  * hold any such voxel, out[8..15] unused.  Load-time, one launch; the caller reads 16 floats back once per density version. */
 int k4_mpi_depth_split_stats(const k4_grid_desc* grid, float interval, float fast_color_thres, float* out16, void* stream);
 
-/* Coarse occupancy summary of a MaskGrid (load-time, like the k0 repack): [ceil(MX/8)][ceil(MY/8)][ceil(MZ/32)] dwords, bit z of
- * cell (cx,cy) = OR of mask[x][y][z] over the 8x8 (x,y) voxels of the cell (K4_OCC_CELL).  A group of consecutive samples of a ray touches only
- * voxels inside the per-axis index interval of its two end samples (the index map is monotone along a ray); when every summary
- * bit of that box is clear no sample of the group can pass MaskGrid.forward (lib/grid.py:295-304) and the group is skipped. */
+/* Coarse occupancy summary of a MaskGrid (load-time, like the k0 repack).  Base: per cell (cx, cy) of 8x8 (x, y) voxels (K4_OCC_CELL) and z word w,
+ * bit z of the word = OR of mask[x][y][32 w + z] over the cell.  Stored (ABI 12) as FOUR tables [t][ceil(MX/8)][ceil(MY/8)][ceil(MZ/32)] of 64-bit
+ * windows: window (cx, cy, w) of table t = (word w | word w+1 << 32) ORed over the cells (cx .. cx + (t & 1), cy .. cy + (t >> 1)) -- the box a group
+ * of samples can touch (<= 2 x 2 cells, <= 32 planes) is tested with ONE 8-byte fetch (round 5: eight 4-byte fetches, 31 % of the geometry kernel's
+ * wave time).  A group of consecutive samples of a ray touches only voxels inside the per-axis index interval of its two end samples (the index map is
+ * monotone along a ray); when every summary bit of that box is clear no sample of the group can pass MaskGrid.forward (lib/grid.py:295-304) and the
+ * group is skipped. */
 #define K4_OCC_CELL  8
 #define K4_OCC_SHIFT 3
 int64_t k4_occupancy_summary_bytes(int32_t mx, int32_t my, int32_t mz);
