@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         L.acnt[lane] = 0;
     }
     K4_GSTAMP(0);                                                                // workgroup prologue + ray setup
+    if (P.debug & 4096) ngrp = 0;                                                // ablation (WRONG results): prologue, arrival and the empty scan only -- the kernel's fixed cost
+    if (P.debug & 8192) { if (lane == 0 && wv == 0) P.counts[B.id] = 0; break; } // ablation: not even the arrival / scan
     int gq = ngrp;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gq = max(gq, __shfl_xor(gq, off));
@@ -506,8 +508,9 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     float T = 1.f;
     bool stopped = false;
     if (slab == 2) { T = myray >= 0 ? P.out_ainv[myray] : 1.f; stopped = T < 1e-3f; }      // where the first launch's scan left this ray
+    const bool any_rec = (na_sh[0] | na_sh[1] | na_sh[2] | na_sh[3]) != 0;                  // (wave-uniform) a bundle without records: nothing to scan or compact
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 4 && any_rec; ++w) {
         uint2* const run = ent_base + run0 + (size_t)w * quarter;
         const int c = lds_all[w].acnt[lane];
         int incl = c;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
     // ---- stage D: keep w > thres, compacted to the front of the bundle's slice, run order preserved ----
     int cnt = slab == 2 ? __builtin_amdgcn_readfirstlane(P.counts[B.id]) : 0, na_all = 0;      // second launch: append behind the first launch's survivors
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 4 && any_rec; ++w) {
         const uint2* const run = ent_base + run0 + (size_t)w * quarter;
         int naw = na_sh[w];
         na_all += naw;
@@ -573,7 +576,16 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
         }
     }
     if (lane == 0) P.counts[B.id] = cnt;
-    if (myray >= 0) P.out_ainv[myray] = my_ainv;
+    if (myray >= 0) {
+        P.out_ainv[myray] = my_ainv;
+        // a bundle without a shaded sample never enters the shading queue (k4_order_kernel): its rays' outputs are final here --
+        // rgb_marched = alphainv_last * bg (lib/dmpigo.py:397), depth 0.  (First launch of the split form: the second one decides.)
+        if (cnt == 0 && slab != 1) {
+            const float ab = my_ainv * P.bg;
+            P.out_rgb[(size_t)myray * 3 + 0] = ab; P.out_rgb[(size_t)myray * 3 + 1] = ab; P.out_rgb[(size_t)myray * 3 + 2] = ab;
+            P.out_depth[myray] = 0.f;
+        }
+    }
     n_alpha += (unsigned long long)na_all; n_shade += (unsigned long long)cnt;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }   // bundle
@@ -1160,7 +1172,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
             const int nbat = k4_batches_of(v[i]);
-            if (b < n_bundles) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
+            if (b < n_bundles && nbat > 0) atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1);
         }
     }
     __syncthreads();
@@ -1191,7 +1203,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
             const int nbat = k4_batches_of(v[i]);
-            if (b < n_bundles) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = b;
+            if (b < n_bundles && nbat > 0) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = b;
         }
     }
 }

@@ -223,15 +223,22 @@ class JointTrainer:
                 if weight > 0 and hasattr(grid, 'finish_grad_seed') and grid.grid.requires_grad:
                     fn(weight / self.n_train_images, 'seed')
                     seeded.append(grid)
-        with torch.enable_grad():
-            rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
-            if hasattr(self.model, '_k4_params_ready'):
-                self.model._k4_params_ready()                # (a forward that never read k0: its pending update still precedes what follows)
-            self.optimizer.zero_grad(set_to_none=True)
-            self.optimizer_sr.zero_grad(set_to_none=True)
-            ls['total'].backward()
-        for grid in seeded:
-            grid.finish_grad_seed()
+        done = False
+        try:
+            with torch.enable_grad():
+                rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
+                if hasattr(self.model, '_k4_params_ready'):
+                    self.model._k4_params_ready()                # (a forward that never read k0: its pending update still precedes what follows)
+                self.optimizer.zero_grad(set_to_none=True)
+                self.optimizer_sr.zero_grad(set_to_none=True)
+                ls['total'].backward()
+            for grid in seeded:
+                grid.finish_grad_seed()
+            done = True
+        finally:
+            if not done:                # forward / loss / backward raised (e.g. an out-of-memory batch the caller skips): a parked seed must not
+                for grid in seeded:     # reach a LATER iteration's gradient -- it holds a TV term of parameters that iteration no longer has
+                    grid._k4_seed = None
         self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
         if tv_now:
             if cfg.weight_tv_density > 0 and getattr(self.model, 'density', None) not in seeded:

@@ -197,15 +197,20 @@ class DenseGrid(nn.Module):
 
     def note_pending_update(self, event):
         self._k4_pending = event
+        self._k4_pending_seen = set()                     # streams that already wait for it
 
     def params_ready(self, stream=None, clear=True):
         """Everything queued on `stream` (default: the current one) after this call sees the finished parameter update.  Called by every
         reader of the parameter in this package (lookups, total variation, resampling, the fused marchers' descriptors, state_dict)."""
         ev = self._k4_pending
         if ev is not None:
-            (stream if stream is not None else torch.cuda.current_stream(self.grid.device)).wait_event(ev)
-            if clear:
-                self._k4_pending = None
+            # the event stays until the NEXT update replaces it: a reader on another stream later on must wait too (a cleared event made only
+            # the first waiting stream safe); a stream waits once
+            st = stream if stream is not None else torch.cuda.current_stream(self.grid.device)
+            seen = self.__dict__.setdefault('_k4_pending_seen', set())
+            if st.cuda_stream not in seen:
+                st.wait_event(ev)
+                seen.add(st.cuda_stream)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         self.params_ready()
@@ -222,7 +227,7 @@ class DenseGrid(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ('_k4_seed', '_k4_pending'):
+            if k in ('_k4_seed', '_k4_pending', '_k4_pending_seen'):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -108,7 +108,7 @@ class MaskedAdam(torch.optim.Optimizer):
                 raise ValueError(msg)
         self.per_lr = None
         self._fast = {}             # id(param group) -> plan of the group's small tensors (see _fast_step)
-        self._side = {}             # id(param) -> owner (an object with ``note_pending_update(event)``): see update_on_side_stream
+        self._side = []             # owners (objects with ``.grid``, ``note_pending_update(event)``, ``params_ready()``): see update_on_side_stream
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def update_on_side_stream(self, param, owner):
@@ -117,13 +117,26 @@ class MaskedAdam(torch.optim.Optimizer):
         parameter wait for it.  The 339 M-float LLFF k0 takes 1.9 ms of HBM time per step (28 bytes per element): on the current stream
         that is 1.9 ms between the end of one training iteration and the first kernel of the next, whose sample selection (a device-to-host
         read of counts, density grid only) the host waits for.  No reference counterpart (one stream there); same values."""
-        self._side[id(param)] = owner
+        assert owner.grid is param
+        if not any(o is owner for o in self._side):
+            self._side.append(owner)             # keyed by the OWNER: its current ``.grid`` is looked up at step time (a .to() / resampled grid is a new Parameter)
 
     def zero_grad(self, set_to_none=True):
         # a gradient an update on the side stream may still be reading goes back to the current stream's allocator here: wait for that update first
-        for owner in self._side.values():
+        for owner in self._side:
             owner.params_ready()
         return super().zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self):
+        # exp_avg / exp_avg_sq of a grid whose step runs on the second stream: a checkpoint copy taken on the current stream waits for it
+        for owner in self._side:
+            owner.params_ready()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        for owner in self._side:
+            owner.params_ready()
+        return super().load_state_dict(state_dict)
 
     def set_pervoxel_lr(self, count):
         assert self.param_groups[0]['params'][0].shape == count.shape
@@ -196,7 +209,7 @@ class MaskedAdam(torch.optim.Optimizer):
                 grad = param.grad.contiguous()
                 moments = (state['exp_avg'], state['exp_avg_sq'])
                 hyper = (state['step'], beta1, beta2, lr, eps)
-                owner = self._side.get(id(param)) if param.is_cuda and param.numel() >= _MULTI_BELOW else None
+                owner = next((o for o in self._side if o.grid is param), None) if param.is_cuda and param.numel() >= _MULTI_BELOW else None
                 if owner is not None:
                     cur, side = torch.cuda.current_stream(param.device), _side_stream(param.device)
                     side.wait_stream(cur)                       # the gradient (and everything that read the old values) is done

@@ -488,6 +488,15 @@ def _up2(t):
     return t.repeat_interleave(2, 0).repeat_interleave(2, 1)
 
 
+def _params_hooked(net):
+    """A parameter with a tensor hook or a post-accumulate-grad hook (DDP-style reducers, clipping hooks) needs its autograd edge: the direct
+    gradient hand-over would never fire the hook."""
+    for p in net.parameters():
+        if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+            return True
+    return False
+
+
 def forward_train(net, x, cond):
     """SFTNet.forward (lib/sr_esrnet.py:446-465) with autograd, every convolution on the HIP kernels.
     x [1,C,h,w], cond [1,num_cond,h,w] -> [1,3,s*h,s*w]."""
@@ -517,7 +526,7 @@ def forward_train(net, x, cond):
     # direct mode: the fused Functions take their parameters as one opaque list and write ``.grad`` themselves (no autograd edges to 438 of
     # the decoder's 458 parameter tensors: ~1.5 ms of host time per iteration in Function.apply and AccumulateGrad).  loss.backward() sees no
     # difference; torch.autograd.grad(..., params), parameter hooks and graph capture need the edges: K4_TRAIN_DIRECT_GRADS=0 / automatic.
-    direct = fused and _DIRECT_GRADS and feat.requires_grad and not torch.cuda.is_current_stream_capturing()
+    direct = fused and _DIRECT_GRADS and feat.requires_grad and not torch.cuda.is_current_stream_capturing() and not _params_hooked(net)
     if acc is not None:
         c = _CondFan.apply(c, acc)
 

@@ -379,6 +379,7 @@ def main():
                 rl['four_k_psnr_vs_oracle_db'] = four_k['psnr_vs_oracle_db']
             if isinstance(four_k.get('rank_share_8gpu'), dict):
                 rl['rank_share_8gpu_ms'] = four_k['rank_share_8gpu'].get('ms')
+                res['roofline_detail']['rank_share_8gpu_pipelined_ms'] = four_k['rank_share_8gpu'].get('pipelined_ms')
             res['roofline_detail']['sr_kernel'] = sr_kernel_from_profiles()
             res['roofline_detail']['four_k_arith'] = four_k.get('arith') or default_mode
         if isinstance(res.get('joint_train_step'), dict):
@@ -579,6 +580,29 @@ def four_k_frames(model, ck, poses, rk, H, W, K, dev, n_frames, world, rank, mod
         b8 = proj['8']['best']
         base['rank_share_8gpu'] = {'ms': b8['share_ms_median'], 'tiles': b8['tiles_of_heaviest_rank'], 'tile_size': b8['tile_size'],
                                    'projected_speedup_before_gather': round(dt * 1e3 / b8['share_ms_median'], 2)}
+        # the same share with frame i+1's march issued BEFORE frame i's decode (tile_parallel.march_frame_tiles / decode_frame_tiles): at tile 168 a
+        # layer of the rank's windows is ~1 round of workgroups and leaves CUs idle, the next frame's march runs under it (verdict r05 item 4b)
+        with torch.no_grad():
+            tl = tp.tile_geometry(H, W, b8['tile_size'], 10)
+            owned = tp.assign_tiles(tl, 8)
+            area = [sum((tl[i][5] - tl[i][4]) * (tl[i][7] - tl[i][6]) for i in o) for o in owned]
+            sub = _SubsetGeometry(tl, owned[max(range(8), key=lambda q: area[q])])
+            nf = len(frames)
+            st_next = sub.march(frames[0], march_fn)
+            for q in range(3):                                                # warm-up of the pipelined order
+                st_cur, st_next = st_next, sub.march(frames[(q + 1) % nf], march_fn)
+                sub.decode(st_cur, sr_fn)
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
+            evs[0].record()
+            for q in range(12):
+                st_cur, st_next = st_next, sub.march(frames[(q + 1) % nf], march_fn)
+                sub.decode(st_cur, sr_fn)
+                evs[q + 1].record()
+            torch.cuda.synchronize()
+            pms = float(np.median([evs[q].elapsed_time(evs[q + 1]) for q in range(12)]))
+        base['rank_share_8gpu']['pipelined_ms'] = round(pms, 2)
+        base['rank_share_8gpu']['projected_speedup_pipelined'] = round(dt * 1e3 / (pms + b8['gather_standin_ms']), 2)
     if check and rank == 0:
         base.update(four_k_parity_and_cpu(ck, net, poses[(n_frames - 1) % len(frames)], hr, tiles, H, W))
     return base
@@ -624,6 +648,17 @@ class _SubsetGeometry:
         self.tiles = [tiles[i] for i in mine]
 
     def render(self, rays, march_fn, sr_fn):
+        return self.decode(self.march(rays, march_fn), sr_fn)
+
+    def decode(self, st, sr_fn):
+        cur = torch.cuda.current_stream(st[2])
+        for ev in st[3]:
+            cur.wait_event(ev)
+        return sr_fn.k4_multi(st[0], st[1])           # one grouped launch per layer over this rank's windows
+
+    def march(self, rays, march_fn):
+        """This rank's windows marched on the pool's streams (they wait for what is queued on the current stream NOW: issued before the
+        previous frame's decode, the march runs under it)."""
         from nerf4k_amd import tile_parallel as tp
         dev = rays[0].device
         pool = tp._stream_pool(dev, min(4, len(self.tiles)))
@@ -640,9 +675,12 @@ class _SubsetGeometry:
                 hh, ww = yp1 - yp0, xp1 - xp0
                 imgs.append(rgb.reshape(hh, ww, 3).permute(2, 0, 1).unsqueeze(0))
                 conds.append(depth.reshape(1, 1, hh, ww))
+        evs = []
         for st in pool:
-            cur.wait_stream(st)
-        return sr_fn.k4_multi(imgs, conds)            # one grouped launch per layer over this rank's windows
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        return imgs, conds, dev, evs
 
 
 def four_k_parity_and_cpu(ck, net, pose, hr, tiles, H, W):

@@ -239,7 +239,10 @@ def test_dense_tv_written_ahead_of_backward_and_side_stream_adam_equal_the_refer
         assert model.k0._k4_seed is None and model.density._k4_seed is None            # every seed was consumed (or folded in by finish_grad_seed)
         assert (model.k0._k4_pending is not None) == adam_side                         # the last step's update may still be running ...
         sd = model.state_dict()                                                         # ... every reader waits for it: state_dict,
-        assert model.k0._k4_pending is None
+        if adam_side:                                                                   # (the event stays until the next update: a reader on ANOTHER stream waits too)
+            assert torch.cuda.current_stream().cuda_stream in model.k0._k4_pending_seen
+            osd = tr.optimizer.state_dict()                                             # the optimizer's own checkpoint copy waits as well
+            assert any(torch.is_tensor(v.get('exp_avg')) for v in osd['state'].values())
         with torch.no_grad():                                                           # the fused marcher
             img = model(*batch[:3], **{k: v for k, v in rk.items() if k != 'rand_bkgd'})['rgb_marched'].clone()
         res.append((hist, {k: v.detach().clone() for k, v in sd.items() if v.is_floating_point()}, [p.detach().clone() for p in net.parameters()], img))
