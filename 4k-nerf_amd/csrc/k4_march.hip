@@ -34,6 +34,7 @@
 #include "k4_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #define MODE_MPI  0
 #define MODE_DVGO 1
@@ -865,6 +866,7 @@ struct MlpLayoutB3 {                      // offsets in floats from the start of
 __device__ __forceinline__ float k4_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // A tile's layer-1 input: the shading kernel's feat[K1P][64] image in LDS.
 struct LdsFeat {
+    static constexpr bool kCompileTimeTile = false;
     const float* feat; int k1p, l31, half;
     __device__ __forceinline__ void load(int kb, int t, float (&v)[8]) {
 #pragma unroll
@@ -877,18 +879,20 @@ struct LdsFeat {
 // FAST shading path (round 6): the 16 layer-1 inputs of a record are built in ITS lane's registers and reach the B-operand layout
 // (lane l: sample l & 31 of tile t, inputs 8 (l >> 5) .. + 7) by 8 v_permlane32_swap -- no LDS image, no ds_write / ds_read round trip.
 struct RegFeat {
+    static constexpr bool kCompileTimeTile = true;
     float x[8], y[8];                                     // tile 0's / tile 1's operand of this lane
-    __device__ __forceinline__ void load(int kb, int t, float (&v)[8]) {
+    template <int T>
+    __device__ __forceinline__ void load(int kb, std::integral_constant<int, T>, float (&v)[8]) {
         (void)kb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = t ? y[e] : x[e];
+        for (int e = 0; e < 8; ++e) v[e] = T ? y[e] : x[e];
     }
 };
 // The general form (any covered width / depth / input size), one 32-sample tile at a time.  NT2 = 3: the exact form of rounds 2-5 (every
 // accumulator receives its products in the order of K4_MFMA_B3); NT2 = 2: the round-6 default (see k4_split2).  The 32-neuron output
 // blocks of a layer are taken two at a time, side by side (independent accumulators: consecutive MFMAs never depend on each other);
 // width 128 = two such passes per layer, so that at most 2 x 16 accumulators are live beside the split hidden activations.
-template <int W, int NHID, int NT1, int NT2, class FS>
+template <int W, int NHID, int NT1, int NT2, class FS, bool TILE0_ONLY = false>      // TILE0_ONLY: the caller guarantees nproc <= 32
 __device__ __forceinline__ void mlp_mfma_bx(const float* ws, FS& fs, int k1p, int lane, int half, int debug, int nproc,
                                             float& out0, float& out1, float& out2 K4_TARGS) {
     constexpr int NB = W / 32;
@@ -904,17 +908,18 @@ __device__ __forceinline__ void mlp_mfma_bx(const float* ws, FS& fs, int k1p, in
     const float* const wot = ws + ML::wot(k1p);
     const float* const bo = ws + ML::bo(k1p);
     out0 = out1 = out2 = 0.f;
-    // one 32-sample tile at a time, NOT unrolled: the second tile reuses the code and the registers
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-        if (t * 32 >= nproc) break;                  // a bundle's last batch: no record in the second tile (wave-uniform)
+    // one 32-sample tile at a time.  LdsFeat: NOT unrolled, the second tile reuses the code and the registers.  RegFeat: the tile index must be a
+    // compile-time constant -- a run-time choice between the two register arrays made hipcc keep them in SCRATCH (64 bytes per lane written and read
+    // back per batch: 350 MB of HBM writes per frame in the first FAST build, profiles/r06_marcher_pmc_raw.md) -- so the two tiles are two instances.
+    auto tile_body = [&](auto tt) {
+        const int t = tt;
         // ---------------- layer 1: H1^T[j][s] = sum_k W1ext[j][k] * X[k][s], exact 3-term products ----------------
         f32x16 h1[NB];
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) h1[mb] = (f32x16)(0.f);
         for (int kb = 0; kb < kb1; ++kb) {
             float v[8];
-            fs.load(kb, t, v);
+            fs.load(kb, tt, v);
             uint4 x[NT1];
             if constexpr (NT1 == 3) k4_split3(v, x[0], x[1], x[2]);
             else k4_split2(v, x[0], x[1]);
@@ -1012,6 +1017,18 @@ __device__ __forceinline__ void mlp_mfma_bx(const float* ws, FS& fs, int k1p, in
         const float q2 = pt2 + __shfl_xor(pt2, 32) + bo[2];
         if (half == t) { out0 = q0; out1 = q1; out2 = q2; }
         K4_TSTAMP(5);                                    // output layer
+    };
+    if constexpr (FS::kCompileTimeTile) {
+        tile_body(std::integral_constant<int, 0>{});
+        if constexpr (!TILE0_ONLY) {
+            if (32 < nproc) tile_body(std::integral_constant<int, 1>{});  // a bundle's last batch may hold no record in the second tile (wave-uniform)
+        }
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            if (t * 32 >= nproc) break;
+            tile_body(t);
+        }
     }
 }
 
@@ -1057,8 +1074,8 @@ __device__ __forceinline__ void mlp_pair64(const float* ws, FS& fs, int lane, in
     const float* const wot = ws + ML::wot(16);
     const float* const bo = ws + ML::bo(16);
     float vA[8], vB[8];
-    fs.load(0, 0, vA);
-    fs.load(0, 1, vB);
+    if constexpr (FS::kCompileTimeTile) { fs.load(0, std::integral_constant<int, 0>{}, vA); fs.load(0, std::integral_constant<int, 1>{}, vB); }
+    else { fs.load(0, 0, vA); fs.load(0, 1, vB); }
     // layer-1 weight fragments (both 32-neuron blocks), shared by the two tiles
     uint4 a[NT1], c[NT1], xA[NT1], xB[NT1];
 #pragma unroll
@@ -1374,8 +1391,8 @@ __global__ __launch_bounds__(256, WG) void k4_shade_kernel(const MarchParams P) 
             K4_TSTAMP(2);                                // remaining features, half-wave exchange
             constexpr int NT2 = ARITH == 3 ? 3 : 2, NT1 = ARITH == 3 ? 3 : K4_B2_L1_TERMS;
             if constexpr (K4_MLP_PAIR && W == 64 && NHID == 1) {
-                if (nproc > 32 && !(P.debug & 2)) mlp_pair64<NT1, NT2>(wl, fs, lane, half, o0, o1, o2 K4_TPASS);
-                else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
+                if (nproc > 32) mlp_pair64<NT1, NT2>(wl, fs, lane, half, o0, o1, o2 K4_TPASS);
+                else mlp_mfma_bx<W, NHID, NT1, NT2, RegFeat, true>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
             } else mlp_mfma_bx<W, NHID, NT1, NT2>(wl, fs, 16, lane, half, P.debug, nproc, o0, o1, o2 K4_TPASS);
         } else if (WIDTH == 0) {
             // rgbnet is None: rgb = sigmoid(k0)   (lib/dvgo.py:377-379)
