@@ -516,7 +516,16 @@ __device__ __forceinline__ void mlp_pair64(const float* ws, FS& fs, int lane, in
         K4_STAGE_SCHED(NM2, NV); \
         __builtin_amdgcn_sched_barrier(0); } while (0)
     K4_TSTAMP(3);                                        // (timing builds) input splits + layer 1 of both tiles + first hidden block's split
-    constexpr int NVS = NT2 == 3 ? 4 : 5;                // vector instructions per MFMA of a ReLU + split stage (~52 / 12, ~32 / 6)
+#ifndef K4_PAIR_NVS
+#define K4_PAIR_NVS 5
+#endif
+#ifndef K4_PAIR_NVO
+#define K4_PAIR_NVO 8
+#endif
+#ifndef K4_PAIR_NVL
+#define K4_PAIR_NVL 4
+#endif
+    constexpr int NVS = NT2 == 3 ? 4 : K4_PAIR_NVS;                // vector instructions per MFMA of a ReLU + split stage (~52 / 12, ~32 / 6)
     K4_L2_STAGE(cA0, cA1, hsA, 0, k4_relu_split8<NT2>(hA0, 1, hsA[1]), NVS);
     K4_L2_STAGE(cA0, cA1, hsA, 1, k4_relu_split8<NT2>(hA1, 0, hsA[2]), NVS);
     K4_L2_STAGE(cA0, cA1, hsA, 2, k4_relu_split8<NT2>(hA1, 1, hsA[3]), NVS);
@@ -535,11 +544,11 @@ __device__ __forceinline__ void mlp_pair64(const float* ws, FS& fs, int lane, in
             else { const k4_f32x2 w01_ = {wo_.x, wo_.y}, aa_ = {a_, a_}; PT01 = __builtin_elementwise_fma(w01_, aa_, PT01); } \
             PT2 = fmaf(wo_.z, a_, PT2); } } while (0)
     K4_TSTAMP(4);                                        // layer 2 of tile A (+ splits)
-    constexpr int NVO = NT2 == 3 ? 5 : 8;                // ... of a ReLU + split + half-block output stage (~76 / 12, ~56 / 6: what does not fit runs behind the stage)
+    constexpr int NVO = NT2 == 3 ? 5 : K4_PAIR_NVO;                // ... of a ReLU + split + half-block output stage (~76 / 12, ~56 / 6: what does not fit runs behind the stage)
     K4_L2_STAGE(cB0, cB1, hsB, 0, k4_relu_split8<NT2>(hB0, 1, hsB[1]); K4_OUT_HALF(cA0, 0, 0, ptA01, ptA2), NVO);
     K4_L2_STAGE(cB0, cB1, hsB, 1, k4_relu_split8<NT2>(hB1, 0, hsB[2]); K4_OUT_HALF(cA0, 0, 8, ptA01, ptA2), NVO);
     K4_L2_STAGE(cB0, cB1, hsB, 2, k4_relu_split8<NT2>(hB1, 1, hsB[3]); K4_OUT_HALF(cA1, 1, 0, ptA01, ptA2), NVO);
-    K4_L2_STAGE(cB0, cB1, hsB, 3, K4_OUT_HALF(cA1, 1, 8, ptA01, ptA2), NT2 == 3 ? 2 : 4);
+    K4_L2_STAGE(cB0, cB1, hsB, 3, K4_OUT_HALF(cA1, 1, 8, ptA01, ptA2), NT2 == 3 ? 2 : K4_PAIR_NVL);
 #undef K4_L2_STAGE
     K4_TSTAMP(5);                                        // layer 2 of tile B (+ splits, tile A's output layer)
     // ---- S11: tile B's output layer ----
