@@ -61,7 +61,7 @@ struct MarchParams {
     float depth_n_inv;              // 1 / depth_n, correctly rounded
     float depth_fx, depth_fx_inv;   // fixed-point scale of the per-ray depth sums (a power of two: 2^30 / the largest s a record can carry) and its reciprocal
     uint2* entries; int* counts; int* qhead;       // workspace: [n_bundles][64*max_steps], [n_bundles], shading work-queue head
-    int* jobs;                                     // workspace: the shading queue = bundle ids, most batches first (k4_order_kernel)
+    int2* jobs;                                    // workspace: the shading queue = {bundle id, its record count}, most batches first (k4_order_kernel)
     int n_bundles;
     int split_k;            // MPI: > 0 = depth-ordered geometry stage -- samples [0, split_k) in a first launch, [split_k, n_samples) in a second one that
                             // drops every ray the first launch's transmittance scan stopped (k4_grid_desc.depth_split; a multiple of 64)
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256, MINW) void k4_geom3_kernel(const MarchParams P
 #define K4_ORDER_SUB 16          // sub-bins per class (bundle id & 15): 16x fewer same-address LDS atomics -- most bundles fall in a few classes
 #define K4_QLEN 32               // qhead[K4_QLEN] = queue length: its own 128-byte line (the head word's line is busy with the queue's atomics)
 __device__ __forceinline__ int k4_batches_of(int count) { return (int)(((unsigned)max(count, 0) + 63u) >> 6); }
-__global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int* __restrict__ jobs, int n_bundles, int* qhead) {
+__global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ counts, int2* __restrict__ jobs, int n_bundles, int* qhead) {
     constexpr int NBIN = K4_ORDER_CLASSES * K4_ORDER_SUB;            // 4096 = 4 per thread
     __shared__ int hist[NBIN];
     __shared__ int wsum[16];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void k4_order_kernel(const int* __restrict__ 
         for (int i = 0; i < 16; ++i) {
             const int b = base + i * 1024 + tid;
             const int nbat = k4_batches_of(v[i]);
-            if (b < n_bundles && nbat > 0) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = b;
+            if (b < n_bundles && nbat > 0) jobs[atomicAdd(&hist[(K4_ORDER_CLASSES - 1 - min(nbat, K4_ORDER_CLASSES - 1)) * K4_ORDER_SUB + (b & (K4_ORDER_SUB - 1))], 1)] = make_int2(b, v[i]);   // the count rides along: one dependent fetch less per job
         }
     }
 }
@@ -683,9 +683,10 @@ __device__ __forceinline__ bool k4_next_job(const MarchParams& P, int lane, Shad
     if (lane == 0) bid = atomicAdd(P.qhead, 1);
     bid = __builtin_amdgcn_readfirstlane(bid);
     if (bid >= __builtin_amdgcn_readfirstlane(P.qhead[K4_QLEN])) return false;
-    const int bundle = __builtin_amdgcn_readfirstlane(P.jobs[bid]);
+    const int2 jb = P.jobs[bid];
+    const int bundle = __builtin_amdgcn_readfirstlane(jb.x);
     J.B = bundle_from_id(P, bundle);
-    J.total = __builtin_amdgcn_readfirstlane(P.counts[bundle]);
+    J.total = __builtin_amdgcn_readfirstlane(jb.y);
     return true;
 }
 // ---- per-ray sums (segment_coo, lib/dmpigo.py:382-386,418-424) in FIXED POINT (round 6; rounds 2-5: fp64 with terms rounded to 2^-40) ----
@@ -1104,7 +1105,7 @@ static int launch_march(const MarchParams& P, const k4_mlp_desc* mlp, hipStream_
 // records per bundle: 64 rays x max_steps rounded up to a whole number of 64-sample blocks per depth quarter
 static inline int64_t ent_stride_of(int32_t max_steps) { return 64 * (((int64_t)max_steps + 255) / 256 * 256); }
 
-// workspace: [records nb x ent_stride x 8 B][counts nb] | [queue head .. queue length: 64 ints] | [jobs: nb x 4 B], each 256-aligned
+// workspace: [records nb x ent_stride x 8 B][counts nb] | [queue head .. queue length: 64 ints] | [jobs: nb x 8 B], each 256-aligned
 struct WsLayout { int64_t counts, qhead, jobs, total; };
 static WsLayout ws_layout(int64_t nb, int64_t ent_stride) {
     auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
@@ -1112,7 +1113,7 @@ static WsLayout ws_layout(int64_t nb, int64_t ent_stride) {
     L.counts = nb * ent_stride * (int64_t)sizeof(uint2);
     L.qhead = up(L.counts + nb * 4);
     L.jobs = up(L.qhead + 64 * 4);
-    L.total = up(L.jobs + nb * 4);
+    L.total = up(L.jobs + nb * 8);
     return L;
 }
 extern "C" int64_t k4_march_workspace_bytes(int64_t n_rays, int32_t img_w, int32_t max_steps) {
@@ -1162,7 +1163,7 @@ static int fill_common(MarchParams& P, const float* rays_o, const float* rays_d,
     P.entries = (uint2*)workspace;
     P.counts = (int*)((char*)workspace + L.counts);
     P.qhead = (int*)((char*)workspace + L.qhead);
-    P.jobs = (int*)((char*)workspace + L.jobs);
+    P.jobs = (int2*)((char*)workspace + L.jobs);
     P.n_bundles = (int)nb;
     P.debug = k4_env().debug; P.serp = 1;
     // XCD bands of the geometry kernel: ONE row of 16x16-pixel workgroup tiles (x 4 bundles) per band, dealt round-robin to

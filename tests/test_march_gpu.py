@@ -635,58 +635,22 @@ def test_full_frame_tile_window_and_linear_bundles_bit_identical():
         assert torch.equal(c[k], a[k][idx]), k
 
 
-def test_fast_shading_path_bit_identical():
-    """The shading kernel's FAST instantiation (LLFF input shape fixed at compile time, features through registers and v_permlane32_swap,
-    step positions from a table) against its general path (K4_DEBUG=1024, read when the library loads: own processes) -- one hash, for the
-    default arithmetic and for the exact one."""
+@pytest.mark.parametrize('which', ['mpi64', 'mpi32', 'mpi_d2', 'dvgo64'])
+def test_fast_shading_path_bit_identical(which):
+    """The shading kernel's FAST instantiation (input shape fixed at compile time, features through registers and v_permlane32_swap, MPI step
+    positions from a table) against its general path (K4_DEBUG=1024, read when the library loads: own processes) -- one hash per scene: the LLFF
+    shape (both tiles of a batch in one pipeline), rgbnet width 32 and no hidden layer (one tile at a time, two instances of the tile body), a
+    bounded DirectVoxGO scene; and, for the LLFF shape, the exact arithmetic too."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(**env):
-        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        e = dict(os.environ, K4_HASH_SCENE=which, **{k: str(v) for k, v in env.items()})
         out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'march_hash.py')], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         return [l for l in out.stdout.splitlines() if l.startswith('MARCH_HASH')][-1]
     base = run(K4_DEBUG=1024)
     assert run(K4_DEBUG=0) == base
-    b3 = run(K4_DEBUG=1024, K4_MLP='b3')
-    assert run(K4_DEBUG=0, K4_MLP='b3') == b3 and b3 != base
-
-
-@pytest.mark.parametrize('cfg,expect_split', [
-    (dict(seed=781, num_voxels=96 * 96 * 128, mpi_depth=128, opaque=True), True),          # opaque wall at 0.4 of the depth: the back launch skips what it hides
-    (dict(seed=31, num_voxels=96 * 96 * 128, mpi_depth=128, n_blobs=6), None),             # translucent blobs: whatever the statistic says, outputs must not move
-])
-def test_depth_ordered_geometry_stage_is_bit_identical(cfg, expect_split, monkeypatch):
-    """k4_grid_desc.depth_split (round 6): front slab, then the back slab only for rays whose transmittance is still >= 1e-3.  Early
-    termination exploited in the density stage (the reference evaluates density behind the stop and drops it: render_utils_kernel.cu:577-651).
-    Every output equals the single-launch form bit for bit -- with the split the load-time statistic proposes and with a forced one."""
-    ck = scene.make_llff_checkpoint(**cfg)
-    model = _model(ck)
-    H, W = 96, 128
-    K = scene.LLFF_K.copy()
-    K[:2] *= W / scene.LLFF_HW[1]
-    rays = [x.cuda().reshape(-1, 3) for x in marcher.get_rays_of_a_view(H, W, K, scene.llff_spiral_poses()[5], ndc=True)]
-    rk = dict(ck['render_kwargs'], render_depth=True)
-    keys = ('rgb_marched', 'depth', 'alphainv_last')
-
-    def run():
-        o = model(*rays, k4_img_w=W, **rk)
-        torch.cuda.synchronize()
-        return {k: o[k].clone() for k in keys}
-    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT', False)
-    base = run()
-    assert float(base['rgb_marched'].abs().sum()) > 0
-    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT', True)
-    auto = run()
-    chosen = model._k4_cache()['dsplit']
-    if expect_split:
-        assert chosen > 0 and chosen % 64 == 0, (chosen, model._k4_cache()['dsplit_stats'])
-        assert float((base['alphainv_last'] < 1e-3).float().mean()) > 0.9
-    monkeypatch.setattr(dmpigo.DirectMPIGO, '_k4_depth_split', lambda self, gd, n, itv: 64)       # a forced split, whatever the statistic says
-    monkeypatch.setattr(dmpigo, 'DEPTH_SPLIT_MIN_GAIN', 0.0499)                                   # (part of the plan key: a new plan)
-    forced = run()
-    for k in keys:
-        assert torch.equal(auto[k], base[k]) and torch.equal(forced[k], base[k]), k
-    want = marcher.forward('DirectMPIGO', ck['model_kwargs'], ck['model_state_dict'], *[r.cpu() for r in rays], **ck['render_kwargs'])
-    _cmp(forced['rgb_marched'].cpu(), want['rgb_marched'], 'rgb_marched', min_psnr=100.0)
+    if which == 'mpi64':
+        b3 = run(K4_DEBUG=1024, K4_MLP='b3')
+        assert run(K4_DEBUG=0, K4_MLP='b3') == b3 and b3 != base
