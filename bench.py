@@ -138,9 +138,13 @@ class MarcherRun:
                 self.step(i)
             self.sync()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            for a, b in ev:                            # torch creates the HIP event at its FIRST record: outside the timed region (2 x steps creations,
+                a.record(); b.record()                 # ~0.1-0.3 ms each on a slow host, made the 3-stream loop host-bound on some boxes)
+            torch.cuda.synchronize()
             t_start = time.perf_counter()
             for i in range(steps):
                 self.step(i, timed=ev[i])
+            self.host_issue_ms_per_step = (time.perf_counter() - t_start) / max(steps, 1) * 1e3      # the host's share: issue only
             self.sync()
             elapsed = time.perf_counter() - t_start
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
@@ -318,6 +322,7 @@ def main():
                          'kernel_ms': round(iso_ms, 4)},
             # what `roofline` is made of (the driver's record keeps ~20 scalar entries of `roofline`: everything nested lives here)
             'roofline_detail': {'kernel_ms_median': round(float(np.median(run.iso_ms_all)), 4), 'overlapped_launch_ms': round(overlapped_ms, 4),
+                                'host_issue_ms_per_step': round(getattr(run, 'host_issue_ms_per_step', 0.0), 4),
                                 'traffic_source': traffic_src,
                                 'second_roof': None if roof2 is None else dict(roof2, frac_of_issue_floor=round(roof2['issue_floor_ms'] / iso_ms, 4),
                                                                                frac_of_measured_floor=round(roof2['issue_floor_measured_ms'] / iso_ms, 4)),
