@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 12
+K4_ABI_VERSION = 13
 # True: the data-path collectives (tile all-gather, gradient exchange) are issued even on a process group of ONE rank -- the RCCL smoke test
 # on a single GPU (tests/test_rccl_gpu.py: communicator + the production collective calls on device buffers); never set in production
 FORCE_COLLECTIVES = False
@@ -186,6 +186,16 @@ _EXTRA_SIGS = {
     'k4_sft_train_bwd_ex': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
+    'k4_tape_begin': ([_P], C.c_void_p),
+    'k4_tape_end': ([_P], C.c_int),
+    'k4_tape_length': ([_P], C.c_int64),
+    'k4_tape_replay': ([_P, _P], C.c_int),
+    'k4_tape_free': ([_P], None),
+    'k4_add_f32': ([_P, _P, _P, _I64, _P], C.c_int),
+    'k4_upsample2x_nhwc': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_upsample2x_bwd_nhwc': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
+    'k4_side_wait_main': ([_P, _P], C.c_int),
+    'k4_main_wait_side': ([_P, _P], C.c_int),
 }
 
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 OUT = os.path.join(PKG, 'lib4k_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip', 'k4_sr_p16.hip', 'k4_sr_bwd.hip', 'k4_opt.hip', 'k4_train.hip']  # missing files are skipped
+SOURCES = ['k4_march.hip', 'k4_staged.hip', 'k4_sr.hip', 'k4_sr_p16.hip', 'k4_sr_bwd.hip', 'k4_opt.hip', 'k4_train.hip', 'k4_tape.hip']  # missing files are skipped
 # -ffp-contract=on: a*b+c fuses only where the SOURCE expression says so (and in explicit fmaf).  hipcc's default
 # (fast-honor-pragmas) lets the backend fuse any fmul/fadd pair it finds after inlining, so two inlined copies of one
 # routine (expf/powf included) could round differently -- a ray's result then depended on which copy served its sample.

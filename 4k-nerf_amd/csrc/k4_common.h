@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
+#include <vector>
 #include "k4nerf.h"
 
 #define K4_WAVE 64
@@ -112,6 +114,23 @@ __device__ __forceinline__ K4Tri k4_tri_setup(float ux, float uy, float uz) {
 #define K4_CX(c) (((c) >> 2) & 1)
 #define K4_CY(c) (((c) >> 1) & 1)
 #define K4_CZ(c) ((c) & 1)
+
+// Launch tapes (k4_tape.hip; include/k4nerf.h k4_tape_*).  A recordable entry point is `return k4_taped(stream, [=](void* stream) -> int { body });`:
+// the body runs as always; while this thread records, a copy of the closure (the call's arguments BY VALUE -- a body must not keep a pointer
+// to a caller's host struct or array) is appended to the tape first.  Calls made from inside a recordable body are not recorded again.
+// A call whose stream is the recording's main stream (k4_tape_begin) follows the replaying stream; a call placed on any other stream (a side
+// stream's weight gradients) stays on the stream it was recorded with.
+struct k4_tape_op { std::function<int(void*)> fn; void* pinned; bool follow; };
+struct k4_tape { std::vector<k4_tape_op> ops; void* main_stream; };
+extern thread_local k4_tape* k4_tape_rec;
+extern thread_local int k4_tape_depth;
+template <class F> static inline int k4_taped(void* stream, F&& f) {
+    if (k4_tape_rec && k4_tape_depth == 0) k4_tape_rec->ops.push_back(k4_tape_op{std::function<int(void*)>(f), stream, stream == k4_tape_rec->main_stream});
+    ++k4_tape_depth;
+    const int rc = f(stream);
+    --k4_tape_depth;
+    return rc;
+}
 
 static inline int k4_check_launch() {
     hipError_t e = hipGetLastError();

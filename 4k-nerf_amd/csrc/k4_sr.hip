@@ -1340,10 +1340,12 @@ extern "C" int k4_conv2d_nhwc_bf16x6(const float* x, int32_t cin, int32_t cin_st
                                      int32_t H, int32_t W, uint32_t flags, float slope,
                                      const float* res, int32_t res_stride, float res_scale,
                                      const float* mod_x, int32_t mod_stride, void* stream) {
-    k4_conv_job j{};
-    j.x = x; j.y = y; j.res = res; j.mod_x = mod_x; j.H = H; j.W = W;
-    return conv_b6_multi(&j, 1, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale, mod_stride,
-                         stream);
+    return k4_taped(stream, [=](void* stream) -> int {                    // recordable (k4_tape.hip): the training graph's convolutions
+        k4_conv_job j{};
+        j.x = x; j.y = y; j.res = res; j.mod_x = mod_x; j.H = H; j.W = W;
+        return conv_b6_multi(&j, 1, cin, cin_stride, w_split, bias, ksize, cout, cout_stride, flags, slope, res_stride, res_scale, mod_stride,
+                             stream);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------------------------

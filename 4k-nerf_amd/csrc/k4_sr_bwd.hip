@@ -167,40 +167,51 @@ static int wgrad_launch(const float* x, int32_t cin, int32_t x_stride, const flo
     return k4_check_launch();
 }
 
+// (the entry points of this file that the decoder's training pass calls are recordable: k4_tape.hip)
 extern "C" int k4_conv2d_wgrad_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                                       int32_t ksize, int32_t H, int32_t W, float* dw, void* stream) {
-    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw, nullptr, (int64_t)cout * cin * ksize * ksize, stream);
+    return k4_taped(stream, [=](void* stream) -> int {
+        return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw, nullptr, (int64_t)cout * cin * ksize * ksize, stream);
+    });
 }
 
 extern "C" int k4_conv2d_wgrad_dbias_bf16x6(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                                             int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream) {
     // dw_db = [cout*cin*k*k floats of dW | cout floats of dbias], ONE buffer: one zero-fill, one launch
     if (!dw_db) return K4_ERR_BAD_ARG;
-    const int64_t nw = (int64_t)cout * cin * ksize * ksize;
-    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, nw + cout, stream);
+    return k4_taped(stream, [=](void* stream) -> int {
+        const int64_t nw = (int64_t)cout * cin * ksize * ksize;
+        return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, nw + cout, stream);
+    });
 }
 
 // ... ADDED to dw_db (no zero-fill): the caller has zeroed it -- k4_rdb_train_bwd zeroes the five buffers of a dense block with one launch
 extern "C" int k4_conv2d_wgrad_dbias_bf16x6_acc(const float* x, int32_t cin, int32_t x_stride, const float* gy, int32_t cout, int32_t gy_stride,
                                                 int32_t ksize, int32_t H, int32_t W, float* dw_db, void* stream) {
     if (!dw_db) return K4_ERR_BAD_ARG;
-    const int64_t nw = (int64_t)cout * cin * ksize * ksize;
-    return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, 0, stream);
+    return k4_taped(stream, [=](void* stream) -> int {
+        const int64_t nw = (int64_t)cout * cin * ksize * ksize;
+        return wgrad_launch(x, cin, x_stride, gy, cout, gy_stride, ksize, H, W, dw_db, dw_db + nw, 0, stream);
+    });
 }
 extern "C" int k4_zero_f32(float* p, int64_t n, void* stream) {
     if (n < 0 || (n > 0 && !p) || (n + 255) / 256 > 0x7fffffffLL) return K4_ERR_BAD_ARG;
     if (n == 0) return K4_OK;
-    wg_zero(p, n, (hipStream_t)stream);
-    return k4_check_launch();
+    return k4_taped(stream, [=](void* stream) -> int {
+        wg_zero(p, n, (hipStream_t)stream);
+        return k4_check_launch();
+    });
 }
 
 extern "C" int k4_conv2d_bias_grad(const float* gy, int32_t cout, int32_t gy_stride, int64_t n_pix, float* dbias, void* stream) {
     if (!gy || !dbias || cout <= 0 || gy_stride < cout || n_pix <= 0) return K4_ERR_BAD_ARG;
-    wg_zero(dbias, cout, (hipStream_t)stream);
     const int64_t slabs = (n_pix + K4_BG_SLAB - 1) / K4_BG_SLAB;
     if (slabs > 65535) return K4_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k4_bias_grad_kernel, dim3((unsigned)((cout + 31) / 32), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, gy, cout, gy_stride, n_pix, dbias);
-    return k4_check_launch();
+    return k4_taped(stream, [=](void* stream) -> int {
+        wg_zero(dbias, cout, (hipStream_t)stream);
+        hipLaunchKernelGGL(k4_bias_grad_kernel, dim3((unsigned)((cout + 31) / 32), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, gy, cout, gy_stride, n_pix, dbias);
+        return k4_check_launch();
+    });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -281,6 +292,9 @@ __global__ __launch_bounds__(256) void k4_pack_conv_multi_kernel(const PackMulti
 
 extern "C" int k4_pack_conv_weight_bf16x6_multi(const k4_pack_job* jobs, int32_t n_jobs, void* stream) {
     if (!jobs || n_jobs < 0) return K4_ERR_BAD_ARG;
+    const std::vector<k4_pack_job> table(jobs, jobs + n_jobs);            // the closure owns a copy of the caller's host array
+    return k4_taped(stream, [table, n_jobs](void* stream) -> int {
+    const k4_pack_job* jobs = table.data();
     for (int base = 0; base < n_jobs; base += K4_PACK_MULTI_MAX) {
         const int nj = n_jobs - base < K4_PACK_MULTI_MAX ? n_jobs - base : K4_PACK_MULTI_MAX;
         PackMultiArgs A{};
@@ -306,6 +320,7 @@ extern "C" int k4_pack_conv_weight_bf16x6_multi(const k4_pack_job* jobs, int32_t
         hipLaunchKernelGGL(k4_pack_conv_multi_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)nj), dim3(256), 0, (hipStream_t)stream, A);
     }
     return k4_check_launch();
+    });
 }
 
 extern "C" int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int32_t cout, int32_t cin, int32_t ksize, int32_t form,
@@ -320,7 +335,9 @@ extern "C" int k4_pack_conv_weight_bf16x6(const float* w, const float* bias, int
     const int n_bias = form >= 2 ? 32 : NOUT;                                   // taps forms: the bias of the 3x3 layer itself (<= 3 channels)
     const int total = nch * taps_l * 2 * NOUT;
     const int threads = total > n_bias ? total : n_bias;
-    hipLaunchKernelGGL(k4_pack_conv_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, cout, cin, taps, form, nch, taps_l, NOUT,
-                       reinterpret_cast<uint4*>(w_split), bias_out, n_bias);
-    return k4_check_launch();
+    return k4_taped(stream, [=](void* stream) -> int {
+        hipLaunchKernelGGL(k4_pack_conv_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, cout, cin, taps, form, nch, taps_l, NOUT,
+                           reinterpret_cast<uint4*>(w_split), bias_out, n_bias);
+        return k4_check_launch();
+    });
 }

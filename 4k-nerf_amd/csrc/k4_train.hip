@@ -795,12 +795,14 @@ extern "C" int k4_sft_train_fwd_ex(const float* x, int32_t x_stride, const float
     if (!w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h || !b1h) return K4_ERR_BAD_ARG;
     if (n_pix == 0) return K4_OK;
     if (!x || !cond || !y) return K4_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((n_pix + 63) / 64)), block(SFT_T);
-    const size_t lds = (size_t)(3 * SFT_G + channels) * TR_LS * sizeof(float);
-    if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
-    else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
-    return k4_check_launch();
+    return k4_taped(stream, [=](void* stream) -> int {                    // recordable (k4_tape.hip), as every entry point of the decoder's training pass below
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 grid((unsigned)((n_pix + 63) / 64)), block(SFT_T);
+        const size_t lds = (size_t)(3 * SFT_G + channels) * TR_LS * sizeof(float);
+        if (channels == 64) hipLaunchKernelGGL(k_sft_train_fwd<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
+        else hipLaunchKernelGGL(k_sft_train_fwd<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, res, res_stride, res_scale);
+        return k4_check_launch();
+    });
 }
 extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, int64_t n_pix, int32_t channels,
                                 const float* w0s, const float* b0s, const float* w1s, const float* b1s,
@@ -838,11 +840,13 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
     if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
     if (!gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < k4_sft_train_bwd_workspace_bytes(n_pix, channels)) return K4_ERR_BAD_ARG;
-    float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
-    hipStream_t st = (hipStream_t)stream;
-    const int acc = accumulate_grad_cond != 0;
-    if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
-    return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
+    return k4_taped(stream, [=](void* stream) -> int {
+        float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
+        hipStream_t st = (hipStream_t)stream;
+        const int acc = accumulate_grad_cond != 0;
+        if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
+        return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
+    });
 }
 extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                 int64_t n_pix, int32_t channels,
@@ -875,10 +879,12 @@ extern "C" int k4_lrelu_bwd(const float* grad, int32_t g_stride, const float* y,
         g_stride < channels || y_stride < channels || out_stride < channels || ((uintptr_t)grad & 15) || ((uintptr_t)y & 15) || ((uintptr_t)out & 15))
         return K4_ERR_BAD_ARG;
     if (n_pix == 0) return 0;
-    const int64_t n = n_pix * (channels / 4);
-    hipLaunchKernelGGL(k_lrelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, g_stride, y, y_stride, n_pix, channels / 4, slope,
-                       out, out_stride);
-    return k4_check_launch();
+    return k4_taped(stream, [=](void* stream) -> int {
+        const int64_t n = n_pix * (channels / 4);
+        hipLaunchKernelGGL(k_lrelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, g_stride, y, y_stride, n_pix, channels / 4, slope,
+                           out, out_stride);
+        return k4_check_launch();
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -940,8 +946,11 @@ static bool k4_rdb_ok(const k4_rdb_train* p, bool bwd) {
 }
 #define K4_RDB_TRY(CALL) do { const int rc_ = (CALL); if (rc_ != 0) return rc_; } while (0)
 
-extern "C" int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream) {
-    if (!k4_rdb_ok(p, false)) return K4_ERR_BAD_ARG;
+extern "C" int k4_rdb_train_fwd(const k4_rdb_train* p_in, void* stream) {
+    if (!k4_rdb_ok(p_in, false)) return K4_ERR_BAD_ARG;
+    const k4_rdb_train desc = *p_in;                                       // (a tape keeps the descriptor by value)
+    return k4_taped(stream, [desc](void* stream) -> int {
+    const k4_rdb_train* const p = &desc;
     const int H = p->H, W = p->W, nf = p->nf, g = p->g, bw = nf + 4 * g;
     const int64_t n = (int64_t)H * W;
     K4_RDB_TRY(k4_sft_train_fwd(p->t, nf, p->c, 32, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6], p->sft0[7],
@@ -953,10 +962,14 @@ extern "C" int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream) {
     K4_RDB_TRY(k4_sft_train_fwd(p->x4, g, p->c, 32, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6], p->sft1[7],
                                 0.2f, p->buf + nf + 3 * g, bw, stream));
     return k4_conv2d_nhwc_bf16x6(p->buf, bw, bw, p->w_fwd[4], p->b_fwd[4], 3, p->out, nf, nf, H, W, K4_EPI_RES, 0.2f, p->t, nf, 0.2f, nullptr, 0, stream);
+    });
 }
 
-extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream) {
-    if (!k4_rdb_ok(p, true)) return K4_ERR_BAD_ARG;
+extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
+    if (!k4_rdb_ok(p_in, true)) return K4_ERR_BAD_ARG;
+    const k4_rdb_train desc = *p_in;
+    return k4_taped(stream, [desc](void* stream) -> int {
+    const k4_rdb_train* const p = &desc;
     const int H = p->H, W = p->W, nf = p->nf, g = p->g, bw = nf + 4 * g;
     const int64_t n = (int64_t)H * W;
     hipStream_t main_s = (hipStream_t)stream, side = p->side_stream ? (hipStream_t)p->side_stream : main_s;
@@ -1019,8 +1032,18 @@ join:
         const int rj = k4_wait_stream(main_s, side);                               // the wgrads are done before anything queued on `stream` after this call
         return rc != 0 ? rc : rj;
     }
+    });
 }
 #undef K4_RDB_TRY
+
+// Fork / join of a second stream for callers that place launches there themselves (lib/sr_tape.py: the weight gradients of the layers outside the
+// dense blocks).  Recordable: `stream` is the call's main stream (the replaying stream on a replay), `side` stays as given.
+extern "C" int k4_side_wait_main(void* side, void* stream) {
+    return k4_taped(stream, [side](void* stream) -> int { return k4_wait_stream((hipStream_t)side, (hipStream_t)stream); });
+}
+extern "C" int k4_main_wait_side(void* side, void* stream) {
+    return k4_taped(stream, [side](void* stream) -> int { return k4_wait_stream((hipStream_t)stream, (hipStream_t)side); });
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Touched voxels of a grid gradient [C][nvox] (any channel non-zero) as a compact int32 index list: what the data-parallel exchange of

@@ -263,6 +263,7 @@ _WGRAD_STREAM = True    # False: the block's weight gradients on the chain's own
 _FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
+_TAPE = os.environ.get('K4_TRAIN_TAPE', '1') != '0'     # 0: the decoder as ~20 autograd nodes per RRDB (below) instead of ONE node on two launch tapes (lib/sr_tape.py)
 _SIDE_STREAMS = {}
 
 
@@ -510,6 +511,16 @@ def forward_train(net, x, cond):
         return F.leaky_relu(t, 0.2)
 
     fused = os.environ.get('K4_TRAIN_SFT', 'fused') != 'convs'               # 'convs': one Function per convolution + elementwise autograd (A/B, tests)
+    # The whole decoder as ONE autograd node whose forward and backward are launch tapes replayed by one native call each (lib/sr_tape.py): what the
+    # direct gradient hand-over below needs (no parameter hooks, no graph capture), on the shapes the fused kernels cover.
+    if (fused and _TAPE and _DIRECT_GRADS and _NATIVE_RDB and _FUSED_LRELU and _COND_ACC and _TAP is None and x.is_cuda
+            and not torch.cuda.is_current_stream_capturing() and not _params_hooked(net)):
+        from . import sr_tape
+        anchor = next((p for p in net.parameters() if p.requires_grad), None)
+        if (anchor is not None or x.requires_grad or cond.requires_grad) and sr_tape.eligible(net, x, cond):
+            prog = sr_tape.program_for(net, cache, x, cond)
+            if prog is not None:
+                return sr_tape.K4DecoderTape.apply(x, cond, prog, anchor)
     convs = net._k4.get(('train_convs', fused))
     if convs is None:                                                     # the SFT layers' 1x1 convolutions are not packed when fused
         convs = net._k4[('train_convs', fused)] = [m for name, m in net.named_modules()

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      12      /* 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -610,6 +610,32 @@ int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int
                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                         float* workspace, int64_t workspace_bytes,
                         const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
+
+/* ---- launch tapes: the decoder's training pass as ONE native call (csrc/k4_tape.hip; SURVEY.md 8f rank 3, run_sr.py:869-1014) ------------------
+ * The reference's joint step is one autograd graph over cuDNN calls; here SFTNet's forward + backward on a 64x64 patch is ~450 launches of 4-30 us
+ * whose issue cost paced the iteration.  Between k4_tape_begin and k4_tape_end every RECORDABLE entry point the calling thread invokes runs as usual
+ * AND is appended to the tape with a copy of its arguments (host structs and job arrays included); k4_tape_replay issues the recorded calls again
+ * from C++, in order.  A call whose `stream` argument was `main_stream` runs on the replaying stream, a call placed on another stream (side-stream
+ * weight gradients) stays there.  Recordable: k4_conv2d_nhwc_bf16x6, k4_conv2d_wgrad_bf16x6, k4_conv2d_wgrad_dbias_bf16x6(_acc), k4_conv2d_bias_grad,
+ * k4_zero_f32, k4_pack_conv_weight_bf16x6(_multi), k4_lrelu_bwd, k4_sft_train_fwd(_ex), k4_sft_train_bwd(_ex), k4_rdb_train_fwd / _bwd (one entry
+ * each) and the five entry points below.  The caller keeps every buffer a tape names alive and in place; one recording per thread at a time
+ * (k4_tape_begin returns NULL otherwise). */
+typedef struct k4_tape k4_tape;
+k4_tape* k4_tape_begin(void* main_stream);
+int k4_tape_end(k4_tape* tape);
+int64_t k4_tape_length(const k4_tape* tape);                   /* recorded calls; -1 for NULL */
+int k4_tape_replay(const k4_tape* tape, void* stream);
+void k4_tape_free(k4_tape* tape);
+/* The elementwise steps of SFTNet's training graph between the fused blocks (PyTorch ops and the autograd engine's gradient sums upstream):
+ *   k4_add_f32             : out[i] = a[i] + b[i]                        (16-byte aligned; out may alias a or b)
+ *   k4_upsample2x_nhwc     : y[2Y+py][2X+px][c] = x[Y][X][c]             (F.interpolate(scale_factor=2, mode='nearest'), lib/sr_esrnet.py:461-463)
+ *   k4_upsample2x_bwd_nhwc : grad_x[Y][X][c] = (gy[2Y][2X] + gy[2Y][2X+1]) + (gy[2Y+1][2X] + gy[2Y+1][2X+1])      (channels % 4 == 0)
+ *   k4_side_wait_main      : everything queued on `stream` so far completes before what `side` gets next (fork); k4_main_wait_side: the join. */
+int k4_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int k4_upsample2x_nhwc(const float* x, int32_t H, int32_t W, int32_t channels, float* y, void* stream);
+int k4_upsample2x_bwd_nhwc(const float* grad_y, int32_t H, int32_t W, int32_t channels, float* grad_x, void* stream);
+int k4_side_wait_main(void* side, void* stream);
+int k4_main_wait_side(void* side, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,7 @@ def test_condition_gradient_accumulator_equals_the_autograd_sums_and_refuses_a_s
         loss.backward(retain_graph=retain)
         return loss, [x.grad, c.grad] + [p.grad for p in net.parameters()]
     assert sr_train._COND_ACC
+    monkeypatch.setattr(sr_train, '_TAPE', False)                # the per-block graph (the one-node tape form: test_decoder_tape_* below)
     _, on = run()
     monkeypatch.setattr(sr_train, '_COND_ACC', False)
     _, off = run()
@@ -127,6 +128,8 @@ def test_direct_parameter_gradients_equal_the_autograd_edges(monkeypatch):
     g = torch.Generator().manual_seed(6)
     x0, c0 = torch.rand([1, 3, 16, 24], generator=g).cuda(), torch.rand([1, 1, 16, 24], generator=g).cuda()
     tgt = torch.rand([1, 3, 64, 96], generator=g).cuda()
+
+    monkeypatch.setattr(sr_train, '_TAPE', False)                # the per-block graph (the one-node tape form: test_decoder_tape_* below)
 
     def run(direct):
         monkeypatch.setattr(sr_train, '_DIRECT_GRADS', direct)
@@ -372,3 +375,158 @@ def test_dense_block_function_matches_module_autograd(H, W, use_acc):
     assert _rel(t.grad.permute(2, 0, 1), tr.grad[0]) <= 1e-5 and _rel(c.grad.permute(2, 0, 1), cr.grad[0]) <= 1e-5
     for (n, p), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
         assert p.grad is not None and _rel(p.grad, pr.grad) <= 1e-5, (n, _rel(p.grad, pr.grad))
+
+
+def _tape_fixture(nb=2, h=20, w=28, seed=17, scale=4):
+    sd = osr.make_state_dict(seed=seed, num_block=nb)
+    g = torch.Generator().manual_seed(seed + 1)
+    x0, c0 = torch.rand([1, 3, h, w], generator=g).cuda(), torch.rand([1, 1, h, w], generator=g).cuda()
+    tgt = torch.rand([1, 3, scale * h, scale * w], generator=g).cuda()
+
+    def make():
+        net = sr_esrnet.SFTNet(3, scale=scale, num_block=nb)
+        net.load_state_dict(sd)
+        return net.cuda().train()
+    return make, x0, c0, tgt
+
+
+def _conv_like(name):
+    return 'SFT_' not in name
+
+
+@pytest.mark.parametrize('cond_grad', [True, False])
+def test_decoder_tape_equals_the_per_block_graph(monkeypatch, cond_grad):
+    """lib/sr_tape.py: SFTNet's training pass as ONE autograd node on two launch tapes (recorded on the first pass, replayed by one native call
+    afterwards) against the per-block autograd graph of lib/sr_train.forward_train: the same kernels in the same order, so the output, the input
+    gradients and the SFT layers' parameter gradients (no atomics on those chains) are BIT-identical, on the recording pass and on replays;
+    the convolutions' weight gradients (split-K atomics in both forms) to rounding.  Three optimizer steps: the tape re-packs the weights."""
+    from nerf4k_amd.lib import sr_tape
+    make, x0, c0, tgt = _tape_fixture()
+
+    def run(tape):
+        monkeypatch.setattr(sr_train, '_TAPE', tape)
+        net = make()
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+        hist = []
+        for it in range(3):
+            x, c = x0.clone().requires_grad_(True), c0.clone().requires_grad_(cond_grad)
+            opt.zero_grad(set_to_none=True)
+            out = net(x, c)
+            F.l1_loss(out, tgt).backward()
+            hist.append((out.detach().clone(), x.grad.clone(), None if not cond_grad else c.grad.clone(),
+                         {n: p.grad.clone() for n, p in net.named_parameters()}))
+            opt.step()
+        return net, hist
+    net_t, ht = run(True)
+    progs = [v for k, v in net_t._k4.items() if isinstance(k, tuple) and k and k[0] == 'tape_programs']
+    assert len(progs) == 1 and len(progs[0][1]) == 1                       # one program, leased and released three times
+    prog = progs[0][1][0]
+    assert not prog.busy and len(prog.fwd_tape) > 20 and len(prog.bwd_tape) > 30
+    net_b, hb = run(False)
+    assert not any(isinstance(k, tuple) and k and k[0] == 'tape_programs' for k in net_b._k4)
+    for it, ((oa, xa, ca, pa), (ob, xb, cb, pb)) in enumerate(zip(ht, hb)):
+        if it == 0:                                                          # (later iterations start from weights that differ by the atomics' rounding)
+            assert torch.equal(oa, ob) and torch.equal(xa, xb), it
+            assert ca is None or torch.equal(ca, cb)
+            for n in pa:
+                if not _conv_like(n):
+                    assert torch.equal(pa[n], pb[n]), n
+        assert _rel(oa, ob) <= 1e-5 and _rel(xa, xb) <= 1e-4
+        assert max(_rel(pa[n], pb[n]) for n in pa) <= 5e-5, it
+
+
+def test_decoder_tape_replay_is_bit_identical_to_its_recording_pass():
+    """The same input through a fresh network (recording pass) and through one whose tapes already exist (replay): identical bits on every chain
+    without atomics."""
+    make, x0, c0, tgt = _tape_fixture(nb=1, h=16, w=24, seed=23)
+    net = make()
+    res = []
+    for it in range(3):
+        x = x0.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        out = net(x, c0)
+        F.l1_loss(out, tgt).backward()
+        res.append((out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
+    for o, gx, pg in res[1:]:
+        assert torch.equal(o, res[0][0]) and torch.equal(gx, res[0][1])
+        for n in pg:
+            if not _conv_like(n):
+                assert torch.equal(pg[n], res[0][2][n]), n
+            else:
+                assert _rel(pg[n], res[0][2][n]) <= 5e-6, n
+
+
+def test_decoder_tape_pool_accumulation_and_frozen_parameters(monkeypatch):
+    """Two forwards before their backward passes take two programs of the pool; gradients of two passes without zero_grad accumulate as a leaf's
+    accumulator does; a frozen parameter gets no gradient; a decoder-only step (input without gradient) works; the fourth forward in flight
+    falls back to the per-block graph."""
+    from nerf4k_amd.lib import sr_tape
+    make, x0, c0, tgt = _tape_fixture(nb=1, h=12, w=16, seed=29)
+    net = make()
+    frozen = net.body[0].rdb2.conv3.weight
+    frozen.requires_grad_(False)
+    xa, xb = x0.clone().requires_grad_(True), (x0 * 0.5).requires_grad_(True)
+    oa, ob = net(xa, c0), net(xb, c0)                                        # two graphs alive
+    pool = [v for k, v in net._k4.items() if isinstance(k, tuple) and k and k[0] == 'tape_programs'][0][1]
+    assert len(pool) == 2 and all(p.busy for p in pool)
+    (F.l1_loss(oa, tgt) + F.l1_loss(ob, tgt)).backward()
+    assert not any(p.busy for p in pool) and frozen.grad is None
+    both = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+    gxa, gxb = xa.grad.clone(), xb.grad.clone()
+    monkeypatch.setattr(sr_train, '_TAPE', False)
+    ref = make()
+    ref.body[0].rdb2.conv3.weight.requires_grad_(False)
+    xa2, xb2 = x0.clone().requires_grad_(True), (x0 * 0.5).requires_grad_(True)
+    (F.l1_loss(ref(xa2, c0), tgt) + F.l1_loss(ref(xb2, c0), tgt)).backward()
+    assert torch.equal(gxa, xa2.grad) and torch.equal(gxb, xb2.grad)
+    want = {n: p.grad for n, p in ref.named_parameters() if p.requires_grad}
+    assert both.keys() == want.keys() and max(_rel(both[n], want[n]) for n in both) <= 5e-6
+    monkeypatch.setattr(sr_train, '_TAPE', True)
+    # decoder-only training: the input carries no gradient
+    net.zero_grad(set_to_none=True)
+    F.l1_loss(net(x0, c0), tgt).backward()
+    assert _rel(net.conv_first.weight.grad, ref_grad_of(ref, x0, c0, tgt, monkeypatch)) <= 5e-6
+    # past the pool: the per-block graph, same values
+    outs = [net(x0.clone().requires_grad_(True), c0) for _ in range(sr_tape.POOL + 1)]
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    assert outs[-1].grad_fn.__class__.__name__ != 'K4DecoderTapeBackward' and outs[0].grad_fn.__class__.__name__ == 'K4DecoderTapeBackward'
+
+
+def ref_grad_of(ref, x0, c0, tgt, monkeypatch):
+    monkeypatch.setattr(sr_train, '_TAPE', False)
+    ref.zero_grad(set_to_none=True)
+    F.l1_loss(ref(x0, c0), tgt).backward()
+    monkeypatch.setattr(sr_train, '_TAPE', True)
+    return ref.conv_first.weight.grad
+
+
+def test_launch_tape_records_and_replays_plain_entry_points():
+    """k4_tape_*: calls made while recording run AND land on the tape; a replay issues them again on the stream it is given; calls on another
+    stream than the recording's main stream stay there."""
+    from nerf4k_amd import _native as N
+    from nerf4k_amd.lib.sr_tape import _Tape
+    L = N.lib()
+    a, b = torch.arange(1000, dtype=torch.float32).cuda(), torch.ones([1000], device='cuda')
+    out, up, back = torch.zeros([1000], device='cuda'), torch.zeros([8, 10, 8], device='cuda'), torch.zeros([4, 5, 8], device='cuda')
+    src = torch.arange(4 * 5 * 8, dtype=torch.float32).cuda().view(4, 5, 8)
+    side = torch.cuda.Stream()
+
+    def calls():
+        N.check(L.k4_add_f32(N.f32(a), N.f32(b), N.f32(out), 1000, N.stream()), 'add')
+        N.check(L.k4_upsample2x_nhwc(N.f32(src), 4, 5, 8, N.f32(up), N.stream()), 'up')
+        N.check(L.k4_side_wait_main(N.C.c_void_p(side.cuda_stream), N.stream()), 'fork')
+        N.check(L.k4_upsample2x_bwd_nhwc(N.f32(up), 4, 5, 8, N.f32(back), N.C.c_void_p(side.cuda_stream)), 'down')
+        N.check(L.k4_main_wait_side(N.C.c_void_p(side.cuda_stream), N.stream()), 'join')
+    tape = _Tape().record(calls)
+    assert len(tape) == 5
+    torch.cuda.synchronize()
+    assert torch.equal(out, a + 1) and torch.equal(up, src.repeat_interleave(2, 0).repeat_interleave(2, 1)) and torch.equal(back, 4 * src)
+    a.mul_(2)
+    src.add_(1)
+    out.zero_(), up.zero_(), back.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        tape.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, a + 1) and torch.equal(up, src.repeat_interleave(2, 0).repeat_interleave(2, 1)) and torch.equal(back, 4 * src)
+    assert L.k4_tape_replay(None, None) != 0 and L.k4_tape_length(None) == -1
