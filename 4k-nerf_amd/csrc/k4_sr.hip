@@ -1000,8 +1000,109 @@ __global__ __launch_bounds__(256, (F16 ? (RPW == 2 ? K4_V2_MINWG_F16 : 2) : NTER
 #undef K4_V2_SETUP
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K-split form of the 3x3 bf16x6 convolution for SMALL images (K4_CONV_SMALL: the 64x64 patch of the joint training step, run_sr.py:829-835).
+// The kernels above give a wave whole rows of a tile and walk ALL input-channel chunks: on a 64x64 image that is 32-128 workgroups whose launch
+// lasts as long as one wave's chain of cin/16 chunks x 9 taps x 6 products plus their staging (10 us at cin = 64, 25 us at cin = 192 -- for
+// 0.5-2.7 GFLOP), and a training iteration issues ~160 of them back to back.  Here a workgroup is ONE row x 32 pixels x 32 output channels and
+// its four waves split the input-channel chunks (wave w: chunks w, w+4, ...): 4x the workgroups, a quarter of the chain each.  No LDS staging:
+// a lane fetches its A fragment (pixel l31 + dx, 8 channels) of each tap straight from L1 / L2, splits it in registers, and the four partial
+// accumulators meet in LDS (16 KB), summed in wave order.  Same products and split as above; the order of the fp32 additions differs from the
+// row kernels' (chunks interleaved over the waves), so results agree to fp32 summation order, not bit for bit -- training only: the caller
+// asks for it with K4_CONV_SMALL, inference (tile == frame bit-identity) never does.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k4_conv_ks_kernel(const ConvMulti M) {
+    const ConvParams& P = M.base;
+    const int H = M.H[0], W = M.W[0];
+    const float* __restrict__ X = M.x[0];
+    float* __restrict__ Y = M.y[0];
+    const int nbc = (P.cout + 31) >> 5, NOUT = nbc * 32;
+    const int tiles_x = M.tiles_x[0];
+    const int b = (int)blockIdx.x;
+    const int nb = b % nbc, t_ = b / nbc;
+    const int x0 = (t_ % tiles_x) * TILE_W, gy = t_ / tiles_x;
+    const int lane = k4_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nchunks = (P.cin + KC2 - 1) / KC2;
+    const bool vec = (P.cin_stride & 3) == 0 && (((size_t)X) & 15) == 0;
+    __shared__ float red[4][16][64];
+    f32x16 acc = (f32x16)(0.f);
+    const uint4* const wbase = reinterpret_cast<const uint4*>(P.w) + (size_t)half * NOUT + nb * 32 + l31;
+    const size_t wterm = (size_t)9 * 2 * NOUT;                  // 16-byte units between the split terms of one chunk
+    for (int ch = wv; ch < nchunks; ch += 4) {
+        const int c0 = ch * KC2 + half * 8;
+        const bool full = vec && ch * KC2 + KC2 <= P.cin;         // wave-uniform
+        uint4 a[9][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int sy = gy - 1 + t / 3, sx = x0 - 1 + t % 3 + l31;
+            const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const float* src = X + ((size_t)(in ? sy : 0) * W + (in ? sx : 0)) * P.cin_stride + c0;
+            float v8[8];
+            if (full) {
+                const float4 va = *reinterpret_cast<const float4*>(src), vb = *reinterpret_cast<const float4*>(src + 4);
+                v8[0] = in ? va.x : 0.f; v8[1] = in ? va.y : 0.f; v8[2] = in ? va.z : 0.f; v8[3] = in ? va.w : 0.f;
+                v8[4] = in ? vb.x : 0.f; v8[5] = in ? vb.y : 0.f; v8[6] = in ? vb.z : 0.f; v8[7] = in ? vb.w : 0.f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool ok = in && c0 + c < P.cin;
+                    const float q = *(ok ? src + c : X);
+                    v8[c] = ok ? q : 0.f;
+                }
+            }
+            k4s_split3(v8, a[t][0], a[t][1], a[t][2]);
+        }
+        const uint4* wp = wbase + (size_t)ch * 3 * wterm;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, wp[(size_t)t * 2 * NOUT]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, wp[wterm + (size_t)t * 2 * NOUT]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, wp[2 * wterm + (size_t)t * 2 * NOUT]);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[t][0]), a1 = __builtin_bit_cast(bf16x8, a[t][1]), a2 = __builtin_bit_cast(bf16x8, a[t][2]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc, 0, 0, 0);          // smallest products first, as the row kernels
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wv][e][lane] = acc[e];
+    __syncthreads();
+    // wave w finishes accumulator elements 4w .. 4w+3 (pixels x0 + (e & 3) + 8 (e >> 2) + 4 half, output channel nb*32 + l31): partial sums in wave order
+    const int co = nb * 32 + l31;
+    if (co >= P.cout) return;
+    const float bias = P.bias[co];
+    const bool lbwd = (P.flags & K4_EPI_LRELU_BWD) && nb == nbc - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = 4 * wv + k;
+        const int gx = x0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (gx >= W) continue;
+        const size_t pix = (size_t)gy * W + gx;
+        float v = ((red[0][e][lane] + red[1][e][lane]) + red[2][e][lane]) + red[3][e][lane];
+        v += bias;
+        if (P.flags & K4_EPI_LRELU) v = v > 0.f ? v : v * P.slope;
+        if (P.flags & K4_EPI_RES) v = k4s_mul_add(v, P.res_scale, M.res[0][pix * P.res_stride + co]);
+        if (lbwd) v = M.modx[0][pix * P.mod_stride + co] > 0.f ? v : v * P.slope;
+        Y[pix * P.cout_stride + co] = v;
+    }
+}
+
 static int launch_conv_b6v2(ConvMulti& M, hipStream_t st) {
     const int nbc = (M.base.cout + 31) / 32;
+    // K4_CONV_SMALL: one window, plain 3-term arithmetic, an image small enough that one-row workgroups do not exceed four per CU
+    if ((M.base.flags & K4_CONV_SMALL) && M.n == 1 && !(M.base.flags & (K4_ARITH_2TERM | K4_ARITH_F16X3 | K4_PRE_UPSAMPLE2X)) && !(k4_env().sr_debug & 2048)) {
+        const long long wgs = (long long)((M.W[0] + TILE_W - 1) / TILE_W) * M.H[0] * nbc;
+        if (wgs <= 4ll * k4_num_cus() && (long long)M.H[0] * M.W[0] * M.base.cin_stride <= 0x7fffffffLL) {
+            M.tiles_x[0] = (M.W[0] + TILE_W - 1) / TILE_W;
+            hipLaunchKernelGGL(k4_conv_ks_kernel, dim3((unsigned)wgs), dim3(256), 0, st, M);
+            return k4_check_launch();
+        }
+    }
     const int slots = 2 * k4_num_cus();
     auto count = [&](int trows) {
         int total = 0;

@@ -498,6 +498,24 @@ __device__ __forceinline__ void sft_store_tile(const float* lds, float* __restri
         if (s < nv) g[(base + s) * stride + k] = lds[k * TR_LS + s];
     }
 }
+// The weight matrices are read below with dependent wave-uniform (scalar) loads.  Inside a training iteration every layer's weights are cold -- Adam
+// rewrote them, 35 other layers ran since -- and each scalar miss went to HBM one after the other: a layer took 47-57 us in the iteration against 28 us
+// when the same layer is launched repeatedly.  One coalesced vector sweep over the 24 KB at kernel entry brings them to L2 in a single round trip
+// (the values are summed into a number that is never stored).
+template <int C>
+__device__ __forceinline__ float sft_warm_weights(const float* __restrict__ w0s, const float* __restrict__ w0h, const float* __restrict__ w1s, const float* __restrict__ w1h, int t) {
+    float d = 0.f;
+    if ((((uintptr_t)w0s | (uintptr_t)w0h | (uintptr_t)w1s | (uintptr_t)w1h) & 15u) != 0) return d;       // (workgroup-uniform)
+    for (int i = t * 4; i < SFT_G * SFT_G; i += SFT_T * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(w0s + i), b = *reinterpret_cast<const float4*>(w0h + i);
+        d += a.x + b.x;
+    }
+    for (int i = t * 4; i < C * SFT_G; i += SFT_T * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(w1s + i), b = *reinterpret_cast<const float4*>(w1h + i);
+        d += a.x + b.x;
+    }
+    return d;
+}
 // hidden activations of both branches: hs[j] = lrelu(b0[j] + sum_k w0[j][k] c[k]), j < 32 scale branch, j >= 32 shift branch
 __device__ __forceinline__ void sft_hidden(const float* cs, k4_cptr w0s, k4_cptr b0s, k4_cptr w0h, k4_cptr b0h, float slope,
                                            float* as, float* ah, int wv, int lane) {
@@ -530,8 +548,10 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_fwd(const float* __restrict
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+    const float warm = sft_warm_weights<C>(w0s, w0h, w1s, w1h, t);            // (see sft_warm_weights)
     sft_load_tile(cond, base, c_stride, SFT_G, nv, cs, t);
     sft_load_tile(x, base, x_stride, C, nv, xs, t);
+    if (warm == 1.2345e38f) xs[0] = warm;                                     // (keeps the loads alive; never true)
     __syncthreads();
     sft_hidden(cs, k4_const(w0s), k4_const(b0s), k4_const(w0h), k4_const(b0h), slope, as, ah, wv, lane);
     __syncthreads();
@@ -586,6 +606,11 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
     float* const gc = gx + C * TR_LS;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifndef K4_SFT_NO_WARM
+    const float warm = sft_warm_weights<C>(w0s, w0h, w1s, w1h, t);
+#else
+    const float warm = 0.f;
+#endif
     for (int i = t; i < L::ROWS * TR_LS; i += SFT_T) smem[i] = 0.f;           // the zero padding rows stay zero for the whole kernel
 
     TrBlock blk[MAXB];
@@ -721,6 +746,7 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
         __syncthreads();
     }
     float* const mine = part + (size_t)blockIdx.x * L::N_PART;
+    if (warm == 1.2345e38f) mine[0] = warm;                                   // (keeps the warm-up loads alive; never true for finite weights of this size)
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
         if (blk[q].aoff < 0) continue;
@@ -811,10 +837,14 @@ extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* c
     return k4_sft_train_fwd_ex(x, x_stride, cond, cond_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, nullptr, 0, 1.f, stream);
 }
 
+static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller);
+// red_st: the stream of the partial sums' reduction (the eight parameter gradients).  Nothing on the chain reads those: with red_st != st the reduction is
+// forked to red_st (which the caller joins before the gradients are read), one launch and one launch gap less on the chain per layer.
 template <int C>
 static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, float gy_scale, hipStream_t st) {
+                          float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, float gy_scale, hipStream_t st,
+                          hipStream_t red_st) {
     typedef SftBwdLayout<C> L;
     const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
     K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
@@ -823,18 +853,23 @@ static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, con
     int rc = k4_check_launch();
     if (rc) return rc;
     const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
-    hipLaunchKernelGGL(k_sft_train_reduce, dim3((total + TR_RED_ELEMS - 1) / TR_RED_ELEMS), dim3(256), 0, st, ws, grid, C,
+    if (red_st != st) {
+        rc = k4_wait_stream(red_st, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_sft_train_reduce, dim3((total + TR_RED_ELEMS - 1) / TR_RED_ELEMS), dim3(256), 0, red_st, ws, grid, C,
                        gout[0], gout[1], gout[2], gout[3], gout[4], gout[5], gout[6], gout[7]);
     return k4_check_launch();
 }
 
-extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
-                                   int64_t n_pix, int32_t channels,
-                                   const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                                   float slope, float* grad_x, float* grad_cond,
-                                   float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
-                                   float* workspace, int64_t workspace_bytes,
-                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
+extern "C" int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                     int64_t n_pix, int32_t channels,
+                                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                     float slope, float* grad_x, float* grad_cond,
+                                     float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                                     float* workspace, int64_t workspace_bytes,
+                                     const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
+                                     void* side_stream, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
     if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
@@ -844,9 +879,21 @@ extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float
         float* const gout[8] = {gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h};
         hipStream_t st = (hipStream_t)stream;
         const int acc = accumulate_grad_cond != 0;
-        if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
-        return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st);
+        hipStream_t red = side_stream ? (hipStream_t)side_stream : st;
+        if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red);
+        return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red);
     });
+}
+extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                   int64_t n_pix, int32_t channels,
+                                   const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                   float slope, float* grad_x, float* grad_cond,
+                                   float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                                   float* workspace, int64_t workspace_bytes,
+                                   const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
+    return k4_sft_train_bwd_side(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
+                                 gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, grad_x_add, gxa_stride, accumulate_grad_cond, grad_x_lrelu,
+                                 grad_y_scale, nullptr, stream);
 }
 extern "C" int k4_sft_train_bwd(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                 int64_t n_pix, int32_t channels,
@@ -957,11 +1004,11 @@ extern "C" int k4_rdb_train_fwd(const k4_rdb_train* p_in, void* stream) {
                                 0.2f, p->buf, bw, stream));
     for (int k = 1; k <= 3; ++k)
         K4_RDB_TRY(k4_conv2d_nhwc_bf16x6(p->buf, nf + (k - 1) * g, bw, p->w_fwd[k - 1], p->b_fwd[k - 1], 3, p->buf + nf + (k - 1) * g, g, bw, H, W,
-                                         K4_EPI_LRELU, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
-    K4_RDB_TRY(k4_conv2d_nhwc_bf16x6(p->buf, nf + 3 * g, bw, p->w_fwd[3], p->b_fwd[3], 3, p->x4, g, g, H, W, K4_EPI_LRELU, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
+                                         K4_EPI_LRELU | K4_CONV_SMALL, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
+    K4_RDB_TRY(k4_conv2d_nhwc_bf16x6(p->buf, nf + 3 * g, bw, p->w_fwd[3], p->b_fwd[3], 3, p->x4, g, g, H, W, K4_EPI_LRELU | K4_CONV_SMALL, 0.2f, nullptr, 0, 0.f, nullptr, 0, stream));
     K4_RDB_TRY(k4_sft_train_fwd(p->x4, g, p->c, 32, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6], p->sft1[7],
                                 0.2f, p->buf + nf + 3 * g, bw, stream));
-    return k4_conv2d_nhwc_bf16x6(p->buf, bw, bw, p->w_fwd[4], p->b_fwd[4], 3, p->out, nf, nf, H, W, K4_EPI_RES, 0.2f, p->t, nf, 0.2f, nullptr, 0, stream);
+    return k4_conv2d_nhwc_bf16x6(p->buf, bw, bw, p->w_fwd[4], p->b_fwd[4], 3, p->out, nf, nf, H, W, K4_EPI_RES | K4_CONV_SMALL, 0.2f, p->t, nf, 0.2f, nullptr, 0, stream);
     });
 }
 
@@ -989,7 +1036,7 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     // MASK (fused_lrelu): the last 32 channels this launch completes are x_k's gradient slice -- LeakyReLU backward from buf's slice in the epilogue
 #define K4_RDB_DGRAD(K, SRC, SS, CIN_OF_LAYER, ACC, MASK) \
         K4_RDB_TRY(k4_conv2d_nhwc_bf16x6((SRC), (K) == 4 ? nf : g, (SS), p->w_bwd[K], p->b_bwd[K], 3, p->G, (CIN_OF_LAYER), bw, H, W, \
-                                         ((ACC) ? K4_EPI_RES : 0u) | ((MASK) ? K4_EPI_LRELU_BWD : 0u), 0.2f, \
+                                         ((ACC) ? K4_EPI_RES : 0u) | ((MASK) ? K4_EPI_LRELU_BWD : 0u) | K4_CONV_SMALL, 0.2f, \
                                          (ACC) ? p->G : nullptr, (ACC) ? bw : 0, 1.f, (MASK) ? p->buf : nullptr, (MASK) ? bw : 0, stream))
     // dwdb_span_floats > 0: the five [dW | dbias] buffers are one span starting at dwdb_span: ONE zero-fill on the side stream (ordered before every
     // weight gradient there) instead of one per layer
@@ -1009,9 +1056,9 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
     K4_RDB_DGRAD(4, p->g5, nf, bw, false, false);                                  // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
-    K4_RDB_TRY(k4_sft_train_bwd_ex(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
-                                   0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
-                                   p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, stream));
+    K4_RDB_TRY(k4_sft_train_bwd_side(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+                                     0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
+                                     p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, p->side_stream, stream));
     if (!fl) K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
     K4_RDB_WGRAD(nf + 3 * g, p->gx4, g, g, 3);
     K4_RDB_DGRAD(3, p->gx4, g, nf + 3 * g, true, fl);                              // G[:, 0:nf+3g] += dgrad (+ the mask of x3's slice, its last 32 channels)
@@ -1022,14 +1069,15 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
         K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true, fl && k > 1);               // (k == 1 completes xc0's slice: sft0's output, no activation)
     }
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
-    K4_RDB_TRY(k4_sft_train_bwd_ex(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
-                                   0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
-                                   p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, stream));
+    K4_RDB_TRY(k4_sft_train_bwd_side(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+                                     0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
+                                     p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, p->side_stream, stream));
 join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD
     {
-        const int rj = k4_wait_stream(main_s, side);                               // the wgrads are done before anything queued on `stream` after this call
+        // the wgrads are done before anything queued on `stream` after this call -- unless the caller joins itself, once (no_join; a failed launch joins anyway)
+        const int rj = (p->no_join && rc == 0) ? 0 : k4_wait_stream(main_s, side);
         return rc != 0 ? rc : rj;
     }
     });
@@ -1038,6 +1086,16 @@ join:
 
 // Fork / join of a second stream for callers that place launches there themselves (lib/sr_tape.py: the weight gradients of the layers outside the
 // dense blocks).  Recordable: `stream` is the call's main stream (the replaying stream on a replay), `side` stays as given.
+// A stream of the LOWEST priority the device offers, non-blocking towards the legacy default stream (as the streams of PyTorch's pool): the weight
+// gradients of the decoder's training pass go there -- they fill every CU (ksize^2 x channel blocks x bands workgroups) while the chain they fork
+// from runs 16-64 workgroups per launch and waits for nothing else; with equal priorities the chain's launches queued behind them.
+extern "C" void* k4_stream_create_low_priority(void) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+    return (void*)s;
+}
 extern "C" int k4_side_wait_main(void* side, void* stream) {
     return k4_taped(stream, [side](void* stream) -> int { return k4_wait_stream((hipStream_t)side, (hipStream_t)stream); });
 }

@@ -30,6 +30,7 @@ from torch.nn import init as init
 from .. import _native as N
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
+CONV_SMALL = 512       # K4_CONV_SMALL: the training graph's convolutions may run on the K-split small-image kernel (include/k4nerf.h)
 DEFAULT_MODE = 'f16x3p'         # decoder arithmetic when K4_SR_MODE is unset (see SFTNet.k4_mode)
 SR_GROUP = None                 # windows of tile_process decoded per grouped launch (None: as many as the ABI takes, K4_MAX_JOBS); results do not depend on it (tests)
 P16_TARGET_EXP = 9              # calibration maps a tensor's largest magnitude into [2^9, 2^10): 64-128x head room below fp16's 65504

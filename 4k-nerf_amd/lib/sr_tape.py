@@ -20,7 +20,7 @@ of the pool; past the pool ``forward_train`` keeps the per-block path.  There is
 import torch
 
 from .. import _native as N
-from .sr_esrnet import EPI_LRELU, EPI_RES
+from .sr_esrnet import EPI_LRELU, EPI_RES, CONV_SMALL
 from . import sr_train as T
 
 POOL = 3            # programs per (network, shape): forwards in flight before their backward
@@ -89,10 +89,13 @@ def eligible(net, x, cond):
     if x.shape[1] != net.conv_first.in_channels or cond.shape[1] != net.CondNet[0].in_channels or getattr(net, 'dswise', False):
         return False
     dev = net.conv_first.weight.device
-    for p in net.parameters():
-        if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
-            return False
     return x.device == dev and cond.device == dev and x.dtype == torch.float32 and cond.dtype == torch.float32
+
+
+def _params_ok(net):
+    """fp32, contiguous, on one device: checked when a program is built (a program is rebuilt whenever a parameter's storage moves)."""
+    dev = net.conv_first.weight.device
+    return all(p.dtype == torch.float32 and p.is_contiguous() and p.device == dev for p in net.parameters())
 
 
 class DecoderProgram:
@@ -168,7 +171,8 @@ class DecoderProgram:
         L = N.lib()
         n = h * w
         self.sft_ws_bytes = {C: int(L.k4_sft_train_bwd_workspace_bytes(n, C)) for C in (nf, g)}
-        self.sft_ws = torch.empty([self.sft_ws_bytes[nf] // 4], **f32)              # the stand-alone SFT layers' backward workspace (stream-ordered reuse)
+        # the stand-alone SFT layers' backward workspaces: one per layer (their reductions run on the side stream while the chain moves on)
+        self.sft_ws = {name: torch.empty([self.sft_ws_bytes[nf] // 4], **f32) for name in ['sftbody'] + [f'sft{b}' for b in range(nb)]}
         # ---- parameter gradients: ONE flat buffer; a convolution's [dW | dbias] adjacent (one launch writes both)
         self.hand = []                      # (parameter, offset, shape)
         off = 0
@@ -241,6 +245,7 @@ class DecoderProgram:
             d.g5_from_gx0_add, d.fused_lrelu = 1, 1
             d.gc_acc = G['acc'].data_ptr()
             d.side_stream = self.side
+            d.no_join = int(self.side is not None)                # ONE join, behind the whole backward pass (_backward_calls): the buffers are this program's own
             self.scr.append(scr)
             self.desc.append(d)
         self.signature = signature(net)
@@ -249,7 +254,7 @@ class DecoderProgram:
     @staticmethod
     def _conv(pk, x, cin_stride, y, cout, cout_stride, H, W, flags=0, res=None, res_scale=0.0):
         N.check(N.lib().k4_conv2d_nhwc_bf16x6(N.f32(x), pk.cin, cin_stride, N.ptr(pk.w), N.f32(pk.b), pk.k, N.f32(y), cout, cout_stride, H, W,
-                                              flags | pk.flags_extra, 0.2, None if res is None else N.f32(res), 0 if res is None else cout_stride,
+                                              flags | pk.flags_extra | (CONV_SMALL if pk.k == 3 and not pk.flags_extra else 0), 0.2, None if res is None else N.f32(res), 0 if res is None else cout_stride,
                                               res_scale, None, 0, N.stream()), 'k4_conv2d_nhwc_bf16x6')
 
     def _wgrad(self, mod, x, gy, H, W, name):
@@ -272,13 +277,14 @@ class DecoderProgram:
         N.check(N.lib().k4_sft_train_fwd_ex(N.f32(x), C, N.f32(self.A['c']), 32, self.h * self.w, C, *[N.f32(p) for p in _sft_params(layer)], 0.2,
                                             N.f32(y), C, None if res is None else N.f32(res), C, float(res_scale), N.stream()), 'k4_sft_train_fwd_ex')
 
-    def _sft_bwd(self, layer, x, gy, gx, goffs, gy_scale):
+    def _sft_bwd(self, layer, x, gy, gx, name, gy_scale):
         C = x.shape[2]
         ps = _sft_params(layer)
         pb = self.pg.data_ptr()
-        N.check(N.lib().k4_sft_train_bwd_ex(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, self.h * self.w, C, *[N.f32(p) for p in ps[:7]], 0.2,
-                                            N.f32(gx), N.f32(self.G['acc']), *[N.C.c_void_p(pb + 4 * o) for o in goffs],
-                                            N.f32(self.sft_ws), self.sft_ws_bytes[C], None, 0, 1, 0, float(gy_scale), N.stream()), 'k4_sft_train_bwd_ex')
+        N.check(N.lib().k4_sft_train_bwd_side(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, self.h * self.w, C, *[N.f32(p) for p in ps[:7]], 0.2,
+                                              N.f32(gx), N.f32(self.G['acc']), *[N.C.c_void_p(pb + 4 * o) for o in self.pg_off[name]],
+                                              N.f32(self.sft_ws[name]), self.sft_ws_bytes[C], None, 0, 1, 0, float(gy_scale),
+                                              None if self.side is None else N.C.c_void_p(self.side), N.stream()), 'k4_sft_train_bwd_side')
 
     # ------------------------------------------------------------------------------------------------ the pass, call by call
     def _forward_calls(self):
@@ -344,10 +350,10 @@ class DecoderProgram:
         self._conv(self.bw_(net.conv_body), G['bf'], nf, G['sb'], nf, nf, h, w)
         nb = self.nb
         g_body, g_other = G['body'], G['body2']
-        self._sft_bwd(net.sftbody, A[f'body{nb - 1}'] if nb else A['feat'], G['sb'], g_body, self.pg_off['sftbody'], 1.0)
+        self._sft_bwd(net.sftbody, A[f'body{nb - 1}'] if nb else A['feat'], G['sb'], g_body, 'sftbody', 1.0)
         for b in range(nb - 1, -1, -1):
             rr = net.body[b]
-            self._sft_bwd(rr.sft0, A[f'o{3 * b + 2}'], g_body, G['o3'], self.pg_off[f'sft{b}'], 0.2)      # body_b = sft(o3) * 0.2 + body_{b-1}
+            self._sft_bwd(rr.sft0, A[f'o{3 * b + 2}'], g_body, G['o3'], f'sft{b}', 0.2)      # body_b = sft(o3) * 0.2 + body_{b-1}
             go = G['o3']
             for r in (2, 1, 0):
                 q = 3 * b + r
@@ -464,7 +470,9 @@ def program_for(net, cache, x, cond):
     sig = signature(net)
     pool = net._k4.get(key)
     if pool is None or pool[0] != sig or (pool[1] and (cache._plan is None or pool[1][0].packplan is not cache._plan[1])):
-        pool = net._k4[key] = (sig, [])                                            # parameters moved / the pack plan was rebuilt: the old tapes name dead buffers
+        pool = net._k4[key] = (sig, [] if _params_ok(net) else None)               # parameters moved / the pack plan was rebuilt: the old tapes name dead buffers
+    if pool[1] is None:
+        return None
     for prog in pool[1]:
         if not prog.busy:
             return prog

@@ -26,7 +26,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import _native as N
-from .sr_esrnet import _Packed, _PackPlan, SFTNet, EPI_LRELU, EPI_RES
+from .sr_esrnet import _Packed, _PackPlan, SFTNet, EPI_LRELU, EPI_RES, CONV_SMALL
 
 
 class _WeightCache:
@@ -131,7 +131,8 @@ class K4Conv2d(torch.autograd.Function):
         cout, cin_w, k, _ = weight.shape
         assert cin == cin_w and x.dtype == torch.float32
         y = torch.empty([H, W, cout], dtype=torch.float32, device=x.device)
-        SFTNet._conv(cache.fwd(weight, bias), x, 0, cin, y, 0, cout, cout, H, W, flags=EPI_LRELU if act else 0)
+        small = CONV_SMALL if k == 3 else 0                # (the K-split kernel on small images: include/k4nerf.h K4_CONV_SMALL)
+        SFTNet._conv(cache.fwd(weight, bias), x, 0, cin, y, 0, cout, cout, H, W, flags=(EPI_LRELU if act else 0) | small)
         if act:
             ctx.save_for_backward(x, weight, y)
         else:
@@ -154,7 +155,7 @@ class K4Conv2d(torch.autograd.Function):
         L = N.lib()
         if ctx.needs_input_grad[0]:
             gx = torch.empty([H, W, cin], dtype=torch.float32, device=x.device)
-            SFTNet._conv(ctx.cache.bwd(weight), gy, 0, cout, gx, 0, cin, cin, H, W)
+            SFTNet._conv(ctx.cache.bwd(weight), gy, 0, cout, gx, 0, cin, cin, H, W, flags=CONV_SMALL if k == 3 else 0)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw, gb = _wgrad(x, 0, cin, cin, gy, 0, cout, cout, k, H, W, weight.shape, want_b)
@@ -260,6 +261,7 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
 
 _NATIVE_RDB = True      # False: a dense block's launches issued one by one from Python (A/B)
 _WGRAD_STREAM = True    # False: the block's weight gradients on the chain's own stream (A/B)
+_SIDE_LOW_PRIORITY = True       # False: the weight gradients' stream at PyTorch's default priority (A/B)
 _FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
@@ -271,10 +273,18 @@ def _side_stream(device):
     """The second HIP stream (per device) a dense block's weight-gradient launches go to (k4_rdb_train_bwd: forked / joined inside the call)."""
     if not _WGRAD_STREAM:
         return None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)       # one side stream per MAIN stream: callers on different streams do not share one
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, _SIDE_LOW_PRIORITY)       # one side stream per MAIN stream: callers on different streams do not share one
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        if _SIDE_LOW_PRIORITY:                            # the weight gradients fill the chip: the chain they fork from must not queue behind them
+            with torch.cuda.device(device):
+                raw = N.lib().k4_stream_create_low_priority()
+            if not raw:
+                raise N.K4Error('k4_stream_create_low_priority failed')
+            st = torch.cuda.ExternalStream(raw, device=device)
+        else:
+            st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = st
     return st.cuda_stream
 
 

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_low_priority, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -304,6 +304,10 @@ int k4_alpha_maxpool3_gt(const float* alpha, int32_t x, int32_t y, int32_t z, fl
 #define K4_EPI_LRELU_BWD 256u    /* k4_conv2d_nhwc_bf16x6(_multi), 3x3 layers with cout % 32 == 0: after everything else the LAST 32 output channels are
                                     multiplied by (mod_x[pix][co] > 0 ? 1 : slope), mod_x = [H][W][mod_stride] addressed with the OUTPUT's channel index:
                                     LeakyReLU backward (k4_lrelu_bwd) of the gradient slice a dgrad accumulation has just completed, in its epilogue */
+#define K4_CONV_SMALL    512u    /* k4_conv2d_nhwc_bf16x6, plain 3x3 layers (no K4_ARITH_* / K4_PRE_UPSAMPLE2X), one window: when the image is small (one-row
+                                    workgroups <= 4 per CU: the 64x64 training patch) the layer runs on the K-split kernel -- a workgroup is one row x 32
+                                    pixels x 32 output channels, its four waves split the input-channel chunks.  Same products; the fp32 additions are
+                                    ordered differently than in the row kernels (not bit-identical to them).  Training graph only. */
 #define K4_W_TAPS_AS_COUT 32u    /* k4_conv2d_nhwc_bf16x6 only, 3x3 with cout <= 3: w_split holds the 1x1 layer [9*cout -> 32][cin]
                                     (n = tap*cout + co) in the bf16x6 layout; the kernel sums the 9 taps from LDS        */
 #define K4_PRE_UPSAMPLE2X 16u    /* the input is read through a nearest x2 upsample (lib/sr_esrnet.py:461-463)  */
@@ -504,6 +508,9 @@ typedef struct k4_rdb_train {
     int32_t fused_lrelu;            /* != 0: the four k4_lrelu_bwd launches run inside the epilogues of the launches in front of them (K4_EPI_LRELU_BWD, grad_x_lrelu):
                                        same values */
     int32_t g5_from_gx0_add;        /* != 0: g5 (a caller's [n_pix][nf] buffer) is WRITTEN here as 0.2 * gx0_add (= grad_out) */
+    int32_t no_join;                /* ABI 13, != 0: k4_rdb_train_bwd does NOT make `stream` wait for side_stream before it returns -- the caller joins once,
+                                       behind the last block (k4_main_wait_side), and keeps every buffer of the descriptor alive until then: with a join per
+                                       block the chain waited ~40 us at every block for the weight gradient it had forked last */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -630,12 +637,25 @@ void k4_tape_free(k4_tape* tape);
  *   k4_add_f32             : out[i] = a[i] + b[i]                        (16-byte aligned; out may alias a or b)
  *   k4_upsample2x_nhwc     : y[2Y+py][2X+px][c] = x[Y][X][c]             (F.interpolate(scale_factor=2, mode='nearest'), lib/sr_esrnet.py:461-463)
  *   k4_upsample2x_bwd_nhwc : grad_x[Y][X][c] = (gy[2Y][2X] + gy[2Y][2X+1]) + (gy[2Y+1][2X] + gy[2Y+1][2X+1])      (channels % 4 == 0)
+ *   k4_stream_create_low_priority : a side stream for the weight gradients (they fill the chip; the chain they fork from must not queue behind them)
  *   k4_side_wait_main      : everything queued on `stream` so far completes before what `side` gets next (fork); k4_main_wait_side: the join. */
 int k4_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 int k4_upsample2x_nhwc(const float* x, int32_t H, int32_t W, int32_t channels, float* y, void* stream);
 int k4_upsample2x_bwd_nhwc(const float* grad_y, int32_t H, int32_t W, int32_t channels, float* grad_x, void* stream);
+void* k4_stream_create_low_priority(void);     /* hipStreamNonBlocking, the device's least priority; NULL on failure; lives until the process ends */
 int k4_side_wait_main(void* side, void* stream);
 int k4_main_wait_side(void* side, void* stream);
+
+/* k4_sft_train_bwd_ex whose reduction of the per-workgroup partial sums (the eight parameter gradients; nothing on the caller's chain reads them) is forked
+ * to side_stream (NULL = `stream`: k4_sft_train_bwd_ex): the caller joins side_stream before the gradients are read and keeps `workspace` untouched until then. */
+int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                          int64_t n_pix, int32_t channels,
+                          const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                          float slope, float* grad_x, float* grad_cond,
+                          float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                          float* workspace, int64_t workspace_bytes,
+                          const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
+                          void* side_stream, void* stream);
 
 #ifdef __cplusplus
 }

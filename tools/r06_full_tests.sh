@@ -1,0 +1,3 @@
+O=gpurun_out/r06_full_tests; mkdir -p $O
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log
+tail -15 $O/tests.log

@@ -6,7 +6,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nerf4k_amd
 from nerf4k_amd import _native as N
-from nerf4k_amd.lib.sr_esrnet import _Packed, SFTNet, EPI_LRELU
+from nerf4k_amd.lib.sr_esrnet import _Packed, SFTNet, EPI_LRELU, CONV_SMALL
 from nerf4k_amd.lib import sr_train
 
 torch.manual_seed(0)
@@ -31,7 +31,7 @@ for cin, cout in [(64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64)]
     y = torch.zeros([H, W, 64], device=dev)
     gy = torch.randn([H, W, 64], device=dev)
     pk = _Packed(w, b, 'bf16x6')
-    t_f = med(lambda: SFTNet._conv(pk, x, 0, 192, y, 0, 64, cout, H, W, EPI_LRELU))
+    t_f = med(lambda: SFTNet._conv(pk, x, 0, 192, y, 0, 64, cout, H, W, EPI_LRELU | CONV_SMALL))      # K4_SR_DEBUG=2048: the row kernel
     t_w = med(lambda: sr_train._wgrad(x, 0, cin, 192, gy, 0, cout, 64, 3, H, W, w.shape, True))
     print(f'conv {cin:3d}->{cout:2d} {H}x{W}: forward {t_f:6.1f} us   wgrad+dbias (zero-fill + kernel) {t_w:6.1f} us')
 
