@@ -1033,34 +1033,57 @@ __global__ __launch_bounds__(256) void k4_conv_ks_kernel(const ConvMulti M) {
     for (int ch = wv; ch < nchunks; ch += 4) {
         const int c0 = ch * KC2 + half * 8;
         const bool full = vec && ch * KC2 + KC2 <= P.cin;         // wave-uniform
-        uint4 a[9][3];
+        // every fetch of the chunk is issued before the first wait: 18 x 16 bytes of activations (9 taps) and the 27 weight fragments -- ONE round trip
+        // to L2 / the fabric per chunk (as a per-tap `if (full)` the compiler emitted nine load-wait pairs in a row)
+        float4 ra[9][2];
+        if (full) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int sy = gy - 1 + t / 3, sx = x0 - 1 + t % 3 + l31;
-            const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
-            const float* src = X + ((size_t)(in ? sy : 0) * W + (in ? sx : 0)) * P.cin_stride + c0;
-            float v8[8];
-            if (full) {
-                const float4 va = *reinterpret_cast<const float4*>(src), vb = *reinterpret_cast<const float4*>(src + 4);
-                v8[0] = in ? va.x : 0.f; v8[1] = in ? va.y : 0.f; v8[2] = in ? va.z : 0.f; v8[3] = in ? va.w : 0.f;
-                v8[4] = in ? vb.x : 0.f; v8[5] = in ? vb.y : 0.f; v8[6] = in ? vb.z : 0.f; v8[7] = in ? vb.w : 0.f;
-            } else {
+            for (int t = 0; t < 9; ++t) {
+                const int sy = gy - 1 + t / 3, sx = x0 - 1 + t % 3 + l31;
+                const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                const float* src = X + ((size_t)(in ? sy : 0) * W + (in ? sx : 0)) * P.cin_stride + c0;
+                ra[t][0] = *reinterpret_cast<const float4*>(src);
+                ra[t][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sy = gy - 1 + t / 3, sx = x0 - 1 + t % 3 + l31;
+                const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                const float* src = X + ((size_t)(in ? sy : 0) * W + (in ? sx : 0)) * P.cin_stride + c0;
+                float v8[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const bool ok = in && c0 + c < P.cin;
-                    const float q = *(ok ? src + c : X);
-                    v8[c] = ok ? q : 0.f;
+                    const bool ok = c0 + c < P.cin;
+                    v8[c] = ok ? src[c] : 0.f;                    // (a pixel outside the image reads pixel (0, 0): zeroed below)
                 }
+                ra[t][0] = make_float4(v8[0], v8[1], v8[2], v8[3]); ra[t][1] = make_float4(v8[4], v8[5], v8[6], v8[7]);
             }
-            k4s_split3(v8, a[t][0], a[t][1], a[t][2]);
         }
-        const uint4* wp = wbase + (size_t)ch * 3 * wterm;
+        const uint4* const wp = wbase + (size_t)ch * 3 * wterm;
+        uint4 bw[9][3];
 #pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bw[t][q] = wp[q * wterm + (size_t)t * 2 * NOUT];
+        __builtin_amdgcn_sched_barrier(0);                       // (the scheduler sank the fetches to their uses, 3-6 in flight: keep these 36 in front;
+#pragma unroll                                                   //  the last three taps' fragments follow behind the third tap: 240 registers, two waves per SIMD)
         for (int t = 0; t < 9; ++t) {
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, wp[(size_t)t * 2 * NOUT]);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, wp[wterm + (size_t)t * 2 * NOUT]);
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, wp[2 * wterm + (size_t)t * 2 * NOUT]);
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[t][0]), a1 = __builtin_bit_cast(bf16x8, a[t][1]), a2 = __builtin_bit_cast(bf16x8, a[t][2]);
+            if (t == 3) {
+#pragma unroll
+                for (int u = 6; u < 9; ++u)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bw[u][q] = wp[q * wterm + (size_t)u * 2 * NOUT];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int sy = gy - 1 + t / 3, sx = x0 - 1 + t % 3 + l31;
+            const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const float v8[8] = {in ? ra[t][0].x : 0.f, in ? ra[t][0].y : 0.f, in ? ra[t][0].z : 0.f, in ? ra[t][0].w : 0.f,
+                                 in ? ra[t][1].x : 0.f, in ? ra[t][1].y : 0.f, in ? ra[t][1].z : 0.f, in ? ra[t][1].w : 0.f};
+            uint4 s0, s1, s2;
+            k4s_split3(v8, s0, s1, s2);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, s0), a1 = __builtin_bit_cast(bf16x8, s1), a2 = __builtin_bit_cast(bf16x8, s2);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, bw[t][0]), b1 = __builtin_bit_cast(bf16x8, bw[t][1]), b2 = __builtin_bit_cast(bf16x8, bw[t][2]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc, 0, 0, 0);          // smallest products first, as the row kernels
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);

@@ -852,6 +852,22 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
                                       'touched_voxels_per_rank': [{'counts': c, 'of': v} for c, v in ex.get('touched', [])]},
                 'workload': f'configs[4] fern_lg_joint_l1, patch-parallel over {world} GPUs: one 64x64 patch per rank, decoder + small tensors in ONE '
                             'all-reduce bucket, voxel-grid gradients as (index, value) lists in ONE all-gather per grid (RCCL)'}
+    # A/B on this box: the decoder as ~20 autograd nodes per RRDB issued call by call (round 5's form; K4_TRAIN_TAPE=0) instead of ONE node on two launch tapes
+    from nerf4k_amd.lib import sr_train
+    sr_train._TAPE = False
+    try:
+        for i in range(2):
+            tr.step(*batch(it), global_step=it + 1)
+            it += 1
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(per_block):
+            tr.step(*batch(it), global_step=it + 1)
+            it += 1
+        torch.cuda.synchronize()
+        dt_blocks_graph = (time.perf_counter() - t) / per_block
+    finally:
+        sr_train._TAPE = True
     # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
     b = batch(it + 1)
     torch.cuda.synchronize()
@@ -874,7 +890,9 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     n_samples = int(rr['weights'].numel())
     return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2),
             'ms_per_iteration_blocks': [round(v * 1e3, 2) for v in blocks], 'statistic': f'median of 5 blocks of {per_block} iterations after 3 warm-up iterations',
-            'ms_per_iteration_decoder_as_hipgraph': 'not measured here: 17.2 ms against 11.2-11.3 eager on the same box (tools/joint_step_time.py, K4_TRAIN_GRAPH=1, round 5; 23.7 against 16.8 in round 3)',
+            'ms_per_iteration_per_block_graph': round(dt_blocks_graph * 1e3, 2),
+            'decoder_pass': 'ONE autograd node on two launch tapes replayed by one native call each (lib/sr_tape.py, k4_tape_*), 3x3 layers of the 64x64 patch on the K-split kernel (K4_CONV_SMALL); '
+                            'ms_per_iteration_per_block_graph = the same kernels issued call by call from ~20 autograd nodes per RRDB (K4_TRAIN_TAPE=0); round 5: 11.0-11.3 ms; hipGraph form 17.2 ms',
             'rays_per_iteration': pr * pc,
             'shaded_samples': n_samples, 'first_loss': round(first, 5),
             'breakdown_ms': {'forward (march train + SFTNet + losses)': round((t1 - t0) * 1e3, 2), 'backward': round((t2 - t1) * 1e3, 2),
