@@ -196,7 +196,8 @@ _EXTRA_SIGS = {
     'k4_add_f32': ([_P, _P, _P, _I64, _P], C.c_int),
     'k4_upsample2x_nhwc': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
     'k4_upsample2x_bwd_nhwc': ([_P, _I32, _I32, _I32, _P, _P], C.c_int),
-    'k4_stream_create_low_priority': ([], C.c_void_p),
+    'k4_stream_create_overlapping': ([_P, C.POINTER(C.c_void_p), _I32, _I32], C.c_void_p),
+    'k4_streams_overlap': ([_P, _P], C.c_int),
     'k4_side_wait_main': ([_P, _P], C.c_int),
     'k4_main_wait_side': ([_P, _P], C.c_int),
 }
@@ -250,3 +251,34 @@ def vec3(t):
     v = [float(x) for x in t.detach().cpu().reshape(-1).tolist()]
     assert len(v) == 3
     return (C.c_float * 3)(*v)
+
+
+_OVERLAP_STREAMS = {}           # (device index, main stream handle, group) -> {tag: torch.cuda.ExternalStream}
+
+
+def overlapping_stream(device, tag, low_priority=False, group='training step', beside_main=True):
+    """The side stream `tag` of the CURRENT stream on `device`: a stream verified to run beside the current stream and beside the streams the other tags of
+    the same group already hold (include/k4nerf.h k4_stream_create_overlapping: HIP streams share a few hardware queues, and a "second stream" that
+    lands on the main stream's queue serialises with it -- the joint training iteration took 9 ms or 21 ms depending on how many streams the process had
+    created before).  One stream per (device, main stream, group, tag) for the life of the process.  beside_main=False: verified against the group's
+    other streams only (a pool of worker streams that run while the main stream idles: four hardware queues cannot hold four workers AND the main stream)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream(idx).cuda_stream
+    mine = _OVERLAP_STREAMS.setdefault((idx, main, group), {})
+    st = mine.get(tag)
+    if st is None:
+        others = [s.cuda_stream for s in mine.values()]
+        first = main
+        if not beside_main:                              # probe against the first worker instead of the main stream (none yet: any stream will do)
+            first, others = (others[0], others[1:]) if others else (None, [])
+        if first is None:
+            st = mine[tag] = torch.cuda.Stream(device=idx)
+            return st
+        arr = (C.c_void_p * max(1, len(others)))(*others)
+        with torch.cuda.device(idx):
+            raw = lib().k4_stream_create_overlapping(C.c_void_p(first), arr, len(others), int(bool(low_priority)))
+        if not raw:
+            raise K4Error('k4_stream_create_overlapping failed')
+        st = mine[tag] = torch.cuda.ExternalStream(raw, device=idx)
+    return st

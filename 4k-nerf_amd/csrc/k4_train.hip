@@ -1086,15 +1086,68 @@ join:
 
 // Fork / join of a second stream for callers that place launches there themselves (lib/sr_tape.py: the weight gradients of the layers outside the
 // dense blocks).  Recordable: `stream` is the call's main stream (the replaying stream on a replay), `side` stays as given.
-// A stream of the LOWEST priority the device offers, non-blocking towards the legacy default stream (as the streams of PyTorch's pool): the weight
-// gradients of the decoder's training pass go there -- they fill every CU (ksize^2 x channel blocks x bands workgroups) while the chain they fork
-// from runs 16-64 workgroups per launch and waits for nothing else; with equal priorities the chain's launches queued behind them.
-extern "C" void* k4_stream_create_low_priority(void) {
+// Side streams that REALLY run beside the streams they are meant to overlap.  The runtime multiplexes HIP streams onto a few hardware queues per
+// priority level (four by default) and hands a new stream the least-referenced queue: in a process that has already created a handful of streams a
+// "second stream" may share its hardware queue with the main stream -- its kernels then run in queue order with the main stream's, and every
+// fork / join between the two becomes a full serialisation.  Measured (profiles/r06_joint_phase_events.md, section 6): the joint training iteration took
+// 9.1 ms in a fresh process and 12.5-20.9 ms behind 6+ earlier streams, same code.  k4_stream_create_overlapping creates candidates until one demonstrably
+// overlaps `main_stream` and every stream of `others`: a kernel that spins for ~200 us is launched on the one, a time stamp kernel on the candidate -- the
+// stamp lands before the spin ends iff the two are on different hardware queues.  Rejected candidates are destroyed afterwards (while they live they keep
+// their queue referenced, so the next candidate goes elsewhere).
+__global__ void k_overlap_spin(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = wall_clock64(); }
+}
+__global__ void k_overlap_stamp(unsigned long long* out) {
+    if (threadIdx.x == 0) out[0] = wall_clock64();
+}
+static int k4_overlap_probe(hipStream_t busy, hipStream_t cand, unsigned long long* dbuf, bool* overlap) {       // dbuf: device, 3 x u64
+    hipLaunchKernelGGL(k_overlap_spin, dim3(1), dim3(64), 0, busy, 20000ull, dbuf);                               // wall_clock64: 100 MHz -> 200 us
+    hipLaunchKernelGGL(k_overlap_stamp, dim3(1), dim3(64), 0, cand, dbuf + 2);
+    hipError_t e = hipStreamSynchronize(busy);
+    if (e == hipSuccess) e = hipStreamSynchronize(cand);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long h[3];
+    e = hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    *overlap = h[2] < h[1];                                                                                       // stamped before the spin ended
+    return k4_check_launch();
+}
+extern "C" int k4_streams_overlap(void* a, void* b) {          // 1: kernels of b run beside kernels of a; 0: they share a hardware queue; < 0: error
+    if (a == b) return 0;
+    unsigned long long* dbuf = nullptr;
+    if (hipMalloc((void**)&dbuf, 3 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    bool ov = false;
+    const int rc = k4_overlap_probe((hipStream_t)a, (hipStream_t)b, dbuf, &ov);
+    (void)hipFree(dbuf);
+    return rc != 0 ? -1 : (ov ? 1 : 0);
+}
+extern "C" void* k4_stream_create_overlapping(void* main_stream, void* const* others, int32_t n_others, int32_t low_priority) {
+    if (n_others < 0 || (n_others > 0 && !others)) return nullptr;
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-    return (void*)s;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    unsigned long long* dbuf = nullptr;
+    if (hipMalloc((void**)&dbuf, 3 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    constexpr int MAX_TRIES = 12;
+    hipStream_t tried[MAX_TRIES];
+    int n_tried = 0;
+    hipStream_t good = nullptr;
+    while (n_tried < MAX_TRIES && !good) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithPriority(&c, hipStreamNonBlocking, low_priority ? least : 0) != hipSuccess) break;
+        tried[n_tried++] = c;
+        bool ok = true;
+        int rc = k4_overlap_probe((hipStream_t)main_stream, c, dbuf, &ok);
+        for (int i = 0; rc == 0 && ok && i < n_others; ++i) rc = k4_overlap_probe((hipStream_t)others[i], c, dbuf, &ok);
+        if (rc != 0) break;
+        if (ok) good = c;
+    }
+    if (!good && n_tried > 0) good = tried[n_tried - 1];        // none verified (one hardware queue? profiling layer?): a plain second stream, as before
+    for (int i = 0; i < n_tried; ++i)
+        if (tried[i] != good) (void)hipStreamDestroy(tried[i]);
+    (void)hipFree(dbuf);
+    return (void*)good;
 }
 extern "C" int k4_side_wait_main(void* side, void* stream) {
     return k4_taped(stream, [side](void* stream) -> int { return k4_wait_stream((hipStream_t)side, (hipStream_t)stream); });

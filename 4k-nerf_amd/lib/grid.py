@@ -110,14 +110,10 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
             'k4_total_variation_add_grad')
 
 
-_TV_STREAMS = {}
-
-
 def _tv_stream(device):
-    st = _TV_STREAMS.get(device)
-    if st is None:
-        st = _TV_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
+    """The stream the dense TV term is written on ahead of the backward pass: verified to run beside the current stream and the package's other side
+    streams (_native.overlapping_stream)."""
+    return N.overlapping_stream(device, 'dense total variation')
 
 
 def _vec3(v):

@@ -44,14 +44,9 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
     _launch('k4_adam_upd_with_perlr', param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps)
 
 
-_SIDE_STREAMS = {}
-
-
 def _side_stream(device):
-    st = _SIDE_STREAMS.get(device)
-    if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
+    """The stream a large grid's update runs on: verified to run beside the current stream and the package's other side streams (_native.overlapping_stream)."""
+    return N.overlapping_stream(device, 'grid optimizer step')
 
 
 _MULTI_BELOW = 1 << 20          # tensors smaller than this are updated through k4_adam_upd_multi (same arithmetic per element)

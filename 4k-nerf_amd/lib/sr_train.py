@@ -261,30 +261,19 @@ def _sft_bwd(x, x_stride, C, cond, gy, gy_off, gy_stride, n_pix, ws):
 
 _NATIVE_RDB = True      # False: a dense block's launches issued one by one from Python (A/B)
 _WGRAD_STREAM = True    # False: the block's weight gradients on the chain's own stream (A/B)
-_SIDE_LOW_PRIORITY = True       # False: the weight gradients' stream at PyTorch's default priority (A/B)
+_SIDE_LOW_PRIORITY = False      # True: the weight gradients' stream at the device's lowest priority (A/B: no effect)
 _FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
 _TAPE = os.environ.get('K4_TRAIN_TAPE', '1') != '0'     # 0: the decoder as ~20 autograd nodes per RRDB (below) instead of ONE node on two launch tapes (lib/sr_tape.py)
-_SIDE_STREAMS = {}
 
 
 def _side_stream(device):
     """The second HIP stream (per device) a dense block's weight-gradient launches go to (k4_rdb_train_bwd: forked / joined inside the call)."""
     if not _WGRAD_STREAM:
         return None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, _SIDE_LOW_PRIORITY)       # one side stream per MAIN stream: callers on different streams do not share one
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        if _SIDE_LOW_PRIORITY:                            # the weight gradients fill the chip: the chain they fork from must not queue behind them
-            with torch.cuda.device(device):
-                raw = N.lib().k4_stream_create_low_priority()
-            if not raw:
-                raise N.K4Error('k4_stream_create_low_priority failed')
-            st = torch.cuda.ExternalStream(raw, device=device)
-        else:
-            st = torch.cuda.Stream(device=device)
-        _SIDE_STREAMS[key] = st
+    # (one per MAIN stream -- callers on different streams do not share one -- and verified to run BESIDE it: _native.overlapping_stream)
+    st = N.overlapping_stream(device, 'decoder weight gradients', low_priority=_SIDE_LOW_PRIORITY)
     return st.cuda_stream
 
 

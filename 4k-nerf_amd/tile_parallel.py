@@ -180,17 +180,14 @@ def _to8b(x):
     return (255.0 * x.clamp(0.0, 1.0)).to(torch.uint8)
 
 
-_POOLS = {}
-
-
 TILE_STREAMS = 4        # HIP streams a rank deals its tiles to (1: sequential; same pixels either way, tests)
 
 
 def _stream_pool(dev, n):
-    pool = _POOLS.setdefault(str(dev), [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
+    """n worker streams verified to run beside EACH OTHER (_native.overlapping_stream: streams share a few hardware queues; two tiles dealt to streams on
+    one queue run one after the other)."""
+    from . import _native as N
+    return [N.overlapping_stream(dev, f'tile worker {i}', group='tile workers', beside_main=False) for i in range(n)]
 
 
 def _n_streams(dev, n_tiles, march_fn, sr_fn):

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_low_priority, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -637,12 +637,16 @@ void k4_tape_free(k4_tape* tape);
  *   k4_add_f32             : out[i] = a[i] + b[i]                        (16-byte aligned; out may alias a or b)
  *   k4_upsample2x_nhwc     : y[2Y+py][2X+px][c] = x[Y][X][c]             (F.interpolate(scale_factor=2, mode='nearest'), lib/sr_esrnet.py:461-463)
  *   k4_upsample2x_bwd_nhwc : grad_x[Y][X][c] = (gy[2Y][2X] + gy[2Y][2X+1]) + (gy[2Y+1][2X] + gy[2Y+1][2X+1])      (channels % 4 == 0)
- *   k4_stream_create_low_priority : a side stream for the weight gradients (they fill the chip; the chain they fork from must not queue behind them)
  *   k4_side_wait_main      : everything queued on `stream` so far completes before what `side` gets next (fork); k4_main_wait_side: the join. */
 int k4_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 int k4_upsample2x_nhwc(const float* x, int32_t H, int32_t W, int32_t channels, float* y, void* stream);
 int k4_upsample2x_bwd_nhwc(const float* grad_y, int32_t H, int32_t W, int32_t channels, float* grad_x, void* stream);
-void* k4_stream_create_low_priority(void);     /* hipStreamNonBlocking, the device's least priority; NULL on failure; lives until the process ends */
+/* A stream (hipStreamNonBlocking; the device's least priority with low_priority != 0) whose kernels demonstrably run BESIDE those of main_stream and of every
+ * stream in `others`: the runtime multiplexes streams onto a few hardware queues, and a second stream that shares the main stream's queue serialises with it
+ * (csrc/k4_train.hip).  Up to 12 candidates are probed (a 200 us spin kernel on the one stream, a time stamp on the candidate); the stream lives until the process
+ * ends.  NULL: creation failed.  k4_streams_overlap: the probe alone (1 / 0, < 0 on error). */
+void* k4_stream_create_overlapping(void* main_stream, void* const* others, int32_t n_others, int32_t low_priority);
+int k4_streams_overlap(void* a, void* b);
 int k4_side_wait_main(void* side, void* stream);
 int k4_main_wait_side(void* side, void* stream);
 

@@ -588,3 +588,34 @@ def test_small_image_ksplit_convolution_equals_the_row_kernel(cin, cout, H, W, f
             ref = ref * m
     assert _rel(outs[0], ref) <= 5e-6 and _rel(outs[1], ref) <= 5e-6 and _rel(outs[1], outs[0]) <= 2e-6
     assert not torch.equal(outs[0], torch.zeros_like(outs[0]))
+
+
+def test_side_streams_are_verified_to_overlap_the_main_stream():
+    """_native.overlapping_stream (k4_stream_create_overlapping): HIP streams are multiplexed onto a few hardware queues, and in a process that already
+    holds a dozen streams a new one may share the main stream's queue -- its kernels then serialise with the main stream's (the joint training iteration
+    ran 9.1 or 12.5-20.9 ms depending on the process's stream history).  The package's side streams are probed: a 200 us spin kernel on the one stream,
+    a time stamp on the other.  Here: behind 12 earlier streams, the three side streams of the training step overlap the main stream and each other."""
+    from nerf4k_amd import _native as N
+    dev = torch.device('cuda', 0)
+    crowd = [torch.cuda.Stream() for _ in range(12)]
+    for s in crowd:
+        with torch.cuda.stream(s):
+            torch.zeros([256], device=dev).add_(1)
+    torch.cuda.synchronize()
+    L = N.lib()
+    main = torch.cuda.current_stream().cuda_stream
+    sides = [N.overlapping_stream(dev, tag) for tag in ('decoder weight gradients', 'grid optimizer step', 'dense total variation')]
+    assert len({s.cuda_stream for s in sides}) == 3 and N.overlapping_stream(dev, 'grid optimizer step') is sides[1]
+    for s in sides:
+        assert L.k4_streams_overlap(N.C.c_void_p(main), N.C.c_void_p(s.cuda_stream)) == 1
+    for a in range(3):
+        for b in range(a + 1, 3):
+            assert L.k4_streams_overlap(N.C.c_void_p(sides[a].cuda_stream), N.C.c_void_p(sides[b].cuda_stream)) == 1
+    assert L.k4_streams_overlap(N.C.c_void_p(main), N.C.c_void_p(main)) == 0
+    # a stream works like any other: ordered against the main stream by events
+    x = torch.zeros([1 << 16], device=dev)
+    with torch.cuda.stream(sides[0]):
+        sides[0].wait_stream(torch.cuda.current_stream(dev)) if False else None
+        x.add_(2)
+    torch.cuda.current_stream().wait_stream(sides[0])
+    assert float(x.sum()) == 2 * (1 << 16)
