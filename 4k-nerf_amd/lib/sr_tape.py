@@ -55,9 +55,12 @@ class _Tape:
         N.check(N.lib().k4_tape_replay(self.h, N.stream()), 'k4_tape_replay')
 
     def __del__(self):
-        if self.h is not None and N._lib is not None:
-            N._lib.k4_tape_free(self.h)
-            self.h = None
+        try:                                                # (at interpreter shutdown the module globals may be gone already)
+            if self.h is not None and N._lib is not None:
+                N._lib.k4_tape_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class _Lease:
