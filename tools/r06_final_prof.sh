@@ -40,4 +40,11 @@ for g in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 done
 python $R/tools/pmc_by_grid.py $R/gpurun_out/pmc_r6s_* > $O/sr_pmc_by_grid_raw.md 2>&1
 rm -rf $R/gpurun_out/pmc_r6s_[0-9]
+# joint training iteration on the final tree: phase events (untraced), blocks, kernel timeline of one iteration
+cd $R
+timeout 300 python tools/joint_phase_events.py > $O/joint_phase_events.txt 2>/dev/null
+BLOCKS=8 SHOW_BLOCKS=1 timeout 300 python tools/joint_step_time.py 2>/dev/null | tail -2 > $O/joint_step_time.txt
+OUT=r6final/joint_timeline timeout 400 bash tools/joint_timeline_detail.sh > $O/joint_timeline_detail.txt 2>&1
+ITERS=20 timeout 400 bash tools/joint_prof.sh > $O/joint_kernel_stats.txt 2>&1; cp $R/gpurun_out/r05_joint/kernel_stats.csv $O/joint_iteration_kernel_stats.csv 2>/dev/null
+cat $O/joint_phase_events.txt $O/joint_step_time.txt
 ls -la $O
