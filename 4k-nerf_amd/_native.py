@@ -272,7 +272,8 @@ def overlapping_stream(device, tag, low_priority=False, group='training step', b
         first = main
         if not beside_main:                              # probe against the first worker instead of the main stream (none yet: any stream will do)
             first, others = (others[0], others[1:]) if others else (None, [])
-        if first is None:
+        if first is None or torch.cuda.is_current_stream_capturing():
+            # (no probe inside a hipGraph capture -- it allocates and synchronises: a plain pool stream, kept for this capture stream only)
             st = mine[tag] = torch.cuda.Stream(device=idx)
             return st
         arr = (C.c_void_p * max(1, len(others)))(*others)
