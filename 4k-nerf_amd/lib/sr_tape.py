@@ -465,8 +465,12 @@ class K4DecoderTape(torch.autograd.Function):
         return gx, gc, None, None
 
 
+MAX_SHAPES = 4      # program pools (patch shape x gradient need x stream) kept per network: a pool owns ~150 MB of buffers per program
+
+
 def program_for(net, cache, x, cond):
-    """A free program for this network / shape / gradient need, or None when the pool is exhausted (forward_train then keeps the per-block path)."""
+    """A free program for this network / shape / gradient need, or None when the pool is exhausted or the network is not eligible (forward_train then keeps
+    the per-block path)."""
     h, w = int(x.shape[2]), int(x.shape[3])
     main = N.stream().value or 0
     key = ('tape_programs', h, w, bool(x.requires_grad), bool(cond.requires_grad), main, T._side_stream(net.conv_first.weight.device))
@@ -474,6 +478,15 @@ def program_for(net, cache, x, cond):
     pool = net._k4.get(key)
     if pool is None or pool[0] != sig or (pool[1] and (cache._plan is None or pool[1][0].packplan is not cache._plan[1])):
         pool = net._k4[key] = (sig, [] if _params_ok(net) else None)               # parameters moved / the pack plan was rebuilt: the old tapes name dead buffers
+    lru = net._k4.setdefault('tape_lru', [])
+    if key in lru:
+        lru.remove(key)
+    lru.append(key)
+    for old in [k for k in lru[:-MAX_SHAPES]]:                                      # edge patches of many sizes: the oldest idle pools go
+        op = net._k4.get(old)
+        if op is None or op[1] is None or not any(p.busy for p in op[1]):
+            net._k4.pop(old, None)
+            lru.remove(old)
     if pool[1] is None:
         return None
     for prog in pool[1]:
@@ -481,6 +494,11 @@ def program_for(net, cache, x, cond):
             return prog
     if len(pool[1]) >= POOL:
         return None
-    prog = DecoderProgram(net, cache, h, w, bool(x.requires_grad), bool(cond.requires_grad))
+    try:
+        prog = DecoderProgram(net, cache, h, w, bool(x.requires_grad), bool(cond.requires_grad))
+    except N.K4Error:
+        if not pool[1]:                                                             # this network cannot be taped (no live pack plan): remember, per-block path
+            net._k4[key] = (sig, None)
+        return None
     pool[1].append(prog)
     return prog

@@ -619,3 +619,23 @@ def test_side_streams_are_verified_to_overlap_the_main_stream():
         x.add_(2)
     torch.cuda.current_stream().wait_stream(sides[0])
     assert float(x.sum()) == 2 * (1 << 16)
+
+
+def test_decoder_tape_keeps_a_bounded_number_of_patch_shapes():
+    """Edge patches of many sizes: every new shape builds a program (its own activation / gradient buffers); the network keeps the MAX_SHAPES most
+    recently used idle pools and every shape still computes the gradients of the per-block graph."""
+    from nerf4k_amd.lib import sr_tape
+    make, _, _, _ = _tape_fixture(nb=1, h=8, w=8, seed=41)
+    net = make()
+    g = torch.Generator().manual_seed(3)
+    for k in range(sr_tape.MAX_SHAPES + 3):
+        h, w = 8 + 2 * k, 12
+        x = torch.rand([1, 3, h, w], generator=g).cuda().requires_grad_(True)
+        c = torch.rand([1, 1, h, w], generator=g).cuda()
+        net.zero_grad(set_to_none=True)
+        out = net(x, c)
+        assert out.grad_fn.__class__.__name__ == 'K4DecoderTapeBackward'
+        out.square().mean().backward()
+        assert x.grad is not None and all(p.grad is not None for p in net.parameters())
+    pools = [k for k in net._k4 if isinstance(k, tuple) and k and k[0] == 'tape_programs']
+    assert len(pools) == sr_tape.MAX_SHAPES and len(net._k4['tape_lru']) == sr_tape.MAX_SHAPES
