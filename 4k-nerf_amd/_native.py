@@ -188,6 +188,7 @@ _EXTRA_SIGS = {
     'k4_sft_train_bwd_side': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
+    'k4_nhwc_window_to_planar': ([_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P], C.c_int),
     'k4_tape_begin': ([_P], C.c_void_p),
     'k4_tape_end': ([_P], C.c_int),
     'k4_tape_length': ([_P], C.c_int64),

@@ -28,6 +28,7 @@ from torch.nn import functional as F
 from torch.nn import init as init
 
 from .. import _native as N
+from .utils import window_to_planes
 
 EPI_LRELU, EPI_RES, EPI_MODULATE, PRE_UP2X, W_TAPS_AS_COUT, ARITH_2TERM, ARITH_F16X3 = 2, 4, 8, 16, 32, 64, 128
 CONV_SMALL = 512       # K4_CONV_SMALL: the training graph's convolutions may run on the K-split small-image kernel (include/k4nerf.h)
@@ -481,10 +482,31 @@ class SFTNet(nn.Module):
         self.k4_mode = os.environ.get('K4_SR_MODE', DEFAULT_MODE)
 
     # ------------------------------------------------------------------ HIP path
+    def k4_parameters(self):
+        """list(self.parameters()) without the module-tree walk: nn.Module.parameters() costs ~250 us for this network's 458 tensors, and the caches below are keyed
+        on the parameters' versions on EVERY call (four times per 4K frame: 1 ms of a 28.5 ms frame with the GPU idle; three times per training iteration).  The
+        (module, name, parameter) triples are kept and re-validated by identity (~40 us): a replaced Parameter object rebuilds the list."""
+        ent = self._k4.get('plist')
+        if ent is not None:
+            for m, n, p in ent:
+                if m._parameters.get(n) is not p:
+                    ent = None
+                    break
+        if ent is None:
+            seen, ent = set(), []
+            for m in self.modules():
+                for n, p in m._parameters.items():
+                    if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        ent.append((m, n, p))
+            self._k4['plist'] = ent
+            self._k4['plist_p'] = [p for _, _, p in ent]
+        return self._k4['plist_p']
+
     def _packed(self):
         """Pack every conv once per parameter version (load-time repack; names/values of parameters never change)."""
         mode = 'f16x3' if self.k4_mode == 'f16x3p' else self.k4_mode       # 'f16x3p' = the 'f16x3' operands + the p16 ones of _p16_state
-        key = tuple(p._version for p in self.parameters()) + (str(self.conv_first.weight.device), mode)
+        key = tuple(p._version for p in self.k4_parameters()) + (str(self.conv_first.weight.device), mode)
         c = self._k4
         if c.get('key') == key:
             return c['packed']
@@ -736,9 +758,10 @@ class SFTNet(nn.Module):
 
     def k4_warm(self):
         """Build the load-time state (packed weights; 'f16x3p': calibration + pre-split weight operands) on the CURRENT stream."""
-        self._packed()
         if self.k4_mode == 'f16x3p':
-            self._p16_state()
+            self._p16_state()                                 # (validates the packed weights first)
+        else:
+            self._packed()
 
     @torch.no_grad()
     def _forward_hip(self, x, cond, slot=0):
@@ -767,22 +790,23 @@ class SFTNet(nn.Module):
         # (the pre-split kernels address an image through 32-bit byte offsets: windows whose 4x images reach 2 GB stay on 'f16x3')
         p16 = self.k4_mode == 'f16x3p' and all(h * w * 4 * max(self.num_feat + 4 * self.num_grow_ch, self.scale ** 2 * self.num_feat) < 2 ** 31 for h, w in hws)
         st = self._p16_state() if p16 else None
+        pk = self._k4['packed'] if p16 else self._packed()    # (_p16_state has validated the packed weights against the parameter versions)
         # (dealing the windows to two or four HIP streams so that one group's last, partly filled round of workgroups overlaps the other's
         # next layer measured neutral on the 4K frame and slower on the 8-GPU rank share: profiles/r04_decoder_streams_neutral.md)
         if p16:
             ovf = self._k4.setdefault(('ovf', slot0, str(dev)), torch.zeros([N.K4_MAX_JOBS], dtype=torch.int32, device=dev))
-            self._run_plan(Bs, hws, slot0, p16={'E': st['E'], 'pk': st['pk'], 'ovf': ovf})
+            self._run_plan(Bs, hws, slot0, p16={'E': st['E'], 'pk': st['pk'], 'ovf': ovf}, pk=pk)
             flags = ovf.cpu().tolist()                                     # the one host synchronisation of the pass
             bad = [j for j in range(len(Bs)) if flags[j]]
             if bad:
                 self._k4['p16_reruns'] = self._k4.get('p16_reruns', 0) + len(bad)
-                self._run_plan([Bs[j] for j in bad], [hws[j] for j in bad], (slot0, 'redo'))
+                self._run_plan([Bs[j] for j in bad], [hws[j] for j in bad], (slot0, 'redo'), pk=pk)
         else:
-            self._run_plan(Bs, hws, slot0)
+            self._run_plan(Bs, hws, slot0, pk=pk)
         return [B['out'].permute(2, 0, 1).unsqueeze(0) for B in Bs]       # views [1,3,H,W] of the NHWC results
 
-    def _run_plan(self, Bs, hws, slot0, p16=None):
-        pk = self._packed()
+    def _run_plan(self, Bs, hws, slot0, p16=None, pk=None):
+        pk = self._packed() if pk is None else pk            # (the caller has just validated the packed weights: one parameter-version sweep per pass, not three)
         key = (tuple(hws), self._k4.get('key'), self.k4_mode, p16 is not None, self._k4.get('p16_gen', 0) if p16 is not None else -1) \
             + tuple(t.data_ptr() for B in Bs for t in B.values())
         plans = self._k4.setdefault(('plans', slot0), {})
@@ -958,7 +982,7 @@ class SFTNet(nn.Module):
                                            [cond[:, :, yp0:yp1, xp0:xp1] for (_, _, _, _, yp0, yp1, xp0, xp1) in part])
             for o, (y0, y1, x0, x1, yp0, yp1, xp0, xp1) in zip(outs, part):
                 oy, ox = (y0 - yp0) * s, (x0 - xp0) * s
-                out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+                window_to_planes(o, oy, ox, (y1 - y0) * s, (x1 - x0) * s, out[0, :, y0 * s:y1 * s, x0 * s:x1 * s])     # (one pass: lib/utils.window_to_planes)
         return out
 
     def tile_process(self, img, cond, tile_size, tile_pad=10):

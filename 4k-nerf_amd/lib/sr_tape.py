@@ -439,7 +439,7 @@ class DecoderProgram:
 
 def signature(net):
     """What a recorded tape depends on besides the shapes: the parameters' storage and the stream pair."""
-    return tuple(p.data_ptr() for p in net.parameters())
+    return tuple(p.data_ptr() for p in net.k4_parameters())
 
 
 class K4DecoderTape(torch.autograd.Function):

@@ -491,7 +491,7 @@ def _up2(t):
 def _params_hooked(net):
     """A parameter with a tensor hook or a post-accumulate-grad hook (DDP-style reducers, clipping hooks) needs its autograd edge: the direct
     gradient hand-over would never fire the hook."""
-    for p in net.parameters():
+    for p in (net.k4_parameters() if hasattr(net, 'k4_parameters') else net.parameters()):
         if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
             return True
     return False
@@ -515,7 +515,7 @@ def forward_train(net, x, cond):
     if (fused and _TAPE and _DIRECT_GRADS and _NATIVE_RDB and _FUSED_LRELU and _COND_ACC and _TAP is None and x.is_cuda
             and not torch.cuda.is_current_stream_capturing() and not _params_hooked(net)):
         from . import sr_tape
-        anchor = next((p for p in net.parameters() if p.requires_grad), None)
+        anchor = next((p for p in net.k4_parameters() if p.requires_grad), None)
         if (anchor is not None or x.requires_grad or cond.requires_grad) and sr_tape.eligible(net, x, cond):
             prog = sr_tape.program_for(net, cache, x, cond)
             if prog is not None:

@@ -24,6 +24,22 @@ def to8b_device(x):
     return out
 
 
+def window_to_planes(hr, oy, ox, th, tw, dst):
+    """dst[c, y, x] = hr[0, c, oy + y, ox + x] for a decoded window `hr` ([1, C, H, W] VIEW of the decoder's NHWC result) and a destination `dst` [C, th, tw]
+    whose rows are contiguous (a tile of the frame, a slice of a gather buffer reshaped): one pass of k4_nhwc_window_to_planar instead of a channel-stride
+    gather by slice assignment.  Falls back to the slice assignment for any other layout (CPU tensors of the gloo tests, other dtypes)."""
+    C, H, W = int(hr.shape[1]), int(hr.shape[2]), int(hr.shape[3])
+    ok = (hr.is_cuda and dst.is_cuda and hr.dtype == torch.float32 and dst.dtype == torch.float32 and C <= 4 and hr.shape[0] == 1
+          and hr.stride(1) == 1 and hr.stride(3) == C and hr.stride(2) == W * C and dst.dim() == 3 and tuple(dst.shape) == (C, th, tw)
+          and dst.stride(2) == 1 and th > 0 and tw > 0)
+    if not ok:
+        dst.copy_(hr[0, :, oy:oy + th, ox:ox + tw])
+        return
+    from .. import _native as N
+    N.check(N.lib().k4_nhwc_window_to_planar(N.C.c_void_p(hr.data_ptr()), W, C, int(oy), int(ox), int(th), int(tw), N.C.c_void_p(dst.data_ptr()),
+                                             int(dst.stride(0)), int(dst.stride(1)), N.stream()), 'k4_nhwc_window_to_planar')
+
+
 def create_optimizer_or_freeze_model(model, cfg_train, global_step):
     """lib/utils.py:21-48: one param group per `lrate_<name>` entry of cfg_train whose attribute exists on the model;
     lr decays by 0.1 every `lrate_decay` k-steps; lr == 0 freezes the parameter.  cfg_train: attribute-style mapping

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as _N
+from .lib.utils import window_to_planes
 
 
 def tile_geometry(height, width, tile_size, tile_pad=10):
@@ -87,7 +88,10 @@ def march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scale
     owned = assign_tiles(tiles, ws)
     counts, slot = _slots(tiles, owned, scale)
     dev = rays[0].device
-    send = torch.zeros([3, slot], dtype=torch.float32, device=dev)
+    multi = getattr(sr_fn, 'k4_multi', None)            # HIP decoder: all of this rank's windows per layer in ONE grouped launch
+    # the gather buffer: filled here by a decoder without a grouped form; decode_frame_tiles makes its own when it needs one (a single process with fp32
+    # output writes the frame directly: no 146 MB zero-fill per 4K frame)
+    send = torch.zeros([3, slot], dtype=torch.float32, device=dev) if multi is None else None
     off = 0
     # this rank's tiles are independent until the gather: on a GPU each runs on its own HIP stream (own marcher workspace
     # and decoder buffers, `slot`), so that the short last round of one tile's kernels is filled by another tile's
@@ -101,7 +105,6 @@ def march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scale
     if pool:
         for st in pool:
             st.wait_stream(cur)
-    multi = getattr(sr_fn, 'k4_multi', None)            # HIP decoder: all of this rank's windows per layer in ONE grouped launch
     pending = []
     for j, i in enumerate(owned[rk]):
         y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
@@ -117,11 +120,11 @@ def march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scale
                 if pool:                                   # produced on a side stream, consumed on the current one after the join
                     rgb.record_stream(cur)
                     depth.record_stream(cur)
-                pending.append((img, cond, off, th, tw, (y0 - yp0) * scale, (x0 - xp0) * scale))
+                pending.append((img, cond, off, th, tw, (y0 - yp0) * scale, (x0 - xp0) * scale, i))
             else:
                 hr = sr_fn(img, cond, **kw)
                 oy, ox = (y0 - yp0) * scale, (x0 - xp0) * scale
-                send[:, off:off + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
+                window_to_planes(hr, oy, ox, th, tw, send[:, off:off + th * tw].view(3, th, tw))
         off += th * tw
     events = None
     if pool:                                               # joined by decode_frame_tiles (events: the pool's streams may carry the NEXT frame's march by then)
@@ -143,12 +146,26 @@ def decode_frame_tiles(state, out=None, out_dtype=None):
         cur = torch.cuda.current_stream(dev)
         for ev in state['events']:
             cur.wait_event(ev)
+    odt = torch.float32 if out_dtype is None else out_dtype
+    # a single process with fp32 output needs no gather buffer: the windows' interiors go straight into the frame (one pass each, utils.window_to_planes)
+    direct = multi is not None and ws == 1 and odt == torch.float32 and not (_N.FORCE_COLLECTIVES and dist.is_initialized())
+    if direct:
+        if out is None:
+            out = torch.empty([1, 3, H * scale, W * scale], dtype=odt, device=dev)
+        assert out.dtype == odt
+    elif send is None:
+        send = torch.zeros([3, slot], dtype=torch.float32, device=dev)
     if multi is not None:
         for p0 in range(0, len(pending), multi.max_jobs):
             part = pending[p0:p0 + multi.max_jobs]
-            for hr, (_, _, o, th, tw, oy, ox) in zip(multi([p[0] for p in part], [p[1] for p in part]), part):
-                send[:, o:o + th * tw] = hr[0, :, oy:oy + th, ox:ox + tw].reshape(3, -1)
-    odt = torch.float32 if out_dtype is None else out_dtype
+            for hr, (_, _, o, th, tw, oy, ox, ti) in zip(multi([p[0] for p in part], [p[1] for p in part]), part):
+                if direct:
+                    y0, y1, x0, x1 = tiles[ti][:4]
+                    window_to_planes(hr, oy, ox, th, tw, out[0, :, y0 * scale:y1 * scale, x0 * scale:x1 * scale])
+                else:
+                    window_to_planes(hr, oy, ox, th, tw, send[:, o:o + th * tw].view(3, th, tw))
+    if direct:
+        return out
     if odt == torch.uint8:
         send = _to8b(send)
     elif odt != torch.float32:

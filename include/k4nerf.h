@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side, k4_nhwc_window_to_planar; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -280,6 +280,11 @@ int k4_get_rays_of_a_view(int32_t H, int32_t W, const float* K_dev, const float*
                           int32_t inverse_y, int32_t flip_x, int32_t flip_y, int32_t mode_center, float focal,
                           float* rays_o, float* rays_d, float* viewdirs, void* stream);
 int k4_to8b(const float* x, int64_t n, uint8_t* out, void* stream);
+/* The interior of a decoded window into the frame (SFTNet.tile_process, lib/sr_esrnet.py:508-524: output_tile[..., crop] -> output[..., tile]) in ONE pass:
+ * dst[c * dst_plane_stride + y * dst_row_stride + x] = src[((oy + y) * src_w + ox + x) * channels + c], 0 <= y < th, 0 <= x < tw, c < channels (<= 4);
+ * src: the window's NHWC result [*][src_w][channels], dst: planes of the [1, 3, 4H, 4W] frame (pre-offset to the tile) or of a gather buffer. */
+int k4_nhwc_window_to_planar(const float* src, int32_t src_w, int32_t channels, int32_t oy, int32_t ox, int32_t th, int32_t tw,
+                             float* dst, int64_t dst_plane_stride, int64_t dst_row_stride, void* stream);
 /* load-time repack of `k0.grid` [C][X][Y][Z] -> [X][Y][Z][CP] (zero padded channels) */
 int k4_repack_k0(const float* k0_cmajor, int32_t channels, int32_t cpad, int64_t n_voxels, float* out, void* stream);
 

@@ -78,3 +78,24 @@ def test_dense_grid_pending_update_hooks_are_inert_without_one():
     g3 = copy.deepcopy(g).double()
     assert g3.grid.dtype == torch.float64 and torch.equal(g3.grid.float(), g.grid)
     assert torch.equal(g.get_dense_grid(), g.grid)
+
+
+def test_fast_parameter_list_tracks_replaced_parameters():
+    """SFTNet.k4_parameters: the cached (module, name, parameter) triples behind the per-call cache keys equal nn.Module.parameters() -- also after a Parameter
+    object was replaced, a module moved / cast (same objects, new storage) or updated in place (version bump seen through the same objects)."""
+    import torch.nn as nn
+    from nerf4k_amd.lib import sr_esrnet
+    net = sr_esrnet.SFTNet(3, scale=4, num_block=1)
+    a = net.k4_parameters()
+    assert len(a) == len(list(net.parameters())) and all(x is y for x, y in zip(a, net.parameters()))
+    assert net.k4_parameters() is a                                     # validated, not rebuilt
+    v0 = tuple(p._version for p in a)
+    with torch.no_grad():
+        net.conv_last.bias.add_(1.0)
+    assert tuple(p._version for p in net.k4_parameters()) != v0
+    net.conv_first.weight = nn.Parameter(torch.zeros_like(net.conv_first.weight))
+    b = net.k4_parameters()
+    assert b is not a and all(x is y for x, y in zip(b, net.parameters()))
+    net.double()
+    c = net.k4_parameters()
+    assert all(x is y for x, y in zip(c, net.parameters())) and c[0].dtype == torch.float64

@@ -1,0 +1,26 @@
+"""Frames of the single-GPU 4K job (tile_parallel.render_frame_tiles at test_tile=510) for a rocprofv3 kernel trace: tools/four_k_timeline.sh."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nerf4k_amd
+from nerf4k_amd import scene, tile_parallel as tp
+from nerf4k_amd.lib import sr_esrnet, utils, dvgo
+dev = torch.device('cuda', 0)
+ck = scene.make_llff_checkpoint()
+model = utils.model_from_checkpoint_dict(ck).to(dev).eval()
+torch.manual_seed(777)
+net = sr_esrnet.SFTNet(3, scale=4, num_feat=64, num_block=5, num_grow_ch=32, num_cond=1).to(dev).eval()
+H, W = scene.LLFF_HW
+poses = scene.llff_spiral_poses()
+rk = dict(ck['render_kwargs'])
+march_fn, sr_fn = tp.hip_march_fn(model, rk), tp.hip_sr_fn(net)
+with torch.no_grad():
+    frames = [dvgo.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(poses[i]).to(dev), True, False, False, False) for i in range(3)]
+    hr = tp.render_frame_tiles(frames[0], H, W, march_fn, sr_fn, 510)
+    hr = tp.render_frame_tiles(frames[1], H, W, march_fn, sr_fn, 510, out=hr)
+    torch.cuda.synchronize()
+    n = int(os.environ.get('FRAMES', '6'))
+    t = time.perf_counter()
+    for i in range(n):
+        hr = tp.render_frame_tiles(frames[i % 3], H, W, march_fn, sr_fn, 510, out=hr)
+    torch.cuda.synchronize()
+    print('ms per 4K frame', round((time.perf_counter() - t) / n * 1e3, 2))

@@ -17,6 +17,8 @@ tiles = tp.tile_geometry(756, 1008, TS, 10)
 owned = tp.assign_tiles(tiles, 8)
 rk = max(range(8), key=lambda q: sum((tiles[i][5] - tiles[i][4]) * (tiles[i][7] - tiles[i][6]) for i in owned[q]))
 mine = [tiles[i] for i in owned[rk]]
+if os.environ.get('ALL') == '1':          # every window of the frame (the single-GPU 4K frame at TS=510: four windows)
+    mine = list(tiles)
 wins = [(x[:, :, t[4]:t[5], t[6]:t[7]], c[:, :, t[4]:t[5], t[6]:t[7]]) for t in mine]
 print('windows', [(int(a.shape[2]), int(a.shape[3])) for a, _ in wins])
 with torch.no_grad():
