@@ -98,14 +98,37 @@ def march_frame_tiles(rays, H, W, march_fn, sr_fn, tile_size, tile_pad=10, scale
     n_str = _n_streams(dev, len(owned[rk]), march_fn, sr_fn)
     pool = _stream_pool(dev, n_str) if n_str > 1 else None
     cur = torch.cuda.current_stream(dev) if n_str > 1 else None
-    for fn in (march_fn, sr_fn):         # cold caches (k0 repack, packed rgbnet / conv weights) are built on the CURRENT stream,
+    multi_ = getattr(sr_fn, 'k4_multi', None)
+    # (a single process marches the whole frame on the current stream, below: the decoder's cache check -- a sweep over its 458 parameter versions -- then
+    # runs on the host while the march runs on the GPU instead of in front of it)
+    whole_ = WHOLE_FRAME_MARCH and ws == 1 and multi_ is not None and dev.type == 'cuda' and getattr(march_fn, 'k4_slots', False) and len(owned[rk]) > 1
+    for fn in ((march_fn,) if whole_ else (march_fn, sr_fn)):         # cold caches (k0 repack, packed rgbnet / conv weights) are built on the CURRENT stream,
         warm = getattr(fn, 'k4_warm', None)      # before the side streams fork from it -- never inside one of them
         if warm is not None:
             warm()
-    if pool:
+    if pool and not whole_:
         for st in pool:
             st.wait_stream(cur)
     pending = []
+    # A single process owns every tile: ONE march of the whole frame (what render_viewpoints -> tile_process does, run_sr.py:1361-1390) instead of one per padded
+    # window -- the windows overlap by their halos (1.05x the rays at tile 510) and four small launches fill the chip worse than one; a window of the frame's
+    # result holds the bits of the window's own march (tests: tile == frame), so the pixels do not change.
+    whole = WHOLE_FRAME_MARCH and ws == 1 and multi is not None and dev.type == 'cuda' and getattr(march_fn, 'k4_slots', False) and len(owned[rk]) > 1
+    if whole:
+        rgb_f, depth_f = march_fn(*[r.reshape(-1, 3) if r.is_contiguous() else r.reshape(-1, 3).contiguous() for r in rays], W)
+        rgb_f, depth_f = rgb_f.reshape(H, W, 3), depth_f.reshape(H, W)
+        warm = getattr(sr_fn, 'k4_warm', None)
+        if warm is not None:
+            warm()
+        for i in owned[rk]:
+            y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
+            th, tw = (y1 - y0) * scale, (x1 - x0) * scale
+            img = rgb_f[yp0:yp1, xp0:xp1].permute(2, 0, 1).unsqueeze(0)          # (views: the decoder copies its windows into its own NHWC buffers)
+            cond = depth_f[yp0:yp1, xp0:xp1].unsqueeze(0).unsqueeze(0)
+            pending.append((img, cond, off, th, tw, (y0 - yp0) * scale, (x0 - xp0) * scale, i))
+            off += th * tw
+        return {'tiles': tiles, 'owned': owned, 'slot': slot, 'send': send, 'pending': pending, 'multi': multi, 'events': None, 'cur': cur,
+                'ws': ws, 'group': group, 'H': H, 'W': W, 'scale': scale, 'dev': dev}
     for j, i in enumerate(owned[rk]):
         y0, y1, x0, x1, yp0, yp1, xp0, xp1 = tiles[i]
         th, tw = (y1 - y0) * scale, (x1 - x0) * scale
@@ -198,6 +221,7 @@ def _to8b(x):
 
 
 TILE_STREAMS = 4        # HIP streams a rank deals its tiles to (1: sequential; same pixels either way, tests)
+WHOLE_FRAME_MARCH = True        # a single process marches the frame ONCE and cuts its windows out of the result (False: one march per padded window, as every rank of a multi-GPU job does; same pixels, tests)
 
 
 def _stream_pool(dev, n):

@@ -75,12 +75,16 @@ def test_tile_parallel_hip_path_vs_oracle(tile, n_tiles, monkeypatch):
     net = net.cuda().eval()
     rays = dvgo.get_rays_of_a_view(H, W, K, torch.from_numpy(pose).cuda(), True, False, False, False)
     march_fn, sr_fn = tp.hip_march_fn(model, ck['render_kwargs']), tp.hip_sr_fn(net)
+    monkeypatch.setattr(tp, 'WHOLE_FRAME_MARCH', False)          # one march per padded window on the worker streams: what every rank of a multi-GPU job runs
     monkeypatch.setattr(tp, 'TILE_STREAMS', 4)
     got = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile).clone()
     got2 = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile).clone()          # warm caches, reused slots
     monkeypatch.setattr(tp, 'TILE_STREAMS', 1)
     seq = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile)
     assert torch.equal(got, seq) and torch.equal(got2, seq)
+    monkeypatch.setattr(tp, 'WHOLE_FRAME_MARCH', True)           # a single process: ONE march of the frame, windows cut out of its result -- the same pixels
+    whole = tp.render_frame_tiles(rays, H, W, march_fn, sr_fn, tile)
+    assert torch.equal(whole, seq)
     want, _ = _oracle_frame(ck, H, W, K, pose, sd, tile)
     _close(got, want)
     # (c) same pixels as the single-GPU drop-in path: fused marcher on the whole frame, then tile_process_device
