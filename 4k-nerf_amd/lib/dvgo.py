@@ -224,6 +224,22 @@ class _FusedMarcher:
                 ts.append(l.weight)
                 ts.append(l.bias)
         key = (tag, extra_key, _LIVE_MASK, os.environ.get('K4_MLP')) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+        return self._k4_plan_for(tag, key, build)
+
+    def _k4_versions_key(self):
+        """(storage, version) of every tensor the fused path's load-time state is derived from (see _k4_plan)."""
+        mc = self.mask_cache
+        ts = [self.density.grid, self.k0.grid, mc.mask, self.xyz_min, self.xyz_max, mc.xyz2ijk_scale, mc.xyz2ijk_shift]
+        act = getattr(self, 'act_shift', None)
+        ts.append(act.grid if isinstance(act, nn.Module) else act)
+        if self.rgbnet is not None:
+            for l in self.rgbnet.modules():
+                if isinstance(l, nn.Linear):
+                    ts.append(l.weight)
+                    ts.append(l.bias)
+        return tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+
+    def _k4_plan_for(self, tag, key, build):
         c = self._k4_cache()
         plan = c.get(('plan', tag))
         st = N.stream().value
@@ -240,6 +256,14 @@ class _FusedMarcher:
         caller names the render stepsize, the live mask) on the current stream.  Callers that fan work out over several HIP streams
         call this before forking them."""
         if self._k4_fusable():
+            # (a render loop warms before every frame: nothing to do while no tensor behind the caches changed -- the per-part caches below rebuild their keys
+            #  and ctypes structs on every call, ~0.2 ms of host time in front of a frame's first kernel)
+            c = self._k4_cache()
+            wkey = None
+            if getattr(self, 'mask_cache', None) is not None:
+                wkey = (None if stepsize is None else float(stepsize), _LIVE_MASK, os.environ.get('K4_MLP'), N.stream().value) + self._k4_versions_key()
+                if c.get('warm_key') == wkey:
+                    return
             act = getattr(self, 'act_shift', None)
             mpi = isinstance(act, nn.Module)
             live = None
@@ -248,6 +272,7 @@ class _FusedMarcher:
             self._k4_grid(act_shift_grid=act.grid if mpi else None, live=live)
             if self.rgbnet is not None:
                 self._k4_mlp(k0_skip=0, spatial_pe=0)
+            c['warm_key'] = wkey
 
     def _k4_host_scalar(self, name, t):
         """float(t) for a 1-element device buffer without a D2H sync per call (cached per version)."""
