@@ -2,10 +2,10 @@
 # Kernel timeline of the single-GPU 4K frame loop (rocprofv3 kernel trace): GPU busy / idle per frame and the largest gaps -- where the frame's time beyond its kernels goes.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${OUT:-r06_four_k_timeline}; mkdir -p $OUT
-python $R/tools/four_k_timeline.py 2>/dev/null | tail -1
+python $R/${FRAME_SCRIPT:-tools/four_k_timeline.py} 2>/dev/null | tail -1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_4k
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_4k -o run -- python $R/tools/four_k_timeline.py > $OUT/timeline.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_4k -o run -- python $R/${FRAME_SCRIPT:-tools/four_k_timeline.py} > $OUT/timeline.log 2>&1
 f=$(find /tmp/prof_4k -name '*kernel_trace.csv' | head -1)
 tail -1 $OUT/timeline.log
 python - <<PY
