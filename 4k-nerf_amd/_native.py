@@ -51,7 +51,7 @@ class RdbTrain(C.Structure):         # k4_rdb_train
                 ('dwdb', C.c_void_p * 5), ('gsft0', C.c_void_p * 8), ('gsft1', C.c_void_p * 8),
                 ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p),
                 ('gc_acc', C.c_void_p), ('gx0_add', C.c_void_p), ('dwdb_span', C.c_void_p), ('dwdb_span_floats', C.c_int64),
-                ('fused_lrelu', C.c_int32), ('g5_from_gx0_add', C.c_int32), ('no_join', C.c_int32)]
+                ('fused_lrelu', C.c_int32), ('g5_from_gx0_add', C.c_int32), ('no_join', C.c_int32), ('defer_side', C.c_int32)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -187,6 +187,8 @@ _EXTRA_SIGS = {
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_sft_train_bwd_side': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
+    'k4_sft_train_bwd_main': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
+    'k4_sft_train_reduce': ([_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
     'k4_nhwc_window_to_planar': ([_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P], C.c_int),
     'k4_tape_begin': ([_P], C.c_void_p),

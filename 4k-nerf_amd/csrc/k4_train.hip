@@ -844,14 +844,14 @@ template <int C>
 static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, const float* gy, int gys, int64_t n,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
                           float slope, float* gx, float* gc, float* ws, float* const* gout, const float* gxa, int gxa_stride, int gc_acc, int gx_lrelu, float gy_scale, hipStream_t st,
-                          hipStream_t red_st) {
+                          hipStream_t red_st, bool do_reduce = true) {
     typedef SftBwdLayout<C> L;
     const size_t lds = (size_t)L::ROWS * TR_LS * sizeof(float);
     K4_ENSURE_DYN_LDS((k_sft_train_bwd<C>), lds);
     const int grid = sft_bwd_grid(n);
     hipLaunchKernelGGL((k_sft_train_bwd<C>), dim3(grid), dim3(SFT_T), lds, st, x, xs, cond, cs, gy, gys, n, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, gx, gc, ws, gxa, gxa_stride, gc_acc, gx_lrelu, gy_scale);
     int rc = k4_check_launch();
-    if (rc) return rc;
+    if (rc || !do_reduce) return rc;
     const int total = 2 * C * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
     if (red_st != st) {
         rc = k4_wait_stream(red_st, st);
@@ -862,14 +862,14 @@ static int sft_launch_bwd(const float* x, int xs, const float* cond, int cs, con
     return k4_check_launch();
 }
 
-extern "C" int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
-                                     int64_t n_pix, int32_t channels,
-                                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
-                                     float slope, float* grad_x, float* grad_cond,
-                                     float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
-                                     float* workspace, int64_t workspace_bytes,
-                                     const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
-                                     void* side_stream, void* stream) {
+static int sft_bwd_entry(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                         int64_t n_pix, int32_t channels,
+                         const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                         float slope, float* grad_x, float* grad_cond,
+                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                         float* workspace, int64_t workspace_bytes,
+                         const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
+                         void* side_stream, bool do_reduce, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
     if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
@@ -880,8 +880,44 @@ extern "C" int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const flo
         hipStream_t st = (hipStream_t)stream;
         const int acc = accumulate_grad_cond != 0;
         hipStream_t red = side_stream ? (hipStream_t)side_stream : st;
-        if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red);
-        return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red);
+        if (channels == 64) return sft_launch_bwd<64>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red, do_reduce);
+        return sft_launch_bwd<32>(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond, workspace, gout, grad_x_add, gxa_stride, acc, grad_x_lrelu != 0, grad_y_scale, st, red, do_reduce);
+    });
+}
+extern "C" int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                     int64_t n_pix, int32_t channels,
+                                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                     float slope, float* grad_x, float* grad_cond,
+                                     float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
+                                     float* workspace, int64_t workspace_bytes,
+                                     const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
+                                     void* side_stream, void* stream) {
+    return sft_bwd_entry(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
+                         gw0s, gb0s, gw1s, gb1s, gw0h, gb0h, gw1h, gb1h, workspace, workspace_bytes, grad_x_add, gxa_stride, accumulate_grad_cond, grad_x_lrelu,
+                         grad_y_scale, side_stream, true, stream);
+}
+// The two halves of k4_sft_train_bwd_ex as calls of their own: the kernel that produces grad_x / grad_cond and the per-workgroup partial sums (`workspace`), and
+// the reduction of the partials to the eight parameter gradients -- a caller that batches its side-stream work issues the reductions of several layers behind
+// ONE fork (every hipEventRecord on the chain's stream costs ~7 us of the chain's time: profiles/r06_joint_phase_events.md, section 8).
+extern "C" int k4_sft_train_bwd_main(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                     int64_t n_pix, int32_t channels,
+                                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                     float slope, float* grad_x, float* grad_cond, float* workspace, int64_t workspace_bytes,
+                                     const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
+    float* const dummy = workspace;                                 // (the entry's NULL checks; the reduction that would write the gradients is not launched)
+    return sft_bwd_entry(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
+                         dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, workspace, workspace_bytes, grad_x_add, gxa_stride, accumulate_grad_cond, grad_x_lrelu,
+                         grad_y_scale, nullptr, false, stream);
+}
+extern "C" int k4_sft_train_reduce(const float* workspace, int64_t n_pix, int32_t channels,
+                                   float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h, void* stream) {
+    if ((channels != 32 && channels != 64) || n_pix <= 0 || !workspace || !gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
+    return k4_taped(stream, [=](void* stream) -> int {
+        const int grid = sft_bwd_grid(n_pix);
+        const int total = 2 * channels * (SFT_G + 1) + 2 * SFT_G * (SFT_G + 1);
+        hipLaunchKernelGGL(k_sft_train_reduce, dim3((total + TR_RED_ELEMS - 1) / TR_RED_ELEMS), dim3(256), 0, (hipStream_t)stream, workspace, grid, channels,
+                           gw1s, gb1s, gw1h, gb1h, gw0s, gb0s, gw0h, gb0h);
+        return k4_check_launch();
     });
 }
 extern "C" int k4_sft_train_bwd_ex(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
@@ -1028,7 +1064,15 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
 #undef K4_RDB_TRY
 #define K4_RDB_TRY(CALL) do { rc = (CALL); if (rc != 0) goto join; } while (0)
     // a weight gradient on the side stream: forked behind everything queued on the main stream so far (= the producer of the gradient slice it reads)
+    // defer_side: every side-stream launch of the block (zero-fill, five weight gradients, two SFT reductions) is issued at the END of the block behind ONE fork.
+    // Forking per weight gradient put a hipEventRecord on the chain's stream in front of every dgrad launch: ~7 us of the chain's time each, 1.0 ms of a 4.1 ms
+    // backward pass (profiles/r06_joint_phase_events.md, section 8).  Needs a caller that does not join per block (no_join): the weight gradients of block b then
+    // run beside the chain of block b - 1.
+    const bool defer = p->defer_side != 0 && side != main_s;
+    struct WgradQ { int cin; const float* gy; int cout; int gys; int k; } wq[5];
+    int nwq = 0;
 #define K4_RDB_WGRAD(CIN, GY, COUT, GYS, K) do { \
+        if (defer) { wq[nwq].cin = (CIN); wq[nwq].gy = (GY); wq[nwq].cout = (COUT); wq[nwq].gys = (GYS); wq[nwq].k = (K); ++nwq; break; } \
         K4_RDB_TRY(k4_wait_stream(side, main_s)); \
         if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); \
         else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, (CIN), bw, (GY), (COUT), (GYS), 3, H, W, p->dwdb[K], (void*)side)); } while (0)
@@ -1042,8 +1086,10 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     // weight gradient there) instead of one per layer
     if (p->dwdb_span_floats > 0) {
         if (!p->dwdb_span) return K4_ERR_BAD_ARG;
-        K4_RDB_TRY(k4_wait_stream(side, main_s));                                  // (the span may be memory the main stream's earlier work still reads)
-        K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
+        if (!defer) {
+            K4_RDB_TRY(k4_wait_stream(side, main_s));                              // (the span may be memory the main stream's earlier work still reads)
+            K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
+        }
     }
     if (p->g5_from_gx0_add) {                                                       // g5 = 0.2 grad_out (conv5's output is scaled by 0.2 in the forward pass)
         const bool vec = (((uintptr_t)p->gx0_add | (uintptr_t)p->g5) & 15u) == 0;
@@ -1056,7 +1102,9 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
     K4_RDB_DGRAD(4, p->g5, nf, bw, false, false);                                  // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
-    K4_RDB_TRY(k4_sft_train_bwd_side(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+    if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+                                                0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, stream));
+    else K4_RDB_TRY(k4_sft_train_bwd_side(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                      0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
                                      p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, p->side_stream, stream));
     if (!fl) K4_RDB_TRY(k4_lrelu_bwd(p->gx4, g, p->x4, g, n, g, 0.2f, p->gx4, g, stream));
@@ -1069,9 +1117,21 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
         K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true, fl && k > 1);               // (k == 1 completes xc0's slice: sft0's output, no activation)
     }
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
-    K4_RDB_TRY(k4_sft_train_bwd_side(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+    if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+                                                0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, stream));
+    else K4_RDB_TRY(k4_sft_train_bwd_side(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                      0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
                                      p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, p->side_stream, stream));
+    if (defer) {                                                                    // the block's side-stream work behind ONE fork
+        K4_RDB_TRY(k4_wait_stream(side, main_s));
+        if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
+        for (int q = 0; q < nwq; ++q) {
+            if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
+            else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
+        }
+        K4_RDB_TRY(k4_sft_train_reduce(p->ws1, n, g, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7], (void*)side));
+        K4_RDB_TRY(k4_sft_train_reduce(p->ws0, n, nf, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7], (void*)side));
+    }
 join:
 #undef K4_RDB_WGRAD
 #undef K4_RDB_DGRAD

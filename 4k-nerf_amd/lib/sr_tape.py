@@ -249,6 +249,7 @@ class DecoderProgram:
             d.gc_acc = G['acc'].data_ptr()
             d.side_stream = self.side
             d.no_join = int(self.side is not None)                # ONE join, behind the whole backward pass (_backward_calls): the buffers are this program's own
+            d.defer_side = int(self.side is not None)             # ... and ONE fork per block: every event record on the chain's stream costs ~7 us of the chain's time
             self.scr.append(scr)
             self.desc.append(d)
         self.signature = signature(net)
@@ -260,16 +261,32 @@ class DecoderProgram:
                                               flags | pk.flags_extra | (CONV_SMALL if pk.k == 3 and not pk.flags_extra else 0), 0.2, None if res is None else N.f32(res), 0 if res is None else cout_stride,
                                               res_scale, None, 0, N.stream()), 'k4_conv2d_nhwc_bf16x6')
 
+    def _side_call(self, fn):
+        """A launch that only produces parameter gradients (weight gradients, SFT reductions): queued for the side stream and issued by _flush_side behind a fork that
+        covers a whole section of the chain (a fork per launch put an event record -- ~7 us of the chain's time -- in front of every dgrad launch); without a side
+        stream it runs now, on the chain's stream."""
+        if self.side is None:
+            fn(N.stream())
+        else:
+            self._side_q.append(fn)
+
+    def _flush_side(self, fork):
+        """Issue the queued side-stream launches.  fork=False: the side stream already waits for everything queued so far (a dense block's call has just forked)."""
+        if self.side is None or not self._side_q:
+            return
+        st = N.C.c_void_p(self.side)
+        if fork:
+            N.check(N.lib().k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
+        for fn in self._side_q:
+            fn(st)
+        self._side_q = []
+
     def _wgrad(self, mod, x, gy, H, W, name):
-        """[dW | dbias] of `mod` into its piece of the flat buffer, on the side stream (forked behind the launch that completed gy)."""
+        """[dW | dbias] of `mod` into its piece of the flat buffer, on the side stream (_side_call)."""
         L = N.lib()
         cout, cin, k, _ = mod.weight.shape
-        side = self.side if self.side is not None else N.stream().value
-        st = N.C.c_void_p(side)
-        if self.side is not None:
-            N.check(L.k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
-        N.check(L.k4_conv2d_wgrad_dbias_bf16x6(N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W,
-                                               N.C.c_void_p(self.pg.data_ptr() + 4 * self.pg_off[name]), st), 'k4_conv2d_wgrad_dbias_bf16x6')
+        args = (N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.C.c_void_p(self.pg.data_ptr() + 4 * self.pg_off[name]))
+        self._side_call(lambda st: N.check(L.k4_conv2d_wgrad_dbias_bf16x6(*args, st), 'k4_conv2d_wgrad_dbias_bf16x6'))
 
     def _lrelu_bwd(self, g, y):
         C = g.shape[2]
@@ -284,10 +301,13 @@ class DecoderProgram:
         C = x.shape[2]
         ps = _sft_params(layer)
         pb = self.pg.data_ptr()
-        N.check(N.lib().k4_sft_train_bwd_side(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, self.h * self.w, C, *[N.f32(p) for p in ps[:7]], 0.2,
-                                              N.f32(gx), N.f32(self.G['acc']), *[N.C.c_void_p(pb + 4 * o) for o in self.pg_off[name]],
-                                              N.f32(self.sft_ws[name]), self.sft_ws_bytes[C], None, 0, 1, 0, float(gy_scale),
-                                              None if self.side is None else N.C.c_void_p(self.side), N.stream()), 'k4_sft_train_bwd_side')
+        L = N.lib()
+        n = self.h * self.w
+        N.check(L.k4_sft_train_bwd_main(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:7]], 0.2,
+                                        N.f32(gx), N.f32(self.G['acc']), N.f32(self.sft_ws[name]), self.sft_ws_bytes[C], None, 0, 1, 0, float(gy_scale), N.stream()),
+                'k4_sft_train_bwd_main')
+        rargs = (N.f32(self.sft_ws[name]), n, C, *[N.C.c_void_p(pb + 4 * o) for o in self.pg_off[name]])
+        self._side_call(lambda st: N.check(L.k4_sft_train_reduce(*rargs, st), 'k4_sft_train_reduce'))
 
     # ------------------------------------------------------------------------------------------------ the pass, call by call
     def _forward_calls(self):
@@ -328,6 +348,7 @@ class DecoderProgram:
         L = N.lib()
         m = s if s in (2, 4) else 1
         n = h * w
+        self._side_q = []
         N.check(L.k4_zero_f32(N.f32(G['acc']), G['acc'].numel(), N.stream()), 'k4_zero_f32')        # every SFT layer ADDS its condition gradient
         # conv_last, conv_hr
         self._wgrad(net.conv_last, A['hr'], G['out'], m * h, m * w, 'conv_last')
@@ -354,6 +375,7 @@ class DecoderProgram:
         nb = self.nb
         g_body, g_other = G['body'], G['body2']
         self._sft_bwd(net.sftbody, A[f'body{nb - 1}'] if nb else A['feat'], G['sb'], g_body, 'sftbody', 1.0)
+        self._flush_side(fork=True)                                                # the high-resolution layers' weight gradients run beside the trunk's chain
         for b in range(nb - 1, -1, -1):
             rr = net.body[b]
             self._sft_bwd(rr.sft0, A[f'o{3 * b + 2}'], g_body, G['o3'], f'sft{b}', 0.2)      # body_b = sft(o3) * 0.2 + body_{b-1}
@@ -363,6 +385,7 @@ class DecoderProgram:
                 d = self.desc[q]
                 d.gx0_add = go.data_ptr()
                 N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
+                self._flush_side(fork=False)                                       # (the block's call ended with a fork: what was queued before it is covered)
                 go = self.scr[q][:n * nf].view(h, w, nf)                           # = go + the gradient through the block's sft0
             # the RRDB's input reaches its first dense block and the skip connection: the sum of both gradients.  The first RRDB's input is `feat`,
             # which the long skip connection reads too: three addends, summed in the order the autograd engine received them (same roundings)
@@ -393,6 +416,7 @@ class DecoderProgram:
         if self.cond_grad:
             ncond = A['ci'].shape[2]
             self._conv(self.bw_(cn[0]), G['c1'], 64, G['ci'], ncond, ncond, h, w)
+        self._flush_side(fork=True)
         if self.side is not None:
             N.check(L.k4_main_wait_side(N.C.c_void_p(self.side), N.stream()), 'k4_main_wait_side')      # the weight gradients are done before the optimizer reads them
 

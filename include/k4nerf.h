@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join, k4_sft_train_bwd_side, k4_nhwc_window_to_planar; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -516,6 +516,9 @@ typedef struct k4_rdb_train {
     int32_t no_join;                /* ABI 13, != 0: k4_rdb_train_bwd does NOT make `stream` wait for side_stream before it returns -- the caller joins once,
                                        behind the last block (k4_main_wait_side), and keeps every buffer of the descriptor alive until then: with a join per
                                        block the chain waited ~40 us at every block for the weight gradient it had forked last */
+    int32_t defer_side;             /* ABI 13, != 0 (with side_stream): the block's side-stream launches (zero-fill, five weight gradients, two SFT reductions) are issued at
+                                       the END of the block behind ONE fork instead of one fork per launch -- an event record on `stream` in front of every dgrad launch cost
+                                       ~7 us of the chain's time each.  Use with no_join (the weight gradients of a block then run beside the next block's chain). */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -655,6 +658,16 @@ int k4_streams_overlap(void* a, void* b);
 int k4_side_wait_main(void* side, void* stream);
 int k4_main_wait_side(void* side, void* stream);
 
+/* The two halves of k4_sft_train_bwd_ex as calls of their own (a caller that batches its side-stream work issues several layers' reductions behind ONE fork):
+ * k4_sft_train_bwd_main = grad_x / grad_cond + the per-workgroup partial sums in `workspace`; k4_sft_train_reduce = the partials of a k4_sft_train_bwd_main
+ * call on (n_pix, channels) summed in workgroup order into the eight parameter gradients (overwritten), on `stream`. */
+int k4_sft_train_bwd_main(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                          int64_t n_pix, int32_t channels,
+                          const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                          float slope, float* grad_x, float* grad_cond, float* workspace, int64_t workspace_bytes,
+                          const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
+int k4_sft_train_reduce(const float* workspace, int64_t n_pix, int32_t channels,
+                        float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h, void* stream);
 /* k4_sft_train_bwd_ex whose reduction of the per-workgroup partial sums (the eight parameter gradients; nothing on the caller's chain reads them) is forked
  * to side_stream (NULL = `stream`: k4_sft_train_bwd_ex): the caller joins side_stream before the gradients are read and keeps `workspace` untouched until then. */
 int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
