@@ -189,6 +189,7 @@ _EXTRA_SIGS = {
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'k4_sft_train_bwd_main': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_sft_train_reduce': ([_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'k4_rgbnet_input_mpi': ([_P, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P, _I32, _P, _I32, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
     'k4_nhwc_window_to_planar': ([_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P], C.c_int),
     'k4_tape_begin': ([_P], C.c_void_p),

@@ -465,6 +465,61 @@ extern "C" int k4_distortion_loss(const float* w, const float* s, const int64_t*
 }
 
 // --------------------------------------------------------------------------------------------------------------------
+// The colour MLP's input of DirectMPIGO's training forward (lib/dmpigo.py:360-374) in ONE launch:
+//   x[i] = [ vox_emb[i] (C) | pe_spa (3) | sin(pe_spa f) (3 P) | cos(pe_spa f) (3 P) | viewdirs[r] (3) | sin(viewdirs[r] g) (3 V) | cos(...) (3 V) ],  r = ray_id[i],
+//   pe_spa[j] = ((p[2 - j] - min[2 - j]) / (max[2 - j] - min[2 - j])) * 2 - 1   (the reference's op sequence: sub, div, flip, mul, sub -- one rounding each),
+//   pe_emb column 3 + d P + f = pe_spa[d] * posfreq[f] (`(pe_spa.unsqueeze(-1) * posfreq).flatten(-2)`), likewise the view directions.
+// As PyTorch ops this was 16 launches (most of them on empty tensors in the LLFF configuration: no frequencies) issued by a host that paces the phase:
+// the GPU needs 0.9 ms for the marcher's training forward and spent 1.9 ms in it (profiles/r06_joint_phase_events.md).
+// --------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rgbnet_input_mpi(const float* __restrict__ vox, int C, const float* __restrict__ pts, const float* __restrict__ vd,
+                                                          const int64_t* __restrict__ ray_id, int64_t n, const float* __restrict__ lo, const float* __restrict__ hi,
+                                                          const float* __restrict__ pf, int P, const float* __restrict__ vf, int V, float* __restrict__ x, int dim0) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * dim0) return;
+    const int64_t i = t / dim0;
+    int col = (int)(t - i * dim0);
+    float v;
+    if (col < C) v = vox[i * C + col];
+    else {
+        col -= C;
+        const int npe = 3 + 6 * P;
+        const bool view = col >= npe;
+        if (view) col -= npe;
+        const int F = view ? V : P;
+        const float* const fr = view ? vf : pf;
+        // component d of the embedded 3-vector; which = 0 plain, 1 sin, 2 cos; f = frequency index
+        int which = 0, d = col, f = 0;
+        if (col >= 3) { const int c2 = col - 3; which = 1 + c2 / (3 * F); const int r = c2 % (3 * F); d = r / F; f = r % F; }
+        float base;
+        if (view) base = vd[ray_id[i] * 3 + d];
+        else {
+            const int a = 2 - d;                                                   // .flip((-1,))
+            const float q = __fdiv_rn(__fsub_rn(pts[i * 3 + a], lo[a]), __fsub_rn(hi[a], lo[a]));
+            base = __fsub_rn(__fmul_rn(q, 2.f), 1.f);
+        }
+        if (which == 0) v = base;
+        else {
+            const float arg = __fmul_rn(base, fr[f]);
+            v = which == 1 ? sinf(arg) : cosf(arg);
+        }
+    }
+    x[t] = v;
+}
+extern "C" int k4_rgbnet_input_mpi(const float* vox_emb, int32_t channels, const float* ray_pts, const float* viewdirs, const int64_t* ray_id, int64_t n_pts,
+                                   const float* xyz_min, const float* xyz_max, const float* posfreq, int32_t n_posfreq, const float* viewfreq, int32_t n_viewfreq,
+                                   float* x, int32_t dim0, void* stream) {
+    if (n_pts < 0 || channels < 0 || n_posfreq < 0 || n_viewfreq < 0 || dim0 != channels + 3 + 6 * n_posfreq + 3 + 6 * n_viewfreq) return K4_ERR_BAD_ARG;
+    if (n_pts == 0) return K4_OK;
+    if (!ray_pts || !viewdirs || !ray_id || !xyz_min || !xyz_max || !x || (channels > 0 && !vox_emb) || (n_posfreq > 0 && !posfreq) || (n_viewfreq > 0 && !viewfreq)) return K4_ERR_BAD_ARG;
+    const int64_t total = n_pts * dim0;
+    if ((total + 255) / 256 > 0x7fffffffLL) return K4_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_rgbnet_input_mpi, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vox_emb, channels, ray_pts, viewdirs, ray_id, n_pts,
+                       xyz_min, xyz_max, posfreq, n_posfreq, viewfreq, n_viewfreq, x, dim0);
+    return k4_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
 // SFTLayer of the VC-Decoder under autograd (lib/sr_esrnet.py:112-123): y = x * (scale(cond) + 1) + shift(cond) with
 //   scale = W1s lrelu(W0s c + b0s) + b1s,  shift = W1h lrelu(W0h c + b0h) + b1h       (1x1 convolutions 32 -> 32 -> C, slope 0.2).
 // The joint training step evaluates 36 of these per iteration on a 64x64 patch; as four convolution Functions + PyTorch elementwise

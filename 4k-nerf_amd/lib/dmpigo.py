@@ -20,8 +20,10 @@ import torch.nn as nn
 from .. import _native as N
 from . import grid
 from . import dvgo as _dvgo
+from . import train_ops
 
 _TRAIN_PRESEL = True
+_FUSED_MLP_INPUT = True       # False: the colour MLP's input of the training forward built op by op as the reference does (A/B, tests)
 DEPTH_SPLIT = True              # fused marcher: depth-ordered geometry stage where the scene's density says it pays (_k4_depth_split); False: always one launch
 DEPTH_SPLIT_MIN_GAIN = 0.05     # smallest share of alpha-passing voxels behind the split in stopped columns for which the geometry stage is cut in two launches
                                 # (measured, profiles/r06_depth_split.md: the cut itself costs 0-2 % of the call at 128 / 192 of 256 samples, +4 % at 64; the opaque scene gains 10 %)
@@ -357,10 +359,15 @@ class DirectMPIGO(torch.nn.Module, _FusedMarcher):
         vox_emb = self.k0(ray_pts)
         if vox_emb.dim() == 1:
             vox_emb = vox_emb.unsqueeze(-1)
-        pe_spa = ((ray_pts - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
-        if self.rgbnet is None:
+        fused_in = None
+        if self.rgbnet is not None and _FUSED_MLP_INPUT:                  # the 16 ops below in one launch (lib/train_ops.RgbnetInputMPI: same values)
+            fused_in = train_ops.rgbnet_input_mpi(vox_emb, ray_pts, viewdirs, ray_id, self.xyz_min, self.xyz_max, self.posfreq, self.viewfreq)
+        if fused_in is not None:
+            rgb_raw = self._k4_rgbnet_sigmoid(fused_in)
+        elif self.rgbnet is None:
             rgb_raw = torch.sigmoid(vox_emb)
         else:
+            pe_spa = ((ray_pts - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
             viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
             viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
             viewdirs_emb = viewdirs_emb[ray_id]

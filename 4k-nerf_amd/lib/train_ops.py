@@ -152,6 +152,36 @@ def _rgbnet_sigmoid_layers(rgbnet, x, add):
     return torch.sigmoid(logit if add is None else logit + add.detach().float())
 
 
+class RgbnetInputMPI(torch.autograd.Function):
+    """The colour MLP's input of DirectMPIGO's training forward, ``cat([vox_emb, pe_emb, viewdirs_emb[ray_id]], -1)`` with both embeddings built from ray_pts /
+    viewdirs as lib/dmpigo.py:360-374 does, in ONE launch (k4_rgbnet_input_mpi) instead of 16 PyTorch ops.  Only vox_emb carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, vox_emb, ray_pts, viewdirs, ray_id, xyz_min, xyz_max, posfreq, viewfreq):
+        n, C = vox_emb.shape
+        P, V = int(posfreq.numel()), int(viewfreq.numel())
+        dim0 = C + 3 + 6 * P + 3 + 6 * V
+        x = torch.empty([n, dim0], dtype=torch.float32, device=vox_emb.device)
+        N.check(N.lib().k4_rgbnet_input_mpi(N.f32(vox_emb.contiguous()), C, N.f32(ray_pts.contiguous()), N.f32(viewdirs.contiguous()), N.ptr(ray_id.contiguous()), n,
+                                            N.f32(xyz_min.contiguous()), N.f32(xyz_max.contiguous()), N.f32(posfreq.contiguous()) if P else None, P,
+                                            N.f32(viewfreq.contiguous()) if V else None, V, N.f32(x), dim0, N.stream()), 'k4_rgbnet_input_mpi')
+        ctx.C = C
+        return x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gx):
+        return gx[:, :ctx.C].contiguous(), None, None, None, None, None, None, None
+
+
+def rgbnet_input_mpi(vox_emb, ray_pts, viewdirs, ray_id, xyz_min, xyz_max, posfreq, viewfreq):
+    """-> [n, dim0] MLP input, or None when the fused form does not apply (CPU tensors, other dtypes): the caller keeps the op-by-op form."""
+    ts = (vox_emb, ray_pts, viewdirs, xyz_min, xyz_max, posfreq, viewfreq)
+    if not all(t.is_cuda and t.dtype == torch.float32 for t in ts) or ray_id.dtype != torch.int64 or vox_emb.dim() != 2:
+        return None
+    return RgbnetInputMPI.apply(vox_emb, ray_pts, viewdirs, ray_id, xyz_min, xyz_max, posfreq, viewfreq)
+
+
 class FlattenEffDistLoss(torch.autograd.Function):
     """sum_rays [ sum_ij w_i w_j |s_i - s_j| + 1/3 sum_i w_i^2 interval ] / (ray_id.max() + 1), gradient w.r.t. w only.
     ray_id: int64, on the device, ASCENDING (samples grouped by ray in marching order, as the marcher emits them): the kernel finds a

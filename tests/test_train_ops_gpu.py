@@ -326,3 +326,34 @@ def test_rgbnet_layer_by_layer_path_and_rejected_shapes():
         for net in rejected:
             with pytest.raises(N.K4Error):
                 train_ops.rgbnet_sigmoid_layers(net.cuda(), x[:, :15].contiguous())
+
+
+@pytest.mark.parametrize('P,V,C', [(0, 0, 9), (2, 3, 12), (1, 0, 4)])
+def test_fused_rgbnet_input_equals_the_reference_op_sequence(P, V, C):
+    """train_ops.RgbnetInputMPI (k4_rgbnet_input_mpi: the colour MLP's input of DirectMPIGO's training forward in one launch) against the reference's op
+    sequence (lib/dmpigo.py:360-374: normalised flipped position, frequency embeddings of position and view direction, gather by ray, concatenation):
+    identical bits -- without frequencies (the LLFF configuration) and with them -- and the same gradient for the voxel features."""
+    from nerf4k_amd.lib import train_ops
+    g = torch.Generator().manual_seed(P * 7 + V * 3 + C)
+    n, nr = 5000, 300
+    vox = torch.randn([n, C], generator=g).cuda().requires_grad_(True)
+    pts = (torch.rand([n, 3], generator=g) * 2 - 1).cuda()
+    vd = torch.nn.functional.normalize(torch.randn([nr, 3], generator=g), dim=-1).cuda()
+    rid = torch.randint(0, nr, [n], generator=g).sort().values.cuda()
+    lo, hi = torch.tensor([-1.0, -1.1, -0.9]).cuda(), torch.tensor([1.2, 1.0, 1.1]).cuda()
+    pf, vf = torch.FloatTensor([2 ** i for i in range(P)]).cuda(), torch.FloatTensor([2 ** i for i in range(V)]).cuda()
+    x = train_ops.rgbnet_input_mpi(vox, pts, vd, rid, lo, hi, pf, vf)
+    assert x is not None and x.shape == (n, C + 3 + 6 * P + 3 + 6 * V)
+    gx = torch.randn(x.shape, generator=g).cuda()
+    x.backward(gx)
+    got_g = vox.grad.clone()
+    vox2 = vox.detach().clone().requires_grad_(True)
+    pe_spa = ((pts - lo) / (hi - lo)).flip((-1,)) * 2 - 1
+    ve = (vd.unsqueeze(-1) * vf).flatten(-2)
+    ve = torch.cat([vd, ve.sin(), ve.cos()], -1)[rid]
+    pe = (pe_spa.unsqueeze(-1) * pf).flatten(-2)
+    pe = torch.cat([pe_spa, pe.sin(), pe.cos()], -1)
+    want = torch.cat([vox2, pe, ve], -1)
+    want.backward(gx)
+    assert torch.equal(x.detach(), want.detach()), float((x.detach() - want.detach()).abs().max())
+    assert torch.equal(got_g, vox2.grad)
