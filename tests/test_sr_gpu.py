@@ -694,3 +694,31 @@ def test_f16x3p_recalibration_after_a_forward_drops_the_recorded_plans():
     assert torch.equal(again, ref)
     sc = float(want.abs().max())                         # the frame's own scale (~100): errors relative to it, like the unit-range tests
     assert psnr(again.cpu() / sc, want / sc) >= 110.0 and psnr(first.cpu() / sc, want / sc) >= 100.0
+
+
+@pytest.mark.parametrize('C,H,W,oy,ox,th,tw,dx', [(3, 40, 52, 8, 8, 24, 36, 0), (3, 33, 47, 5, 3, 20, 31, 1), (1, 16, 20, 0, 0, 16, 20, 2), (4, 9, 13, 2, 1, 3, 7, 3)])
+def test_window_to_planes_equals_the_slice_assignment(C, H, W, oy, ox, th, tw, dx):
+    """utils.window_to_planes (k4_nhwc_window_to_planar: a decoded window's interior into the planar frame in one pass) against the slice assignment of
+    SFTNet.tile_process (lib/sr_esrnet.py:508-524), incl. widths that are no multiple of 4, unaligned destination rows and the layouts it must hand
+    back to the slice assignment (a destination whose rows are not contiguous)."""
+    from nerf4k_amd.lib.utils import window_to_planes
+    g = torch.Generator().manual_seed(C * 100 + H + W)
+    nhwc = torch.randn([H, W, C], generator=g).cuda()
+    hr = nhwc.permute(2, 0, 1).unsqueeze(0)                                # the decoder's result as SFTNet hands it out: a [1, C, H, W] view of NHWC
+    frame = torch.zeros([1, C, th + 6, tw + 9], device='cuda')
+    dst = frame[0, :, 3:3 + th, dx:dx + tw]
+    window_to_planes(hr, oy, ox, th, tw, dst)
+    want = torch.zeros_like(frame)
+    want[0, :, 3:3 + th, dx:dx + tw] = hr[0, :, oy:oy + th, ox:ox + tw]
+    assert torch.equal(frame, want)
+    # a gather-buffer slice viewed as planes (tile_parallel.decode_frame_tiles)
+    send = torch.zeros([C, th * tw + 5], device='cuda')
+    window_to_planes(hr, oy, ox, th, tw, send[:, 2:2 + th * tw].view(C, th, tw))
+    assert torch.equal(send[:, 2:2 + th * tw], hr[0, :, oy:oy + th, ox:ox + tw].reshape(C, -1)) and float(send[:, :2].abs().sum()) == 0
+    # layouts outside the kernel's contract fall back to the slice assignment: strided destination rows, a contiguous NCHW source
+    strided = torch.zeros([C, th, 2 * tw], device='cuda')[:, :, ::2]
+    window_to_planes(hr, oy, ox, th, tw, strided)
+    assert torch.equal(strided, hr[0, :, oy:oy + th, ox:ox + tw])
+    out2 = torch.zeros([C, th, tw], device='cuda')
+    window_to_planes(hr.contiguous(), oy, ox, th, tw, out2)
+    assert torch.equal(out2, hr[0, :, oy:oy + th, ox:ox + tw])
