@@ -590,6 +590,58 @@ __global__ __launch_bounds__(256) void k_nhwc_window_to_planar(const float* __re
     }
 }
 
+// The 3-channel form (every decoded window): a workgroup moves W2P_PX pixels of one row.  The row segment is read as it lies in memory (consecutive
+// lanes, consecutive dwords -- float4s when the segment starts on a 16-byte boundary: one visit per cache line, where the form above visits a line
+// from twelve load instructions), transposed through LDS ([c][px], plane pitch chosen so that three consecutive dwords land on three banks) and written
+// as float4s per plane.
+#define W2P_PX 1024
+#define W2P_PITCH (W2P_PX + 12)
+__global__ __launch_bounds__(256) void k_nhwc3_window_to_planar(const float* __restrict__ src, int src_w, int oy, int ox, int tw, float* __restrict__ dst,
+                                                                int64_t plane, int64_t row) {
+    __shared__ float lds[3 * W2P_PITCH];
+    const int y = blockIdx.y, x0 = blockIdx.x * W2P_PX;
+    const int n = tw - x0 < W2P_PX ? tw - x0 : W2P_PX;             // pixels of this segment
+    const int nf = n * 3;
+    const float* const s = src + ((int64_t)(oy + y) * src_w + ox + x0) * 3;
+    const int t = threadIdx.x;
+    if ((((uintptr_t)s) & 15u) == 0) {
+        const int nq = nf >> 2;
+        for (int q = t; q < nq; q += 256) {
+            const float4 v = reinterpret_cast<const float4*>(s)[q];
+            const int i = q * 4, px = i / 3, c = i - px * 3;        // float i = pixel px, channel c
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = c + k, wrap = cc >= 3;               // (c + k <= 5: at most one pixel further)
+                lds[(cc - 3 * wrap) * W2P_PITCH + px + wrap] = e[k];
+            }
+        }
+        for (int i = nq * 4 + t; i < nf; i += 256) {
+            const int px = i / 3;
+            lds[(i - px * 3) * W2P_PITCH + px] = s[i];
+        }
+    } else {
+        for (int i = t; i < nf; i += 256) {
+            const int px = i / 3;
+            lds[(i - px * 3) * W2P_PITCH + px] = s[i];
+        }
+    }
+    __syncthreads();
+    const int x = t * 4;
+    if (x >= n) return;
+    const int m = n - x < 4 ? n - x : 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float* const d = dst + (int64_t)c * plane + (int64_t)y * row + x0 + x;
+        const float4 v = *reinterpret_cast<const float4*>(&lds[c * W2P_PITCH + x]);
+        if (m == 4 && (((uintptr_t)d) & 15u) == 0) *reinterpret_cast<float4*>(d) = v;
+        else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int p = 0; p < m; ++p) d[p] = e[p];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- k0 repack [C][V] -> [V][CP]
 __global__ void k_repack_k0(const float* __restrict__ in, int C, int CP, int64_t nvox, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,6 +976,10 @@ extern "C" int k4_nhwc_window_to_planar(const float* src, int32_t src_w, int32_t
                                         float* dst, int64_t dst_plane_stride, int64_t dst_row_stride, void* stream) {
     REQ(src && dst && src_w > 0 && channels >= 1 && channels <= 4 && oy >= 0 && ox >= 0 && th >= 0 && tw >= 0 && ox + tw <= src_w && dst_row_stride >= tw);
     if (th == 0 || tw == 0) return K4_OK;
+    if (channels == 3 && th <= 65535) {
+        hipLaunchKernelGGL(k_nhwc3_window_to_planar, dim3((tw + W2P_PX - 1) / W2P_PX, th), dim3(256), 0, ST, src, src_w, oy, ox, tw, dst, dst_plane_stride, dst_row_stride);
+        return k4_check_launch();
+    }
     hipLaunchKernelGGL(k_nhwc_window_to_planar, dim3(k4_blocks((int64_t)th * ((tw + 3) / 4))), dim3(K4_THREADS), 0, ST, src, src_w, channels, oy, ox, th, tw, dst,
                        dst_plane_stride, dst_row_stride);
     return k4_check_launch();

@@ -696,11 +696,13 @@ def test_f16x3p_recalibration_after_a_forward_drops_the_recorded_plans():
     assert psnr(again.cpu() / sc, want / sc) >= 110.0 and psnr(first.cpu() / sc, want / sc) >= 100.0
 
 
-@pytest.mark.parametrize('C,H,W,oy,ox,th,tw,dx', [(3, 40, 52, 8, 8, 24, 36, 0), (3, 33, 47, 5, 3, 20, 31, 1), (1, 16, 20, 0, 0, 16, 20, 2), (4, 9, 13, 2, 1, 3, 7, 3)])
+@pytest.mark.parametrize('C,H,W,oy,ox,th,tw,dx', [(3, 40, 52, 8, 8, 24, 36, 0), (3, 33, 47, 5, 3, 20, 31, 1), (1, 16, 20, 0, 0, 16, 20, 2), (4, 9, 13, 2, 1, 3, 7, 3),
+                                                  (3, 7, 2096, 2, 40, 4, 2016, 0), (3, 6, 2500, 1, 41, 5, 2311, 1), (3, 5, 1030, 0, 4, 5, 1025, 4), (3, 3, 1028, 1, 0, 2, 1024, 0)])
 def test_window_to_planes_equals_the_slice_assignment(C, H, W, oy, ox, th, tw, dx):
     """utils.window_to_planes (k4_nhwc_window_to_planar: a decoded window's interior into the planar frame in one pass) against the slice assignment of
-    SFTNet.tile_process (lib/sr_esrnet.py:508-524), incl. widths that are no multiple of 4, unaligned destination rows and the layouts it must hand
-    back to the slice assignment (a destination whose rows are not contiguous)."""
+    SFTNet.tile_process (lib/sr_esrnet.py:508-524), incl. widths that are no multiple of 4, unaligned destination rows, rows of more than one 1024-pixel
+    segment of the 3-channel form (source segments on and off a 16-byte boundary, a one-pixel last segment) and the layouts it must hand back to the slice
+    assignment (a destination whose rows are not contiguous)."""
     from nerf4k_amd.lib.utils import window_to_planes
     g = torch.Generator().manual_seed(C * 100 + H + W)
     nhwc = torch.randn([H, W, C], generator=g).cuda()
@@ -722,3 +724,4 @@ def test_window_to_planes_equals_the_slice_assignment(C, H, W, oy, ox, th, tw, d
     out2 = torch.zeros([C, th, tw], device='cuda')
     window_to_planes(hr.contiguous(), oy, ox, th, tw, out2)
     assert torch.equal(out2, hr[0, :, oy:oy + th, ox:ox + tw])
+
