@@ -91,6 +91,8 @@ _SIGS = {
     'k4_grid_sample_3d_backward': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
     'k4_touched_voxels': [_P, _I32, _I64, _P, _I64, _P, _P],
     'k4_grid_sample_3d_backward_cl': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P],
+    'k4_grid_sample_3d_backward_cl_scatter': [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P],
+    'k4_grid_sample_3d_backward_cl_sweep': [_I32, _I32, _I32, _I32, _P, _P, _P],
     'k4_segment_sum_backward': [_P, _P, _I64, _I32, _P, _P],
     'k4_get_rays_of_a_view': [_I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _P, _P, _P],
     'k4_to8b': [_P, _I64, _P, _P],
@@ -137,6 +139,7 @@ _EXTRA_SIGS = {
     'k4_sft_nhwc': ([_P, _I32, _P, _P, _I32, _P, _I32, _I32, _I64, _F, _P, _I32, _F, _P], C.c_int),
     'k4_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_masked_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
+    'k4_masked_adam_upd_sparse_cl': ([_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_adam_upd_with_perlr': ([_P, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_total_variation_add_grad': ([_P, _P, _F, _F, _F, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     'k4_conv_weight_bf16x6_bytes': ([_I32, _I32, _I32], C.c_int64),

@@ -97,6 +97,41 @@ extern "C" int k4_masked_adam_upd(float* param, const float* grad, float* exp_av
     return k4_adam_launch<K4_ADAM_MASKED>(param, grad, exp_avg, exp_avg_sq, nullptr, n, step, beta1, beta2, lr, eps,
                                           (hipStream_t)stream);
 }
+// MaskedAdam over the touched voxels of a multi-channel grid, straight from the channel-last scratch image of the lookup's backward
+// (k4_grid_sample_3d_backward_cl_scatter, k4_staged.hip: scratch[voxel][C] sums + one flag byte per voxel).  After tv_before the reference's
+// iteration (run_sr.py:1005-1014 with configs/llff/fern_lg_joint_l1.py: 290,000 of its 300,000) has no other contribution to the grid's
+// gradient, and masked_adam_upd (lib/cuda/adam_upd_kernel.cu:27-42) skips every element whose gradient is zero: the dense gradient -- 1.36 GB
+// cleared, swept into and read again per iteration for the LLFF k0 -- holds nothing this kernel does not find behind the flags.  Same
+// arithmetic per element (k4_adam_one); scratch and flags are all-zero again behind it.
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_sparse_cl_kernel(float* __restrict__ scratch, uint8_t* __restrict__ flags, int C, int64_t nvox,
+                                                                            float* __restrict__ param, float* __restrict__ em, float* __restrict__ ev,
+                                                                            float step_size, float beta1, float beta2, float eps) {
+    const int64_t vx = (int64_t)blockIdx.x * K4_OPT_THREADS + threadIdx.x;
+    if (vx >= nvox || flags[vx] == 0) return;
+    flags[vx] = 0;
+    float* const s = scratch + vx * C;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (int ch = 0; ch < C; ++ch) {
+        const float g = s[ch];
+        if (g == 0.f) continue;
+        s[ch] = 0.f;
+        const int64_t i = (int64_t)ch * nvox + vx;
+        float p = param[i], m = em[i], v = ev[i];
+        k4_adam_one(p, g, m, v, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        param[i] = p; em[i] = m; ev[i] = v;
+    }
+}
+extern "C" int k4_masked_adam_upd_sparse_cl(float* param, float* exp_avg, float* exp_avg_sq, void* workspace, int32_t C, int32_t X, int32_t Y, int32_t Z,
+                                            int32_t step, float beta1, float beta2, float lr, float eps, void* stream) {
+    if (!param || !exp_avg || !exp_avg_sq || !workspace || (((uintptr_t)workspace) & 15) || C <= 1 || C > 32 || X <= 0 || Y <= 0 || Z <= 0 || step < 1) return K4_ERR_BAD_ARG;
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t blocks = (nvox + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+    if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+    const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));      // adam_upd_kernel.cu:71
+    hipLaunchKernelGGL(k4_adam_sparse_cl_kernel, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, (hipStream_t)stream, (float*)workspace,
+                       (uint8_t*)workspace + nvox * C * 4, C, nvox, param, exp_avg, exp_avg_sq, step_size, beta1, beta2, eps);
+    return k4_check_launch();
+}
 extern "C" int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                                       const float* perlr, int64_t n, int32_t step, float beta1, float beta2, float lr,
                                       float eps, void* stream) {

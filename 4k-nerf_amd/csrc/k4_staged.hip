@@ -939,9 +939,10 @@ extern "C" int64_t k4_grid_sample_3d_backward_workspace_bytes(int32_t C, int32_t
     const int64_t nvox = (int64_t)X * Y * Z;
     return nvox * C * 4 + ((nvox + 15) / 16) * 16;
 }
-extern "C" int k4_grid_sample_3d_backward_cl(const float* grad_out, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
-                                             const float* mn, const float* mx, int64_t n, float* grad_grid, void* workspace, void* stream) {
-    REQ(C > 1 && C <= 32 && X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && grad_grid && workspace && (((uintptr_t)workspace) & 15) == 0);
+// scatter and sweep apart: a caller that consumes the touched voxels' sums where they lie (k4_masked_adam_upd_sparse_cl, k4_opt.hip) runs the scatter alone
+extern "C" int k4_grid_sample_3d_backward_cl_scatter(const float* grad_out, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
+                                                     const float* mn, const float* mx, int64_t n, void* workspace, void* stream) {
+    REQ(C > 1 && C <= 32 && X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && workspace && (((uintptr_t)workspace) & 15) == 0);
     if (n == 0) return K4_OK;
     REQ(xyz && grad_out);
     const int64_t nvox = (int64_t)X * Y * Z;
@@ -950,8 +951,21 @@ extern "C" int k4_grid_sample_3d_backward_cl(const float* grad_out, int32_t C, i
 #define K4_GSB_CL(LPS) hipLaunchKernelGGL(k_gsb_cl_scatter<LPS>, dim3(k4_blocks(n * LPS)), dim3(K4_THREADS), 0, ST, grad_out, C, X, Y, Z, xyz, mn, mx, n, scratch, flags)
     if (C <= 2) K4_GSB_CL(2); else if (C <= 4) K4_GSB_CL(4); else if (C <= 8) K4_GSB_CL(8); else if (C <= 16) K4_GSB_CL(16); else K4_GSB_CL(32);
 #undef K4_GSB_CL
-    hipLaunchKernelGGL(k_gsb_cl_sweep, dim3(k4_blocks(nvox)), dim3(K4_THREADS), 0, ST, scratch, flags, C, nvox, grad_grid);
     return k4_check_launch();
+}
+extern "C" int k4_grid_sample_3d_backward_cl_sweep(int32_t C, int32_t X, int32_t Y, int32_t Z, void* workspace, float* grad_grid, void* stream) {
+    REQ(C > 1 && C <= 32 && X > 0 && Y > 0 && Z > 0 && grad_grid && workspace && (((uintptr_t)workspace) & 15) == 0);
+    const int64_t nvox = (int64_t)X * Y * Z;
+    hipLaunchKernelGGL(k_gsb_cl_sweep, dim3(k4_blocks(nvox)), dim3(K4_THREADS), 0, ST, (float*)workspace, (uint8_t*)workspace + nvox * C * 4, C, nvox, grad_grid);
+    return k4_check_launch();
+}
+extern "C" int k4_grid_sample_3d_backward_cl(const float* grad_out, int32_t C, int32_t X, int32_t Y, int32_t Z, const float* xyz,
+                                             const float* mn, const float* mx, int64_t n, float* grad_grid, void* workspace, void* stream) {
+    REQ(C > 1 && C <= 32 && X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && grad_grid && workspace && (((uintptr_t)workspace) & 15) == 0);
+    if (n == 0) return K4_OK;
+    const int rc = k4_grid_sample_3d_backward_cl_scatter(grad_out, C, X, Y, Z, xyz, mn, mx, n, workspace, stream);
+    if (rc) return rc;
+    return k4_grid_sample_3d_backward_cl_sweep(C, X, Y, Z, workspace, grad_grid, stream);
 }
 extern "C" int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n, int32_t C, float* grad_src,
                                        void* stream) {

@@ -25,11 +25,12 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import _native as N
-from .lib import sr_train, train_ops, utils
+from .lib import grid as G, sr_train, train_ops, utils
 from .lib.masked_adam import MaskedAdam
 
 _ADAM_SIDE = True   # False: the k0 grid's optimizer step on the current stream (A/B, tests)
 _TV_SEED = True     # False: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
+_SPARSE_GRID_GRAD = True     # False: k0's gradient as a dense tensor in the iterations without TV too (A/B, tests)
 
 SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
 
@@ -158,6 +159,20 @@ class JointTrainer:
         touched voxels, which a dense seed would make all of them (3.6 GB per rank instead of a few MB)."""
         return _TV_SEED and _world(self.group) == 1 and global_step < self.cfg.tv_dense_before
 
+    def _sparse_grid_owners(self):
+        """The grids whose gradient may stay in the scatter's scratch image this iteration: multi-channel DenseGrids stepped by MaskedAdam on the side stream
+        (the optimizer looks for pending sums there) in a param group that skips zero gradients, without a per-voxel learning rate."""
+        opt = self.optimizer
+        if not isinstance(opt, MaskedAdam):
+            return []
+        out = []
+        for owner in opt._side:
+            g = owner.grid
+            if g.is_cuda and g.dim() == 5 and g.shape[1] > 1 and g.requires_grad and not (opt.per_lr is not None and opt.per_lr.shape == g.shape) \
+                    and any(pg.get('skip_zero_grad') and any(p is g for p in pg['params']) for pg in opt.param_groups):
+                out.append(owner)
+        return out
+
     def _side_stream_updates(self):
         """The feature grid's optimizer step (1.9 ms of HBM time on the LLFF scene) on a second stream: the next iteration's sample selection
         reads the density grid only and no longer queues behind it; DenseGrid makes every reader of k0 wait (lib/grid.DenseGrid.params_ready)."""
@@ -217,6 +232,13 @@ class JointTrainer:
         # the gradient exchange between backward and TV sends the TOUCHED voxels, which a dense seed would make all of them.
         seed_tv = tv_now and self._dense_tv_ahead(global_step)
         seeded = []
+        # Without TV (after tv_before: 290,000 of fern_lg_joint_l1's 300,000 iterations) the lookups' backward is the only contribution to k0's gradient and
+        # MaskedAdam skips voxels without one: the backward stops after its scatter and the optimizer updates the touched voxels from the scratch image
+        # (lib/grid.DenseGrid._k4_sparse_grad, MaskedAdam._sparse_step) -- no dense 1.36 GB gradient per iteration.  Single process only: the data-parallel
+        # exchange reads the dense gradient.
+        sparse = self._sparse_grid_owners() if (_SPARSE_GRID_GRAD and not tv_now and _world(self.group) == 1) else []
+        for grid in sparse:
+            grid._k4_sparse_grad = True
         if seed_tv:
             for weight, grid, fn in ((cfg.weight_tv_density, getattr(self.model, 'density', None), self.model.density_total_variation_add_grad),
                                      (cfg.weight_tv_k0, getattr(self.model, 'k0', None), self.model.k0_total_variation_add_grad)):
@@ -236,16 +258,27 @@ class JointTrainer:
                 grid.finish_grad_seed()
             done = True
         finally:
+            for grid in sparse:
+                grid._k4_sparse_grad = False
+                if not done:
+                    G.discard_pending_grad(grid)
             if not done:                # forward / loss / backward raised (e.g. an out-of-memory batch the caller skips): a parked seed must not
                 for grid in seeded:     # reach a LATER iteration's gradient -- it holds a TV term of parameters that iteration no longer has
                     grid._k4_seed = None
-        self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
-        if tv_now:
-            if cfg.weight_tv_density > 0 and getattr(self.model, 'density', None) not in seeded:
-                self.model.density_total_variation_add_grad(cfg.weight_tv_density / self.n_train_images, global_step < cfg.tv_dense_before)
-            if cfg.weight_tv_k0 > 0 and getattr(self.model, 'k0', None) not in seeded:
-                self.model.k0_total_variation_add_grad(cfg.weight_tv_k0 / self.n_train_images, global_step < cfg.tv_dense_before)
-        self.optimizer.step()
+        stepped = False
+        try:
+            self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
+            if tv_now:
+                if cfg.weight_tv_density > 0 and getattr(self.model, 'density', None) not in seeded:
+                    self.model.density_total_variation_add_grad(cfg.weight_tv_density / self.n_train_images, global_step < cfg.tv_dense_before)
+                if cfg.weight_tv_k0 > 0 and getattr(self.model, 'k0', None) not in seeded:
+                    self.model.k0_total_variation_add_grad(cfg.weight_tv_k0 / self.n_train_images, global_step < cfg.tv_dense_before)
+            self.optimizer.step()
+            stepped = True
+        finally:
+            if not stepped:             # sums a scatter-only backward left in the scratch image must not be added to by the next iteration's
+                for grid in sparse:
+                    G.discard_pending_grad(grid)
         self.optimizer_sr.step()
         factor = 0.1 ** (1 / (cfg.lrate_decay * 1000))                                                           # run_sr.py:1052-1061
         for opt in (self.optimizer, self.optimizer_sr):

@@ -40,6 +40,12 @@ class GridSample3D(torch.autograd.Function):
     def backward(ctx, grad_out):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         _, C_, X, Y, Z = ctx.grid_shape
+        owner = ctx.owner
+        if owner is not None and owner._k4_sparse_grad and owner._k4_seed is None:
+            # the trainer consumes this gradient where the scatter leaves it (MaskedAdam -> k4_masked_adam_upd_sparse_cl): no dense tensor, `.grad` stays None
+            if grid_sample_3d_backward_scatter(grad_out.float().contiguous(), C_, X, Y, Z, pts, xyz_min, xyz_max):
+                owner._k4_sparse_pending = True
+                return None, None, None, None, None
         gg = ctx.owner._take_grad_seed(ctx.grid_shape, grad_out.device) if ctx.owner is not None else None
         if gg is None:
             gg = torch.zeros(ctx.grid_shape, dtype=torch.float32, device=grad_out.device)
@@ -60,6 +66,72 @@ def release_grid_sample_workspace(device=None):
 GSB_CHANNEL_LAST = True
 
 
+def _gsb_workspace(device, C_, X, Y, Z):
+    """The device's cleared scratch image for this grid shape ([shape, int32 tensor, event of its last use]) or None (one channel, switched off, out of memory)."""
+    nbytes = int(N.lib().k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if GSB_CHANNEL_LAST else -1
+    if nbytes <= 0:
+        return None
+    hit = _GSB_WS.get(device)
+    if hit is None or hit[0] != (C_, X, Y, Z):
+        _GSB_WS.pop(device, None)
+        try:
+            hit = _GSB_WS[device] = [(C_, X, Y, Z), torch.zeros([nbytes // 4], dtype=torch.int32, device=device), None]
+        except torch.OutOfMemoryError:
+            return None
+    return hit
+
+
+def grid_sample_3d_backward_scatter(go, C_, X, Y, Z, pts, xyz_min, xyz_max):
+    """The scatter half of ``grid_sample_3d_backward``: the touched voxels' sums stay in the device's scratch image (added to what an earlier scatter left
+    there) until ``sweep_pending_grad`` moves them into a dense gradient or MaskedAdam consumes them in place.  -> False when there is no scratch image for
+    this grid (the caller takes the dense path)."""
+    hit = _gsb_workspace(go.device, C_, X, Y, Z)
+    if hit is None:
+        return False
+    n = pts.shape[0]
+    if n == 0:
+        return True
+    ws, cur = hit[1], torch.cuda.current_stream(go.device)
+    if hit[2] is not None:
+        cur.wait_event(hit[2])
+    ws.record_stream(cur)
+    try:
+        N.check(N.lib().k4_grid_sample_3d_backward_cl_scatter(N.f32(go), C_, X, Y, Z, N.f32(pts), N.f32(xyz_min), N.f32(xyz_max), n, N.ptr(ws), N.stream()),
+                'grid_sample_3d_backward_cl_scatter')
+    except Exception:
+        _GSB_WS.pop(go.device, None)
+        raise
+    hit[2] = torch.cuda.Event()
+    hit[2].record(cur)
+    return True
+
+
+def sweep_pending_grad(owner):
+    """Move the sums a scatter-only backward left in the scratch image into ``owner.grid.grad`` (created when missing): the dense gradient after all."""
+    owner._k4_sparse_pending = False
+    g = owner.grid
+    _, C_, X, Y, Z = g.shape
+    hit = _GSB_WS.get(g.device)
+    if hit is None or hit[0] != (C_, X, Y, Z):
+        raise N.K4Error('sweep_pending_grad: the scratch image of the pending gradient is gone')
+    if g.grad is None:
+        g.grad = torch.zeros_like(g, memory_format=torch.contiguous_format)
+    cur = torch.cuda.current_stream(g.device)
+    if hit[2] is not None:
+        cur.wait_event(hit[2])
+    hit[1].record_stream(cur)
+    N.check(N.lib().k4_grid_sample_3d_backward_cl_sweep(C_, X, Y, Z, N.ptr(hit[1]), N.f32(g.grad), N.stream()), 'grid_sample_3d_backward_cl_sweep')
+    hit[2] = torch.cuda.Event()
+    hit[2].record(cur)
+
+
+def discard_pending_grad(owner):
+    """Forget a scatter-only backward's sums (an iteration the caller gives up on): the scratch image is dropped, the next use allocates a cleared one."""
+    if owner._k4_sparse_pending:
+        owner._k4_sparse_pending = False
+        _GSB_WS.pop(owner.grid.device, None)
+
+
 def grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg):
     """gg [1|-, C, X, Y, Z] += d(trilinear lookup)/d(grid) for grad_out `go` [n, C] at `pts` [n, 3].  More than one channel: through the
     channel-last scratch image (k4_grid_sample_3d_backward_cl; the workspace, as large as the gradient, is allocated and cleared once
@@ -68,16 +140,7 @@ def grid_sample_3d_backward(go, C_, X, Y, Z, pts, xyz_min, xyz_max, gg):
     stream waits for the previous use (event), and a failed launch drops it (the next call allocates a cleared one)."""
     L = N.lib()
     n = pts.shape[0]
-    nbytes = int(L.k4_grid_sample_3d_backward_workspace_bytes(C_, X, Y, Z)) if GSB_CHANNEL_LAST else -1
-    hit = None
-    if nbytes > 0 and n > 0:
-        hit = _GSB_WS.get(go.device)
-        if hit is None or hit[0] != (C_, X, Y, Z):
-            _GSB_WS.pop(go.device, None)
-            try:
-                hit = _GSB_WS[go.device] = [(C_, X, Y, Z), torch.zeros([nbytes // 4], dtype=torch.int32, device=go.device), None]
-            except torch.OutOfMemoryError:
-                hit = None
+    hit = _gsb_workspace(go.device, C_, X, Y, Z) if n > 0 else None
     if hit is not None:
         ws, cur = hit[1], torch.cuda.current_stream(go.device)
         if hit[2] is not None:
@@ -188,6 +251,12 @@ class DenseGrid(nn.Module):
     # buffer first (8 B / voxel, on a side stream under the iteration's host-paced phases) and the lookup's backward accumulates into
     # that buffer instead of into zeros: grad = term + scatter, the same sum.
     _k4_seed = None
+    # ---- iterations in which the lookups' backward is the ONLY contribution to the gradient and MaskedAdam skips zero-gradient voxels (the joint loop after
+    # tv_before: 290,000 of fern_lg_joint_l1's 300,000 iterations): the trainer sets _k4_sparse_grad, the backward then stops after its scatter (sums in the
+    # channel-last scratch image, `.grad` stays None, _k4_sparse_pending raised) and MaskedAdam.step updates exactly the touched voxels from there
+    # (k4_masked_adam_upd_sparse_cl) -- no 1.36 GB gradient cleared, swept into and read again per iteration.
+    _k4_sparse_grad = False
+    _k4_sparse_pending = False
     # ---- an optimizer step of the grid running on a second stream (lib/masked_adam.MaskedAdam.update_on_side_stream) ----
     _k4_pending = None
 
@@ -223,7 +292,7 @@ class DenseGrid(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ('_k4_seed', '_k4_pending', '_k4_pending_seen'):
+            if k in ('_k4_seed', '_k4_pending', '_k4_pending_seen', '_k4_sparse_grad', '_k4_sparse_pending'):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -186,11 +186,50 @@ class MaskedAdam(torch.optim.Optimizer):
                                  'numel': [p.numel() for p in plist], 'ids': {id(p) for p in plist},
                                  'touched': [t for ts in items for t in (ts[0], ts[2], ts[3])]}
 
+    def _sparse_step(self, param, owner, masked, beta1, beta2, lr, eps):
+        """`param`'s gradient of this iteration is the sums its lookups' backward left in the channel-last scratch image (DenseGrid._k4_sparse_grad, set by the
+        trainer for iterations without any other contribution to it): the masked update of exactly those voxels from there (k4_masked_adam_upd_sparse_cl), on
+        the grid's side stream like the dense step.  Anything the in-place form does not cover (a `.grad` that exists after all, no zero-gradient skipping,
+        a per-voxel learning rate on this tensor) sweeps the sums into the dense gradient instead and leaves the tensor to the regular path."""
+        from . import grid as G
+        if param.grad is not None or not masked or (self.per_lr is not None and param.shape == self.per_lr.shape):
+            G.sweep_pending_grad(owner)
+            return
+        owner._k4_sparse_pending = False
+        _, C_, X, Y, Z = param.shape
+        hit = G._GSB_WS.get(param.device)
+        if hit is None or hit[0] != (C_, X, Y, Z):
+            raise N.K4Error('MaskedAdam: the scratch image of the pending grid gradient is gone')
+        state = self.state[param]
+        if not state:
+            state.update(step=0, exp_avg=torch.zeros_like(param, memory_format=torch.preserve_format),
+                         exp_avg_sq=torch.zeros_like(param, memory_format=torch.preserve_format))
+        state['step'] += 1
+        for t in (param, state['exp_avg'], state['exp_avg_sq']):
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError('k4_masked_adam_upd_sparse_cl: tensors must be contiguous fp32 device tensors')
+        cur, side = torch.cuda.current_stream(param.device), _side_stream(param.device)
+        side.wait_stream(cur)                                  # the scatter (and everything that read the old values) is done
+        hit[1].record_stream(side)
+        with torch.cuda.stream(side):
+            N.check(N.lib().k4_masked_adam_upd_sparse_cl(N.ptr(param), N.ptr(state['exp_avg']), N.ptr(state['exp_avg_sq']), N.ptr(hit[1]), C_, X, Y, Z,
+                                                         int(state['step']), float(beta1), float(beta2), float(lr), float(eps), N.stream()),
+                    'k4_masked_adam_upd_sparse_cl')
+            ev = torch.cuda.Event()
+            ev.record(side)
+        hit[2] = ev                                            # the next scatter into the image waits for the sweep half of this kernel
+        owner.note_pending_update(ev)
+        for t in (param, state['exp_avg'], state['exp_avg_sq']):
+            torch.autograd.graph.increment_version(t)
+
     @torch.no_grad()
     def step(self):
         for group in self.param_groups:
             (beta1, beta2), lr, eps = group['betas'], group['lr'], group['eps']
             masked = group['skip_zero_grad']                   # KeyError without it, as upstream (masked_adam.py:45)
+            for owner in self._side:
+                if owner._k4_sparse_pending and any(p is owner.grid for p in group['params']):
+                    self._sparse_step(owner.grid, owner, masked, beta1, beta2, lr, eps)
             small = {}
             fast_ids = self._fast[id(group)]['ids'] if self._fast_step(group, masked, beta1, beta2, lr, eps) else ()
             for param in (p for p in group['params'] if p.grad is not None):

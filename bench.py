@@ -391,6 +391,7 @@ def main():
             res['roofline_detail']['four_k_arith'] = four_k.get('arith') or default_mode
         if isinstance(res.get('joint_train_step'), dict):
             rl['joint_iteration_ms'] = res['joint_train_step'].get('ms_per_iteration')
+            res['roofline_detail']['joint_iteration_after_tv_before_ms'] = res['joint_train_step'].get('ms_per_iteration_after_tv_before')
         if roof2 is not None:
             rl['issue_floor_ms'] = roof2['issue_floor_ms']
             rl['frac_of_issue_floor'] = round(roof2['issue_floor_ms'] / iso_ms, 4)
@@ -868,6 +869,22 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
         dt_blocks_graph = (time.perf_counter() - t) / per_block
     finally:
         sr_train._TAPE = True
+    # the OTHER 290,000 of the configuration's 300,000 iterations (global_step >= tv_before = 10,000: no total variation, run_sr.py:1005-1011): k0's gradient
+    # is the lookups' scatter alone and MaskedAdam skips voxels without one -- the step updates the touched voxels straight from the scatter's scratch image
+    late0 = int(cfg.tv_before) + 10
+    for i in range(2):
+        tr.step(*batch(it), global_step=late0 + it)
+        it += 1
+    torch.cuda.synchronize()
+    blocks_late = []
+    for b in range(3):
+        t = time.perf_counter()
+        for i in range(per_block):
+            tr.step(*batch(it), global_step=late0 + it)
+            it += 1
+        torch.cuda.synchronize()
+        blocks_late.append((time.perf_counter() - t) / per_block)
+    dt_late = float(np.median(blocks_late))
     # the same iteration's pieces (forward / backward / grid maintenance + optimizers), synchronised
     b = batch(it + 1)
     torch.cuda.synchronize()
@@ -891,6 +908,10 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
     return {'ms_per_iteration': round(dt * 1e3, 2), 'iterations_per_s': round(1.0 / dt, 2),
             'ms_per_iteration_blocks': [round(v * 1e3, 2) for v in blocks], 'statistic': f'median of 5 blocks of {per_block} iterations after 3 warm-up iterations',
             'ms_per_iteration_per_block_graph': round(dt_blocks_graph * 1e3, 2),
+            'ms_per_iteration_after_tv_before': round(dt_late * 1e3, 2), 'ms_per_iteration_after_tv_before_blocks': [round(v * 1e3, 2) for v in blocks_late],
+            'phases': 'ms_per_iteration = an iteration of the first 10,000 (dense total variation on both grids, every voxel of k0 stepped: the dearer phase, the headline); '
+                      'ms_per_iteration_after_tv_before = an iteration of the other 290,000 of fern_lg_joint_l1 (no TV; k0 stepped on its touched voxels from the scatter image)',
+
             'decoder_pass': 'ONE autograd node on two launch tapes replayed by one native call each (lib/sr_tape.py, k4_tape_*), 3x3 layers of the 64x64 patch on the K-split kernel (K4_CONV_SMALL); '
                             'ms_per_iteration_per_block_graph = the same kernels issued call by call from ~20 autograd nodes per RRDB (K4_TRAIN_TAPE=0); round 5: 11.0-11.3 ms; hipGraph form 17.2 ms',
             'rays_per_iteration': pr * pc,

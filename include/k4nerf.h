@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -270,6 +270,13 @@ int64_t k4_grid_sample_3d_backward_workspace_bytes(int32_t channels, int32_t X, 
 int k4_grid_sample_3d_backward_cl(const float* grad_out, int32_t channels, int32_t X, int32_t Y, int32_t Z,
                                   const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
                                   float* grad_grid, void* workspace, void* stream);
+/* Its two halves: the scatter alone leaves the touched voxels' sums in the workspace (scratch[voxel][channels] + one flag byte per voxel behind it);
+ * the sweep moves them into grad_grid and clears the workspace.  Between the two a caller may consume the sums where they lie:
+ * k4_masked_adam_upd_sparse_cl (below, optimizer section) is MaskedAdam's masked update over exactly those voxels. */
+int k4_grid_sample_3d_backward_cl_scatter(const float* grad_out, int32_t channels, int32_t X, int32_t Y, int32_t Z,
+                                          const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n_pts,
+                                          void* workspace, void* stream);
+int k4_grid_sample_3d_backward_cl_sweep(int32_t channels, int32_t X, int32_t Y, int32_t Z, void* workspace, float* grad_grid, void* stream);
 int k4_segment_sum_backward(const float* grad_out, const int64_t* index, int64_t n_pts, int32_t channels,
                             float* grad_src, void* stream);
 /* get_rays_of_a_view (lib/dvgo.py:516-582: get_rays + viewdirs + ndc_rays with near = 1) in one launch.  K_dev: [3][3]
@@ -536,6 +543,14 @@ int k4_masked_adam_upd(float* param, const float* grad, float* exp_avg, float* e
                        float beta1, float beta2, float lr, float eps, void* stream);
 int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* perlr,
                            int64_t n, int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
+
+/* k4_masked_adam_upd of a grid [channels][X][Y][Z] whose gradient is still the channel-last scratch image of
+ * k4_grid_sample_3d_backward_cl_scatter (`workspace`): the touched voxels' non-zero sums are the gradient's only non-zero elements, every one of
+ * them gets the masked update (same arithmetic per element), the workspace is all zero again on return.  For iterations in which nothing else
+ * contributes to the grid's gradient (run_sr.py:1005-1014 after tv_before: no total variation) this is MaskedAdam.step
+ * (lib/masked_adam.py:58-71, skip_zero_grad) without the dense gradient tensor. */
+int k4_masked_adam_upd_sparse_cl(float* param, float* exp_avg, float* exp_avg_sq, void* workspace, int32_t channels, int32_t X, int32_t Y, int32_t Z,
+                                 int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
 
 /* The same update for MANY tensors in as few launches as possible (the decoder's optimizer step, run_sr.py:665-667,1014: 458 parameter
  * tensors = 458 launches of k4_adam_upd otherwise).  `jobs` is a HOST array; hyper-parameters and the step count are shared (one

@@ -287,3 +287,47 @@ def test_masked_adam_fast_path_for_small_tensors_is_the_regular_step(masked, mon
     give_grads()
     oa.step(); ob.step()
     same()
+
+
+@pytest.mark.parametrize('C', [2, 9, 12])
+def test_sparse_masked_adam_from_the_scatter_image_is_the_dense_masked_step(C):
+    """k4_masked_adam_upd_sparse_cl (MaskedAdam's masked update of the touched voxels, straight from the channel-last scratch image of the lookups'
+    backward) against the dense route -- sweep into a zero gradient, k4_masked_adam_upd (lib/masked_adam.py:58-71 with skip_zero_grad) -- from the
+    SAME scratch image: parameters and both moments bit for bit, a channel whose sums are all zero untouched, the image all zero afterwards."""
+    from nerf4k_amd import _native as N
+    g = torch.Generator().manual_seed(40 + C)
+    X, Y, Z = 11, 9, 33
+    n = 1500
+    pts = (torch.rand([n, 3], generator=g) * 2.2 - 1.1).cuda()
+    gout = torch.randn([n, C], generator=g)
+    gout[:, 1] = 0                                                        # one channel without gradient anywhere
+    gout[::7] = 0                                                         # samples that flag voxels without contributing
+    gout = gout.cuda()
+    mn, mx = torch.tensor([-1., -1., -1.]).cuda(), torch.tensor([1., 1., 1.]).cuda()
+    L = N.lib()
+    nb = int(L.k4_grid_sample_3d_backward_workspace_bytes(C, X, Y, Z))
+    ws = torch.zeros([nb // 4], dtype=torch.int32, device='cuda')
+    N.check(L.k4_grid_sample_3d_backward_cl_scatter(N.f32(gout), C, X, Y, Z, N.f32(pts), N.f32(mn), N.f32(mx), n, N.ptr(ws), N.stream()), 'scatter')
+    assert int(ws.count_nonzero()) > 0
+    ws2 = ws.clone()
+    shape = [1, C, X, Y, Z]
+    p0 = torch.randn(shape, generator=g).cuda()
+    m0 = (torch.randn(shape, generator=g) * 0.1).cuda()
+    v0 = (torch.rand(shape, generator=g) * 0.1).cuda()
+    hyper = (7, 0.9, 0.99, 1e-1, 1e-8)
+    # dense route
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    grad = torch.zeros(shape, device='cuda')
+    N.check(L.k4_grid_sample_3d_backward_cl_sweep(C, X, Y, Z, N.ptr(ws), N.f32(grad), N.stream()), 'sweep')
+    assert int(ws.count_nonzero()) == 0 and int(grad.count_nonzero()) > 0
+    N.check(L.k4_masked_adam_upd(N.ptr(pa), N.ptr(grad), N.ptr(ma), N.ptr(va), pa.numel(), *hyper, N.stream()), 'masked_adam_upd')
+    # in place
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    N.check(L.k4_masked_adam_upd_sparse_cl(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), C, X, Y, Z, *hyper, N.stream()), 'sparse')
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert int(ws2.count_nonzero()) == 0
+    changed = pb != p0
+    assert torch.equal(changed, grad != 0) or int((changed != (grad != 0)).sum()) <= 2        # (an update smaller than half an ulp of p leaves p's bits)
+    assert not bool(changed[0, 1].any()) and torch.equal(mb[0, 1], m0[0, 1])
+    assert int(L.k4_masked_adam_upd_sparse_cl(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), 1, X, Y, Z, *hyper, N.stream())) == 10001
+    assert int(L.k4_masked_adam_upd_sparse_cl(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), C, X, Y, Z, 0, 0.9, 0.99, 1e-1, 1e-8, N.stream())) == 10001

@@ -266,6 +266,60 @@ def test_dense_tv_written_ahead_of_backward_and_side_stream_adam_equal_the_refer
     assert g._k4_seed is None and torch.equal(g.grid.grad, want)
 
 
+def test_iterations_without_tv_update_k0_from_the_scatter_image(monkeypatch):
+    """After tv_before (run_sr.py:1005-1011: no total variation; 290,000 of fern_lg_joint_l1's 300,000 iterations) JointTrainer.step leaves k0's gradient in
+    the scratch image of the lookups' backward and MaskedAdam updates the touched voxels from there (DenseGrid._k4_sparse_grad, MaskedAdam._sparse_step):
+    four steps each way from the same state -- step 1 with dense TV (dense gradient both ways), steps 2-4 without -- same losses, parameters, moments and
+    step counts (scatter atomics reorder sums: 1e-5 relative); `.grad` of k0 stays None in the in-place form; an iteration that raises drops its sums."""
+    from nerf4k_amd.lib import masked_adam
+    from nerf4k_amd.lib import grid as k4grid
+    monkeypatch.setattr(masked_adam, '_MULTI_BELOW', 1000)
+    res = []
+    for sparse_on in (False, True):
+        z, model, net, rk, cfg, batch = _load_joint()
+        cfg = joint_train.JointCfg(dict(cfg, tv_before=2, tv_dense_before=2))
+        monkeypatch.setattr(joint_train, '_SPARSE_GRID_GRAD', sparse_on)
+        tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+        assert [o is model.k0 for o in tr._sparse_grid_owners()] == [True]
+        hist = []
+        for i in range(4):
+            hist.append(float(tr.step(*batch, global_step=1 + i)['total']))
+            assert (model.k0.grid.grad is None) == (sparse_on and i >= 1), i
+            assert not model.k0._k4_sparse_pending and not model.k0._k4_sparse_grad
+            assert model.density.grid.grad is not None
+        st = tr.optimizer.state[model.k0.grid]
+        assert st['step'] == 4
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+        res.append((hist, sd, st['exp_avg'].clone(), st['exp_avg_sq'].clone()))
+        ws = k4grid._GSB_WS[model.k0.grid.device][1]
+        assert int(ws.count_nonzero()) == 0                               # the image is all zero between iterations
+    (h0, m0, a0, b0), (h1, m1, a1, b1) = res
+    assert np.allclose(h1, h0, rtol=1e-6, atol=0), (h1, h0)
+    for k in m1:
+        _close(m1[k], m0[k].cpu(), k, rel=1e-5, abs_=1e-8)
+    _close(a1, a0.cpu(), 'exp_avg', rel=1e-5, abs_=1e-9)
+    _close(b1, b0.cpu(), 'exp_avg_sq', rel=1e-5, abs_=1e-12)
+    assert torch.equal(a1 == 0, a0 == 0)                                  # the same voxels ever touched
+    # an iteration that raises after its backward: the pending sums do not reach the next one
+    before = model.k0.grid.detach().clone()
+    with monkeypatch.context() as mp:
+        mp.setattr(joint_train, 'exchange_gradients', lambda *a, **k: (_ for _ in ()).throw(RuntimeError('skip this batch')))
+        with pytest.raises(RuntimeError, match='skip this batch'):
+            tr.step(*batch, global_step=9)
+    assert not model.k0._k4_sparse_pending and not model.k0._k4_sparse_grad and model.k0.grid.device not in k4grid._GSB_WS
+    assert torch.equal(model.k0.grid.detach(), before)
+    # ... and a pending gradient met by a step that cannot take the in-place form is swept into the dense tensor
+    model.k0._k4_sparse_grad = True
+    with torch.enable_grad():
+        rr, rgb_sr, ls = tr.forward(*batch, global_step=9)
+        tr.optimizer.zero_grad(set_to_none=True)
+        ls['total'].backward()
+    model.k0._k4_sparse_grad = False
+    k4grid.sweep_pending_grad(model.k0)
+    assert model.k0.grid.grad is not None and int(model.k0.grid.grad.count_nonzero()) > 0 and not model.k0._k4_sparse_pending
+    assert torch.equal(model.k0.grid.detach(), before)
+
+
 def test_graphed_decoder_matches_eager_and_sees_weight_updates():
     """lib/sr_train.GraphedDecoder: SFTNet's training forward + backward captured as hipGraphs (the weight packers run inside them).
     Replays must equal the eager path (same kernels; wgrad / dbias sum with atomics: 2e-5 relative) -- also after the weights changed."""

@@ -20,4 +20,4 @@ if "cpu_baseline" in d:
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"].get("threads_used"))
 print("json chars", len(json.dumps(d)))
 j = d.get("joint_train_step") or {}
-print("joint", {k: j.get(k) for k in ("ms_per_iteration", "iterations_per_s", "error")})
+print("joint", {k: j.get(k) for k in ("ms_per_iteration", "ms_per_iteration_after_tv_before", "iterations_per_s", "error")})

@@ -11,6 +11,7 @@ from nerf4k_amd.lib import dvgo, sr_esrnet, sr_train, utils
 if os.environ.get('SIDE_PRIO') is not None and hasattr(sr_train, '_SIDE_LOW_PRIORITY'):
     sr_train._SIDE_LOW_PRIORITY = os.environ['SIDE_PRIO'] != '0'
 dev = torch.device('cuda', 0)
+S0 = int(os.environ.get('STEP0', '0'))              # >= 10000: the iterations after tv_before (no TV, sparse grid gradients)
 ck = scene.make_llff_checkpoint()
 H, W = scene.LLFF_HW
 ro, rd, vd = dvgo.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(scene.llff_spiral_poses()[0]).to(dev), True, False, False, False)
@@ -55,7 +56,7 @@ wrap(tr, '_decoder', 'marcher forward done', 'decoder forward issued')
 wrap(tr, 'losses', None, 'losses issued')
 wrap(joint_train, 'exchange_gradients', 'backward issued', None)
 for i in range(4):
-    tr.step(*batch(i), global_step=1 + i)
+    tr.step(*batch(i), global_step=S0 + 1 + i)
 torch.cuda.synchronize()
 rows = []
 n = int(os.environ.get('ITERS', '24'))
@@ -63,7 +64,7 @@ t_all = time.perf_counter()
 for i in range(n):
     marks.clear()
     mark('start')
-    tr.step(*batch(4 + i), global_step=5 + i)
+    tr.step(*batch(4 + i), global_step=S0 + 5 + i)
     mark('end')
     rows.append(list(marks))
 torch.cuda.synchronize()

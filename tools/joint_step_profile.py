@@ -8,6 +8,7 @@ from nerf4k_amd.lib import dvgo, sr_esrnet, utils
 import contextlib
 
 dev = torch.device('cuda', 0)
+S0 = int(os.environ.get('STEP0', '0'))              # >= 10000: the iterations after tv_before (no TV, sparse grid gradients)
 ck = scene.make_llff_checkpoint()
 H, W = scene.LLFF_HW
 ro, rd, vd = dvgo.get_rays_of_a_view(H, W, scene.LLFF_K, torch.from_numpy(scene.llff_spiral_poses()[0]).to(dev), True, False, False, False)
@@ -27,18 +28,18 @@ def batch(i):
 
 
 for i in range(2):
-    tr.step(*batch(i), global_step=1 + i)
+    tr.step(*batch(i), global_step=S0 + 1 + i)
 torch.cuda.synchronize()
 # K4_PROF_BWD=1: the backward pass on the calling thread (no engine worker threads), so that the Function.backward bodies show up below
 ctx = torch.autograd.set_multithreading_enabled(False) if os.environ.get('K4_PROF_BWD', '0') == '1' else contextlib.nullcontext()
 pr = cProfile.Profile()
 with ctx:
     for i in range(2):
-        tr.step(*batch(2 + i), global_step=3 + i)
+        tr.step(*batch(2 + i), global_step=S0 + 3 + i)
     torch.cuda.synchronize()
     pr.enable()
     for i in range(3):
-        tr.step(*batch(4 + i), global_step=5 + i)
+        tr.step(*batch(4 + i), global_step=S0 + 5 + i)
     torch.cuda.synchronize()
     pr.disable()
 st = pstats.Stats(pr)

@@ -21,8 +21,9 @@ def batch(i):
     rays = [x[r0:r0 + 64, c0:c0 + 64].reshape(-1, 3).contiguous() for x in (ro, rd, vd)]
     return rays + [torch.rand([4096, 3], device=dev, generator=g), torch.rand([65536, 3], device=dev, generator=g), 64, 64]
 losses = []
+S0 = int(os.environ.get('STEP0', '0'))              # 0: the first 10,000 iterations of fern_lg_joint_l1 (dense TV on both grids, every voxel's Adam state moves); >= 10000: the other 290,000 (no TV, MaskedAdam skips voxels without gradient)
 for i in range(3):
-    losses.append(float(tr.step(*batch(i), global_step=1 + i)['total']))
+    losses.append(float(tr.step(*batch(i), global_step=S0 + 1 + i)['total']))
 torch.cuda.synchronize()
 n = int(os.environ.get('ITERS', '6'))
 if os.environ.get('K4_TOOL_NOGC') == '1':                               # diagnosis: are the slow blocks Python's cyclic garbage collector?
@@ -32,7 +33,7 @@ blocks = []
 for b in range(int(os.environ.get('BLOCKS', '5'))):                  # the iteration is paced by the host: one block of 6 iterations is noisy from box to box
     t = time.perf_counter()
     for i in range(n):
-        tr.step(*batch(3 + b * n + i), global_step=4 + b * n + i)
+        tr.step(*batch(3 + b * n + i), global_step=S0 + 4 + b * n + i)
     t_host = time.perf_counter() - t              # the host has issued everything (a step that reads a loss back synchronises inside: then host == wall)
     torch.cuda.synchronize()
     blocks.append(((time.perf_counter() - t) / n * 1e3, t_host / n * 1e3))
@@ -47,7 +48,7 @@ if os.environ.get('PROFILE_HOST') == '1':
     pr = cProfile.Profile()
     pr.enable()
     for i in range(n):
-        tr.step(*batch(20 + i), global_step=30 + i)
+        tr.step(*batch(20 + i), global_step=S0 + 30 + i)
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr, stream=sys.stdout)
