@@ -42,6 +42,14 @@ class ConvSftJob(C.Structure):       # k4_conv_sft_job
     _fields_ = [('cond', C.c_void_p), ('y2', C.c_void_p)]
 
 
+class JointLosses(C.Structure):      # k4_joint_losses
+    _fields_ = [('rgb_feature', C.c_void_p), ('target', C.c_void_p), ('n_rays', C.c_int64),
+                ('rgb_sr', C.c_void_p), ('target_4x', C.c_void_p), ('n_hr', C.c_int64), ('sr_cstride', C.c_int64), ('sr_pstride', C.c_int64),
+                ('alphainv_last', C.c_void_p),
+                ('raw_rgb', C.c_void_p), ('weights', C.c_void_p), ('ray_id', C.c_void_p), ('n_pts', C.c_int64),
+                ('weight_main', C.c_float), ('weight_entropy_last', C.c_float), ('weight_rgbper', C.c_float)]
+
+
 class RdbTrain(C.Structure):         # k4_rdb_train
     _fields_ = [('H', C.c_int32), ('W', C.c_int32), ('nf', C.c_int32), ('g', C.c_int32),
                 ('t', C.c_void_p), ('c', C.c_void_p), ('buf', C.c_void_p), ('x4', C.c_void_p), ('out', C.c_void_p),
@@ -193,6 +201,8 @@ _EXTRA_SIGS = {
     'k4_sft_train_bwd_main': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_sft_train_reduce': ([_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     'k4_rgbnet_input_mpi': ([_P, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P, _I32, _P, _I32, _P], C.c_int),
+    'k4_joint_losses_fwd': ([_P, _P, _P, _P, _P], C.c_int),
+    'k4_joint_losses_bwd': ([_P, _P, _P, _P, _P, _P, _P], C.c_int),
     'k4_distortion_loss': ([_P, _P, _P, _I64, _I64, _F, _P, _P, _P], C.c_int),
     'k4_nhwc_window_to_planar': ([_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _P], C.c_int),
     'k4_tape_begin': ([_P], C.c_void_p),

@@ -465,6 +465,153 @@ extern "C" int k4_distortion_loss(const float* w, const float* s, const int64_t*
 }
 
 // --------------------------------------------------------------------------------------------------------------------
+// The elementwise loss terms of the joint iteration (run_sr.py:877-995) in one launch each way:
+//   photo   = weight_main * mean |rgb_feature - target|                                    (:877-881, F.l1_loss)
+//   l1      = mean |rgb_sr - rgb_hr|,  psnr_sr = -10 log10 mean (clamp(rgb_sr, 0, 1) - rgb_hr)^2   (:925, :930)
+//   entropy = -mean(p log p + (1 - p) log(1 - p)) * weight_entropy_last,  p = clamp(alphainv_last, 1e-6, 1 - 1e-6)      (:962-964)
+//   rgbper  = weight_rgbper * sum_m [ |raw_rgb[m] - target[ray_id[m]]|^2 * weights[m] ] / n_rays                      (:993-995, weights detached)
+// As tensor-library ops these are ~20 launches of 2-4 us forward and as many in the backward pass, each behind ~10 us of dispatch: the GPU sat
+// idle for most of the 0.4 ms between the decoder's forward and its backward pass (profiles/r06_joint_phase_events.md, section 12).
+// Per element the fp32 expression of the op sequence; the sums in fp64 (block partials, one atomic per block and term).
+// --------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double jl_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ void jl_block_add(double v, double* __restrict__ dst, double* sm) {
+    v = jl_wave_sum(v);
+    const int lane = k4_lane(), wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+struct JlSeg { int b1, b2, b3, b4; };        // first block of the segments 1 .. 3 and the grid size (segment 0 starts at block 0)
+__device__ __forceinline__ float jl_clamp_lo() { return 1e-6f; }
+__device__ __forceinline__ float jl_clamp_hi() { return (float)(1.0 - 1e-6); }
+
+__global__ __launch_bounds__(256) void k_joint_losses_sum(k4_joint_losses D, JlSeg S, double* __restrict__ acc) {
+    __shared__ double sm[4];
+    const int b = blockIdx.x;
+    if (b < S.b1) {                                                        // photo
+        const int64_t i = (int64_t)b * 256 + threadIdx.x;
+        const float v = i < D.n_rays * 3 ? fabsf(D.rgb_feature[i] - D.target[i]) : 0.f;
+        jl_block_add((double)v, acc + 0, sm);
+    } else if (b < S.b2) {                                                 // decoder output against the 4x target
+        const int64_t e = (int64_t)(b - S.b1) * 256 + threadIdx.x;
+        float v = 0.f, q = 0.f;
+        if (e < D.n_hr * 3) {
+            const int64_t px = e / 3;
+            const int c = (int)(e - px * 3);
+            const float x = D.rgb_sr[c * D.sr_cstride + px * D.sr_pstride], t = D.target_4x[e];
+            v = fabsf(x - t);
+            const float d = fminf(fmaxf(x, 0.f), 1.f) - t;
+            q = d * d;
+        }
+        jl_block_add((double)v, acc + 1, sm);
+        jl_block_add((double)q, acc + 2, sm);
+    } else if (b < S.b3) {                                                 // entropy of the last transmittance
+        const int64_t i = (int64_t)(b - S.b2) * 256 + threadIdx.x;
+        float v = 0.f;
+        if (i < D.n_rays) {
+            const float p = fminf(fmaxf(D.alphainv_last[i], jl_clamp_lo()), jl_clamp_hi());
+            v = p * logf(p) + (1.f - p) * logf(1.f - p);
+        }
+        jl_block_add((double)v, acc + 3, sm);
+    } else {                                                               // per-sample colour
+        const int64_t m = (int64_t)(b - S.b3) * 256 + threadIdx.x;
+        float v = 0.f;
+        if (m < D.n_pts) {
+            const int64_t r = D.ray_id[m];
+            const float d0 = D.raw_rgb[m * 3] - D.target[r * 3], d1 = D.raw_rgb[m * 3 + 1] - D.target[r * 3 + 1], d2 = D.raw_rgb[m * 3 + 2] - D.target[r * 3 + 2];
+            v = ((d0 * d0 + d1 * d1) + d2 * d2) * D.weights[m];
+        }
+        jl_block_add((double)v, acc + 4, sm);
+    }
+}
+__global__ void k_joint_losses_finish(k4_joint_losses D, double* __restrict__ acc, float* __restrict__ terms, float* __restrict__ total) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float photo = D.weight_main * (float)(acc[0] / (double)(D.n_rays * 3));
+    const float l1 = (float)(acc[1] / (double)(D.n_hr * 3));
+    const float psnr = -10.f * log10f((float)(acc[2] / (double)(D.n_hr * 3)));
+    const float ent = D.alphainv_last ? -(float)(acc[3] / (double)D.n_rays) * D.weight_entropy_last : 0.f;
+    const float per = D.raw_rgb ? (D.weight_rgbper * (float)acc[4]) / (float)D.n_rays : 0.f;
+    terms[0] = photo; terms[1] = l1; terms[2] = psnr; terms[3] = ent; terms[4] = per;
+    float t = photo + l1;
+    if (D.alphainv_last) t += ent;
+    if (D.raw_rgb) t += per;
+    total[0] = t;
+    for (int k = 0; k < 5; ++k) acc[k] = 0.0;
+}
+__global__ __launch_bounds__(256) void k_joint_losses_bwd(k4_joint_losses D, JlSeg S, const float* __restrict__ gtot, float* __restrict__ g_feat, float* __restrict__ g_sr,
+                                                          float* __restrict__ g_alpha, float* __restrict__ g_raw) {
+    const float g = gtot[0];
+    const int b = blockIdx.x;
+    if (b < S.b1) {
+        const int64_t i = (int64_t)b * 256 + threadIdx.x;
+        if (g_feat && i < D.n_rays * 3) {
+            const float gs = (g * D.weight_main) / (float)(D.n_rays * 3), d = D.rgb_feature[i] - D.target[i];
+            g_feat[i] = d > 0.f ? gs : d < 0.f ? -gs : 0.f;
+        }
+    } else if (b < S.b2) {
+        const int64_t e = (int64_t)(b - S.b1) * 256 + threadIdx.x;
+        if (g_sr && e < D.n_hr * 3) {
+            const int64_t px = e / 3;
+            const int c = (int)(e - px * 3);
+            const int64_t o = c * D.sr_cstride + px * D.sr_pstride;
+            const float gs = g / (float)(D.n_hr * 3), d = D.rgb_sr[o] - D.target_4x[e];
+            g_sr[o] = d > 0.f ? gs : d < 0.f ? -gs : 0.f;
+        }
+    } else if (b < S.b3) {
+        const int64_t i = (int64_t)(b - S.b2) * 256 + threadIdx.x;
+        if (g_alpha && i < D.n_rays) {
+            const float a = D.alphainv_last[i];
+            const bool inside = a >= jl_clamp_lo() && a <= jl_clamp_hi();
+            const float p = fminf(fmaxf(a, jl_clamp_lo()), jl_clamp_hi());
+            const float ge = -(g * D.weight_entropy_last) / (float)D.n_rays;
+            g_alpha[i] = inside ? ge * (logf(p) - logf(1.f - p)) : 0.f;
+        }
+    } else {
+        const int64_t m = (int64_t)(b - S.b3) * 256 + threadIdx.x;
+        if (g_raw && m < D.n_pts) {
+            const int64_t r = D.ray_id[m];
+            const float gw = ((g / (float)D.n_rays) * D.weight_rgbper) * D.weights[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_raw[m * 3 + c] = gw * (2.f * (D.raw_rgb[m * 3 + c] - D.target[r * 3 + c]));
+        }
+    }
+}
+static int jl_segments(const k4_joint_losses* d, JlSeg* S) {
+    if (!d || d->n_rays <= 0 || d->n_hr <= 0 || d->n_pts < 0 || !d->rgb_feature || !d->target || !d->rgb_sr || !d->target_4x) return K4_ERR_BAD_ARG;
+    if (d->raw_rgb && (!d->weights || !d->ray_id)) return K4_ERR_BAD_ARG;
+    const int64_t s0 = (d->n_rays * 3 + 255) / 256, s1 = (d->n_hr * 3 + 255) / 256, s2 = d->alphainv_last ? (d->n_rays + 255) / 256 : 0,
+                  s3 = d->raw_rgb ? (d->n_pts + 255) / 256 : 0;
+    if (s0 + s1 + s2 + s3 > 0x3fffffffLL) return K4_ERR_BAD_ARG;
+    S->b1 = (int)s0; S->b2 = (int)(s0 + s1); S->b3 = (int)(s0 + s1 + s2); S->b4 = (int)(s0 + s1 + s2 + s3);
+    return K4_OK;
+}
+extern "C" int k4_joint_losses_fwd(const k4_joint_losses* d, double* acc, float* terms, float* total, void* stream) {
+    JlSeg S;
+    const int rc = jl_segments(d, &S);
+    if (rc) return rc;
+    if (!acc || !terms || !total || (((uintptr_t)acc) & 7u)) return K4_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_joint_losses_sum, dim3((unsigned)S.b4), dim3(256), 0, (hipStream_t)stream, *d, S, acc);
+    hipLaunchKernelGGL(k_joint_losses_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, *d, acc, terms, total);
+    return k4_check_launch();
+}
+extern "C" int k4_joint_losses_bwd(const k4_joint_losses* d, const float* grad_total, float* grad_rgb_feature, float* grad_rgb_sr, float* grad_alphainv_last,
+                                   float* grad_raw_rgb, void* stream) {
+    JlSeg S;
+    const int rc = jl_segments(d, &S);
+    if (rc) return rc;
+    if (!grad_total || (grad_alphainv_last && !d->alphainv_last) || (grad_raw_rgb && !d->raw_rgb)) return K4_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_joint_losses_bwd, dim3((unsigned)S.b4), dim3(256), 0, (hipStream_t)stream, *d, S, grad_total, grad_rgb_feature, grad_rgb_sr, grad_alphainv_last,
+                       grad_raw_rgb);
+    return k4_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
 // The colour MLP's input of DirectMPIGO's training forward (lib/dmpigo.py:360-374) in ONE launch:
 //   x[i] = [ vox_emb[i] (C) | pe_spa (3) | sin(pe_spa f) (3 P) | cos(pe_spa f) (3 P) | viewdirs[r] (3) | sin(viewdirs[r] g) (3 V) | cos(...) (3 V) ],  r = ray_id[i],
 //   pe_spa[j] = ((p[2 - j] - min[2 - j]) / (max[2 - j] - min[2 - j])) * 2 - 1   (the reference's op sequence: sub, div, flip, mul, sub -- one rounding each),

@@ -30,6 +30,7 @@ from .lib.masked_adam import MaskedAdam
 
 _ADAM_SIDE = True   # False: the k0 grid's optimizer step on the current stream (A/B, tests)
 _TV_SEED = True     # False: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
+_FUSED_LOSSES = True     # False: the elementwise loss terms as tensor-library ops (A/B, tests; CPU tensors always)
 _SPARSE_GRID_GRAD = True     # False: k0's gradient as a dense tensor in the iterations without TV too (A/B, tests)
 
 SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
@@ -183,6 +184,23 @@ class JointTrainer:
     def losses(self, rr, rgb_sr, target, target_4x, pr, pc, n_rays):
         """run_sr.py:877-995: the scalar terms of one iteration (dict of tensors; 'total' is what is back-propagated)."""
         cfg, s = self.cfg, self.sr_ratio
+        if _FUSED_LOSSES and rgb_sr.is_cuda and rgb_sr.dtype == torch.float32 and rr['rgb_feature'].dtype == torch.float32 and cfg.weight_nearclip <= 0 \
+                and tuple(rgb_sr.shape) == (1, 3, s * pr, s * pc):
+            # the elementwise terms as ONE autograd node (two launches forward, one backward: lib/train_ops.JointSmallLosses) instead of ~40 tensor-library launches
+            ent, per = cfg.weight_entropy_last > 0, cfg.weight_rgbper > 0
+            small, terms = train_ops.joint_small_losses(rr['rgb_feature'], rgb_sr, rr['alphainv_last'] if ent else None, rr['raw_rgb'] if per else None,
+                                                        target, target_4x.detach().reshape(-1, 3), rr['weights'] if per else None, rr['ray_id'] if per else None,
+                                                        cfg.weight_main, cfg.weight_entropy_last if ent else 0.0, cfg.weight_rgbper if per else 0.0)
+            out = {'photo': terms[0], 'l1': terms[1], 'psnr_sr': terms[2]}
+            if ent:
+                out['entropy_last'] = terms[3]
+            if cfg.weight_distortion > 0:
+                out['distortion'] = cfg.weight_distortion * train_ops.flatten_eff_distloss(rr['weights'], rr['s'], 1 / rr['n_max'], rr['ray_id'],
+                                                                                            n_rays=rr['alphainv_last'].shape[0])
+            if per:
+                out['rgbper'] = terms[4]
+            out['total'] = small + out['distortion'] if cfg.weight_distortion > 0 else small
+            return out
         out = {'photo': cfg.weight_main * F.l1_loss(rr['rgb_feature'], target)}
         rgb_hr = target_4x.detach().reshape(s * pr, s * pc, 3).movedim(-1, 0).unsqueeze(0)
         out['l1'] = F.l1_loss(rgb_sr, rgb_hr)

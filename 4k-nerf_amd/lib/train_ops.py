@@ -226,6 +226,84 @@ class FlattenEffDistLoss(torch.autograd.Function):
         return grad * (grad_back / n_rays_t), None, None, None, None
 
 
+_JL_ACC = {}         # device -> 8 fp64 accumulators of k4_joint_losses_fwd (all zero between calls: the finishing kernel clears them)
+
+
+class JointSmallLosses(torch.autograd.Function):
+    """The elementwise loss terms of the joint iteration (run_sr.py:877-995: photo L1, decoder L1 + its PSNR, last-transmittance entropy, per-sample colour)
+    as ONE node: k4_joint_losses_fwd -> (their sum, the five terms [photo, l1, psnr_sr, entropy_last, rgbper]); k4_joint_losses_bwd -> the gradients w.r.t.
+    rgb_feature, rgb_sr, alphainv_last and raw_rgb in one launch.  ``alphainv_last`` / ``raw_rgb`` None switch their term off (weight 0 in the config)."""
+
+    @staticmethod
+    def forward(ctx, rgb_feature, rgb_sr, alphainv_last, raw_rgb, target, target_4x, weights, ray_id, w_main, w_ent, w_per):
+        dev = rgb_feature.device
+        feat, tgt, t4 = rgb_feature.detach().contiguous(), target.contiguous(), target_4x.contiguous()
+        n_rays, n_hr = int(feat.shape[0]), int(t4.shape[0])
+        sr = rgb_sr.detach()
+        if tuple(sr.shape[:2]) != (1, 3) or sr.shape[2] * sr.shape[3] != n_hr or feat.shape != tgt.shape or feat.shape[1] != 3 or t4.shape[1] != 3:
+            raise ValueError('joint losses: rgb_sr [1, 3, H, W] against target_4x [H * W, 3], rgb_feature / target [n_rays, 3]')
+        W = int(sr.shape[3])
+        if not ((sr.stride(1) == 1 and sr.stride(3) == 3 and sr.stride(2) == 3 * W) or sr.is_contiguous()):
+            sr = sr.contiguous()
+        cs, ps = (1, 3) if (sr.stride(1) == 1 and sr.stride(3) == 3) else (n_hr, 1)
+        d = N.JointLosses()
+        d.rgb_feature, d.target, d.n_rays = feat.data_ptr(), tgt.data_ptr(), n_rays
+        d.rgb_sr, d.target_4x, d.n_hr, d.sr_cstride, d.sr_pstride = sr.data_ptr(), t4.data_ptr(), n_hr, cs, ps
+        keep = [feat, tgt, t4, sr]
+        if alphainv_last is not None:
+            a = alphainv_last.detach().contiguous()
+            d.alphainv_last = a.data_ptr()
+            keep.append(a)
+        if raw_rgb is not None:
+            raw, w, rid = raw_rgb.detach().contiguous(), weights.detach().contiguous(), ray_id.contiguous()
+            if rid.dtype != torch.int64 or raw.shape != (w.shape[0], 3) or rid.shape != w.shape:
+                raise ValueError('joint losses: raw_rgb [n, 3], weights [n], ray_id int64 [n]')
+            d.raw_rgb, d.weights, d.ray_id, d.n_pts = raw.data_ptr() or None, w.data_ptr() or None, rid.data_ptr() or None, int(w.shape[0])
+            if d.n_pts == 0:
+                d.raw_rgb = None
+            keep += [raw, w, rid]
+        for t in keep:
+            if not t.is_cuda or t.dtype != (torch.int64 if t is ray_id or (raw_rgb is not None and t is keep[-1]) else torch.float32):
+                raise N.K4Error('joint losses: fp32 device tensors (no CPU path exists for this op)')
+        d.weight_main, d.weight_entropy_last, d.weight_rgbper = float(w_main), float(w_ent), float(w_per)
+        acc = _JL_ACC.get(dev)
+        if acc is None:
+            acc = _JL_ACC[dev] = torch.zeros([8], dtype=torch.float64, device=dev)
+        terms = torch.empty([5], dtype=torch.float32, device=dev)
+        total = torch.empty([], dtype=torch.float32, device=dev)
+        try:
+            N.check(N.lib().k4_joint_losses_fwd(N.C.byref(d), N.ptr(acc), N.f32(terms), N.f32(total), N.stream()), 'k4_joint_losses_fwd')
+        except Exception:
+            _JL_ACC.pop(dev, None)
+            raise
+        ctx.desc, ctx.keep, ctx.sr_like = d, keep, sr
+        ctx.shapes = (rgb_feature.shape, alphainv_last.shape if alphainv_last is not None else None, raw_rgb.shape if raw_rgb is not None else None)
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_total, _g_terms):
+        d, sr = ctx.desc, ctx.sr_like
+        need = ctx.needs_input_grad
+        dev = sr.device
+        g = g_total.detach().to(torch.float32).contiguous()
+        g_feat = torch.empty(ctx.shapes[0], dtype=torch.float32, device=dev) if need[0] else None
+        g_sr = torch.empty_strided(sr.shape, sr.stride(), dtype=torch.float32, device=dev) if need[1] else None
+        g_a = torch.empty(ctx.shapes[1], dtype=torch.float32, device=dev) if (need[2] and ctx.shapes[1] is not None) else None
+        g_raw = None
+        if need[3] and ctx.shapes[2] is not None:
+            g_raw = torch.empty(ctx.shapes[2], dtype=torch.float32, device=dev) if d.n_pts > 0 and d.raw_rgb else torch.zeros(ctx.shapes[2], dtype=torch.float32, device=dev)
+        vp = lambda t: None if t is None else N.C.c_void_p(t.data_ptr())          # (g_sr carries rgb_sr's strides: NHWC for the training tape's result)
+        N.check(N.lib().k4_joint_losses_bwd(N.C.byref(d), N.f32(g), vp(g_feat), vp(g_sr), vp(g_a), vp(g_raw) if d.raw_rgb else None, N.stream()), 'k4_joint_losses_bwd')
+        return g_feat, g_sr, g_a, g_raw, None, None, None, None, None, None, None
+
+
+def joint_small_losses(rgb_feature, rgb_sr, alphainv_last, raw_rgb, target, target_4x, weights, ray_id, w_main, w_ent, w_per):
+    """-> (photo + l1 + entropy_last + rgbper as one differentiable scalar, detached [photo, l1, psnr_sr, entropy_last, rgbper])."""
+    return JointSmallLosses.apply(rgb_feature, rgb_sr, alphainv_last, raw_rgb, target, target_4x, weights, ray_id, w_main, w_ent, w_per)
+
+
 def flatten_eff_distloss(w, s, interval, ray_id, n_rays=None):
     """Drop-in for ``torch_efficient_distloss.flatten_eff_distloss`` as run_sr.py:985 calls it.  ``n_rays`` (optional, not in the
     package's signature): the number of rays of the batch -- any integer > max(ray_id) -- saves the host synchronisation that reading

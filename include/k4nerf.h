@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl, k4_joint_losses_fwd / _bwd; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -597,6 +597,28 @@ int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_t width, in
 int k4_rgbnet_input_mpi(const float* vox_emb, int32_t channels, const float* ray_pts, const float* viewdirs, const int64_t* ray_id, int64_t n_pts,
                         const float* xyz_min, const float* xyz_max, const float* posfreq, int32_t n_posfreq, const float* viewfreq, int32_t n_viewfreq,
                         float* x, int32_t dim0, void* stream);
+/* The elementwise loss terms of the joint training iteration (run_sr.py:877-995) in one launch each way (as tensor-library ops: ~20 launches of a few
+ * microseconds forward and as many backward):
+ *   terms[0] photo   = weight_main * mean |rgb_feature - target|                                              (run_sr.py:877-881)
+ *   terms[1] l1      = mean |rgb_sr - rgb_hr|,  rgb_hr[c][p] = target_4x[p][c]                                 (:925)
+ *   terms[2] psnr_sr = -10 log10 mean (clamp(rgb_sr, 0, 1) - rgb_hr)^2                                         (:930; a metric, no gradient)
+ *   terms[3] entropy = -mean(p log p + (1 - p) log(1 - p)) * weight_entropy_last, p = clamp(alphainv_last, 1e-6, 1 - 1e-6)   (:962-964; alphainv_last NULL: off)
+ *   terms[4] rgbper  = weight_rgbper * sum_m |raw_rgb[m] - target[ray_id[m]]|^2 weights[m] / n_rays          (:993-995, weights a constant; raw_rgb NULL: off)
+ *   total[0] = photo + l1 (+ entropy) (+ rgbper); the distortion term (k4_distortion_loss) is added by the caller.
+ * rgb_sr element (channel c, pixel p) lies at c * sr_cstride + p * sr_pstride (NCHW: n_hr, 1; the decoder's NHWC result: 1, 3); grad_rgb_sr has the same
+ * layout.  `acc`: 8 doubles, ALL ZERO on entry and again on return (allocate and clear once).  k4_joint_losses_bwd: gradients of total[0] times the device
+ * scalar grad_total w.r.t. rgb_feature, rgb_sr, alphainv_last, raw_rgb (a NULL output is skipped). */
+typedef struct k4_joint_losses {
+    const float* rgb_feature; const float* target; int64_t n_rays;                 /* [n_rays][3] each */
+    const float* rgb_sr; const float* target_4x; int64_t n_hr;                     /* n_hr pixels; target_4x [n_hr][3] */
+    int64_t sr_cstride, sr_pstride;
+    const float* alphainv_last;                                                    /* [n_rays] or NULL */
+    const float* raw_rgb; const float* weights; const int64_t* ray_id; int64_t n_pts;   /* [n_pts][3], [n_pts], [n_pts]; raw_rgb NULL: term off */
+    float weight_main, weight_entropy_last, weight_rgbper;
+} k4_joint_losses;
+int k4_joint_losses_fwd(const k4_joint_losses* d, double* acc, float* terms, float* total, void* stream);
+int k4_joint_losses_bwd(const k4_joint_losses* d, const float* grad_total, float* grad_rgb_feature, float* grad_rgb_sr, float* grad_alphainv_last,
+                        float* grad_raw_rgb, void* stream);
 /* Distortion loss of the joint training step: run_sr.py:976-988 calls `flatten_eff_distloss(w, s, 1/n_max, ray_id)` of the
  * third-party package torch_efficient_distloss (not vendored in the reference tree).  Its published form is evaluated per
  * ray over samples sorted by s (ray_id ascending, as the marcher emits them):

@@ -320,6 +320,50 @@ def test_iterations_without_tv_update_k0_from_the_scatter_image(monkeypatch):
     assert torch.equal(model.k0.grid.detach(), before)
 
 
+@pytest.mark.parametrize('nhwc', [False, True])
+@pytest.mark.parametrize('terms_on', [(True, True, True), (False, False, False), (True, False, True)])
+def test_fused_joint_loss_terms_equal_the_op_sequence(nhwc, terms_on, monkeypatch):
+    """JointTrainer.losses with the elementwise terms as ONE autograd node (train_ops.JointSmallLosses: k4_joint_losses_fwd / _bwd) against the same method on
+    the tensor-library op sequence of run_sr.py:877-995 (checked against the oracle's restatement in tests/test_joint_cpu.py): every term, the total and the
+    gradients w.r.t. rgb_feature, rgb_sr, alphainv_last, raw_rgb and weights (the distortion term's) -- values 2e-6 relative (fp64 sums against the library's
+    fp32 trees), gradients 1e-6 of their scale; decoder result as NCHW and as the NHWC view the training tape hands out; transmittances on and beyond the clamp."""
+    ent_on, dist_on, per_on = terms_on
+    g = torch.Generator().manual_seed(31 + int(nhwc) + 2 * int(ent_on))
+    pr, pc, n_pts = 7, 9, 333
+    n = pr * pc
+    base = {'rgb_feature': torch.rand([n, 3], generator=g), 'alphainv_last': torch.rand([n], generator=g),
+            'weights': torch.rand([n_pts], generator=g) * 0.1, 'raw_rgb': torch.rand([n_pts, 3], generator=g),
+            'ray_id': torch.sort(torch.randint(0, n, [n_pts], generator=g)).values, 's': torch.sort(torch.rand([n_pts], generator=g)).values, 'n_max': 12}
+    base['alphainv_last'][:5] = torch.tensor([0.0, 1.0, 1e-9, 1e-6, 1 - 1e-6])
+    base['rgb_feature'][3] = 0.25                                           # exact ties: sign(0) = 0
+    sr0 = torch.rand([1, 3, 4 * pr, 4 * pc], generator=g) * 1.4 - 0.2      # beyond [0, 1]: the PSNR clamps
+    target, target_4x = torch.rand([n, 3], generator=g).cuda(), torch.rand([16 * n, 3], generator=g).cuda()
+    target[3] = 0.25
+    cfg = joint_train.JointCfg.fern_lg_joint_l1(weight_entropy_last=0.001 if ent_on else 0, weight_distortion=0.01 if dist_on else 0, weight_rgbper=0.01 if per_on else 0)
+    tr = joint_train.JointTrainer.__new__(joint_train.JointTrainer)
+    tr.cfg, tr.sr_ratio = cfg, 4
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(joint_train, '_FUSED_LOSSES', fused)
+        rr = {k: (v.cuda().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and k != 's' else (v.cuda() if torch.is_tensor(v) else v)) for k, v in base.items()}
+        leaf = (sr0.permute(0, 2, 3, 1).contiguous().cuda() if nhwc else sr0.cuda()).requires_grad_(True)
+        rgb_sr = leaf.permute(0, 3, 1, 2) if nhwc else leaf
+        with torch.enable_grad():
+            out = tr.losses(rr, rgb_sr, target, target_4x, pr, pc, n)
+            out['total'].backward()
+        res.append(({k: float(v) for k, v in out.items()}, [rr[k].grad for k in ('rgb_feature', 'alphainv_last', 'raw_rgb', 'weights')] + [leaf.grad]))
+    (v0, g0), (v1, g1) = res
+    assert set(v0) == set(v1) == {'photo', 'l1', 'psnr_sr', 'total'} | ({'entropy_last'} if ent_on else set()) | ({'distortion'} if dist_on else set()) | ({'rgbper'} if per_on else set())
+    for k in v0:
+        assert abs(v1[k] - v0[k]) <= 2e-6 * abs(v0[k]) + 1e-9, (k, v1[k], v0[k])
+    for name, a, b in zip(('rgb_feature', 'alphainv_last', 'raw_rgb', 'weights', 'rgb_sr'), g1, g0):
+        assert (a is None) == (b is None), name
+        if b is not None:
+            assert a.shape == b.shape
+            _close(a, b.cpu(), name, rel=1e-6, abs_=1e-12)
+    assert g0[4] is not None and g0[0] is not None and (g0[1] is not None) == ent_on and (g0[2] is not None) == per_on and (g0[3] is not None) == dist_on
+
+
 def test_graphed_decoder_matches_eager_and_sees_weight_updates():
     """lib/sr_train.GraphedDecoder: SFTNet's training forward + backward captured as hipGraphs (the weight packers run inside them).
     Replays must equal the eager path (same kernels; wgrad / dbias sum with atomics: 2e-5 relative) -- also after the weights changed."""
