@@ -56,6 +56,7 @@ struct WgradParams {
     float* dw;                                  // [cout][cin][ks][ks]
     float* db;                                  // NULL, or [cout]: the bias gradient, summed by the workgroups of tap 0 / input block 0
     int ci_blocks, co_blocks, bands;
+    int units, upw, groups;                     // nine-tap kernel: (row, 16-pixel chunk) units, units per wave, workgroups per (ci block, co block)
 };
 
 __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P) {
@@ -124,6 +125,123 @@ __global__ __launch_bounds__(256) void k4_conv_wgrad_kernel(const WgradParams P)
     }
 }
 
+// The 3x3 layers: ALL NINE TAPS in one workgroup.  In the kernel above every (tap, ci block) workgroup fetches and splits the same dY fragment and every
+// (tap, co block) workgroup the same input pixels (one pixel to the side): 16 fetches and two 3-term splits (~100 vector instructions) per 6 matrix
+// instructions -- the weight gradients of the 64x64 training patch ran at 37 us a layer, 85 layers an iteration, and were the longer of the two chains of the
+// decoder's backward pass (profiles/r06_joint_phase_events.md, section 13).  Here a wave takes units of (row y, 16 pixels): the dY fragment is fetched and
+// split ONCE for the nine taps; of each of the three input rows y - 1, y, y + 1 it fetches the 10 pixels px - 1 .. px + 8 once and splits them once as the
+// pairs (0,1) (2,3) (4,5) (6,7) (8,9): pairs 0..3 are the fragment of tap dx = -1, pairs 1..4 that of dx = +1, and dx = 0 is one v_alignbit per dword --
+// 38 fetches and ~280 vector instructions per 54 matrix instructions.  The nine 32 x 32 tiles of the four waves are summed in LDS in dW's own order
+// ([co][ci][tap]: 288 consecutive floats per output channel) and added to dW with fp32 atomics on CONSECUTIVE addresses (the tiles of the kernel above go
+// out with one cache line per lane).  Units per wave (P.upw) are chosen by the launcher: 4 on the 64 x 64 patch (96 workgroups for 192 -> 32), more on the
+// decoder's 256 x 256 layers.  Same products, same 3-term splits; the order of the fp32 sums differs (as it does from run to run with the atomics).
+__device__ __forceinline__ void wg_split_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = wg_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = wg_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
+    p2 = wg_pk_bf16(sa, sb);
+}
+#define K4_WG9_PITCH 73
+__global__ __launch_bounds__(256, 2) void k4_conv_wgrad9_kernel(const WgradParams P) {
+    __shared__ float red[4 * 32 * K4_WG9_PITCH];
+    const int lane = k4_lane();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    int b = (int)blockIdx.x;
+    const int grp = b % P.groups; b /= P.groups;
+    const int cob = b % P.co_blocks;
+    const int cib = b / P.co_blocks;
+    const int ci = cib * 32 + l31, co = cob * 32 + l31;
+    const bool ci_ok = ci < P.cin, co_ok = co < P.cout;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x16)(0.f);
+    const bool do_bias = P.db != nullptr && cib == 0;                    // workgroup-uniform: these workgroups see every dY value of their units once
+    double bsum = 0.0;
+    const int xchunks = (P.W + 15) >> 4;
+    for (int u = 0; u < P.upw; ++u) {
+        const int unit = (grp * 4 + wv) * P.upw + u;                     // a wave's units are consecutive: neighbouring chunks of a row
+        if (unit >= P.units) break;                                      // (wave-uniform)
+        const int y = unit / xchunks, x0 = (unit - y * xchunks) * 16 + half * 8;
+        float b8[8], a10[3][10];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = (co_ok && x0 + e < P.W) ? P.gy[((size_t)y * P.W + x0 + e) * P.gy_stride + co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sy = y + r - 1;
+            const bool row_ok = ci_ok && sy >= 0 && sy < P.H;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int sx = x0 - 1 + j;
+                a10[r][j] = (row_ok && sx >= 0 && sx < P.W) ? P.x[((size_t)sy * P.W + sx) * P.x_stride + ci] : 0.f;
+            }
+        }
+        if (do_bias) bsum += (double)(((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7])));
+        uint4 b0, b1, b2;
+        wg_split3(b8, b0, b1, b2);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            unsigned t0[5], t1[5], t2[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wg_split_pair(a10[r][2 * k], a10[r][2 * k + 1], t0[k], t1[k], t2[k]);
+#define WG_MFMA(T, A, B) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, A), __builtin_bit_cast(wg_bf16x8, B), acc[T], 0, 0, 0)
+#define WG_TAP(T, A0, A1, A2) WG_MFMA(T, A2, b0); WG_MFMA(T, A0, b2); WG_MFMA(T, A1, b1); WG_MFMA(T, A1, b0); WG_MFMA(T, A0, b1); WG_MFMA(T, A0, b0)
+            {
+                const uint4 a0 = make_uint4(t0[0], t0[1], t0[2], t0[3]), a1 = make_uint4(t1[0], t1[1], t1[2], t1[3]), a2 = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+                WG_TAP(r * 3 + 0, a0, a1, a2);                             // dx = -1: input pixels px - 1 .. px + 6
+            }
+            {
+#define WG_AL(t, k) __builtin_amdgcn_alignbit(t[k + 1], t[k], 16)
+                const uint4 a0 = make_uint4(WG_AL(t0, 0), WG_AL(t0, 1), WG_AL(t0, 2), WG_AL(t0, 3)), a1 = make_uint4(WG_AL(t1, 0), WG_AL(t1, 1), WG_AL(t1, 2), WG_AL(t1, 3)),
+                            a2 = make_uint4(WG_AL(t2, 0), WG_AL(t2, 1), WG_AL(t2, 2), WG_AL(t2, 3));
+#undef WG_AL
+                WG_TAP(r * 3 + 1, a0, a1, a2);                             // dx = 0: px .. px + 7
+            }
+            {
+                const uint4 a0 = make_uint4(t0[1], t0[2], t0[3], t0[4]), a1 = make_uint4(t1[1], t1[2], t1[3], t1[4]), a2 = make_uint4(t2[1], t2[2], t2[3], t2[4]);
+                WG_TAP(r * 3 + 2, a0, a1, a2);                             // dx = +1: px + 1 .. px + 8
+            }
+#undef WG_TAP
+#undef WG_MFMA
+        }
+    }
+    // The four waves' tiles summed through LDS and added to dW, eight input channels at a time: accumulator register r of lane l = D[i = (r&3)+8*(r>>2)+4*half][j = l31],
+    // so the registers 4p .. 4p+3 of the nine taps are the input channels 8p .. 8p+7 -- in dW ([co][ci][tap]) 72 consecutive floats per output channel.  Plain stores
+    // into the wave's own region, plain loads of the four regions (LDS float atomics and a read-modify-write per wave in turn both cost tens of microseconds).
+    const int ci_left = P.cin - cib * 32;                                // input channels of this block that exist
+    for (int p = 0; p < 4; ++p) {
+        float* const mine = red + wv * (32 * K4_WG9_PITCH);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // (a runtime p would index the accumulator vectors dynamically: the four cases are spelled out)
+            const float v0 = p == 0 ? acc[t][0] : p == 1 ? acc[t][4] : p == 2 ? acc[t][8] : acc[t][12];
+            const float v1 = p == 0 ? acc[t][1] : p == 1 ? acc[t][5] : p == 2 ? acc[t][9] : acc[t][13];
+            const float v2 = p == 0 ? acc[t][2] : p == 1 ? acc[t][6] : p == 2 ? acc[t][10] : acc[t][14];
+            const float v3 = p == 0 ? acc[t][3] : p == 1 ? acc[t][7] : p == 2 ? acc[t][11] : acc[t][15];
+            float* const d = mine + l31 * K4_WG9_PITCH + (4 * half) * 9 + t;
+            d[0] = v0; d[9] = v1; d[18] = v2; d[27] = v3;
+        }
+        __syncthreads();
+        for (int idx = (int)threadIdx.x; idx < 32 * 72; idx += 256) {
+            const int j = idx / 72, q = idx - j * 72;
+            const int co_ = cob * 32 + j;
+            const int o = j * K4_WG9_PITCH + q;
+            const float v = (red[o] + red[32 * K4_WG9_PITCH + o]) + (red[2 * 32 * K4_WG9_PITCH + o] + red[3 * 32 * K4_WG9_PITCH + o]);
+            if (co_ < P.cout && p * 72 + q < ci_left * 9) unsafeAtomicAdd(&P.dw[((size_t)co_ * P.cin + cib * 32) * 9 + p * 72 + q], v);
+        }
+        __syncthreads();
+    }
+    if (do_bias) {                                                      // dbias[co] += the dY sums of this workgroup's units: both pixel halves, four waves
+        bsum += __shfl_xor(bsum, 32);
+        double* const redd = reinterpret_cast<double*>(&red[0]);
+        __syncthreads();                                                // `red` is free again
+        if (half == 0) redd[wv * 32 + l31] = bsum;
+        __syncthreads();
+        if (wv == 0 && half == 0 && co_ok) unsafeAtomicAdd(P.db + co, (float)((redd[l31] + redd[32 + l31]) + (redd[64 + l31] + redd[96 + l31])));
+    }
+}
+
 // dbias[co] = sum over pixels of gy[p][co].  Workgroup = 32 channels x a slab of K4_BG_SLAB pixels; lanes = channel x 8 pixel phases, 8
 // independent loads in flight per thread; the slab sums are added to the zeroed dbias with one fp32 atomic per channel and workgroup
 // (like wgrad's split-K).  The first form -- ONE workgroup per 32 channels walking the whole image with a dependent add per load -- took
@@ -161,8 +279,18 @@ static int wgrad_launch(const float* x, int32_t cin, int32_t x_stride, const flo
     P.x = x; P.cin = cin; P.x_stride = x_stride; P.gy = gy; P.cout = cout; P.gy_stride = gy_stride;
     P.ks = ksize; P.H = H; P.W = W; P.dw = dw; P.db = dbias;
     P.ci_blocks = (cin + 31) / 32; P.co_blocks = (cout + 31) / 32; P.bands = (H + K4_WG_BAND - 1) / K4_WG_BAND;
-    const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
     if (zero_floats > 0) wg_zero(dw, zero_floats, (hipStream_t)stream);                                                 // split-K partial sums are ADDED
+    if (ksize == 3 && !(k4_env().sr_debug & 4096)) {
+        // units per wave: as many workgroups as ~3 per CU allow, at least 4 units (the tile reduction amortises over them)
+        P.units = H * ((W + 15) / 16);
+        const int want_groups = 768 / (P.ci_blocks * P.co_blocks) > 0 ? 768 / (P.ci_blocks * P.co_blocks) : 1;
+        P.upw = (P.units + 4 * want_groups - 1) / (4 * want_groups);
+        if (P.upw < 4) P.upw = 4;            // (64 x 64 patch, isolated launch: 24 / 29 / 39 us at 2 / 4 / 8 units; inside the iteration, beside the other stream's kernels: 8.05 / 7.88 / 8.5 ms)
+        P.groups = (P.units + 4 * P.upw - 1) / (4 * P.upw);
+        hipLaunchKernelGGL(k4_conv_wgrad9_kernel, dim3((unsigned)(P.ci_blocks * P.co_blocks * P.groups)), dim3(256), 0, (hipStream_t)stream, P);
+        return k4_check_launch();
+    }
+    const unsigned grid = (unsigned)(ksize * ksize * P.ci_blocks * P.co_blocks * P.bands);
     hipLaunchKernelGGL(k4_conv_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
     return k4_check_launch();
 }

@@ -43,7 +43,8 @@ def _close_but_for_kinks(got, want, tol=2e-5, kink=1e-3, frac=0.25):
 
 
 @pytest.mark.parametrize('cin,cout,k,H,W', [(64, 32, 3, 19, 37), (160, 32, 3, 16, 32), (192, 64, 3, 9, 20), (3, 64, 3, 21, 18),
-                                             (64, 3, 3, 33, 17), (1, 64, 3, 8, 8), (32, 64, 1, 13, 40), (64, 64, 1, 5, 70)])
+                                             (64, 3, 3, 33, 17), (1, 64, 3, 8, 8), (32, 64, 1, 13, 40), (64, 64, 1, 5, 70),
+                                             (65, 40, 3, 30, 50), (32, 32, 3, 256, 256), (96, 32, 3, 64, 64), (64, 64, 3, 3, 5)])
 def test_conv_function_matches_torch_autograd(cin, cout, k, H, W):
     g = torch.Generator().manual_seed(cin * 7 + cout)
     x = torch.randn([H, W, cin], generator=g).cuda().requires_grad_(True)
