@@ -44,7 +44,11 @@ rm -rf $R/gpurun_out/pmc_r6s_[0-9]
 cd $R
 timeout 300 python tools/joint_phase_events.py > $O/joint_phase_events.txt 2>/dev/null
 BLOCKS=8 SHOW_BLOCKS=1 timeout 300 python tools/joint_step_time.py 2>/dev/null | tail -2 > $O/joint_step_time.txt
+# ... and an iteration after tv_before (STEP0 >= 10000: no total variation, k0 stepped from the scatter image)
+STEP0=20000 timeout 300 python tools/joint_phase_events.py > $O/joint_phase_events_after_tv_before.txt 2>/dev/null
+STEP0=20000 BLOCKS=8 SHOW_BLOCKS=1 timeout 300 python tools/joint_step_time.py 2>/dev/null | tail -2 > $O/joint_step_time_after_tv_before.txt
+STEP0=20000 OUT=r6final/joint_timeline_after_tv_before timeout 400 bash tools/joint_timeline_detail.sh > $O/joint_timeline_detail_after_tv_before.txt 2>&1
 OUT=r6final/joint_timeline timeout 400 bash tools/joint_timeline_detail.sh > $O/joint_timeline_detail.txt 2>&1
 ITERS=20 timeout 400 bash tools/joint_prof.sh > $O/joint_kernel_stats.txt 2>&1; cp $R/gpurun_out/r05_joint/kernel_stats.csv $O/joint_iteration_kernel_stats.csv 2>/dev/null
-cat $O/joint_phase_events.txt $O/joint_step_time.txt
+cat $O/joint_phase_events.txt $O/joint_step_time.txt $O/joint_step_time_after_tv_before.txt
 ls -la $O
