@@ -144,7 +144,7 @@ static inline int k4_check_launch() {
 struct K4Env {
     int geom_skip;       // K4_GEOM_SKIP    (1) 0: do not use the coarse occupancy summary (A/B of the empty-space skipping)
     int debug;           // K4_DEBUG        (0) ablation bits of the marcher kernels, profiling only
-    int sr_debug;        // K4_SR_DEBUG     (0) profiling bits of the decoder kernels (1: input channel stride 0 = no memory traffic, WRONG results; 2..16: phases of the 3x3 kernel off; 32: SFT layers on the unpipelined kernel)
+    int sr_debug;        // K4_SR_DEBUG     (0) profiling bits of the decoder kernels (1: input channel stride 0 = no memory traffic, WRONG results; 2..16: phases of the 3x3 kernel off; 32: SFT layers on the unpipelined kernel; exact ones: 2048: row kernel instead of the K-split 3x3 kernel on small images, 4096: per-tap weight-gradient kernel instead of the nine-tap one)
     bool no_fast_shade;  // K4_DEBUG & 1024: the shading kernel's general path on shapes the FAST path covers (A/B, tests: identical outputs)
 };
 // Settled by measurement and no longer switchable (the evidence is in profiles/ and DESIGN.md): geometry kernel bounded for 5 waves per
