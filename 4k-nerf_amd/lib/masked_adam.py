@@ -2,6 +2,7 @@
 csrc/k4_opt.hip.  Same constructor, param-group keys (`lr`, `betas`, `eps`, `skip_zero_grad`), state keys (`step`,
 `exp_avg`, `exp_avg_sq`), `set_pervoxel_lr` and kernel selection order as upstream; there is no CPU path."""
 import contextlib
+from operator import is_ as _is
 
 import torch
 
@@ -155,16 +156,28 @@ class MaskedAdam(torch.optim.Optimizer):
             if sget(p) is not st:
                 return False
         grads = [p.grad for p in plist]
-        step = states[0]['step']
-        f32 = torch.float32
-        for g, st, nel in zip(grads, states, f['numel']):
-            if g is None or st['step'] != step or g.dtype is not f32 or not g.is_cuda or not g.is_contiguous() or g.numel() != nel:
-                return False
-        if [st['exp_avg'].data_ptr() for st in states] != f['mptr'] or [st['exp_avg_sq'].data_ptr() for st in states] != f['vptr']:
+        steps = [st['step'] for st in states]
+        step = steps[0]
+        if steps.count(step) != len(steps):
             return False
+        if not all(map(_is, [st['exp_avg'] for st in states], f['m'])) or not all(map(_is, [st['exp_avg_sq'] for st in states], f['v'])):
+            return False                                    # a moment tensor was replaced inside its state dict
+        # The SAME gradient tensors as at the previous step?  (The decoder's training tape hands every parameter the same view of its flat gradient buffer on
+        # every pass; `last_grads` keeps them alive, so "same object" cannot be a recycled id.)  Then their dtype / contiguity / size were checked at that step
+        # and their addresses are in the job table already: 458 x (four attribute checks, three data_ptr calls, a pointer store) less per step -- which counts
+        # once the iteration is paced by the host (profiles/r06_joint_phase_events.md, section 16).
+        last = f['last_grads']
+        if last is None or not all(map(_is, grads, last)):
+            f32 = torch.float32
+            for g, nel in zip(grads, f['numel']):
+                if g is None or g.dtype is not f32 or not g.is_cuda or not g.is_contiguous() or g.numel() != nel:
+                    return False
+            if [t.data_ptr() for t in f['m']] != f['mptr'] or [t.data_ptr() for t in f['v']] != f['vptr']:
+                return False
+            for j, g in enumerate(grads):
+                jobs[j].grad = g.data_ptr()
+            f['last_grads'] = grads
         step += 1
-        for j, g in enumerate(grads):
-            jobs[j].grad = g.data_ptr()
         for st in states:
             st['step'] = step
         N.check(N.lib().k4_adam_upd_multi(jobs, len(plist), int(bool(masked)), int(step), float(beta1), float(beta2), float(lr), float(eps),
@@ -183,6 +196,7 @@ class MaskedAdam(torch.optim.Optimizer):
         self._fast[id(group)] = {'params': plist, 'states': states, 'jobs': jobs, 'masked': bool(masked), 'n_group': len(group['params']),
                                  'pptr': [p.data_ptr() for p in plist], 'mptr': [st['exp_avg'].data_ptr() for st in states],
                                  'vptr': [st['exp_avg_sq'].data_ptr() for st in states],
+                                 'm': [st['exp_avg'] for st in states], 'v': [st['exp_avg_sq'] for st in states], 'last_grads': None,
                                  'numel': [p.numel() for p in plist], 'ids': {id(p) for p in plist},
                                  'touched': [t for ts in items for t in (ts[0], ts[2], ts[3])]}
 
