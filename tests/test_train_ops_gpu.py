@@ -364,6 +364,36 @@ def test_fused_joint_loss_terms_equal_the_op_sequence(nhwc, terms_on, monkeypatc
     assert g0[4] is not None and g0[0] is not None and (g0[1] is not None) == ent_on and (g0[2] is not None) == per_on and (g0[3] is not None) == dist_on
 
 
+def test_fused_joint_loss_terms_without_any_sample(monkeypatch):
+    """A patch whose rays pick up no sample (empty space): the per-sample terms are zero, their gradients empty, in both forms."""
+    g = torch.Generator().manual_seed(5)
+    pr, pc = 4, 6
+    n = pr * pc
+    target, target_4x = torch.rand([n, 3], generator=g).cuda(), torch.rand([16 * n, 3], generator=g).cuda()
+    cfg = joint_train.JointCfg.fern_lg_joint_l1()
+    tr = joint_train.JointTrainer.__new__(joint_train.JointTrainer)
+    tr.cfg, tr.sr_ratio = cfg, 4
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(joint_train, '_FUSED_LOSSES', fused)
+        rr = {'rgb_feature': torch.rand([n, 3], generator=torch.Generator().manual_seed(6)).cuda().requires_grad_(True),
+              'alphainv_last': torch.ones([n]).cuda().requires_grad_(True), 'weights': torch.zeros([0]).cuda().requires_grad_(True),
+              'raw_rgb': torch.zeros([0, 3]).cuda().requires_grad_(True), 'ray_id': torch.zeros([0], dtype=torch.int64).cuda(), 's': torch.zeros([0]).cuda(), 'n_max': 12}
+        sr = torch.rand([1, 3, 4 * pr, 4 * pc], generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
+        with torch.enable_grad():
+            out = tr.losses(rr, sr, target, target_4x, pr, pc, n)
+            out['total'].backward()
+        res.append(({k: float(v) for k, v in out.items()}, rr['rgb_feature'].grad, sr.grad, rr['alphainv_last'].grad))
+    (v0, *g0), (v1, *g1) = res
+    assert v0['rgbper'] == 0.0 and v1['rgbper'] == 0.0 and v0['distortion'] == 0.0 and v1['distortion'] == 0.0
+    for k in v0:
+        assert abs(v1[k] - v0[k]) <= 2e-6 * abs(v0[k]) + 1e-9, (k, v1[k], v0[k])
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None)
+        if b is not None:
+            _close(a, b.cpu(), 'grad', rel=1e-6, abs_=1e-12)
+
+
 def test_graphed_decoder_matches_eager_and_sees_weight_updates():
     """lib/sr_train.GraphedDecoder: SFTNet's training forward + backward captured as hipGraphs (the weight packers run inside them).
     Replays must equal the eager path (same kernels; wgrad / dbias sum with atomics: 2e-5 relative) -- also after the weights changed."""
