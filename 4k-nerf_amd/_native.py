@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('K4_LIB') or os.path.join(_PKG, 'lib4k_hip.so')      # K4_LIB: a variant build (A/B experiments, tools/)
-K4_ABI_VERSION = 13
+K4_ABI_VERSION = 14
 # True: the data-path collectives (tile all-gather, gradient exchange) are issued even on a process group of ONE rank -- the RCCL smoke test
 # on a single GPU (tests/test_rccl_gpu.py: communicator + the production collective calls on device buffers); never set in production
 FORCE_COLLECTIVES = False
@@ -59,7 +59,8 @@ class RdbTrain(C.Structure):         # k4_rdb_train
                 ('dwdb', C.c_void_p * 5), ('gsft0', C.c_void_p * 8), ('gsft1', C.c_void_p * 8),
                 ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p),
                 ('gc_acc', C.c_void_p), ('gx0_add', C.c_void_p), ('dwdb_span', C.c_void_p), ('dwdb_span_floats', C.c_int64),
-                ('fused_lrelu', C.c_int32), ('g5_from_gx0_add', C.c_int32), ('no_join', C.c_int32), ('defer_side', C.c_int32)]
+                ('fused_lrelu', C.c_int32), ('g5_from_gx0_add', C.c_int32), ('no_join', C.c_int32), ('defer_side', C.c_int32),
+                ('aux_stream', C.c_void_p)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -200,6 +201,8 @@ _EXTRA_SIGS = {
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'k4_sft_train_bwd_main': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_sft_train_reduce': ([_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    'k4_sft_train_bwd_gx': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _F, _P, _P, _I32, _I32, _F, _P], C.c_int),
+    'k4_sft_train_bwd_rest': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I64, _I32, _F, _P], C.c_int),
     'k4_rgbnet_input_mpi': ([_P, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P, _I32, _P, _I32, _P], C.c_int),
     'k4_joint_losses_fwd': ([_P, _P, _P, _P, _P], C.c_int),
     'k4_joint_losses_bwd': ([_P, _P, _P, _P, _P, _P, _P], C.c_int),

@@ -862,6 +862,9 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
         sft_hidden(cs, w0sc, k4_const(b0s), w0hc, k4_const(b0h), slope, as, ah, wv, lane);
         __syncthreads();
         // gx = gy * (scale + 1);  gs = gy * x   (the shift branch's output gradient is gy itself)
+        if (!gxg) {                                            // the chain's own launch (k_sft_train_bwd_gx) has written grad_x: gs only
+            for (int co = wv * (C / SFT_NW); co < (wv + 1) * (C / SFT_NW); ++co) gs[co * TR_LS + lane] = gs[co * TR_LS + lane] * gy[co * TR_LS + lane];
+        } else
         for (int co = wv * (C / SFT_NW); co < (wv + 1) * (C / SFT_NW); co += 2) {
             float s0 = b1sc[co], s1 = b1sc[co + 1];
             for (int k = 0; k < SFT_G; ++k) {
@@ -933,7 +936,8 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
             }
         }
         __syncthreads();
-        if (gxa) {                                         // grad_x = this layer's gradient + gxa (the block's skip connection: one add kernel less per block)
+        if (!gxg) {
+        } else if (gxa) {                                  // grad_x = this layer's gradient + gxa (the block's skip connection: one add kernel less per block)
             for (int i = t; i < 64 * C; i += SFT_T) {
                 const int s = i / C, k = i - s * C;
                 if (s < nv) gxg[(base + s) * C + k] = gx[k * TR_LS + s] + gxa[(base + s) * gxa_stride + k];
@@ -957,6 +961,72 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd(const float* __restrict
 #pragma unroll
             for (int b = 0; b < 2; ++b) mine[blk[q].ooff + a * blk[q].ostride + b] = acc[q][a * 2 + b];
     }
+}
+
+// The part of the layer's backward the CHAIN waits for: grad_x = gy * (scale(cond) + 1) [LeakyReLU mask] [+ gxa] -- the scale branch's 32 hidden neurons and its
+// output layer, the arithmetic of k_sft_train_bwd's first two stages value for value (same FMA chains, same roundings).  Everything else of the layer
+// (both branches' hidden gradients, the condition gradient, the eight parameter gradients) is read by nothing on the chain before the CondNet's backward pass /
+// the optimizer: a caller with a third stream runs it there as k_sft_train_bwd with gxg == NULL (k4_sft_train_bwd_rest) while the chain moves on.  In the joint
+// iteration the 36 full launches were 28-37 us each on the chain (1.2 ms of a 3.4 ms backward pass); this one is the size of the forward launch.
+template <int C>
+__global__ __launch_bounds__(SFT_T) void k_sft_train_bwd_gx(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride,
+                                                          const float* __restrict__ gyg, int gy_stride, int64_t n,
+                                                          const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
+                                                          float slope, float* __restrict__ gxg, const float* __restrict__ gxa, int gxa_stride, int gx_lrelu, float gy_scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const cs = smem;                       // [32][LS]
+    float* const as = cs + SFT_G * TR_LS;         // [32][LS]
+    float* const gy = as + SFT_G * TR_LS;         // [C][LS]  gy, then grad_x in place
+    float* const xs = gy + C * TR_LS;             // [C][LS]  (gx_lrelu only)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nv = (n - base) < 64 ? (int)(n - base) : 64;
+    const float warm = sft_warm_weights<C>(w0s, w0s, w1s, w1s, t);
+    sft_load_tile(cond, base, c_stride, SFT_G, nv, cs, t);
+    if (gy_scale != 1.f) {
+        for (int i = t; i < 64 * C; i += SFT_T) {
+            const int s = i / C, k = i - s * C;
+            gy[k * TR_LS + s] = s < nv ? gyg[(base + s) * gy_stride + k] * gy_scale : 0.f;
+        }
+    } else sft_load_tile(gyg, base, gy_stride, C, nv, gy, t);
+    if (gx_lrelu) sft_load_tile(x, base, x_stride, C, nv, xs, t);
+    if (warm == 1.2345e38f) cs[0] = warm;                                     // (keeps the loads alive; never true)
+    __syncthreads();
+    {
+        static_assert(SFT_NW == 16, "wave -> 2 hidden neurons of the scale branch");
+        const int j0 = wv * 2;
+        const k4_cptr w = k4_const(w0s) + j0 * SFT_G, b = k4_const(b0s) + j0;
+        float a0 = b[0], a1 = b[1];
+        for (int k = 0; k < SFT_G; ++k) {
+            const float v = cs[k * TR_LS + lane];
+            a0 = fmaf(v, w[k], a0); a1 = fmaf(v, w[SFT_G + k], a1);
+        }
+        as[j0 * TR_LS + lane] = a0 > 0.f ? a0 : a0 * slope; as[(j0 + 1) * TR_LS + lane] = a1 > 0.f ? a1 : a1 * slope;
+    }
+    __syncthreads();
+    const k4_cptr w1sc = k4_const(w1s), b1sc = k4_const(b1s);
+    for (int co = wv * (C / SFT_NW); co < (wv + 1) * (C / SFT_NW); co += 2) {
+        float s0 = b1sc[co], s1 = b1sc[co + 1];
+        for (int k = 0; k < SFT_G; ++k) {
+            const float a = as[k * TR_LS + lane];
+            s0 = fmaf(a, w1sc[co * SFT_G + k], s0); s1 = fmaf(a, w1sc[(co + 1) * SFT_G + k], s1);
+        }
+        const float g0 = gy[co * TR_LS + lane], g1 = gy[(co + 1) * TR_LS + lane];
+        float o0 = g0 * (s0 + 1.f), o1 = g1 * (s1 + 1.f);
+        if (gx_lrelu) {
+            const float x0 = xs[co * TR_LS + lane], x1 = xs[(co + 1) * TR_LS + lane];
+            o0 = x0 > 0.f ? o0 : o0 * slope; o1 = x1 > 0.f ? o1 : o1 * slope;
+        }
+        gy[co * TR_LS + lane] = o0; gy[(co + 1) * TR_LS + lane] = o1;
+    }
+    __syncthreads();
+    if (gxa) {
+        for (int i = t; i < 64 * C; i += SFT_T) {
+            const int s = i / C, k = i - s * C;
+            if (s < nv) gxg[(base + s) * C + k] = gy[k * TR_LS + s] + gxa[(base + s) * gxa_stride + k];
+        }
+    } else sft_store_tile(gy, gxg, base, C, C, nv, t);
 }
 
 // partials [n_wg][P1s | P1h | P0s | P0h] -> gw1s [C][32], gb1s [C], gw1h, gb1h, gw0s [32][32], gb0s [32], gw0h, gb0h; fixed order (see k_rgbnet_reduce)
@@ -1039,7 +1109,7 @@ extern "C" int k4_sft_train_fwd(const float* x, int32_t x_stride, const float* c
     return k4_sft_train_fwd_ex(x, x_stride, cond, cond_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, b1h, slope, y, y_stride, nullptr, 0, 1.f, stream);
 }
 
-static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller);
+static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller, hipStream_t waiter2 = nullptr);
 // red_st: the stream of the partial sums' reduction (the eight parameter gradients).  Nothing on the chain reads those: with red_st != st the reduction is
 // forked to red_st (which the caller joins before the gradients are read), one launch and one launch gap less on the chain per layer.
 template <int C>
@@ -1071,10 +1141,10 @@ static int sft_bwd_entry(const float* x, int32_t x_stride, const float* cond, in
                          float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h,
                          float* workspace, int64_t workspace_bytes,
                          const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale,
-                         void* side_stream, bool do_reduce, void* stream) {
+                         void* side_stream, bool do_reduce, void* stream, bool rest_only = false) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || x_stride < channels || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels)) return K4_ERR_BAD_ARG;
-    if (!x || !cond || !grad_y || !grad_x || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
+    if (!x || !cond || !grad_y || (!grad_x && !rest_only) || !grad_cond || !w0s || !b0s || !w1s || !b1s || !w0h || !b0h || !w1h) return K4_ERR_BAD_ARG;
     if (!gw0s || !gb0s || !gw1s || !gb1s || !gw0h || !gb0h || !gw1h || !gb1h) return K4_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < k4_sft_train_bwd_workspace_bytes(n_pix, channels)) return K4_ERR_BAD_ARG;
     return k4_taped(stream, [=](void* stream) -> int {
@@ -1110,6 +1180,37 @@ extern "C" int k4_sft_train_bwd_main(const float* x, int32_t x_stride, const flo
     return sft_bwd_entry(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, grad_x, grad_cond,
                          dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, workspace, workspace_bytes, grad_x_add, gxa_stride, accumulate_grad_cond, grad_x_lrelu,
                          grad_y_scale, nullptr, false, stream);
+}
+// The layer's backward in two launches for a caller with a third stream (k_sft_train_bwd_gx above): k4_sft_train_bwd_gx on the chain, k4_sft_train_bwd_rest
+// (+ k4_sft_train_reduce) wherever the caller likes, ordered behind the producer of grad_y and in front of the first reader of grad_cond / the gradients.
+extern "C" int k4_sft_train_bwd_gx(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                   int64_t n_pix, int32_t channels, const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                                   float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
+    if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
+    if (n_pix <= 0 || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels) || (grad_x_lrelu && (!x || x_stride < channels))) return K4_ERR_BAD_ARG;
+    if (!cond || !grad_y || !grad_x || !w0s || !b0s || !w1s || !b1s) return K4_ERR_BAD_ARG;
+    return k4_taped(stream, [=](void* stream) -> int {
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 grid((unsigned)((n_pix + 63) / 64)), block(SFT_T);
+        const size_t lds = (size_t)(2 * SFT_G + 2 * channels) * TR_LS * sizeof(float);
+        if (channels == 64) {
+            K4_ENSURE_DYN_LDS((k_sft_train_bwd_gx<64>), lds);
+            hipLaunchKernelGGL(k_sft_train_bwd_gx<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale);
+        } else {
+            K4_ENSURE_DYN_LDS((k_sft_train_bwd_gx<32>), lds);
+            hipLaunchKernelGGL(k_sft_train_bwd_gx<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale);
+        }
+        return k4_check_launch();
+    });
+}
+extern "C" int k4_sft_train_bwd_rest(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                                     int64_t n_pix, int32_t channels,
+                                     const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                                     float slope, float* grad_cond, float* workspace, int64_t workspace_bytes, int32_t accumulate_grad_cond, float grad_y_scale, void* stream) {
+    float* const dummy = workspace;
+    return sft_bwd_entry(x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, channels, w0s, b0s, w1s, b1s, w0h, b0h, w1h, slope, nullptr, grad_cond,
+                         dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, workspace, workspace_bytes, nullptr, 0, accumulate_grad_cond, 0,
+                         grad_y_scale, nullptr, false, stream, true);
 }
 extern "C" int k4_sft_train_reduce(const float* workspace, int64_t n_pix, int32_t channels,
                                    float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h, void* stream) {
@@ -1185,8 +1286,9 @@ static hipEvent_t k4_ev_ring[K4_EV_DEVS][K4_EV_RING];
 static std::atomic<unsigned> k4_ev_next[K4_EV_DEVS];
 static std::once_flag k4_ev_once[K4_EV_DEVS];
 static bool k4_ev_ok[K4_EV_DEVS];
-static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // everything queued on `signaller` so far completes before what `waiter` gets next
-    if (waiter == signaller) return 0;
+static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller, hipStream_t waiter2) {      // everything queued on `signaller` so far completes before what `waiter` (and `waiter2`: the same event record) gets next
+    if (waiter2 == signaller || waiter2 == waiter) waiter2 = nullptr;
+    if (waiter == signaller) { if (!waiter2) return 0; waiter = waiter2; waiter2 = nullptr; }
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -1196,6 +1298,7 @@ static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // e
         if (e != hipSuccess) return (int)e;
         e = hipEventRecord(ev, signaller);
         if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+        if (e == hipSuccess && waiter2) e = hipStreamWaitEvent(waiter2, ev, 0);
         const hipError_t d = hipEventDestroy(ev);                          // (released by the runtime once the recorded work has completed)
         return (int)(e != hipSuccess ? e : d);
     }
@@ -1208,6 +1311,7 @@ static int k4_wait_stream(hipStream_t waiter, hipStream_t signaller) {      // e
     hipEvent_t ev = k4_ev_ring[dev][k4_ev_next[dev].fetch_add(1u) % K4_EV_RING];
     e = hipEventRecord(ev, signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+    if (e == hipSuccess && waiter2) e = hipStreamWaitEvent(waiter2, ev, 0);
     return (int)e;
 }
 template <bool VEC>
@@ -1271,6 +1375,10 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     // backward pass (profiles/r06_joint_phase_events.md, section 8).  Needs a caller that does not join per block (no_join): the weight gradients of block b then
     // run beside the chain of block b - 1.
     const bool defer = p->defer_side != 0 && side != main_s;
+    // aux_stream (ABI 14; with defer_side + no_join + gc_acc): the chain runs only the grad_x part of the two SFT layers' backward (k4_sft_train_bwd_gx); the rest of
+    // both layers goes to aux_stream at the end of the block.  The caller joins aux_stream before grad_cond's first reader and before the optimizer.
+    hipStream_t aux = (hipStream_t)p->aux_stream;
+    const bool split = defer && p->no_join != 0 && p->gc_acc != nullptr && aux != nullptr && aux != main_s;
     struct WgradQ { int cin; const float* gy; int cout; int gys; int k; } wq[5];
     int nwq = 0;
 #define K4_RDB_WGRAD(CIN, GY, COUT, GYS, K) do { \
@@ -1304,7 +1412,8 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
     K4_RDB_DGRAD(4, p->g5, nf, bw, false, false);                                  // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
-    if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], 0.2f, p->gx4, nullptr, 0, fl, 1.f, stream));
+    else if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                                 0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, stream));
     else K4_RDB_TRY(k4_sft_train_bwd_side(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                      0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7],
@@ -1319,20 +1428,28 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
         K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true, fl && k > 1);               // (k == 1 completes xc0's slice: sft0's output, no activation)
     }
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
-    if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], 0.2f, p->gx0, p->gx0_add, nf, 0, 1.f, stream));
+    else if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                                 0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, stream));
     else K4_RDB_TRY(k4_sft_train_bwd_side(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                      0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7],
                                      p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, p->side_stream, stream));
-    if (defer) {                                                                    // the block's side-stream work behind ONE fork
-        K4_RDB_TRY(k4_wait_stream(side, main_s));
+    if (defer) {                                                                    // the block's side-stream work behind ONE fork (one event record, both streams wait for it)
+        K4_RDB_TRY(k4_wait_stream(side, main_s, split ? aux : nullptr));
         if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
         for (int q = 0; q < nwq; ++q) {
             if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
             else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
         }
-        K4_RDB_TRY(k4_sft_train_reduce(p->ws1, n, g, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7], (void*)side));
-        K4_RDB_TRY(k4_sft_train_reduce(p->ws0, n, nf, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7], (void*)side));
+        // split: what the chain did not wait for -- both SFT layers' hidden / condition gradients and partial sums, then their reductions -- on the third stream,
+        // in the order the one-launch form adds into gc_acc (sft1, then sft0)
+        hipStream_t red = split ? aux : side;
+        if (split) K4_RDB_TRY(k4_sft_train_bwd_rest(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
+                                                    0.2f, p->gc_acc, p->ws1, p->ws1_bytes, 1, 1.f, (void*)aux));
+        K4_RDB_TRY(k4_sft_train_reduce(p->ws1, n, g, p->gsft1[0], p->gsft1[1], p->gsft1[2], p->gsft1[3], p->gsft1[4], p->gsft1[5], p->gsft1[6], p->gsft1[7], (void*)red));
+        if (split) K4_RDB_TRY(k4_sft_train_bwd_rest(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
+                                                    0.2f, p->gc_acc, p->ws0, p->ws0_bytes, 1, 1.f, (void*)aux));
+        K4_RDB_TRY(k4_sft_train_reduce(p->ws0, n, nf, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7], (void*)red));
     }
 join:
 #undef K4_RDB_WGRAD
@@ -1340,6 +1457,7 @@ join:
     {
         // the wgrads are done before anything queued on `stream` after this call -- unless the caller joins itself, once (no_join; a failed launch joins anyway)
         const int rj = (p->no_join && rc == 0) ? 0 : k4_wait_stream(main_s, side);
+        if (rc != 0 && split) (void)k4_wait_stream(main_s, aux);
         return rc != 0 ? rc : rj;
     }
     });

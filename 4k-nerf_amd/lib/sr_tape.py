@@ -112,6 +112,8 @@ class DecoderProgram:
         cin, ncond = net.conv_first.in_channels, net.CondNet[0].in_channels
         self.main = N.stream().value or 0
         self.side = T._side_stream(dev)
+        # a third stream for what the chain does not read of the SFT layers' backward (k4_sft_train_bwd_rest + reductions: condition gradient, parameter gradients)
+        self.aux = T._aux_stream(dev) if self.side is not None else None
         f32 = dict(dtype=torch.float32, device=dev)
 
         def E(*shape):
@@ -161,8 +163,10 @@ class DecoderProgram:
         A['hr'], A['out'] = E(m * h, m * w, nf), E(m * h, m * w, 3)
         # ---- gradients
         G = self.G = {'out': E(m * h, m * w, 3), 'hr': E(m * h, m * w, nf), 'top': E(m * h, m * w, nf), 'bf': E(h, w, nf), 'sb': E(h, w, nf),
-                      'body': E(h, w, nf), 'body2': E(h, w, nf), 'o3': E(h, w, nf), 'feat': E(h, w, nf), 'acc': E(h, w, 32),
+                      'o3': E(h, w, nf), 'feat': E(h, w, nf), 'acc': E(h, w, 32),
                       'c3': E(h, w, 64), 'c2': E(h, w, 64), 'c1': E(h, w, 64)}
+        for b in range(nb + 1):                # gradient of RRDB b's input (b = nb: of the trunk's output): one buffer each -- a layer's deferred backward on the
+            G[f'gb{b}'] = E(h, w, nf)          # third stream still reads its grad_y while the chain is an RRDB further
         if s > 1:
             G['ubf'], G['u1'] = E(2 * h, 2 * w, nf), E(2 * h, 2 * w, nf)
             if s == 4:
@@ -250,6 +254,7 @@ class DecoderProgram:
             d.side_stream = self.side
             d.no_join = int(self.side is not None)                # ONE join, behind the whole backward pass (_backward_calls): the buffers are this program's own
             d.defer_side = int(self.side is not None)             # ... and ONE fork per block: every event record on the chain's stream costs ~7 us of the chain's time
+            d.aux_stream = self.aux                               # ... and only the grad_x part of the two SFT layers' backward on the chain
             self.scr.append(scr)
             self.desc.append(d)
         self.signature = signature(net)
@@ -303,6 +308,16 @@ class DecoderProgram:
         pb = self.pg.data_ptr()
         L = N.lib()
         n = self.h * self.w
+        if self.aux is not None:              # the chain's launch writes grad_x only; the rest of the layer on the third stream (k4_rdb_train.aux_stream does the same inside a block)
+            N.check(L.k4_sft_train_bwd_gx(None, C, N.f32(self.A['c']), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx), None, 0, 0, float(gy_scale),
+                                          N.stream()), 'k4_sft_train_bwd_gx')
+            # issued NOW, behind a fork of its own (six of these layers per pass): the third stream adds the layers' condition gradients in the chain's order
+            st = N.C.c_void_p(self.aux)
+            N.check(L.k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
+            N.check(L.k4_sft_train_bwd_rest(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:7]], 0.2, N.f32(self.G['acc']),
+                                            N.f32(self.sft_ws[name]), self.sft_ws_bytes[C], 1, float(gy_scale), st), 'k4_sft_train_bwd_rest')
+            N.check(L.k4_sft_train_reduce(N.f32(self.sft_ws[name]), n, C, *[N.C.c_void_p(pb + 4 * o) for o in self.pg_off[name]], st), 'k4_sft_train_reduce')
+            return
         N.check(L.k4_sft_train_bwd_main(N.f32(x), C, N.f32(self.A['c']), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:7]], 0.2,
                                         N.f32(gx), N.f32(self.G['acc']), N.f32(self.sft_ws[name]), self.sft_ws_bytes[C], None, 0, 1, 0, float(gy_scale), N.stream()),
                 'k4_sft_train_bwd_main')
@@ -373,7 +388,7 @@ class DecoderProgram:
         self._wgrad(net.conv_body, A['sb'], G['bf'], h, w, 'conv_body')
         self._conv(self.bw_(net.conv_body), G['bf'], nf, G['sb'], nf, nf, h, w)
         nb = self.nb
-        g_body, g_other = G['body'], G['body2']
+        g_body = G[f'gb{nb}']
         self._sft_bwd(net.sftbody, A[f'body{nb - 1}'] if nb else A['feat'], G['sb'], g_body, 'sftbody', 1.0)
         self._flush_side(fork=True)                                                # the high-resolution layers' weight gradients run beside the trunk's chain
         for b in range(nb - 1, -1, -1):
@@ -389,9 +404,10 @@ class DecoderProgram:
                 go = self.scr[q][:n * nf].view(h, w, nf)                           # = go + the gradient through the block's sft0
             # the RRDB's input reaches its first dense block and the skip connection: the sum of both gradients.  The first RRDB's input is `feat`,
             # which the long skip connection reads too: three addends, summed in the order the autograd engine received them (same roundings)
+            g_other = G[f'gb{b}']
             if b > 0:
                 N.check(L.k4_add_f32(N.f32(go), N.f32(g_body), N.f32(g_other), n * nf, N.stream()), 'k4_add_f32')
-                g_body, g_other = g_other, g_body
+                g_body = g_other
             else:
                 N.check(L.k4_add_f32(N.f32(G['bf']), N.f32(g_body), N.f32(g_other), n * nf, N.stream()), 'k4_add_f32')
                 N.check(L.k4_add_f32(N.f32(g_other), N.f32(go), N.f32(G['feat']), n * nf, N.stream()), 'k4_add_f32')
@@ -401,7 +417,9 @@ class DecoderProgram:
         if self.x_grad:
             cin = A['xi'].shape[2]
             self._conv(self.bw_(net.conv_first), G['feat'], nf, G['xi'], cin, cin, h, w)
-        # CondNet: G['acc'] holds the sum over every SFT layer
+        # CondNet: G['acc'] holds the sum over every SFT layer -- once the third stream has added the last of them
+        if self.aux is not None:
+            N.check(L.k4_main_wait_side(N.C.c_void_p(self.aux), N.stream()), 'k4_main_wait_side')
         cn = net.CondNet
         self._wgrad(cn[6], A['c3'], G['acc'], h, w, 'cn6')
         self._conv(self.bw_(cn[6]), G['acc'], 32, G['c3'], 64, 64, h, w)

@@ -265,6 +265,7 @@ _SIDE_LOW_PRIORITY = False      # True: the weight gradients' stream at the devi
 _FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
+_SFT_SPLIT = True       # False: the SFT layers' whole backward on the chain's stream, as one launch each (A/B, tests)
 _TAPE = os.environ.get('K4_TRAIN_TAPE', '1') != '0'     # 0: the decoder as ~20 autograd nodes per RRDB (below) instead of ONE node on two launch tapes (lib/sr_tape.py)
 
 
@@ -275,6 +276,15 @@ def _side_stream(device):
     # (one per MAIN stream -- callers on different streams do not share one -- and verified to run BESIDE it: _native.overlapping_stream)
     st = N.overlapping_stream(device, 'decoder weight gradients', low_priority=_SIDE_LOW_PRIORITY)
     return st.cuda_stream
+
+
+def _aux_stream(device):
+    """The third stream of the decoder's backward pass (lib/sr_tape.py): the SFT layers' deferred backward (k4_sft_train_bwd_rest) and their reductions.  It is
+    the stream the dense total-variation term uses (lib/grid.py: that work is done long before the decoder's backward pass starts, and stream order keeps any
+    overlap correct) -- main + weight gradients + grid optimizer step + this one are the four hardware queues a process gets (_native.overlapping_stream)."""
+    if not (_WGRAD_STREAM and _SFT_SPLIT):
+        return None
+    return N.overlapping_stream(device, 'dense total variation').cuda_stream
 
 
 def _hand_over_grads(params, grads):

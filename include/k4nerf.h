@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      13      /* 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl, k4_joint_losses_fwd / _bwd; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      14      /* 14: k4_sft_train_bwd_gx / k4_sft_train_bwd_rest, k4_rdb_train.aux_stream (the SFT layers' backward split into the chain's grad_x launch and the rest on a third stream); 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl, k4_joint_losses_fwd / _bwd; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -526,6 +526,10 @@ typedef struct k4_rdb_train {
     int32_t defer_side;             /* ABI 13, != 0 (with side_stream): the block's side-stream launches (zero-fill, five weight gradients, two SFT reductions) are issued at
                                        the END of the block behind ONE fork instead of one fork per launch -- an event record on `stream` in front of every dgrad launch cost
                                        ~7 us of the chain's time each.  Use with no_join (the weight gradients of a block then run beside the next block's chain). */
+    void* aux_stream;               /* ABI 14, != NULL (with defer_side, no_join, gc_acc): the chain runs only k4_sft_train_bwd_gx for the block's two SFT layers; the rest of
+                                       their backward (k4_sft_train_bwd_rest: condition gradient into gc_acc, partial sums) and the two reductions are issued on aux_stream
+                                       at the end of the block, behind the same event as the side stream's launches.  The caller joins aux_stream (k4_main_wait_side) before
+                                       the first reader of gc_acc and before the optimizer; the descriptor's buffers stay alive until then. */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -712,6 +716,19 @@ int k4_sft_train_bwd_main(const float* x, int32_t x_stride, const float* cond, i
                           const float* grad_x_add, int32_t gxa_stride, int32_t accumulate_grad_cond, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
 int k4_sft_train_reduce(const float* workspace, int64_t n_pix, int32_t channels,
                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h, void* stream);
+/* ABI 14 -- the layer's backward as TWO launches for a caller with a third stream (the chain of the decoder's backward pass reads only grad_x):
+ *   k4_sft_train_bwd_gx   : grad_x = grad_y * grad_y_scale * (scale(cond) + 1) [LeakyReLU mask from x when grad_x_lrelu] [+ grad_x_add] -- k4_sft_train_bwd_main's
+ *                           grad_x bit for bit; x is read only when grad_x_lrelu != 0 (NULL otherwise)
+ *   k4_sft_train_bwd_rest : everything else of k4_sft_train_bwd_main (grad_cond written or, accumulate_grad_cond != 0, added to; the partial sums in `workspace`
+ *                           for k4_sft_train_reduce), same values.  Ordered by the caller behind grad_y's producer and in front of grad_cond's first reader.
+ * Reference: autograd through SFTLayer.forward, lib/sr_esrnet.py:112-123. */
+int k4_sft_train_bwd_gx(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                        int64_t n_pix, int32_t channels, const float* w0s, const float* b0s, const float* w1s, const float* b1s,
+                        float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
+int k4_sft_train_bwd_rest(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
+                          int64_t n_pix, int32_t channels,
+                          const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,
+                          float slope, float* grad_cond, float* workspace, int64_t workspace_bytes, int32_t accumulate_grad_cond, float grad_y_scale, void* stream);
 /* k4_sft_train_bwd_ex whose reduction of the per-workgroup partial sums (the eight parameter gradients; nothing on the caller's chain reads them) is forked
  * to side_stream (NULL = `stream`: k4_sft_train_bwd_ex): the caller joins side_stream before the gradients are read and keeps `workspace` untouched until then. */
 int k4_sft_train_bwd_side(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,

@@ -640,3 +640,66 @@ def test_decoder_tape_keeps_a_bounded_number_of_patch_shapes():
         assert x.grad is not None and all(p.grad is not None for p in net.parameters())
     pools = [k for k in net._k4 if isinstance(k, tuple) and k and k[0] == 'tape_programs']
     assert len(pools) == sr_tape.MAX_SHAPES and len(net._k4['tape_lru']) == sr_tape.MAX_SHAPES
+
+
+@pytest.mark.parametrize('C,n,lrelu,add,scale', [(64, 64 * 64, 0, True, 1.0), (32, 64 * 64, 1, False, 1.0), (64, 21 * 30 + 5, 0, False, 0.2), (32, 77, 1, True, 0.2)])
+def test_sft_backward_in_two_launches_equals_the_one_launch_form(C, n, lrelu, add, scale):
+    """ABI 14: k4_sft_train_bwd_gx (the launch the chain waits for: grad_x) + k4_sft_train_bwd_rest (condition gradient, partial sums) against
+    k4_sft_train_bwd_main, which does both: grad_x, the accumulated condition gradient and the reduced parameter gradients are bit-identical --
+    full tiles and a ragged last tile, the LeakyReLU mask of a dense block's sft1, the folded skip connection of sft0, the 0.2 of an RRDB's layer."""
+    from nerf4k_amd import _native as N
+    L = N.lib()
+    g = torch.Generator().manual_seed(5 * C + n)
+    dev = 'cuda'
+    x, cond, gy, gxa = (torch.randn([n, k], generator=g).to(dev) for k in (C, 32, C, C))
+    ps = [torch.randn(s, generator=g).to(dev) * 0.4 for s in ([32, 32], [32], [C, 32], [C], [32, 32], [32], [C, 32])]
+    acc0 = torch.randn([n, 32], generator=g).to(dev)
+    wsb = int(L.k4_sft_train_bwd_workspace_bytes(n, C))
+
+    def reduce(ws):
+        out = [torch.full_like(t, float('nan')) for t in (ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], ps[3])]
+        N.check(L.k4_sft_train_reduce(N.f32(ws), n, C, *[N.f32(t) for t in out], N.stream()), 'k4_sft_train_reduce')
+        return out
+    ws_a, ws_b = (torch.zeros([wsb // 4], device=dev) for _ in range(2))
+    gx_a, gx_b = (torch.full([n, C], float('nan'), device=dev) for _ in range(2))
+    acc_a, acc_b = acc0.clone(), acc0.clone()
+    N.check(L.k4_sft_train_bwd_main(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps], 0.2, N.f32(gx_a), N.f32(acc_a), N.f32(ws_a), wsb,
+                                    N.f32(gxa) if add else None, C if add else 0, 1, lrelu, scale, N.stream()), 'k4_sft_train_bwd_main')
+    N.check(L.k4_sft_train_bwd_gx(N.f32(x) if lrelu else None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b),
+                                  N.f32(gxa) if add else None, C if add else 0, lrelu, scale, N.stream()), 'k4_sft_train_bwd_gx')
+    N.check(L.k4_sft_train_bwd_rest(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps], 0.2, N.f32(acc_b), N.f32(ws_b), wsb, 1, scale,
+                                    N.stream()), 'k4_sft_train_bwd_rest')
+    assert torch.equal(gx_a, gx_b) and torch.equal(acc_a, acc_b) and not torch.equal(acc_a, acc0) and torch.isfinite(gx_b).all()
+    for a, b in zip(reduce(ws_a), reduce(ws_b)):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    # rejected: no grad_x, a LeakyReLU mask without x
+    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, None, None, 0, 0, 1.0, N.stream()) != 0
+    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b), None, 0, 1, 1.0, N.stream()) != 0
+
+
+def test_decoder_tape_with_the_sft_backward_on_a_third_stream_is_bit_identical(monkeypatch):
+    """lib/sr_tape.py with sr_train._SFT_SPLIT: the chain runs the grad_x launch of every SFT layer, the rest of the 36 layers' backward runs on a third
+    stream that adds the condition gradients in the chain's order -- output, input / condition gradients and the SFT layers' parameter gradients equal
+    the one-launch form's bit for bit, on the recording pass and on a replay."""
+    make, x0, c0, tgt = _tape_fixture()
+
+    def run(split):
+        monkeypatch.setattr(sr_train, '_SFT_SPLIT', split)
+        net = make()
+        hist = []
+        for it in range(2):
+            x, c = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            out = net(x, c)
+            F.l1_loss(out, tgt).backward()
+            torch.cuda.synchronize()
+            hist.append((out.detach().clone(), x.grad.clone(), c.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
+        prog = [v for k, v in net._k4.items() if isinstance(k, tuple) and k and k[0] == 'tape_programs'][0][1][0]
+        assert (prog.aux is not None) == split
+        return hist
+    for (oa, xa, ca, pa), (ob, xb, cb, pb) in zip(run(True), run(False)):
+        assert torch.equal(oa, ob) and torch.equal(xa, xb) and torch.equal(ca, cb)
+        for n in pa:
+            if not _conv_like(n):
+                assert torch.equal(pa[n], pb[n]), n
+            assert _rel(pa[n], pb[n]) <= 5e-5, n

@@ -5,6 +5,9 @@ import torch
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import scene, joint_train
 from nerf4k_amd.lib import dvgo, sr_esrnet, utils
+if os.environ.get('TOOL_SFT_SPLIT') == '0':                               # A/B: the SFT layers' whole backward on the chain (one launch each)
+    from nerf4k_amd.lib import sr_train as _T
+    _T._SFT_SPLIT = False
 dev = torch.device('cuda', 0)
 ck = scene.make_llff_checkpoint()
 H, W = scene.LLFF_HW
