@@ -284,7 +284,7 @@ def _aux_stream(device):
     overlap correct) -- main + weight gradients + grid optimizer step + this one are the four hardware queues a process gets (_native.overlapping_stream)."""
     if not (_WGRAD_STREAM and _SFT_SPLIT):
         return None
-    return N.overlapping_stream(device, 'dense total variation').cuda_stream
+    return N.overlapping_stream(device, 'dense total variation', low_priority=_SIDE_LOW_PRIORITY).cuda_stream
 
 
 def _hand_over_grads(params, grads):

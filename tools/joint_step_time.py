@@ -5,6 +5,9 @@ import torch
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import scene, joint_train
 from nerf4k_amd.lib import dvgo, sr_esrnet, utils
+if os.environ.get('TOOL_SIDE_LOW') == '1':                                # A/B: the decoder's side streams at the device's lowest priority
+    from nerf4k_amd.lib import sr_train as _T2
+    _T2._SIDE_LOW_PRIORITY = True
 if os.environ.get('TOOL_SFT_SPLIT') == '0':                               # A/B: the SFT layers' whole backward on the chain (one launch each)
     from nerf4k_amd.lib import sr_train as _T
     _T._SFT_SPLIT = False
