@@ -912,7 +912,7 @@ def joint_train_step(ck, frame_rays, H, W, dev, iters=8, world=1, rank=0):
             'phases': 'ms_per_iteration = an iteration of the first 10,000 (dense total variation on both grids, every voxel of k0 stepped: the dearer phase, the headline); '
                       'ms_per_iteration_after_tv_before = an iteration of the other 290,000 of fern_lg_joint_l1 (no TV; k0 stepped on its touched voxels from the scatter image)',
 
-            'decoder_pass': 'ONE autograd node on two launch tapes replayed by one native call each (lib/sr_tape.py, k4_tape_*), 3x3 layers of the 64x64 patch on the K-split kernel (K4_CONV_SMALL); '
+            'decoder_pass': 'ONE autograd node on two launch tapes replayed by one native call each (lib/sr_tape.py, k4_tape_*), 3x3 layers of the 64x64 patch on the K-split kernel (K4_CONV_SMALL); every SFT layer backward in two launches (grad_x on the chain, the rest on a third stream: k4_sft_train_bwd_gx / _rest); '
                             'ms_per_iteration_per_block_graph = the same kernels issued call by call from ~20 autograd nodes per RRDB (K4_TRAIN_TAPE=0); round 5: 11.0-11.3 ms; hipGraph form 17.2 ms',
             'rays_per_iteration': pr * pc,
             'shaded_samples': n_samples, 'first_loss': round(first, 5),
