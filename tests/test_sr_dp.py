@@ -82,3 +82,21 @@ def test_single_process_is_a_no_op_on_values():
     a.grad = torch.tensor([1., 2., 3.])
     n = sr_train.allreduce_gradients([a, b])
     assert n == 28 and torch.equal(a.grad, torch.tensor([1., 2., 3.])) and torch.equal(b.grad, torch.zeros(2, 2))
+
+
+def test_gradient_bucket_round_trip_without_a_process_group():
+    """allreduce_gradients outside a job (world 1): the bucket is one concatenation in and one multi-tensor copy out -- gradients keep their values and their
+    storage (the decoder's hand-over gives every parameter a view of ONE flat buffer), a parameter without a gradient receives zeros, frozen ones are skipped."""
+    import torch
+    from nerf4k_amd.lib import sr_train
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ([4, 3, 3, 3], [4], [5, 7], [2], [6])]
+    ps[3].requires_grad_(False)
+    flat = torch.randn([4 * 27 + 4 + 35], generator=g)
+    want = flat.clone()
+    ps[0].grad, ps[1].grad, ps[2].grad = flat[:108].view(4, 3, 3, 3), flat[108:112], flat[112:147].view(5, 7)
+    ptrs = [p.grad.data_ptr() for p in ps[:3]]
+    n = sr_train.allreduce_gradients(ps)
+    assert n == 4 * (108 + 4 + 35 + 6)
+    assert torch.equal(flat, want) and [p.grad.data_ptr() for p in ps[:3]] == ptrs
+    assert ps[3].grad is None and torch.equal(ps[4].grad, torch.zeros([6]))
