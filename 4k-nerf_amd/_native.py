@@ -60,7 +60,8 @@ class RdbTrain(C.Structure):         # k4_rdb_train
                 ('ws0', C.c_void_p), ('ws0_bytes', C.c_int64), ('ws1', C.c_void_p), ('ws1_bytes', C.c_int64), ('side_stream', C.c_void_p),
                 ('gc_acc', C.c_void_p), ('gx0_add', C.c_void_p), ('dwdb_span', C.c_void_p), ('dwdb_span_floats', C.c_int64),
                 ('fused_lrelu', C.c_int32), ('g5_from_gx0_add', C.c_int32), ('no_join', C.c_int32), ('defer_side', C.c_int32),
-                ('aux_stream', C.c_void_p)]
+                ('aux_stream', C.c_void_p), ('g5_next', C.c_void_p), ('gx0_add2', C.c_void_p), ('gx0_sum2', C.c_void_p),
+                ('g5_given', C.c_int32), ('aux_wgrad', C.c_int32)]
 
 
 class AdamJob(C.Structure):          # k4_adam_job
@@ -201,7 +202,7 @@ _EXTRA_SIGS = {
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P], C.c_int),
     'k4_sft_train_bwd_main': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P], C.c_int),
     'k4_sft_train_reduce': ([_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    'k4_sft_train_bwd_gx': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _F, _P, _P, _I32, _I32, _F, _P], C.c_int),
+    'k4_sft_train_bwd_gx': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _F, _P, _P, _I32, _I32, _F, _P, _F, _P, _P, _P], C.c_int),
     'k4_sft_train_bwd_rest': ([_P, _I32, _P, _I32, _P, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I64, _I32, _F, _P], C.c_int),
     'k4_rgbnet_input_mpi': ([_P, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _P, _I32, _P, _I32, _P], C.c_int),
     'k4_joint_losses_fwd': ([_P, _P, _P, _P, _P], C.c_int),

@@ -972,7 +972,8 @@ template <int C>
 __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd_gx(const float* __restrict__ x, int x_stride, const float* __restrict__ cond, int c_stride,
                                                           const float* __restrict__ gyg, int gy_stride, int64_t n,
                                                           const float* __restrict__ w0s, const float* __restrict__ b0s, const float* __restrict__ w1s, const float* __restrict__ b1s,
-                                                          float slope, float* __restrict__ gxg, const float* __restrict__ gxa, int gxa_stride, int gx_lrelu, float gy_scale) {
+                                                          float slope, float* __restrict__ gxg, const float* __restrict__ gxa, int gxa_stride, int gx_lrelu, float gy_scale,
+                                                          float* __restrict__ gs_out, float gs_scale, const float* __restrict__ add2, float* __restrict__ sum2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const cs = smem;                       // [32][LS]
     float* const as = cs + SFT_G * TR_LS;         // [32][LS]
@@ -1021,12 +1022,18 @@ __global__ __launch_bounds__(SFT_T) void k_sft_train_bwd_gx(const float* __restr
         gy[co * TR_LS + lane] = o0; gy[(co + 1) * TR_LS + lane] = o1;
     }
     __syncthreads();
-    if (gxa) {
-        for (int i = t; i < 64 * C; i += SFT_T) {
-            const int s = i / C, k = i - s * C;
-            if (s < nv) gxg[(base + s) * C + k] = gy[k * TR_LS + s] + gxa[(base + s) * gxa_stride + k];
-        }
-    } else sft_store_tile(gy, gxg, base, C, C, nv, t);
+    // grad_x [+ gxa], and two by-products the chain's next launches would otherwise compute in launches of their own: gs_out = grad_x * gs_scale (the next dense
+    // block's g5 = 0.2 grad_out) and sum2 = grad_x + add2 (the sum of the two gradients an RRDB's input receives) -- one rounding each, as k_scale_f32 / k_add_f32
+    for (int i = t; i < 64 * C; i += SFT_T) {
+        const int s = i / C, k = i - s * C;
+        if (s >= nv) continue;
+        float v = gy[k * TR_LS + s];
+        if (gxa) v = v + gxa[(base + s) * gxa_stride + k];
+        const int64_t o = (base + s) * C + k;
+        gxg[o] = v;
+        if (gs_out) gs_out[o] = v * gs_scale;
+        if (sum2) sum2[o] = v + add2[o];
+    }
 }
 
 // partials [n_wg][P1s | P1h | P0s | P0h] -> gw1s [C][32], gb1s [C], gw1h, gb1h, gw0s [32][32], gb0s [32], gw0h, gb0h; fixed order (see k_rgbnet_reduce)
@@ -1185,9 +1192,11 @@ extern "C" int k4_sft_train_bwd_main(const float* x, int32_t x_stride, const flo
 // (+ k4_sft_train_reduce) wherever the caller likes, ordered behind the producer of grad_y and in front of the first reader of grad_cond / the gradients.
 extern "C" int k4_sft_train_bwd_gx(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                                    int64_t n_pix, int32_t channels, const float* w0s, const float* b0s, const float* w1s, const float* b1s,
-                                   float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale, void* stream) {
+                                   float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale,
+                                   float* grad_x_scaled, float scaled_by, const float* add2, float* sum2, void* stream) {
     if (channels != 32 && channels != 64) return K4_ERR_UNSUPPORTED;
     if (n_pix <= 0 || gy_stride < channels || cond_stride < SFT_G || (grad_x_add && gxa_stride < channels) || (grad_x_lrelu && (!x || x_stride < channels))) return K4_ERR_BAD_ARG;
+    if ((add2 != nullptr) != (sum2 != nullptr)) return K4_ERR_BAD_ARG;
     if (!cond || !grad_y || !grad_x || !w0s || !b0s || !w1s || !b1s) return K4_ERR_BAD_ARG;
     return k4_taped(stream, [=](void* stream) -> int {
         hipStream_t st = (hipStream_t)stream;
@@ -1195,10 +1204,10 @@ extern "C" int k4_sft_train_bwd_gx(const float* x, int32_t x_stride, const float
         const size_t lds = (size_t)(2 * SFT_G + 2 * channels) * TR_LS * sizeof(float);
         if (channels == 64) {
             K4_ENSURE_DYN_LDS((k_sft_train_bwd_gx<64>), lds);
-            hipLaunchKernelGGL(k_sft_train_bwd_gx<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale);
+            hipLaunchKernelGGL(k_sft_train_bwd_gx<64>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale, grad_x_scaled, scaled_by, add2, sum2);
         } else {
             K4_ENSURE_DYN_LDS((k_sft_train_bwd_gx<32>), lds);
-            hipLaunchKernelGGL(k_sft_train_bwd_gx<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale);
+            hipLaunchKernelGGL(k_sft_train_bwd_gx<32>, grid, block, lds, st, x, x_stride, cond, cond_stride, grad_y, gy_stride, n_pix, w0s, b0s, w1s, b1s, slope, grad_x, grad_x_add, gxa_stride, grad_x_lrelu, grad_y_scale, grad_x_scaled, scaled_by, add2, sum2);
         }
         return k4_check_launch();
     });
@@ -1401,7 +1410,8 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
             K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
         }
     }
-    if (p->g5_from_gx0_add) {                                                       // g5 = 0.2 grad_out (conv5's output is scaled by 0.2 in the forward pass)
+    if (!split && (p->g5_next || p->gx0_add2 || p->gx0_sum2)) return K4_ERR_BAD_ARG;        // by-products of the chain's grad_x launch (aux_stream form only)
+    if (p->g5_from_gx0_add && !p->g5_given) {                                       // g5 = 0.2 grad_out (conv5's output is scaled by 0.2 in the forward pass)
         const bool vec = (((uintptr_t)p->gx0_add | (uintptr_t)p->g5) & 15u) == 0;
         const int64_t units = vec ? n * nf / 4 : n * nf;
         if (vec) hipLaunchKernelGGL(k_scale_f32<true>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, main_s, p->gx0_add, 0.2f, (float*)p->g5, units);
@@ -1412,7 +1422,8 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
     K4_RDB_WGRAD(bw, p->g5, nf, nf, 4);
     K4_RDB_DGRAD(4, p->g5, nf, bw, false, false);                                  // G = dgrad (every channel)
     // xc1 = sft1(x4), x4 = lrelu(conv4(buf[:, 0:nf+3g]))
-    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], 0.2f, p->gx4, nullptr, 0, fl, 1.f, stream));
+    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], 0.2f, p->gx4, nullptr, 0, fl, 1.f,
+                                              nullptr, 0.f, nullptr, nullptr, stream));
     else if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
                                                 0.2f, p->gx4, p->gc_acc ? p->gc_acc : p->gc1, p->ws1, p->ws1_bytes, nullptr, 0, p->gc_acc != nullptr, fl, 1.f, stream));
     else K4_RDB_TRY(k4_sft_train_bwd_side(p->x4, g, p->c, 32, p->G + nf + 3 * g, bw, n, g, p->sft1[0], p->sft1[1], p->sft1[2], p->sft1[3], p->sft1[4], p->sft1[5], p->sft1[6],
@@ -1428,7 +1439,8 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
         K4_RDB_DGRAD(k - 1, p->G + off, bw, off, true, fl && k > 1);               // (k == 1 completes xc0's slice: sft0's output, no activation)
     }
     // gx0_add != NULL: gx0 = the gradient through sft0 + gx0_add (the block's skip connection: grad_out itself)
-    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], 0.2f, p->gx0, p->gx0_add, nf, 0, 1.f, stream));
+    if (split) K4_RDB_TRY(k4_sft_train_bwd_gx(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], 0.2f, p->gx0, p->gx0_add, nf, 0, 1.f,
+                                              p->g5_next, 0.2f, p->gx0_add2, p->gx0_sum2, stream));
     else if (defer) K4_RDB_TRY(k4_sft_train_bwd_main(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                                 0.2f, p->gx0, p->gc_acc ? p->gc_acc : p->gc0, p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, stream));
     else K4_RDB_TRY(k4_sft_train_bwd_side(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
@@ -1436,8 +1448,14 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
                                      p->ws0, p->ws0_bytes, p->gx0_add, nf, p->gc_acc != nullptr, 0, 1.f, p->side_stream, stream));
     if (defer) {                                                                    // the block's side-stream work behind ONE fork (one event record, both streams wait for it)
         K4_RDB_TRY(k4_wait_stream(side, main_s, split ? aux : nullptr));
-        if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_zero_f32(p->dwdb_span, p->dwdb_span_floats, (void*)side));
+        // aux_wgrad: conv1's weight gradient (the first piece of the span) runs on the third stream behind the SFT layers' deferred launches -- per block the
+        // weight gradients' stream carried ~130 us of launches against ~70 us on the third stream and ~110 us on the chain: it had become the pace of the pass
+        const bool wg_aux = split && p->aux_wgrad != 0 && p->dwdb_span_floats > 0 && p->dwdb[0] == p->dwdb_span && p->dwdb[1] > p->dwdb[0] &&
+                            (p->dwdb[1] - p->dwdb[0]) < p->dwdb_span_floats;
+        const int64_t n_aux = wg_aux ? (int64_t)(p->dwdb[1] - p->dwdb[0]) : 0;
+        if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_zero_f32(p->dwdb_span + n_aux, p->dwdb_span_floats - n_aux, (void*)side));
         for (int q = 0; q < nwq; ++q) {
+            if (wg_aux && wq[q].k == 0) continue;
             if (p->dwdb_span_floats > 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
             else K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[wq[q].k], (void*)side));
         }
@@ -1450,6 +1468,11 @@ extern "C" int k4_rdb_train_bwd(const k4_rdb_train* p_in, void* stream) {
         if (split) K4_RDB_TRY(k4_sft_train_bwd_rest(p->t, nf, p->c, 32, p->G, bw, n, nf, p->sft0[0], p->sft0[1], p->sft0[2], p->sft0[3], p->sft0[4], p->sft0[5], p->sft0[6],
                                                     0.2f, p->gc_acc, p->ws0, p->ws0_bytes, 1, 1.f, (void*)aux));
         K4_RDB_TRY(k4_sft_train_reduce(p->ws0, n, nf, p->gsft0[0], p->gsft0[1], p->gsft0[2], p->gsft0[3], p->gsft0[4], p->gsft0[5], p->gsft0[6], p->gsft0[7], (void*)red));
+        if (wg_aux) {
+            K4_RDB_TRY(k4_zero_f32(p->dwdb_span, n_aux, (void*)aux));
+            for (int q = 0; q < nwq; ++q)
+                if (wq[q].k == 0) K4_RDB_TRY(k4_conv2d_wgrad_dbias_bf16x6_acc(p->buf, wq[q].cin, bw, wq[q].gy, wq[q].cout, wq[q].gys, 3, H, W, p->dwdb[0], (void*)aux));
+        }
     }
 join:
 #undef K4_RDB_WGRAD

@@ -255,6 +255,7 @@ class DecoderProgram:
             d.no_join = int(self.side is not None)                # ONE join, behind the whole backward pass (_backward_calls): the buffers are this program's own
             d.defer_side = int(self.side is not None)             # ... and ONE fork per block: every event record on the chain's stream costs ~7 us of the chain's time
             d.aux_stream = self.aux                               # ... and only the grad_x part of the two SFT layers' backward on the chain
+            d.aux_wgrad = int(T._AUX_WGRAD and q > 0)             # ... one of the five weight gradients on the third stream (not in the last block of the pass: the chain joins that stream right after it)
             self.scr.append(scr)
             self.desc.append(d)
         self.signature = signature(net)
@@ -302,15 +303,16 @@ class DecoderProgram:
         N.check(N.lib().k4_sft_train_fwd_ex(N.f32(x), C, N.f32(self.A['c']), 32, self.h * self.w, C, *[N.f32(p) for p in _sft_params(layer)], 0.2,
                                             N.f32(y), C, None if res is None else N.f32(res), C, float(res_scale), N.stream()), 'k4_sft_train_fwd_ex')
 
-    def _sft_bwd(self, layer, x, gy, gx, name, gy_scale):
+    def _sft_bwd(self, layer, x, gy, gx, name, gy_scale, scaled_out=None):
         C = x.shape[2]
         ps = _sft_params(layer)
         pb = self.pg.data_ptr()
         L = N.lib()
         n = self.h * self.w
         if self.aux is not None:              # the chain's launch writes grad_x only; the rest of the layer on the third stream (k4_rdb_train.aux_stream does the same inside a block)
+            # scaled_out: the g5 (= 0.2 grad_out) of the dense block that receives gx as its grad_out, written here instead of by a launch of its own
             N.check(L.k4_sft_train_bwd_gx(None, C, N.f32(self.A['c']), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx), None, 0, 0, float(gy_scale),
-                                          N.stream()), 'k4_sft_train_bwd_gx')
+                                          None if scaled_out is None else N.C.c_void_p(scaled_out), 0.2, None, None, N.stream()), 'k4_sft_train_bwd_gx')
             # issued NOW, behind a fork of its own (six of these layers per pass): the third stream adds the layers' condition gradients in the chain's order
             st = N.C.c_void_p(self.aux)
             N.check(L.k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
@@ -393,19 +395,31 @@ class DecoderProgram:
         self._flush_side(fork=True)                                                # the high-resolution layers' weight gradients run beside the trunk's chain
         for b in range(nb - 1, -1, -1):
             rr = net.body[b]
-            self._sft_bwd(rr.sft0, A[f'o{3 * b + 2}'], g_body, G['o3'], f'sft{b}', 0.2)      # body_b = sft(o3) * 0.2 + body_{b-1}
+            fold = self.aux is not None          # the chain's grad_x launches also write what k_scale_f32 (a block's g5) and k4_add_f32 (the RRDB's input gradient) did
+            self._sft_bwd(rr.sft0, A[f'o{3 * b + 2}'], g_body, G['o3'], f'sft{b}', 0.2,      # body_b = sft(o3) * 0.2 + body_{b-1}
+                          scaled_out=self.desc[3 * b + 2].g5 if fold else None)
             go = G['o3']
+            # the RRDB's input reaches its first dense block and the skip connection: the sum of both gradients.  The first RRDB's input is `feat`,
+            # which the long skip connection reads too: three addends, summed in the order the autograd engine received them (same roundings)
+            g_other = G[f'gb{b}']
             for r in (2, 1, 0):
                 q = 3 * b + r
                 d = self.desc[q]
                 d.gx0_add = go.data_ptr()
+                if fold:
+                    d.g5_given = 1
+                    d.g5_next = self.desc[q - 1].g5 if r > 0 else None
+                    if r == 0 and b > 0:
+                        d.gx0_add2, d.gx0_sum2 = g_body.data_ptr(), g_other.data_ptr()
+                    elif r == 0:
+                        N.check(L.k4_add_f32(N.f32(G['bf']), N.f32(g_body), N.f32(g_other), n * nf, N.stream()), 'k4_add_f32')
+                        d.gx0_add2, d.gx0_sum2 = g_other.data_ptr(), G['feat'].data_ptr()
                 N.check(L.k4_rdb_train_bwd(N.C.byref(d), N.stream()), 'k4_rdb_train_bwd')
                 self._flush_side(fork=False)                                       # (the block's call ended with a fork: what was queued before it is covered)
                 go = self.scr[q][:n * nf].view(h, w, nf)                           # = go + the gradient through the block's sft0
-            # the RRDB's input reaches its first dense block and the skip connection: the sum of both gradients.  The first RRDB's input is `feat`,
-            # which the long skip connection reads too: three addends, summed in the order the autograd engine received them (same roundings)
-            g_other = G[f'gb{b}']
-            if b > 0:
+            if fold:
+                g_body = g_other
+            elif b > 0:
                 N.check(L.k4_add_f32(N.f32(go), N.f32(g_body), N.f32(g_other), n * nf, N.stream()), 'k4_add_f32')
                 g_body = g_other
             else:

@@ -530,6 +530,11 @@ typedef struct k4_rdb_train {
                                        their backward (k4_sft_train_bwd_rest: condition gradient into gc_acc, partial sums) and the two reductions are issued on aux_stream
                                        at the end of the block, behind the same event as the side stream's launches.  The caller joins aux_stream (k4_main_wait_side) before
                                        the first reader of gc_acc and before the optimizer; the descriptor's buffers stay alive until then. */
+    float* g5_next;                 /* ABI 14 (aux_stream form): sft0's grad_x launch also writes 0.2 * gx0 here -- the g5 of the block that receives gx0 as its grad_out */
+    const float* gx0_add2; float* gx0_sum2;   /* ABI 14 (aux_stream form): ... and gx0_sum2 = gx0 + gx0_add2 (the RRDB's input gradient: last block's gx0 + the skip connection's) */
+    int32_t g5_given;               /* ABI 14, != 0 with g5_from_gx0_add: g5 already holds 0.2 * gx0_add (the producer of gx0_add wrote it: g5_next / grad_x_scaled) */
+    int32_t aux_wgrad;              /* ABI 14 (aux_stream form), != 0: conv1's weight gradient is issued on aux_stream (behind the SFT layers' deferred launches) instead of
+                                       side_stream: the two streams carry about the same time per block */
 } k4_rdb_train;
 int k4_rdb_train_fwd(const k4_rdb_train* p, void* stream);
 int k4_rdb_train_bwd(const k4_rdb_train* p, void* stream);
@@ -718,13 +723,16 @@ int k4_sft_train_reduce(const float* workspace, int64_t n_pix, int32_t channels,
                         float* gw0s, float* gb0s, float* gw1s, float* gb1s, float* gw0h, float* gb0h, float* gw1h, float* gb1h, void* stream);
 /* ABI 14 -- the layer's backward as TWO launches for a caller with a third stream (the chain of the decoder's backward pass reads only grad_x):
  *   k4_sft_train_bwd_gx   : grad_x = grad_y * grad_y_scale * (scale(cond) + 1) [LeakyReLU mask from x when grad_x_lrelu] [+ grad_x_add] -- k4_sft_train_bwd_main's
- *                           grad_x bit for bit; x is read only when grad_x_lrelu != 0 (NULL otherwise)
+ *                           grad_x bit for bit; x is read only when grad_x_lrelu != 0 (NULL otherwise).  Optional by-products, [n_pix][channels] each, that the
+ *                           chain's next launches would otherwise compute in launches of their own: grad_x_scaled = grad_x * scaled_by (k4_rdb_train.g5 of the next
+ *                           dense block), sum2 = grad_x + add2 (both or neither) -- one rounding each
  *   k4_sft_train_bwd_rest : everything else of k4_sft_train_bwd_main (grad_cond written or, accumulate_grad_cond != 0, added to; the partial sums in `workspace`
  *                           for k4_sft_train_reduce), same values.  Ordered by the caller behind grad_y's producer and in front of grad_cond's first reader.
  * Reference: autograd through SFTLayer.forward, lib/sr_esrnet.py:112-123. */
 int k4_sft_train_bwd_gx(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                         int64_t n_pix, int32_t channels, const float* w0s, const float* b0s, const float* w1s, const float* b1s,
-                        float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale, void* stream);
+                        float slope, float* grad_x, const float* grad_x_add, int32_t gxa_stride, int32_t grad_x_lrelu, float grad_y_scale,
+                        float* grad_x_scaled, float scaled_by, const float* add2, float* sum2, void* stream);
 int k4_sft_train_bwd_rest(const float* x, int32_t x_stride, const float* cond, int32_t cond_stride, const float* grad_y, int32_t gy_stride,
                           int64_t n_pix, int32_t channels,
                           const float* w0s, const float* b0s, const float* w1s, const float* b1s, const float* w0h, const float* b0h, const float* w1h,

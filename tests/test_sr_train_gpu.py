@@ -665,22 +665,29 @@ def test_sft_backward_in_two_launches_equals_the_one_launch_form(C, n, lrelu, ad
     acc_a, acc_b = acc0.clone(), acc0.clone()
     N.check(L.k4_sft_train_bwd_main(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps], 0.2, N.f32(gx_a), N.f32(acc_a), N.f32(ws_a), wsb,
                                     N.f32(gxa) if add else None, C if add else 0, 1, lrelu, scale, N.stream()), 'k4_sft_train_bwd_main')
+    add2 = torch.randn([n, C], generator=g).to(dev)
+    scaled, sum2 = (torch.full([n, C], float('nan'), device=dev) for _ in range(2))
     N.check(L.k4_sft_train_bwd_gx(N.f32(x) if lrelu else None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b),
-                                  N.f32(gxa) if add else None, C if add else 0, lrelu, scale, N.stream()), 'k4_sft_train_bwd_gx')
+                                  N.f32(gxa) if add else None, C if add else 0, lrelu, scale, N.f32(scaled), 0.2, N.f32(add2), N.f32(sum2), N.stream()), 'k4_sft_train_bwd_gx')
+    assert torch.equal(scaled, gx_a * 0.2) and torch.equal(sum2, gx_a + add2)             # the by-products: one rounding each, as the launches they replace
     N.check(L.k4_sft_train_bwd_rest(N.f32(x), C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps], 0.2, N.f32(acc_b), N.f32(ws_b), wsb, 1, scale,
                                     N.stream()), 'k4_sft_train_bwd_rest')
     assert torch.equal(gx_a, gx_b) and torch.equal(acc_a, acc_b) and not torch.equal(acc_a, acc0) and torch.isfinite(gx_b).all()
     for a, b in zip(reduce(ws_a), reduce(ws_b)):
         assert torch.equal(a, b) and torch.isfinite(a).all()
     # rejected: no grad_x, a LeakyReLU mask without x
-    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, None, None, 0, 0, 1.0, N.stream()) != 0
-    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b), None, 0, 1, 1.0, N.stream()) != 0
+    tail = (None, 0.0, None, None, N.stream())
+    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, None, None, 0, 0, 1.0, *tail) != 0
+    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b), None, 0, 1, 1.0, *tail) != 0
+    assert L.k4_sft_train_bwd_gx(None, C, N.f32(cond), 32, N.f32(gy), C, n, C, *[N.f32(p) for p in ps[:4]], 0.2, N.f32(gx_b), None, 0, 0, 1.0,
+                                 None, 0.0, N.f32(add2), None, N.stream()) != 0                   # add2 without sum2
 
 
 def test_decoder_tape_with_the_sft_backward_on_a_third_stream_is_bit_identical(monkeypatch):
     """lib/sr_tape.py with sr_train._SFT_SPLIT: the chain runs the grad_x launch of every SFT layer, the rest of the 36 layers' backward runs on a third
     stream that adds the condition gradients in the chain's order -- output, input / condition gradients and the SFT layers' parameter gradients equal
-    the one-launch form's bit for bit, on the recording pass and on a replay."""
+    the one-launch form's bit for bit, on the recording pass and on a replay; so are the by-products of the grad_x launches (a dense block's g5, the RRDB's
+    input gradient) that replace the k_scale_f32 / k4_add_f32 launches of the one-launch form."""
     make, x0, c0, tgt = _tape_fixture()
 
     def run(split):
