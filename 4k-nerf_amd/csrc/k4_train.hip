@@ -21,9 +21,10 @@
 // rgbnet forward: tile = 64 samples, lane = sample, wave w owns a quarter of a layer's neurons (4 per pass: one LDS read
 // of the input feeds 4 FMAs whose weights are wave-uniform -> scalar loads, SGPR operands)
 // --------------------------------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NT>
 __device__ __forceinline__ void tr_dense_relu(const float* in, int K, k4_cptr w, k4_cptr b, float* out, int wv, int lane) {
-    constexpr int PER = W / 4;
+    constexpr int PER = W / (NT / 64);
+    static_assert(PER % 4 == 0, "a wave owns whole groups of 4 neurons");
     for (int j0 = wv * PER; j0 < (wv + 1) * PER; j0 += 4) {
         float a0 = b[j0], a1 = b[j0 + 1], a2 = b[j0 + 2], a3 = b[j0 + 3];
         for (int k = 0; k < K; ++k) {
@@ -41,23 +42,28 @@ __device__ __forceinline__ void tr_dense_relu(const float* in, int K, k4_cptr w,
 }
 
 // [n][K] row-major global tile (64 samples from `base`) -> LDS [K][TR_LS] (sample fastest); samples >= nv read as 0
+template <int NT = 256>
 __device__ __forceinline__ void tr_load_tile(const float* __restrict__ g, int64_t base, int K, int nv, float* lds, int t) {
     const float* const src = g + base * K;
-    for (int i = t; i < 64 * K; i += 256) {
+    for (int i = t; i < 64 * K; i += NT) {
         const int s = i / K, k = i - s * K;
         lds[k * TR_LS + s] = s < nv ? src[i] : 0.f;
     }
 }
+template <int NT = 256>
 __device__ __forceinline__ void tr_store_tile(const float* lds, float* __restrict__ g, int64_t base, int K, int nv, int t) {
     float* const dst = g + base * K;
-    for (int i = t; i < 64 * K; i += 256) {
+    for (int i = t; i < 64 * K; i += NT) {
         const int s = i / K, k = i - s * K;
         if (s < nv) dst[i] = lds[k * TR_LS + s];
     }
 }
 
-template <int W>
-__global__ __launch_bounds__(256) void k_rgbnet_fwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
+// NT threads: 256, or 1024 for width >= 64 -- a training batch is a few hundred 64-sample tiles (one or two per workgroup), so a launch lasts as long as ONE tile's chain:
+// with 4 waves (one per SIMD, nothing to hide the LDS / scalar-load latencies behind) the backward launch of the joint iteration's 37 k samples took 114 us and the forward
+// 25 us; 16 waves split the same per-element FMA chains four times finer (same values, same order: cf. the SFT kernels below)
+template <int W, int NT>
+__global__ __launch_bounds__(NT) void k_rgbnet_fwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
                                                     const float* __restrict__ w1, const float* __restrict__ b1,
                                                     const float* __restrict__ w2, const float* __restrict__ b2,
                                                     const float* __restrict__ w3, const float* __restrict__ b3,
@@ -71,15 +77,15 @@ __global__ __launch_bounds__(256) void k_rgbnet_fwd(const float* __restrict__ x,
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nv = (n - base) < 64 ? (int)(n - base) : 64;
-    tr_load_tile(x, base, dim0, nv, xs, t);
+    tr_load_tile<NT>(x, base, dim0, nv, xs, t);
     __syncthreads();
-    tr_dense_relu<W>(xs, dim0, k4_const(w1), k4_const(b1), h1s, wv, lane);
+    tr_dense_relu<W, NT>(xs, dim0, k4_const(w1), k4_const(b1), h1s, wv, lane);
     __syncthreads();
-    if (h1g) tr_store_tile(h1s, h1g, base, W, nv, t);
+    if (h1g) tr_store_tile<NT>(h1s, h1g, base, W, nv, t);
     if (n_hidden) {
-        tr_dense_relu<W>(h1s, W, k4_const(w2), k4_const(b2), h2s, wv, lane);
+        tr_dense_relu<W, NT>(h1s, W, k4_const(w2), k4_const(b2), h2s, wv, lane);
         __syncthreads();
-        if (h2g) tr_store_tile(h2s, h2g, base, W, nv, t);
+        if (h2g) tr_store_tile<NT>(h2s, h2g, base, W, nv, t);
     }
     const float* const hl = n_hidden ? h2s : h1s;
     if (wv < 3 && lane < nv) {
@@ -112,8 +118,8 @@ struct TrBwdLayout {
     static __host__ __device__ int n_part(int dim0) { return 4 * WB + W * WB + W * d1b(dim0); }   // P3 [4][WB] | P2 [W][WB] | P1 [W][D1B]
 };
 
-template <int W, int MAXB>
-__global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
+template <int W, int MAXB, int NT>
+__global__ __launch_bounds__(NT) void k_rgbnet_bwd(const float* __restrict__ x, int64_t n, int dim0, int n_hidden,
                                                     const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                                     const float* __restrict__ h1g, const float* __restrict__ h2g,
                                                     const float* __restrict__ rgb, const float* __restrict__ grgb,
@@ -130,7 +136,8 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
     float* const gh2 = gh1 + W * TR_LS;          // [GH2_ROWS][LS]; reused as the gx staging tile
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    for (int i = t; i < L::lds_floats(dim0); i += 256) smem[i] = 0.f;       // the zero padding rows stay zero for the whole kernel
+    constexpr int NW = NT / 64;
+    for (int i = t; i < L::lds_floats(dim0); i += NT) smem[i] = 0.f;       // the zero padding rows stay zero for the whole kernel
 
     float* const hls = n_hidden ? h2s : h1s;     // last hidden activation, its gradient:
     float* const ghl = n_hidden ? gh2 : gh1;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
     float acc[MAXB][16];
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
-        int b = t + 256 * q;
+        int b = t + NT * q;
         blk[q].aoff = -1;
         if (b < nb3) {
             blk[q] = {(int)(g3s - smem), (int)(hls - smem) + 4 * b * TR_LS, 4 * b, WB};
@@ -164,9 +171,9 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
         const int64_t base = tile * 64;
         const int nv = (n - base) < 64 ? (int)(n - base) : 64;
         // ---- loads ----
-        tr_load_tile(x, base, dim0, nv, xs, t);
-        tr_load_tile(h1g, base, W, nv, h1s, t);
-        if (n_hidden) tr_load_tile(h2g, base, W, nv, h2s, t);
+        tr_load_tile<NT>(x, base, dim0, nv, xs, t);
+        tr_load_tile<NT>(h1g, base, W, nv, h1s, t);
+        if (n_hidden) tr_load_tile<NT>(h2g, base, W, nv, h2s, t);
         if (t < 64) {
             const float one = t < nv ? 1.f : 0.f;
             xs[dim0 * TR_LS + t] = one;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
         {
             const k4_cptr w3c = k4_const(w3);
             const float g0 = g3s[lane], g1 = g3s[TR_LS + lane], g2 = g3s[2 * TR_LS + lane];
-            constexpr int PER = W / 4;
+            constexpr int PER = W / NW;
             for (int j = wv * PER; j < (wv + 1) * PER; ++j) {
                 float a = g0 * w3c[j];
                 a = fmaf(g1, w3c[W + j], a);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
         // ---- gh_1 = relu'(h_1) * (gh_2 W2) ----
         if (n_hidden) {
             const k4_cptr w2c = k4_const(w2);
-            constexpr int PER = W / 4;
+            constexpr int PER = W / NW;
             for (int k0 = wv * PER; k0 < (wv + 1) * PER; k0 += 4) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 for (int j = 0; j < W; ++j) {
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
         if (gx) {
             const k4_cptr w1c = k4_const(w1);
             const int nbx = (dim0 + 3) / 4;
-            for (int bi = wv; bi < nbx; bi += 4) {
+            for (int bi = wv; bi < nbx; bi += NW) {
                 const int i0 = bi * 4;
                 const int i1 = min(i0 + 1, dim0 - 1), i2 = min(i0 + 2, dim0 - 1), i3 = min(i0 + 3, dim0 - 1);    // clamped: never out of W1
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void k_rgbnet_bwd(const float* __restrict__ x,
                 if (i0 + 3 < dim0) gh2[(i0 + 3) * TR_LS + lane] = a3;
             }
             __syncthreads();
-            tr_store_tile(gh2, gx, base, dim0, nv, t);
+            tr_store_tile<NT>(gh2, gx, base, dim0, nv, t);
         }
         __syncthreads();
     }
@@ -333,8 +340,9 @@ template <int W>
 static int tr_launch_fwd(const float* x, int64_t n, int dim0, int n_hidden, const float* w1, const float* b1, const float* w2, const float* b2,
                          const float* w3, const float* b3, const float* add, float* h1, float* h2, float* rgb, hipStream_t st) {
     const size_t lds = (size_t)(TR_MAX_DIM0 + 2 * W) * TR_LS * sizeof(float);
-    K4_ENSURE_DYN_LDS(k_rgbnet_fwd<W>, lds);
-    hipLaunchKernelGGL(k_rgbnet_fwd<W>, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, st, x, n, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb);
+    constexpr int NT = W >= 64 ? 1024 : 256;
+    K4_ENSURE_DYN_LDS((k_rgbnet_fwd<W, NT>), lds);
+    hipLaunchKernelGGL((k_rgbnet_fwd<W, NT>), dim3((unsigned)((n + 63) / 64)), dim3(NT), lds, st, x, n, dim0, n_hidden, w1, b1, w2, b2, w3, b3, add, h1, h2, rgb);
     return k4_check_launch();
 }
 
@@ -344,9 +352,10 @@ static int tr_launch_bwd(const float* x, int64_t n, int dim0, int n_hidden, cons
                          float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3, float* ws, hipStream_t st) {
     typedef TrBwdLayout<W> L;
     const size_t lds = (size_t)L::lds_floats(dim0) * sizeof(float);
-    K4_ENSURE_DYN_LDS((k_rgbnet_bwd<W, MAXB>), lds);
+    constexpr int NT = W == 64 ? 1024 : 256;                   // (width 128 at 1024 threads: two blocks per thread spill at the 128 registers a 16-wave workgroup leaves)
+    K4_ENSURE_DYN_LDS((k_rgbnet_bwd<W, MAXB, NT>), lds);
     const int grid = tr_bwd_grid(n);
-    hipLaunchKernelGGL((k_rgbnet_bwd<W, MAXB>), dim3(grid), dim3(256), lds, st, x, n, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grgb, gx, glogit, ws);
+    hipLaunchKernelGGL((k_rgbnet_bwd<W, MAXB, NT>), dim3(grid), dim3(NT), lds, st, x, n, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grgb, gx, glogit, ws);
     int rc = k4_check_launch();
     if (rc) return rc;
     const int total = 3 * (W + 1) + (n_hidden ? W * (W + 1) : 0) + W * (dim0 + 1);
@@ -390,9 +399,9 @@ extern "C" int k4_rgbnet_bwd(const float* x, int64_t n_pts, int32_t dim0, int32_
     if (!workspace || workspace_bytes < k4_rgbnet_bwd_workspace_bytes(n_pts, dim0, width, n_hidden)) return K4_ERR_BAD_ARG;
     if (n_pts > 0 && (!x || !h1 || !rgb || !grad_rgb || (n_hidden && !h2))) return K4_ERR_BAD_ARG;      // n_pts == 0: the gradients are zeros
     hipStream_t st = (hipStream_t)stream;
-    switch (width) {          // MAXB = ceil(blocks / 256) at dim0 = TR_MAX_DIM0: 32 -> 226, 64 -> 561, 128 -> 1633 blocks
+    switch (width) {          // MAXB = ceil(blocks / threads) at dim0 = TR_MAX_DIM0: 32 -> 226 and 128 -> 1633 blocks (256 threads), 64 -> 561 (1024 threads)
         case 32: return tr_launch_bwd<32, 1>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
-        case 64: return tr_launch_bwd<64, 3>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
+        case 64: return tr_launch_bwd<64, 1>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
         default: return tr_launch_bwd<128, 7>(x, n_pts, dim0, n_hidden, w1, w2, w3, h1, h2, rgb, grad_rgb, grad_x, grad_logit, gw1, gb1, gw2, gb2, gw3, gb3, workspace, st);
     }
 }
