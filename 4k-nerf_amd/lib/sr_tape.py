@@ -267,32 +267,38 @@ class DecoderProgram:
                                               flags | pk.flags_extra | (CONV_SMALL if pk.k == 3 and not pk.flags_extra else 0), 0.2, None if res is None else N.f32(res), 0 if res is None else cout_stride,
                                               res_scale, None, 0, N.stream()), 'k4_conv2d_nhwc_bf16x6')
 
-    def _side_call(self, fn):
+    def _side_call(self, fn, aux=False):
         """A launch that only produces parameter gradients (weight gradients, SFT reductions): queued for the side stream and issued by _flush_side behind a fork that
         covers a whole section of the chain (a fork per launch put an event record -- ~7 us of the chain's time -- in front of every dgrad launch); without a side
-        stream it runs now, on the chain's stream."""
+        stream it runs now, on the chain's stream.  aux: queued for the third stream instead (the tail of the pass: both streams share the last weight gradients)."""
         if self.side is None:
             fn(N.stream())
+        elif aux and self.aux is not None:
+            self._aux_q.append(fn)
         else:
             self._side_q.append(fn)
 
     def _flush_side(self, fork):
         """Issue the queued side-stream launches.  fork=False: the side stream already waits for everything queued so far (a dense block's call has just forked)."""
-        if self.side is None or not self._side_q:
+        if self.side is None:
             return
-        st = N.C.c_void_p(self.side)
-        if fork:
-            N.check(N.lib().k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
-        for fn in self._side_q:
-            fn(st)
-        self._side_q = []
+        for which, stream in (('_side_q', self.side), ('_aux_q', self.aux)):
+            q = getattr(self, which)
+            if not q:
+                continue
+            st = N.C.c_void_p(stream)
+            if fork:
+                N.check(N.lib().k4_side_wait_main(st, N.stream()), 'k4_side_wait_main')
+            for fn in q:
+                fn(st)
+            setattr(self, which, [])
 
-    def _wgrad(self, mod, x, gy, H, W, name):
+    def _wgrad(self, mod, x, gy, H, W, name, aux=False):
         """[dW | dbias] of `mod` into its piece of the flat buffer, on the side stream (_side_call)."""
         L = N.lib()
         cout, cin, k, _ = mod.weight.shape
         args = (N.f32(x), cin, cin, N.f32(gy), cout, cout, k, H, W, N.C.c_void_p(self.pg.data_ptr() + 4 * self.pg_off[name]))
-        self._side_call(lambda st: N.check(L.k4_conv2d_wgrad_dbias_bf16x6(*args, st), 'k4_conv2d_wgrad_dbias_bf16x6'))
+        self._side_call(lambda st: N.check(L.k4_conv2d_wgrad_dbias_bf16x6(*args, st), 'k4_conv2d_wgrad_dbias_bf16x6'), aux=aux)
 
     def _lrelu_bwd(self, g, y):
         C = g.shape[2]
@@ -365,7 +371,7 @@ class DecoderProgram:
         L = N.lib()
         m = s if s in (2, 4) else 1
         n = h * w
-        self._side_q = []
+        self._side_q, self._aux_q = [], []
         N.check(L.k4_zero_f32(N.f32(G['acc']), G['acc'].numel(), N.stream()), 'k4_zero_f32')        # every SFT layer ADDS its condition gradient
         # conv_last, conv_hr
         self._wgrad(net.conv_last, A['hr'], G['out'], m * h, m * w, 'conv_last')
@@ -428,6 +434,12 @@ class DecoderProgram:
         if nb == 0:
             N.check(L.k4_add_f32(N.f32(G['bf']), N.f32(g_body), N.f32(G['feat']), n * nf, N.stream()), 'k4_add_f32')
         self._wgrad(net.conv_first, A['xi'], G['feat'], h, w, 'conv_first')
+        # The tail of the pass.  Behind the last dense block the weight gradients' stream still holds that block's five launches; conv_first's joins them at once when the
+        # block's closing fork covers G['feat'] (it does when the block's grad_x launch wrote it), and the CondNet's four are dealt to both side streams behind the closing fork:
+        # the pass ends ~75 us earlier than with all nine in one queue behind the chain's last launch.
+        tail_split = self.aux is not None and nb > 0 and T._TAIL_SPLIT
+        if tail_split:
+            self._flush_side(fork=False)
         if self.x_grad:
             cin = A['xi'].shape[2]
             self._conv(self.bw_(net.conv_first), G['feat'], nf, G['xi'], cin, cin, h, w)
@@ -438,19 +450,21 @@ class DecoderProgram:
         self._wgrad(cn[6], A['c3'], G['acc'], h, w, 'cn6')
         self._conv(self.bw_(cn[6]), G['acc'], 32, G['c3'], 64, 64, h, w)
         self._lrelu_bwd(G['c3'], A['c3'])
-        self._wgrad(cn[4], A['c2'], G['c3'], h, w, 'cn4')
+        self._wgrad(cn[4], A['c2'], G['c3'], h, w, 'cn4', aux=tail_split)
         self._conv(self.bw_(cn[4]), G['c3'], 64, G['c2'], 64, 64, h, w)
         self._lrelu_bwd(G['c2'], A['c2'])
         self._wgrad(cn[2], A['c1'], G['c2'], h, w, 'cn2')
         self._conv(self.bw_(cn[2]), G['c2'], 64, G['c1'], 64, 64, h, w)
         self._lrelu_bwd(G['c1'], A['c1'])
-        self._wgrad(cn[0], A['ci'], G['c1'], h, w, 'cn0')
+        self._wgrad(cn[0], A['ci'], G['c1'], h, w, 'cn0', aux=tail_split)
         if self.cond_grad:
             ncond = A['ci'].shape[2]
             self._conv(self.bw_(cn[0]), G['c1'], 64, G['ci'], ncond, ncond, h, w)
         self._flush_side(fork=True)
         if self.side is not None:
             N.check(L.k4_main_wait_side(N.C.c_void_p(self.side), N.stream()), 'k4_main_wait_side')      # the weight gradients are done before the optimizer reads them
+            if tail_split:
+                N.check(L.k4_main_wait_side(N.C.c_void_p(self.aux), N.stream()), 'k4_main_wait_side')
 
     # ------------------------------------------------------------------------------------------------ entry points of the autograd node
     def run_forward(self, x, cond):

@@ -265,6 +265,7 @@ _SIDE_LOW_PRIORITY = False      # True: the weight gradients' stream at the devi
 _FUSED_LRELU = True     # False: a dense block's four LeakyReLU backward passes as launches of their own (A/B, tests)
 _DIRECT_GRADS = os.environ.get('K4_TRAIN_DIRECT_GRADS', '1') != '0'  # 0: every parameter an autograd input of its Function (torch.autograd.grad, parameter hooks)
 _COND_ACC = True        # False: every SFT consumer returns its condition gradient, autograd adds them (A/B)
+_TAIL_SPLIT = True      # False: the last weight gradients of the backward pass (conv_first, CondNet) in one queue behind the chain's last launch (A/B)
 _AUX_WGRAD = True       # False: all five weight gradients of a dense block on the weight gradients' stream (A/B)
 _SFT_SPLIT = True       # False: the SFT layers' whole backward on the chain's stream, as one launch each (A/B, tests)
 _TAPE = os.environ.get('K4_TRAIN_TAPE', '1') != '0'     # 0: the decoder as ~20 autograd nodes per RRDB (below) instead of ONE node on two launch tapes (lib/sr_tape.py)

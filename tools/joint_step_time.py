@@ -8,6 +8,9 @@ from nerf4k_amd.lib import dvgo, sr_esrnet, utils
 if os.environ.get('TOOL_AUX_WGRAD') == '0':                              # A/B: all weight gradients on their own stream
     from nerf4k_amd.lib import sr_train as _T3
     _T3._AUX_WGRAD = False
+if os.environ.get('TOOL_TAIL_SPLIT') == '0':                             # A/B: the tail's weight gradients in one queue
+    from nerf4k_amd.lib import sr_train as _T4
+    _T4._TAIL_SPLIT = False
 if os.environ.get('TOOL_SIDE_LOW') == '1':                                # A/B: the decoder's side streams at the device's lowest priority
     from nerf4k_amd.lib import sr_train as _T2
     _T2._SIDE_LOW_PRIORITY = True
