@@ -150,6 +150,9 @@ _EXTRA_SIGS = {
     'k4_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_masked_adam_upd': ([_P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_masked_adam_upd_sparse_cl': ([_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),
+    'k4_grid_flag_corners': ([_I32, _I32, _I32, _P, _P, _P, _I64, _P, _P], C.c_int),
+    'k4_masked_adam_upd_unflagged': ([_P, _P, _P, _P, _I32, _I64, _P, _I32, _F, _F, _F, _F, _I32, _P], C.c_int),
+    'k4_masked_adam_upd_sparse_cl_seeded': ([_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_adam_upd_with_perlr': ([_P, _P, _P, _P, _P, _I64, _I32, _F, _F, _F, _F, _P], C.c_int),
     'k4_total_variation_add_grad': ([_P, _P, _F, _F, _F, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     'k4_conv_weight_bf16x6_bytes': ([_I32, _I32, _I32], C.c_int64),

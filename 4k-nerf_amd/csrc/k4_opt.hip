@@ -132,6 +132,81 @@ extern "C" int k4_masked_adam_upd_sparse_cl(float* param, float* exp_avg, float*
                        (uint8_t*)workspace + nvox * C * 4, C, nvox, param, exp_avg, exp_avg_sq, step_size, beta1, beta2, eps);
     return k4_check_launch();
 }
+// The masked step of a multi-channel grid [C][nvox] in TWO parts (exact: Adam is elementwise, every element is stepped once with its complete gradient).
+//   k4_masked_adam_upd_unflagged          : every voxel whose flag byte is 0, gradient = `grad` (the dense TV term written ahead of the backward pass: for a voxel
+//                                           the lookups' scatter cannot touch that IS the iteration's gradient) -- runs beside the rest of the iteration;
+//   k4_masked_adam_upd_sparse_cl_seeded   : the flagged voxels after the backward pass, gradient = seed + the scatter's sum in the channel-last scratch image
+//                                           (the sweep's `grad += sum`, same operand order); scratch, its flags and `flags` are all-zero again behind it.
+// In the first 10,000 iterations of fern_lg_joint_l1 the dense k0 step (1.8 ms at 0.72-0.77 of the HBM roof) sat between the end of one iteration's backward pass
+// and the next iteration's k0 lookup; of its 37.7 M voxels the scatter touches a few 10^5.
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_unflagged_kernel(float4* __restrict__ param, const float4* __restrict__ grad, float4* __restrict__ em,
+                                                                            float4* __restrict__ ev, const uint32_t* __restrict__ flags4, int64_t nvox4,
+                                                                            float step_size, float beta1, float beta2, float eps) {
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    // grid-stride: the launch may be capped at a few workgroups per channel (max_workgroups) -- this pass runs BESIDE latency-bound kernels of other streams
+    for (int64_t v4 = (int64_t)blockIdx.x * K4_OPT_THREADS + threadIdx.x; v4 < nvox4; v4 += (int64_t)gridDim.x * K4_OPT_THREADS) {
+        const uint32_t f = flags4[v4];
+        if ((f & 0xffu) && (f & 0xff00u) && (f & 0xff0000u) && (f & 0xff000000u)) continue;
+        const int64_t i = (int64_t)blockIdx.y * nvox4 + v4;
+        const float4 g = grad[i];
+        if (g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+        float4 p = param[i], m = em[i], v = ev[i];
+        if (!(f & 0xffu) && g.x != 0.f) k4_adam_one(p.x, g.x, m.x, v.x, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        if (!(f & 0xff00u) && g.y != 0.f) k4_adam_one(p.y, g.y, m.y, v.y, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        if (!(f & 0xff0000u) && g.z != 0.f) k4_adam_one(p.z, g.z, m.z, v.z, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        if (!(f & 0xff000000u) && g.w != 0.f) k4_adam_one(p.w, g.w, m.w, v.w, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        param[i] = p; em[i] = m; ev[i] = v;
+    }
+}
+extern "C" int k4_masked_adam_upd_unflagged(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t C, int64_t nvox, const uint8_t* flags,
+                                            int32_t step, float beta1, float beta2, float lr, float eps, int32_t max_workgroups, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !flags || C < 1 || C > 65535 || nvox <= 0 || step < 1 || max_workgroups < 0) return K4_ERR_BAD_ARG;
+    if ((nvox & 3) || !k4_aligned16(param) || !k4_aligned16(grad) || !k4_aligned16(exp_avg) || !k4_aligned16(exp_avg_sq) || ((uintptr_t)flags & 3u)) return K4_ERR_UNSUPPORTED;
+    const int64_t nvox4 = nvox / 4;
+    int64_t blocks = (nvox4 + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+    if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+    if (max_workgroups > 0) {                              // `max_workgroups` in total: per channel (blockIdx.y) its share
+        const int64_t per = (max_workgroups + C - 1) / C;
+        if (per < blocks) blocks = per;
+    }
+    const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));      // adam_upd_kernel.cu:71
+    hipLaunchKernelGGL(k4_adam_unflagged_kernel, dim3((unsigned)blocks, (unsigned)C), dim3(K4_OPT_THREADS), 0, (hipStream_t)stream, (float4*)param, (const float4*)grad,
+                       (float4*)exp_avg, (float4*)exp_avg_sq, (const uint32_t*)flags, nvox4, step_size, beta1, beta2, eps);
+    return k4_check_launch();
+}
+__global__ __launch_bounds__(K4_OPT_THREADS) void k4_adam_sparse_cl_seeded_kernel(float* __restrict__ scratch, uint8_t* __restrict__ sflags, uint8_t* __restrict__ flags,
+                                                                                   const float* __restrict__ seed, int C, int64_t nvox, float* __restrict__ param,
+                                                                                   float* __restrict__ em, float* __restrict__ ev, float step_size, float beta1,
+                                                                                   float beta2, float eps) {
+    const int64_t vx = (int64_t)blockIdx.x * K4_OPT_THREADS + threadIdx.x;
+    if (vx >= nvox || flags[vx] == 0) return;
+    flags[vx] = 0;
+    sflags[vx] = 0;
+    float* const s = scratch + vx * C;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (int ch = 0; ch < C; ++ch) {
+        const int64_t i = (int64_t)ch * nvox + vx;
+        const float q = s[ch];
+        s[ch] = 0.f;
+        const float g = seed[i] + q;                       // (k_gsb_cl_sweep: grad[i] += q)
+        if (g == 0.f) continue;
+        float p = param[i], m = em[i], v = ev[i];
+        k4_adam_one(p, g, m, v, 1.f, step_size, beta1, beta2, omb1, omb2, eps);
+        param[i] = p; em[i] = m; ev[i] = v;
+    }
+}
+extern "C" int k4_masked_adam_upd_sparse_cl_seeded(float* param, float* exp_avg, float* exp_avg_sq, void* workspace, const float* seed, uint8_t* flags,
+                                                   int32_t C, int32_t X, int32_t Y, int32_t Z, int32_t step, float beta1, float beta2, float lr, float eps, void* stream) {
+    if (!param || !exp_avg || !exp_avg_sq || !workspace || !seed || !flags || (((uintptr_t)workspace) & 15) || C <= 1 || C > 32 || X <= 0 || Y <= 0 || Z <= 0 || step < 1)
+        return K4_ERR_BAD_ARG;
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t blocks = (nvox + K4_OPT_THREADS - 1) / K4_OPT_THREADS;
+    if (blocks > 0x7fffffffLL) return K4_ERR_BAD_ARG;
+    const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));      // adam_upd_kernel.cu:71
+    hipLaunchKernelGGL(k4_adam_sparse_cl_seeded_kernel, dim3((unsigned)blocks), dim3(K4_OPT_THREADS), 0, (hipStream_t)stream, (float*)workspace,
+                       (uint8_t*)workspace + nvox * C * 4, flags, seed, C, nvox, param, exp_avg, exp_avg_sq, step_size, beta1, beta2, eps);
+    return k4_check_launch();
+}
 extern "C" int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                                       const float* perlr, int64_t n, int32_t step, float beta1, float beta2, float lr,
                                       float eps, void* stream) {

@@ -488,6 +488,24 @@ __global__ __launch_bounds__(256) void k_gsb_cl_scatter(const float* __restrict_
     }
 }
 
+// flags[voxel] = 1 for every voxel a scatter of the points `xyz` will touch (the eight corners, k_gsb_cl_scatter's index arithmetic and range test): known
+// as soon as the lookup's FORWARD has its points -- MaskedAdam steps every other voxel of a grid whose only other gradient term is already known (the
+// dense TV term written ahead) while the rest of the iteration runs (k4_masked_adam_upd_unflagged / k4_masked_adam_upd_sparse_cl_seeded, k4_opt.hip).
+__global__ __launch_bounds__(256) void k_gsb_flag_corners(int X, int Y, int Z, const float* __restrict__ xyz, const float* __restrict__ mn, const float* __restrict__ mx,
+                                                           int64_t n, uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float nx = k4_norm_coord(xyz[i * 3 + 0], mn[0], mx[0]);
+    const float ny = k4_norm_coord(xyz[i * 3 + 1], mn[1], mx[1]);
+    const float nz = k4_norm_coord(xyz[i * 3 + 2], mn[2], mx[2]);
+    const K4Tri tr = k4_tri_setup(k4_unnorm(nx, X), k4_unnorm(ny, Y), k4_unnorm(nz, Z));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int x = tr.x0 + K4_CX(c), y = tr.y0 + K4_CY(c), z = tr.z0 + K4_CZ(c);
+        if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z) flags[((size_t)x * Y + y) * Z + z] = 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gsb_cl_sweep(float* __restrict__ scratch, uint8_t* __restrict__ flags, int C, int64_t nvox,
                                                        float* __restrict__ ggrid) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -951,6 +969,13 @@ extern "C" int k4_grid_sample_3d_backward_cl_scatter(const float* grad_out, int3
 #define K4_GSB_CL(LPS) hipLaunchKernelGGL(k_gsb_cl_scatter<LPS>, dim3(k4_blocks(n * LPS)), dim3(K4_THREADS), 0, ST, grad_out, C, X, Y, Z, xyz, mn, mx, n, scratch, flags)
     if (C <= 2) K4_GSB_CL(2); else if (C <= 4) K4_GSB_CL(4); else if (C <= 8) K4_GSB_CL(8); else if (C <= 16) K4_GSB_CL(16); else K4_GSB_CL(32);
 #undef K4_GSB_CL
+    return k4_check_launch();
+}
+extern "C" int k4_grid_flag_corners(int32_t X, int32_t Y, int32_t Z, const float* xyz, const float* mn, const float* mx, int64_t n, uint8_t* flags, void* stream) {
+    REQ(X > 0 && Y > 0 && Z > 0 && mn && mx && n >= 0 && flags);
+    if (n == 0) return K4_OK;
+    REQ(xyz);
+    hipLaunchKernelGGL(k_gsb_flag_corners, dim3(k4_blocks(n)), dim3(K4_THREADS), 0, ST, X, Y, Z, xyz, mn, mx, n, flags);
     return k4_check_launch();
 }
 extern "C" int k4_grid_sample_3d_backward_cl_sweep(int32_t C, int32_t X, int32_t Y, int32_t Z, void* workspace, float* grad_grid, void* stream) {

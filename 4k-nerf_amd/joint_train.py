@@ -31,6 +31,7 @@ from .lib.masked_adam import MaskedAdam
 _ADAM_SIDE = True   # False: the k0 grid's optimizer step on the current stream (A/B, tests)
 _TV_SEED = True     # False: dense total variation added after the backward pass, as run_sr.py orders it (A/B, tests)
 _FUSED_LOSSES = True     # False: the elementwise loss terms as tensor-library ops (A/B, tests; CPU tensors always)
+_SPLIT_GRID_STEP = True      # False: k0's optimizer step of an iteration with a dense TV term in one pass after the backward pass (A/B, tests)
 _SPARSE_GRID_GRAD = True     # False: k0's gradient as a dense tensor in the iterations without TV too (A/B, tests)
 
 SPARSE_MIN_NUMEL = 1 << 20          # tensors at least this large are exchanged as (index, value) lists
@@ -143,6 +144,7 @@ class JointTrainer:
         self.optimizer_sr = MaskedAdam([{'params': net_sr.parameters(), 'lr': cfg_train.lrate_srnet, 'kname': 'srnet',
                                          'skip_zero_grad': False}])                                               # run_sr.py:665-667
         self.last_exchange = None
+        self._after_march = None
         # K4_TRAIN_GRAPH=1 / use_graph: the decoder's forward + backward of the full-size patch replayed as hipGraphs (lib/sr_train.GraphedDecoder)
         self.use_graph = (os.environ.get('K4_TRAIN_GRAPH', '0') == '1') if use_graph is None else bool(use_graph)
         self._graphed = None
@@ -221,6 +223,8 @@ class JointTrainer:
 
     def forward(self, rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step):
         rr = self.model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **self.render_kwargs)
+        if self._after_march is not None:                        # (step: the first part of a split grid step, as early as the lookups' points are known)
+            self._after_march()
         rgb_cache = rr['rgb_feature'].reshape(1, pr, pc, -1).movedim(-1, 1)
         cond = rr['depth'].reshape(1, pr, pc, 1).movedim(-1, 1)                          # num_cond == 1 (run_sr.py:894-897)
         rgb_sr = self._decoder(rgb_cache, cond)                                          # run_sr.py:918
@@ -263,14 +267,42 @@ class JointTrainer:
                 if weight > 0 and hasattr(grid, 'finish_grad_seed') and grid.grid.requires_grad:
                     fn(weight / self.n_train_images, 'seed')
                     seeded.append(grid)
+        # ... and a grid whose gradient is that term + what its lookups' backward scatters is stepped in two exact parts: every voxel the scatter cannot touch right after
+        # the forward pass (beside the decoder's passes), the touched ones after the backward pass (MaskedAdam.early_step) -- the dense pass over k0 (1.8 ms) no longer
+        # sits between this iteration's backward pass and the next iteration's lookup
+        split = [g for g in self._sparse_grid_owners() if g in seeded] if (_SPLIT_GRID_STEP and seed_tv) else []
+        for grid in split:
+            flags = grid.__dict__.get('_k4_split_flags')
+            if flags is None or flags.numel() != grid.grid[0, 0].numel() or flags.device != grid.grid.device:
+                flags = grid.__dict__['_k4_split_flags'] = torch.zeros([grid.grid[0, 0].numel()], dtype=torch.uint8, device=grid.grid.device)
+            grid._k4_split = {'flags': flags}
         done = False
+
+        def early():                                             # between the marcher's forward pass and the decoder's: the lookups' points are known
+            for grid in split:
+                seed, ev = grid._k4_seed
+                if self.optimizer.early_step(grid, seed, ev):
+                    grid._k4_seed = None                         # consumed: the backward pass leaves its sums in the scratch image
+                else:
+                    grid._k4_split = None                        # one-pass step after all
+                    grid.__dict__.pop('_k4_split_flags', None)
         try:
             with torch.enable_grad():
-                rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
+                if split:
+                    # (zero_grad makes the current stream wait for a grid's pending update: in front of the first part, not behind it; its place relative to the
+                    # forward pass changes nothing -- run_sr.py:1003 clears the gradients right before the backward pass)
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self.optimizer_sr.zero_grad(set_to_none=True)
+                    self._after_march = early
+                try:
+                    rr, rgb_sr, ls = self.forward(rays_o, rays_d, viewdirs, target, target_4x, pr, pc, global_step)
+                finally:
+                    self._after_march = None
                 if hasattr(self.model, '_k4_params_ready'):
                     self.model._k4_params_ready()                # (a forward that never read k0: its pending update still precedes what follows)
-                self.optimizer.zero_grad(set_to_none=True)
-                self.optimizer_sr.zero_grad(set_to_none=True)
+                if not split:
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self.optimizer_sr.zero_grad(set_to_none=True)
                 ls['total'].backward()
             for grid in seeded:
                 grid.finish_grad_seed()
@@ -283,6 +315,10 @@ class JointTrainer:
             if not done:                # forward / loss / backward raised (e.g. an out-of-memory batch the caller skips): a parked seed must not
                 for grid in seeded:     # reach a LATER iteration's gradient -- it holds a TV term of parameters that iteration no longer has
                     grid._k4_seed = None
+                for grid in split:      # (a split step's first part stays applied -- those voxels' step of this iteration; flags and scratch image start afresh)
+                    G.discard_pending_grad(grid)
+                    grid._k4_split = None
+                    grid.__dict__.pop('_k4_split_flags', None)
         stepped = False
         try:
             self.last_exchange = exchange_gradients(self.model, self.net_sr, self.group)
@@ -295,8 +331,12 @@ class JointTrainer:
             stepped = True
         finally:
             if not stepped:             # sums a scatter-only backward left in the scratch image must not be added to by the next iteration's
-                for grid in sparse:
+                for grid in sparse + split:
                     G.discard_pending_grad(grid)
+            for grid in split:
+                if grid._k4_split is not None:                   # (the second part did not run)
+                    grid._k4_split = None
+                    grid.__dict__.pop('_k4_split_flags', None)
         self.optimizer_sr.step()
         factor = 0.1 ** (1 / (cfg.lrate_decay * 1000))                                                           # run_sr.py:1052-1061
         for opt in (self.optimizer, self.optimizer_sr):

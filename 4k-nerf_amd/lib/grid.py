@@ -41,6 +41,13 @@ class GridSample3D(torch.autograd.Function):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         _, C_, X, Y, Z = ctx.grid_shape
         owner = ctx.owner
+        split = owner is not None and owner._k4_split is not None and owner._k4_split.get('early', False)
+        if split:
+            # MaskedAdam has stepped every voxel this scatter cannot touch already (early_step): the sums stay in the scratch image for the second part
+            if not grid_sample_3d_backward_scatter(grad_out.float().contiguous(), C_, X, Y, Z, pts, xyz_min, xyz_max):
+                raise N.K4Error('GridSample3D.backward: the scratch image of a grid whose step was split is gone')
+            owner._k4_sparse_pending = True
+            return None, None, None, None, None
         if owner is not None and owner._k4_sparse_grad and owner._k4_seed is None:
             # the trainer consumes this gradient where the scatter leaves it (MaskedAdam -> k4_masked_adam_upd_sparse_cl): no dense tensor, `.grad` stays None
             if grid_sample_3d_backward_scatter(grad_out.float().contiguous(), C_, X, Y, Z, pts, xyz_min, xyz_max):
@@ -208,6 +215,13 @@ class DenseGrid(nn.Module):
         pts = xyz.reshape(-1, 3).contiguous()
         self.params_ready()
         if torch.is_grad_enabled() and self.grid.requires_grad:
+            sp = self._k4_split
+            if sp is not None and pts.shape[0] > 0:            # (a split optimizer step, JointTrainer.step: the voxels this lookup's backward will touch)
+                if sp.get('early', False):
+                    raise N.K4Error('DenseGrid.forward: a lookup under autograd after the first part of the split optimizer step')
+                _, _, X, Y, Z = self.grid.shape
+                N.check(N.lib().k4_grid_flag_corners(X, Y, Z, N.f32(pts), N.f32(self.xyz_min), N.f32(self.xyz_max), pts.shape[0], N.ptr(sp['flags']), N.stream()),
+                        'k4_grid_flag_corners')
             out = GridSample3D.apply(self.grid, pts.detach(), self.xyz_min, self.xyz_max, self)
         else:
             out = _grid_sample_fwd(self.grid.detach(), pts, self.xyz_min, self.xyz_max)
@@ -257,6 +271,10 @@ class DenseGrid(nn.Module):
     # (k4_masked_adam_upd_sparse_cl) -- no 1.36 GB gradient cleared, swept into and read again per iteration.
     _k4_sparse_grad = False
     _k4_sparse_pending = False
+    # The step of this grid in two exact parts (MaskedAdam.early_step / _sparse_step; JointTrainer.step sets this for the iterations with a dense TV term written
+    # ahead): {'flags': uint8 [X*Y*Z], all-zero before the iteration's first lookup} -- lookups under autograd flag the voxels their backward will touch;
+    # early_step adds 'early', 'seed', 'step', 'hyper'
+    _k4_split = None
     # ---- an optimizer step of the grid running on a second stream (lib/masked_adam.MaskedAdam.update_on_side_stream) ----
     _k4_pending = None
 
@@ -292,7 +310,7 @@ class DenseGrid(nn.Module):
         memo[id(self)] = new
         import copy
         for k, v in self.__dict__.items():
-            if k in ('_k4_seed', '_k4_pending', '_k4_pending_seen', '_k4_sparse_grad', '_k4_sparse_pending'):
+            if k in ('_k4_seed', '_k4_pending', '_k4_pending_seen', '_k4_sparse_grad', '_k4_sparse_pending', '_k4_split'):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -47,7 +47,14 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
 
 def _side_stream(device):
     """The stream a large grid's update runs on: verified to run beside the current stream and the package's other side streams (_native.overlapping_stream)."""
-    return N.overlapping_stream(device, 'grid optimizer step')
+    return N.overlapping_stream(device, 'grid optimizer step', low_priority=_SIDE_LOW_PRIORITY)
+
+
+# The first part of a split grid step on at most this many workgroups (0: no cap).  It runs BESIDE the decoder's latency-bound kernels, which an HBM-saturating pass
+# slows by more than it saves (uncapped: 7.26 against 7.21 ms per joint iteration without the split); at 384-512 workgroups -- under two per CU, ~2.5 TB/s, the pass
+# then ends about where the backward pass does -- the iteration is 6.8-7.0 ms (profiles/r06_split_grid_step.md)
+_EARLY_WORKGROUPS = 448
+_SIDE_LOW_PRIORITY = False      # True: the grids' step stream at the device's lowest priority (A/B)
 
 
 _MULTI_BELOW = 1 << 20          # tensors smaller than this are updated through k4_adam_upd_multi (same arithmetic per element)
@@ -200,12 +207,94 @@ class MaskedAdam(torch.optim.Optimizer):
                                  'numel': [p.numel() for p in plist], 'ids': {id(p) for p in plist},
                                  'touched': [t for ts in items for t in (ts[0], ts[2], ts[3])]}
 
+    @torch.no_grad()
+    def early_step(self, owner, seed, seed_event):
+        """First part of this iteration's step of ``owner.grid`` (a multi-channel grid whose step runs on the side stream), BEFORE the backward pass: every voxel the
+        lookups' backward cannot touch -- ``owner._k4_split['flags']`` marks those it can -- is stepped with gradient `seed` (the dense TV term written ahead, complete at
+        `seed_event`): for such a voxel that is the iteration's whole gradient.  The second part (the flagged voxels, gradient = seed + the scatter's sums) runs in
+        ``step`` through ``_sparse_step``.  Adam is elementwise: every element is stepped exactly once with its complete gradient, the same values as the one-pass step.
+        What it buys: the dense pass over the grid (1.8 ms for the LLFF k0) runs beside the rest of the iteration instead of between its backward pass and the next
+        iteration's lookup.  -> False (nothing done, take the one-pass path) when the split form does not apply."""
+        from . import grid as G
+        param, sp = owner.grid, owner._k4_split
+        group = next((g for g in self.param_groups if any(p is param for p in g['params'])), None)
+        if sp is None or sp.get('early', False) or group is None or not group.get('skip_zero_grad') or not any(o is owner for o in self._side):
+            return False
+        if not param.is_cuda or param.dim() != 5 or param.shape[1] <= 1 or param.grad is not None or not param.is_contiguous() or param.dtype != torch.float32:
+            return False
+        if self.per_lr is not None and self.per_lr.shape == param.shape:
+            return False
+        if seed.shape != param.shape or not seed.is_contiguous() or seed.dtype != torch.float32:
+            return False
+        _, C_, X, Y, Z = param.shape
+        if G._gsb_workspace(param.device, C_, X, Y, Z) is None:           # the second part reads the scatter's scratch image
+            return False
+        (beta1, beta2), lr, eps = group['betas'], group['lr'], group['eps']
+        state = self.state[param]
+        if not state:
+            state.update(step=0, exp_avg=torch.zeros_like(param, memory_format=torch.preserve_format),
+                         exp_avg_sq=torch.zeros_like(param, memory_format=torch.preserve_format))
+        step = int(state['step']) + 1
+        for t in (state['exp_avg'], state['exp_avg_sq']):
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                return False
+        cur, side = torch.cuda.current_stream(param.device), _side_stream(param.device)
+        side.wait_stream(cur)                                  # the flags are complete, every read of the old values (lookups, the TV term's stencil) is issued ...
+        side.wait_event(seed_event)                            # ... and the TV term itself is done
+        seed.record_stream(side)
+        sp['flags'].record_stream(side)
+        with torch.cuda.stream(side):
+            rc = N.lib().k4_masked_adam_upd_unflagged(N.ptr(param), N.ptr(seed), N.ptr(state['exp_avg']), N.ptr(state['exp_avg_sq']), C_, X * Y * Z, N.ptr(sp['flags']),
+                                                      step, float(beta1), float(beta2), float(lr), float(eps), int(_EARLY_WORKGROUPS), N.stream())
+            if rc == N.K4_ERR_UNSUPPORTED:
+                return False
+            N.check(rc, 'k4_masked_adam_upd_unflagged')
+            ev = torch.cuda.Event()
+            ev.record(side)
+        owner.note_pending_update(ev)
+        owner._k4_sparse_pending = True                        # the second part runs even if no backward pass reaches the grid (its flagged voxels: seed alone)
+        sp.update(early=True, seed=seed, step=step, hyper=(float(beta1), float(beta2), float(lr), float(eps)))
+        for t in (param, state['exp_avg'], state['exp_avg_sq']):
+            torch.autograd.graph.increment_version(t)
+        return True
+
+    def _split_late_step(self, param, owner):
+        """Second part of a split step (early_step): the flagged voxels, gradient = seed + the sums the scatter left in the scratch image."""
+        from . import grid as G
+        sp = owner._k4_split
+        owner._k4_sparse_pending = False
+        owner._k4_split = None
+        _, C_, X, Y, Z = param.shape
+        hit = G._GSB_WS.get(param.device)
+        if hit is None or hit[0] != (C_, X, Y, Z):
+            raise N.K4Error('MaskedAdam: the scratch image of the pending grid gradient is gone')
+        state = self.state[param]
+        if int(state['step']) + 1 != sp['step'] or param.grad is not None:
+            raise N.K4Error('MaskedAdam: the second part of a split step does not follow its first part')
+        state['step'] = sp['step']
+        beta1, beta2, lr, eps = sp['hyper']
+        cur, side = torch.cuda.current_stream(param.device), _side_stream(param.device)
+        side.wait_stream(cur)                                  # the scatter is done
+        hit[1].record_stream(side)
+        with torch.cuda.stream(side):
+            N.check(N.lib().k4_masked_adam_upd_sparse_cl_seeded(N.ptr(param), N.ptr(state['exp_avg']), N.ptr(state['exp_avg_sq']), N.ptr(hit[1]), N.ptr(sp['seed']),
+                                                                N.ptr(sp['flags']), C_, X, Y, Z, int(sp['step']), beta1, beta2, lr, eps, N.stream()),
+                    'k4_masked_adam_upd_sparse_cl_seeded')
+            ev = torch.cuda.Event()
+            ev.record(side)
+        hit[2] = ev
+        owner.note_pending_update(ev)
+        for t in (param, state['exp_avg'], state['exp_avg_sq']):
+            torch.autograd.graph.increment_version(t)
+
     def _sparse_step(self, param, owner, masked, beta1, beta2, lr, eps):
         """`param`'s gradient of this iteration is the sums its lookups' backward left in the channel-last scratch image (DenseGrid._k4_sparse_grad, set by the
         trainer for iterations without any other contribution to it): the masked update of exactly those voxels from there (k4_masked_adam_upd_sparse_cl), on
         the grid's side stream like the dense step.  Anything the in-place form does not cover (a `.grad` that exists after all, no zero-gradient skipping,
         a per-voxel learning rate on this tensor) sweeps the sums into the dense gradient instead and leaves the tensor to the regular path."""
         from . import grid as G
+        if owner._k4_split is not None and owner._k4_split.get('early', False):
+            return self._split_late_step(param, owner)
         if param.grad is not None or not masked or (self.per_lr is not None and param.shape == self.per_lr.shape):
             G.sweep_pending_grad(owner)
             return

@@ -36,7 +36,7 @@ extern "C" {
 #define K4_ERR_BAD_ARG      10001   /* null pointer / non-positive size / unsupported combination */
 #define K4_ERR_UNSUPPORTED  10002   /* configuration not covered by the fused kernel (use the staged ops) */
 
-#define K4_ABI_VERSION      14      /* 14: k4_sft_train_bwd_gx / k4_sft_train_bwd_rest, k4_rdb_train.aux_stream (the SFT layers' backward split into the chain's grad_x launch and the rest on a third stream); 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl, k4_joint_losses_fwd / _bwd; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
+#define K4_ABI_VERSION      14      /* 14: k4_sft_train_bwd_gx / k4_sft_train_bwd_rest, k4_rdb_train.aux_stream (the SFT layers' backward split into the chain's grad_x launch and the rest on a third stream), k4_grid_flag_corners / k4_masked_adam_upd_unflagged / k4_masked_adam_upd_sparse_cl_seeded (a grid's masked step in two exact parts); 13: launch tapes (k4_tape_*), k4_add_f32, k4_upsample2x_nhwc / _bwd_nhwc, k4_side_wait_main / k4_main_wait_side, k4_stream_create_overlapping / k4_streams_overlap, K4_CONV_SMALL, k4_rdb_train.no_join / defer_side, k4_sft_train_bwd_side / _main / k4_sft_train_reduce, k4_nhwc_window_to_planar, k4_rgbnet_input_mpi, k4_grid_sample_3d_backward_cl_scatter / _sweep, k4_masked_adam_upd_sparse_cl, k4_joint_losses_fwd / _bwd; 12: round-5 experiments removed (k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4, k4_repack_k0_brick4, k4_k0_brick4_floats: profiles/r05_split_path_brick_parts_removed.patch), k4_mlp_desc.arith K4_MLP_ARITH_B2; 11: k4_sft_train_bwd_ex, k4_sft_train_fwd_ex, k4_conv2d_wgrad_dbias_bf16x6_acc, k4_zero_f32, K4_EPI_LRELU_BWD, k4_rdb_train.gc_acc / gx0_add / dwdb_span / fused_lrelu / g5_from_gx0_add, k4_total_variation_add_grad dense_mode 2; 10: k4_train_select_mpi, k4_train_compact, k4_ndc_points_of (training forward with one read-back instead of four); 9: split shading path: k4_march_workspace_bytes_pre, k4_march_pre_supported, K4_K0_BRICK4 + k4_repack_k0_brick4 / k4_k0_brick4_floats; 8: k4_conv3x3_p16_sft_multi, k4_conv_sft_epilogue_bytes, k4_rdb_train_fwd / k4_rdb_train_bwd; 7: pre-split decoder activations: k4_conv3x3_p16_multi, k4_conv_weight_p16_bytes, k4_sft_nhwc_p16_multi, k4_absmax_slice; 6: k4_conv2d_sft_nhwc_bf16x6_multi removed; k4_conv2d_wgrad_dbias_bf16x6, k4_pack_conv_weight_bf16x6_multi, k4_lrelu_bwd, k4_grid_sample_3d_backward_cl, k4_touched_voxels; 5: k4_build_live_mask, k4_sft_train_*, K4_ARITH_F16X3 / k4_conv_weight_f16x3_bytes, no tile_queue, round-1 bf16x3 entry points removed; 4: marcher training entry points (k4_rgbnet_*, k4_distortion_loss); 2: SR / optimizer / ray-generation entry points, k4_mlp_desc.arith; 3: larger marcher workspace (bundle order), k4_sft_nhwc_multi arith, fused conv + SFT entry */
 int k4_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -558,6 +558,17 @@ int k4_adam_upd_with_perlr(float* param, const float* grad, float* exp_avg, floa
  * them gets the masked update (same arithmetic per element), the workspace is all zero again on return.  For iterations in which nothing else
  * contributes to the grid's gradient (run_sr.py:1005-1014 after tv_before: no total variation) this is MaskedAdam.step
  * (lib/masked_adam.py:58-71, skip_zero_grad) without the dense gradient tensor. */
+/* ABI 14 -- the masked step of a multi-channel grid in two exact parts (Adam is elementwise): k4_grid_flag_corners marks the voxels a scatter of `xyz` will touch
+ * (the lookup's forward knows them: flags [X*Y*Z] bytes, the caller's, all-zero before the iteration's first lookup); k4_masked_adam_upd_unflagged steps every
+ * unflagged voxel of [C][nvox] tensors with gradient `grad` (the dense TV term written ahead: K4_ERR_UNSUPPORTED unless nvox % 4 == 0 and the tensors are 16-byte
+ * aligned); k4_masked_adam_upd_sparse_cl_seeded steps the flagged ones after the backward pass with gradient seed + the scatter's sums (the sweep's operand order)
+ * and leaves `workspace` and `flags` all-zero.  Same `step` for both.  max_workgroups > 0 caps the first part's launch (grid-stride): it is meant to run beside
+ * latency-bound kernels of other streams, which a pass at the full HBM rate slows by more than it saves.  Reference: lib/masked_adam.py:39-71 after run_sr.py:1005-1011. */
+int k4_grid_flag_corners(int32_t X, int32_t Y, int32_t Z, const float* xyz, const float* xyz_min, const float* xyz_max, int64_t n, uint8_t* flags, void* stream);
+int k4_masked_adam_upd_unflagged(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t channels, int64_t n_vox, const uint8_t* flags,
+                                 int32_t step, float beta1, float beta2, float lr, float eps, int32_t max_workgroups, void* stream);
+int k4_masked_adam_upd_sparse_cl_seeded(float* param, float* exp_avg, float* exp_avg_sq, void* workspace, const float* seed, uint8_t* flags,
+                                        int32_t channels, int32_t X, int32_t Y, int32_t Z, int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
 int k4_masked_adam_upd_sparse_cl(float* param, float* exp_avg, float* exp_avg_sq, void* workspace, int32_t channels, int32_t X, int32_t Y, int32_t Z,
                                  int32_t step, float beta1, float beta2, float lr, float eps, void* stream);
 

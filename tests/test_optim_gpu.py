@@ -331,3 +331,52 @@ def test_sparse_masked_adam_from_the_scatter_image_is_the_dense_masked_step(C):
     assert not bool(changed[0, 1].any()) and torch.equal(mb[0, 1], m0[0, 1])
     assert int(L.k4_masked_adam_upd_sparse_cl(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), 1, X, Y, Z, *hyper, N.stream())) == 10001
     assert int(L.k4_masked_adam_upd_sparse_cl(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), C, X, Y, Z, 0, 0.9, 0.99, 1e-1, 1e-8, N.stream())) == 10001
+
+
+@pytest.mark.parametrize('C', [3, 12])
+def test_split_masked_adam_step_equals_the_one_pass_step(C):
+    """The masked step of a grid in two parts -- k4_grid_flag_corners (the voxels a scatter of the lookup's points will touch), k4_masked_adam_upd_unflagged
+    (every other voxel, gradient = the dense term written ahead) and, after the scatter, k4_masked_adam_upd_sparse_cl_seeded (the flagged voxels, gradient =
+    seed + the scatter's sums) -- against the one-pass route from the SAME scratch image: sweep into the seed, k4_masked_adam_upd.  Parameters and both moments
+    bit for bit; the flags equal the scatter's own; scratch image and flags all zero afterwards; seed zeros (skipped elements) on both sides of the flags."""
+    from nerf4k_amd import _native as N
+    g = torch.Generator().manual_seed(90 + C)
+    X, Y, Z = 11, 9, 32                                                   # (X * Y * Z % 4 == 0: the vector form of the first part)
+    n = 700
+    pts = (torch.rand([n, 3], generator=g) * 2.2 - 1.1).cuda()           # some points outside the grid: corners out of range
+    gout = torch.randn([n, C], generator=g)
+    gout[::5] = 0                                                         # samples that flag voxels without contributing
+    gout = gout.cuda()
+    mn, mx = torch.tensor([-1., -1., -1.]).cuda(), torch.tensor([1., 1., 1.]).cuda()
+    L = N.lib()
+    nvox = X * Y * Z
+    shape = [1, C, X, Y, Z]
+    seed = torch.randn(shape, generator=g)
+    seed[0, :, ::3, ::2] = 0                                              # TV terms that are exactly zero: skipped unless the scatter adds to them
+    seed = seed.cuda()
+    nb = int(L.k4_grid_sample_3d_backward_workspace_bytes(C, X, Y, Z))
+    ws = torch.zeros([nb // 4], dtype=torch.int32, device='cuda')
+    flags = torch.zeros([nvox], dtype=torch.uint8, device='cuda')
+    N.check(L.k4_grid_flag_corners(X, Y, Z, N.f32(pts), N.f32(mn), N.f32(mx), n, N.ptr(flags), N.stream()), 'k4_grid_flag_corners')
+    N.check(L.k4_grid_sample_3d_backward_cl_scatter(N.f32(gout), C, X, Y, Z, N.f32(pts), N.f32(mn), N.f32(mx), n, N.ptr(ws), N.stream()), 'scatter')
+    sflags = ws.view(torch.uint8)[nvox * C * 4: nvox * C * 4 + nvox]
+    assert torch.equal(sflags, flags) and 0 < int(flags.sum()) < nvox
+    ws2 = ws.clone()
+    p0 = torch.randn(shape, generator=g).cuda()
+    m0 = (torch.randn(shape, generator=g) * 0.1).cuda()
+    v0 = (torch.rand(shape, generator=g) * 0.1).cuda()
+    hyper = (5, 0.9, 0.99, 1e-1, 1e-8)
+    # one pass: the sweep adds the sums to the seed, the masked step reads the result
+    pa, ma, va, grad = p0.clone(), m0.clone(), v0.clone(), seed.clone()
+    N.check(L.k4_grid_sample_3d_backward_cl_sweep(C, X, Y, Z, N.ptr(ws), N.f32(grad), N.stream()), 'sweep')
+    N.check(L.k4_masked_adam_upd(N.ptr(pa), N.ptr(grad), N.ptr(ma), N.ptr(va), pa.numel(), *hyper, N.stream()), 'masked_adam_upd')
+    # two parts
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    N.check(L.k4_masked_adam_upd_unflagged(N.ptr(pb), N.f32(seed), N.ptr(mb), N.ptr(vb), C, nvox, N.ptr(flags), *hyper, 5, N.stream()), 'unflagged')
+    fl = flags.bool().view(1, 1, X, Y, Z).expand(shape)
+    assert torch.equal(pb[fl], p0[fl]) and torch.equal(pb[~fl], pa[~fl])                  # the first part stepped exactly the unflagged voxels
+    N.check(L.k4_masked_adam_upd_sparse_cl_seeded(N.ptr(pb), N.ptr(mb), N.ptr(vb), N.ptr(ws2), N.f32(seed), N.ptr(flags), C, X, Y, Z, *hyper, N.stream()), 'seeded')
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert int(ws2.count_nonzero()) == 0 and int(flags.count_nonzero()) == 0
+    # the vector form's preconditions
+    assert int(L.k4_masked_adam_upd_unflagged(N.ptr(pb), N.f32(seed), N.ptr(mb), N.ptr(vb), C, nvox - 1, N.ptr(flags), *hyper, 0, N.stream())) == N.K4_ERR_UNSUPPORTED

@@ -279,6 +279,7 @@ def test_iterations_without_tv_update_k0_from_the_scatter_image(monkeypatch):
         z, model, net, rk, cfg, batch = _load_joint()
         cfg = joint_train.JointCfg(dict(cfg, tv_before=2, tv_dense_before=2))
         monkeypatch.setattr(joint_train, '_SPARSE_GRID_GRAD', sparse_on)
+        monkeypatch.setattr(joint_train, '_SPLIT_GRID_STEP', False)       # (step 1, the dense-TV iteration: the one-pass step -- the split form has its own test)
         tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
         assert [o is model.k0 for o in tr._sparse_grid_owners()] == [True]
         hist = []
@@ -485,3 +486,47 @@ def test_fused_rgbnet_input_equals_the_reference_op_sequence(P, V, C):
     want.backward(gx)
     assert torch.equal(x.detach(), want.detach()), float((x.detach() - want.detach()).abs().max())
     assert torch.equal(got_g, vox2.grad)
+
+
+def test_split_grid_step_of_the_dense_tv_iterations_equals_the_one_pass_step(monkeypatch):
+    """JointTrainer.step with a dense TV term written ahead: k0's optimizer step in two exact parts (MaskedAdam.early_step right after the forward pass for every voxel
+    the lookups' backward cannot touch, the touched ones after the backward pass from the scatter's scratch image) against the one-pass step after the backward pass.
+    Three iterations each way from the same state: same losses, same parameters / moments to the scatter atomics' rounding; the split form was really taken (the
+    grid's gradient never exists, its flags are all zero again), and the sparse-TV iteration after tv_dense_before takes the one-pass route in both."""
+    from nerf4k_amd.lib import masked_adam
+    monkeypatch.setattr(masked_adam, '_MULTI_BELOW', 1000)
+    res = []
+    for split in (False, True):
+        z, model, net, rk, cfg, batch = _load_joint()
+        cfg = joint_train.JointCfg(dict(cfg, tv_before=100, tv_dense_before=3))          # steps 1, 2 dense; step 3 sparse
+        monkeypatch.setattr(joint_train, '_SPLIT_GRID_STEP', split)
+        tr = joint_train.JointTrainer(model, net, cfg, rk, n_train_images=17)
+        taken = []
+        early = masked_adam.MaskedAdam.early_step
+
+        def spy(self, owner, seed, ev, _early=early, _taken=taken):
+            ok = _early(self, owner, seed, ev)
+            _taken.append(ok)
+            return ok
+        monkeypatch.setattr(masked_adam.MaskedAdam, 'early_step', spy)
+        hist = []
+        for i in range(3):
+            hist.append(float(tr.step(*batch, global_step=1 + i)['total']))
+            assert model.k0._k4_split is None and model.k0._k4_seed is None and not model.k0._k4_sparse_pending
+            if split and i < 2:
+                assert model.k0.grid.grad is None and int(model.k0.__dict__['_k4_split_flags'].count_nonzero()) == 0
+        monkeypatch.setattr(masked_adam.MaskedAdam, 'early_step', early)
+        assert taken == ([True, True] if split else [])
+        sd = model.state_dict()
+        tr.optimizer.state_dict()                                                       # (waits for the grid's pending update)
+        st = [tr.optimizer.state[p] for _, p in model.named_parameters() if p in tr.optimizer.state]      # (the split form creates k0's state earlier: keyed by parameter)
+        moments = [v[k].detach().clone() for v in st for k in ('exp_avg', 'exp_avg_sq')]
+        steps = [int(v['step']) for v in st]
+        res.append((hist, {k: v.detach().clone() for k, v in sd.items() if v.is_floating_point()}, moments, steps))
+    (h0, m0, a0, s0), (h1, m1, a1, s1) = res
+    assert np.allclose(h1, h0, rtol=1e-6, atol=0), (h1, h0)
+    assert s0 == s1 and len(a0) == len(a1)
+    for k in m1:
+        _close(m1[k], m0[k].cpu(), k, rel=1e-5, abs_=1e-8)
+    for a, b in zip(a1, a0):
+        _close(a, b.cpu(), 'optimizer moment', rel=1e-5, abs_=1e-9)

@@ -8,6 +8,8 @@ import torch
 import nerf4k_amd  # noqa: F401
 from nerf4k_amd import scene, joint_train
 from nerf4k_amd.lib import dvgo, sr_esrnet, sr_train, utils
+if os.environ.get('TOOL_SPLIT_STEP') == '0':                             # A/B: k0's step of the dense-TV iterations in one pass after the backward pass
+    joint_train._SPLIT_GRID_STEP = False
 if os.environ.get('TOOL_SFT_SPLIT') == '0':                               # A/B: the SFT layers' whole backward on the chain (one launch each)
     sr_train._SFT_SPLIT = False
 if os.environ.get('SIDE_PRIO') is not None and hasattr(sr_train, '_SIDE_LOW_PRIORITY'):

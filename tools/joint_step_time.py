@@ -14,6 +14,14 @@ if os.environ.get('TOOL_TAIL_SPLIT') == '0':                             # A/B: 
 if os.environ.get('TOOL_SIDE_LOW') == '1':                                # A/B: the decoder's side streams at the device's lowest priority
     from nerf4k_amd.lib import sr_train as _T2
     _T2._SIDE_LOW_PRIORITY = True
+if os.environ.get('TOOL_EARLY_WGS'):
+    from nerf4k_amd.lib import masked_adam as _MA2
+    _MA2._EARLY_WORKGROUPS = int(os.environ['TOOL_EARLY_WGS'])
+if os.environ.get('TOOL_ADAM_LOW') == '1':
+    from nerf4k_amd.lib import masked_adam as _MA
+    _MA._SIDE_LOW_PRIORITY = True
+if os.environ.get('TOOL_SPLIT_STEP') == '0':                             # A/B: k0's step of the dense-TV iterations in one pass after the backward pass
+    joint_train._SPLIT_GRID_STEP = False
 if os.environ.get('TOOL_SFT_SPLIT') == '0':                               # A/B: the SFT layers' whole backward on the chain (one launch each)
     from nerf4k_amd.lib import sr_train as _T
     _T._SFT_SPLIT = False
