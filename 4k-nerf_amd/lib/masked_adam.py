@@ -51,8 +51,8 @@ def _side_stream(device):
 
 
 # The first part of a split grid step on at most this many workgroups (0: no cap).  It runs BESIDE the decoder's latency-bound kernels, which an HBM-saturating pass
-# slows by more than it saves (uncapped: 7.26 against 7.21 ms per joint iteration without the split); at 384-512 workgroups -- under two per CU, ~2.5 TB/s, the pass
-# then ends about where the backward pass does -- the iteration is 6.8-7.0 ms (profiles/r06_split_grid_step.md)
+# slows by more than it saves (uncapped: 7.26 against 7.21 ms per joint iteration without the split); at 384-512 workgroups -- under two per CU, 2.1 ms for the LLFF
+# k0's 9.5 GB, beside the decoder's forward pass -- the iteration is 6.8-7.0 ms (profiles/r06_split_grid_step.md)
 _EARLY_WORKGROUPS = 448
 _SIDE_LOW_PRIORITY = False      # True: the grids' step stream at the device's lowest priority (A/B)
 
