@@ -290,7 +290,7 @@ class JointTrainer:
             with torch.enable_grad():
                 if split:
                     # (zero_grad makes the current stream wait for a grid's pending update: in front of the first part, not behind it; its place relative to the
-                    # forward pass changes nothing -- run_sr.py:1003 clears the gradients right before the backward pass)
+                    # forward pass changes nothing -- run_sr.py:961-962 clears the gradients between the loss terms and the backward pass (:1003))
                     self.optimizer.zero_grad(set_to_none=True)
                     self.optimizer_sr.zero_grad(set_to_none=True)
                     self._after_march = early
